@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Run only inside the build container (needs /root/reference, read-only):
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The outputs (*.npz: inputs + the reference's outputs, no reference source) are
+committed; nothing at test/bench time reads /root/reference.  Work-arounds for
+the reference's latent bugs (SURVEY.md headline list): tqdm injected into
+``solvers``, ``low_storage=True``, ``wave_number=`` instead of ``k=``, default
+dtype set BEFORE constructing Grid/operator/IC.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "fno", "data_gen"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from torch_cfd.grids import Grid  # noqa: E402
+from torch_cfd.equations import NavierStokes2DSpectral, RK4CrankNicolsonStepper  # noqa: E402
+from torch_cfd.forcings import KolmogorovForcing, SinCosForcing  # noqa: E402
+from torch_cfd.initial_conditions import vorticity_field, filtered_velocity_field  # noqa: E402
+from torch_cfd.finite_differences import curl_2d  # noqa: E402
+from torch_cfd.spectral import vorticity_to_velocity  # noqa: E402
+
+L = 2 * math.pi
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def make_op(n, real, forcing=None, drag=0.0, nu=1e-3):
+    torch.set_default_dtype(real)
+    grid = Grid(shape=(n, n), domain=((0, L), (0, L)))
+    if forcing == "kolmogorov":
+        fn = KolmogorovForcing(grid=grid, scale=1.0, wave_number=4, swap_xy=False)
+    elif forcing == "kolmogorov_vort":
+        fn = KolmogorovForcing(grid=grid, scale=1.0, wave_number=2, swap_xy=False, vorticity=True)
+    elif forcing == "sincos":
+        fn = SinCosForcing(grid=grid, scale=0.1, k=1.0, diam=L)
+    else:
+        fn = None
+    op = NavierStokes2DSpectral(viscosity=nu, grid=grid, drag=drag, smooth=True, forcing_fn=fn,
+                                solver=RK4CrankNicolsonStepper())
+    return grid, op
+
+
+def ic_batch(grid, seeds, real):
+    torch.set_default_dtype(real)
+    w = torch.stack([vorticity_field(grid, 4, s).data for s in seeds])
+    return torch.fft.rfft2(w)
+
+
+def gen_tables():
+    out = {}
+    for n in (8, 16, 64, 128):
+        for real, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            _, op = make_op(n, real, drag=0.1)
+            for key in ("kx", "ky", "laplace", "linear_term", "filter"):
+                out[f"{key}_{n}_{tag}"] = npy(getattr(op, key))
+    for n in (256, 512, 1024):
+        _, op = make_op(n, torch.float64)
+        f = npy(op.filter)
+        rows = np.nonzero(f[:, 0])[0]
+        cols = np.nonzero(f[0, :])[0]
+        out[f"mask_rows_{n}"] = rows.astype(np.int32)
+        out[f"mask_cols_{n}"] = cols.astype(np.int32)
+        out[f"mask_sum_{n}"] = np.array(f.sum())
+    save("ns2d_tables.npz", **out)
+
+
+def gen_steps():
+    out = {}
+    dt = 1e-3
+    for n in (16, 64):
+        for real, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            combos = ((None, 0.0), ("kolmogorov", 0.1), ("sincos", 0.0), ("kolmogorov_vort", 0.05))
+            for forcing, drag in (combos if n == 16 else combos[:2]):
+                for B in ((1, 3) if n == 16 else (2,)):
+                    grid, op = make_op(n, real, forcing, drag)
+                    w0 = ic_batch(grid, list(range(B)), real)
+                    key = f"n{n}_{tag}_{forcing}_B{B}"
+                    out[key + "_w0"] = npy(w0)
+                    with torch.no_grad():
+                        out[key + "_F"] = npy(op.explicit_terms(w0))
+                        w1, d1 = op(w0, dt)
+                        out[key + "_w1"] = npy(w1)
+                        out[key + "_dwdt1"] = npy(d1)
+                        w10, d10 = op(w0, dt, steps=10)
+                        out[key + "_w10"] = npy(w10)
+                        out[key + "_dwdt10"] = npy(d10)
+                        out[key + "_res1"] = npy(op.residual(w1, d1))
+                        (uh, vh), psi = vorticity_to_velocity(grid, w0, (op.kx, op.ky))
+                        out[key + "_psi"] = npy(psi)
+                        if n == 16:
+                            out[key + "_uh"] = npy(uh)
+                            out[key + "_vh"] = npy(vh)
+    # 4-D input (B, T, n, m): the time axis marches in parallel (equations.py:454-457)
+    grid, op = make_op(16, torch.float64, "kolmogorov", 0.1)
+    w0 = ic_batch(grid, list(range(6)), torch.float64).reshape(2, 3, 16, 9)
+    with torch.no_grad():
+        w1, d1 = op(w0, dt)
+    out["n16_f64_4d_w0"] = npy(w0)
+    out["n16_f64_4d_w1"] = npy(w1)
+    out["n16_f64_4d_dwdt1"] = npy(d1)
+    save("ns2d_steps.npz", **out)
+
+
+def gen_c1():
+    """BASELINE config 1: Kolmogorov forced, 128^2, B=1, fp64, 200 steps."""
+    torch.set_default_dtype(torch.float64)
+    n = 128
+    grid, op = make_op(n, torch.float64, "kolmogorov", 0.1)
+    v0 = filtered_velocity_field(grid, 5, 4, random_state=0)
+    w_phys = curl_2d(v0).data
+    w0 = torch.fft.rfft2(w_phys)[None]
+    out = {"w0": npy(w0), "forcing_hat": None}
+    w = w0
+    with torch.no_grad():
+        for step in range(1, 201):
+            w, _ = op(w, 1e-3)
+            if step in (1, 10, 200):
+                out[f"w{step}"] = npy(w)
+    del out["forcing_hat"]
+    save("ns2d_c1_kolmogorov128.npz", **out)
+
+
+def gen_mcwilliams():
+    out = {}
+    for n in (64, 128):
+        for real, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            for seed in (0, 7):
+                torch.set_default_dtype(real)
+                grid, op = make_op(n, real)
+                w_phys = vorticity_field(grid, 4, seed).data
+                key = f"n{n}_{tag}_s{seed}"
+                out[key + "_ic"] = npy(w_phys)
+                if n == 64 or (seed == 0 and real == torch.float64):
+                    w = torch.fft.rfft2(w_phys)[None]
+                    with torch.no_grad():
+                        w1, _ = op(w, 1e-3)
+                        out[key + "_w1"] = npy(w1)
+                        w100, _ = op(w, 1e-3, steps=100)
+                        out[key + "_w100"] = npy(w100)
+    save("ns2d_mcwilliams.npz", **out)
+
+
+def gen_trajectory():
+    import tqdm
+    import solvers
+
+    solvers.tqdm = tqdm.tqdm
+    out = {}
+    for real, tag, cdt in ((torch.float64, "f64", torch.complex128), (torch.float32, "f32", torch.complex64)):
+        grid, op = make_op(32, real, "kolmogorov", 0.1)
+        w0 = ic_batch(grid, [0, 1], real)
+        with torch.no_grad():
+            res = solvers.get_trajectory_imex(op, w0, 1e-3, num_steps=7, record_every_steps=3, dtype=cdt)
+        out[f"{tag}_w0"] = npy(w0)
+        for k, v in res.items():
+            out[f"{tag}_{k}"] = npy(v)
+    save("ns2d_trajectory.npz", **out)
+
+
+def gen_irfft2():
+    out = {}
+    g = torch.Generator().manual_seed(123)
+    for n in (8, 16, 32):
+        m = n // 2 + 1
+        x = torch.randn(2, n, m, 2, generator=g, dtype=torch.float64)
+        xc = torch.view_as_complex(x)  # NOT Hermitian: DC/Nyquist bins carry imaginary parts
+        out[f"x_{n}"] = npy(xc)
+        out[f"irfft2_{n}"] = npy(torch.fft.irfft2(xc))
+        r = torch.randn(2, n, n, generator=g, dtype=torch.float64)
+        out[f"r_{n}"] = npy(r)
+        out[f"rfft2_{n}"] = npy(torch.fft.rfft2(r))
+    save("fft_semantics.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2"]
+    for w in which:
+        globals()["gen_" + w]()
