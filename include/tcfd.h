@@ -1,0 +1,108 @@
+/* tcfd.h -- C ABI of libtcfd_hip.so: MI355X (gfx950) kernels for the torch-cfd
+ * spectral hot path.  Plain C: raw device pointers, sizes, a HIP stream handle
+ * passed as void*.  No torch types.
+ *
+ * The reference (scaomath/torch-cfd) has no FFI: the path sits behind Python
+ * nn.Module operators.  Each entry point below names the reference interface
+ * it replaces (paths relative to the reference checkout).  The Python classes
+ * in torch-cfd_amd/ keep those operator signatures and call these symbols via
+ * ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative tcfd_status otherwise and
+ *     never throws; tcfd_last_error() returns a thread-local message.
+ *   - the CALLER owns every data buffer and the workspace (PyTorch's caching
+ *     allocator in practice); the library owns only what a plan holds
+ *     (twiddle tables, wavenumbers, linear/mask/forcing tables).
+ *   - every call is asynchronous on the given stream; no internal sync.
+ *   - a plan is immutable after creation and may be shared by streams; calls
+ *     that share a workspace must be stream-ordered by the caller.
+ *   - complex data are interleaved (re, im) pairs of the plan's real type,
+ *     half spectra are (batch, n, m) row-major with m = n/2 + 1, n = 2^k,
+ *     8 <= n <= 2048.
+ */
+#ifndef TCFD_H
+#define TCFD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TCFD_OK = 0,
+    TCFD_EINVAL = -1,    /* bad argument (size not a supported power of two, null pointer ...) */
+    TCFD_ENOMEM = -2,    /* device allocation for plan tables failed */
+    TCFD_EHIP = -3,      /* a HIP runtime call / kernel launch failed */
+    TCFD_EWORKSPACE = -4 /* workspace smaller than tcfd_ns2d_workspace_bytes() */
+} tcfd_status;
+
+typedef enum { TCFD_C64 = 0, TCFD_C128 = 1 } tcfd_dtype;
+
+typedef struct tcfd_ns2d_plan tcfd_ns2d_plan;
+
+const char* tcfd_last_error(void);
+int tcfd_version(void);
+
+/* ---- plan: constant tables of one NavierStokes2DSpectral instance -----------
+ * Replaces NavierStokes2DSpectral._initialize (torch_cfd/equations.py:394-403)
+ * plus the per-call re-evaluation of the forcing (equations.py:429-437) and of
+ * the patched Laplacian (torch_cfd/spectral.py:41-46).
+ * Host inputs (double, converted to the plan's real type on upload):
+ *   kx[n], ky[m]        ordinal wavenumbers of the rows / columns of the half
+ *                        spectrum (torch_cfd/grids.py:197-201; kx[i] = kx2d[i,0])
+ *   linear_term[n*m]    nu*laplace - drag           (equations.py:401)
+ *   mask[n*m]           2/3-rule filter, or all ones when smooth=False (:424-425)
+ *   forcing_hat[2*n*m]  complex forcing term added to F, or NULL (:429-437)
+ */
+int tcfd_ns2d_plan_create(tcfd_ns2d_plan** plan, int n, int dtype, const double* kx, const double* ky,
+                          const double* linear_term, const double* mask, const double* forcing_hat);
+void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* plan);
+
+/* Bytes of caller-owned scratch needed by the calls below for `batch` fields. */
+size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* plan, long batch);
+
+/* ---- RK4-CN time stepping ----------------------------------------------------
+ * Replaces NavierStokes2DSpectral.forward (equations.py:452-463) driving
+ * RK4CrankNicolsonStepper.forward (equations.py:328-358): `steps` steps of
+ *     h <- F(u) + beta[k] h ;  u <- (u + gdt[k] h + mu[k] L u) / (1 - mu[k] L)
+ * over nstages stages, with gdt[k] = gamma_k*dt and mu[k] = dt/2*(alpha_{k+1}-alpha_k)
+ * precomputed by the caller in the precision the reference would use.
+ *   w_in   (batch, n, m) complex, read only        w_out  (batch, n, m) complex
+ *   dwdt   (batch, n, m) complex or NULL: (w_out - w_in) * inv_total_dt
+ * w_out may alias w_in only when dwdt is NULL.
+ */
+int tcfd_ns2d_step(const tcfd_ns2d_plan* plan, const void* w_in, void* w_out, void* dwdt, long batch,
+                   int nstages, const double* beta, const double* gdt, const double* mu, int steps,
+                   double inv_total_dt, void* workspace, size_t workspace_bytes, void* stream);
+
+/* F(w): NavierStokes2DSpectral.explicit_terms (equations.py:413-441). */
+int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* plan, const void* w, void* out, long batch,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* psi = -w/lap and residual = w_t - F(w) - L w in one call: the record step of
+ * get_trajectory_imex (fno/data_gen/solvers.py:245-247, torch_cfd/spectral.py:113,
+ * equations.py:405-411).  Either output may be NULL. */
+int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* plan, const void* w, const void* wt, void* psi,
+                              void* residual, long batch, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* (u_hat, v_hat, psi_hat) of vorticity_to_velocity (torch_cfd/spectral.py:87-115);
+ * any output may be NULL. */
+int tcfd_ns2d_velocity(const tcfd_ns2d_plan* plan, const void* w, void* u_hat, void* v_hat, void* psi,
+                       long batch, void* stream);
+
+/* ---- plain transforms with torch.fft semantics (tests, IC / output side) -------
+ * rfft2:  real (batch, n, n) -> complex (batch, n, m), unnormalised.
+ * irfft2: complex (batch, n, m) -> real (batch, n, n), 1/n^2, imaginary parts of
+ *         the DC / Nyquist columns ignored AFTER the column transform (the c2r
+ *         semantics the reference relies on, SURVEY note N2). */
+int tcfd_rfft2(const tcfd_ns2d_plan* plan, const void* x_real, void* out_hat, long batch, void* stream);
+int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,22 @@
+"""torch-cfd_amd: MI355X-native (gfx950) implementation of torch-cfd's spectral hot path.
+
+Operator API (same names/signatures as the reference) over hand-written HIP
+kernels reached through the C ABI in ``include/tcfd.h``.  No CPU fallback.
+The directory name carries a hyphen; import it as ``torch_cfd_amd`` (the shim
+package next to it points here).
+"""
+from . import _lib  # noqa: F401
+from .grids import Grid  # noqa: F401
+from .equations import (  # noqa: F401
+    IMEXStepper,
+    ImplicitExplicitODE,
+    NavierStokes2DSpectral,
+    RK4CrankNicolsonStepper,
+    fft_plan,
+    stable_time_step,
+)
+from .forcings import ForcingFn, KolmogorovForcing, SimpleSolenoidalForcing, SinCosForcing  # noqa: F401
+from .solvers import get_trajectory_imex  # noqa: F401
+from .spectral import brick_wall_filter_2d, vorticity_to_velocity  # noqa: F401
+
+__version__ = "0.1.0"

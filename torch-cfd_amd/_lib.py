@@ -1,0 +1,133 @@
+"""ctypes binding of libtcfd_hip.so (the C ABI declared in include/tcfd.h).
+
+The library is built in-tree by ``build_library()`` (hipcc, gfx950) and loaded
+from ``torch-cfd_amd/csrc``.  There is NO fallback: if the shared object is
+missing or fails to load, every operator of this package raises.
+
+``import torch`` happens before the dlopen on purpose: PyTorch-ROCm ships its
+own ``libamdhip64.so.7``; loading it first makes the dynamic loader bind this
+library to the SAME HIP runtime instance (matching SONAME), so device pointers
+and stream handles coming from torch are valid inside the kernels' launches.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import sys
+from typing import Optional
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_NAME = "libtcfd_hip.so"
+LIB_PATH = os.path.join(CSRC, LIB_NAME)
+SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip")
+
+TCFD_C64, TCFD_C128 = 0, 1
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class TcfdError(RuntimeError):
+    pass
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libtcfd_hip.so (cross-compiles
+    without a GPU).  Rebuilds only when a source/header is newer than the .so."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(INCLUDE, "tcfd.h"))
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(d) for d in deps)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise TcfdError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH,
+            "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise TcfdError("link failed: %s\n%s" % (" ".join(link), r.stdout.decode(errors="replace")))
+    return LIB_PATH
+
+
+_vp, _i, _l, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_size_t
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); mirrors include/tcfd.h one to one
+SIGNATURES = {
+    "tcfd_last_error": (ctypes.c_char_p, []),
+    "tcfd_version": (_i, []),
+    "tcfd_ns2d_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i, _dp, _dp, _dp, _dp, _dp]),
+    "tcfd_ns2d_plan_destroy": (None, [_vp]),
+    "tcfd_ns2d_workspace_bytes": (_sz, [_vp, _l]),
+    "tcfd_ns2d_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _dp, _dp, _dp, _i, _d, _vp, _sz, _vp]),
+    "tcfd_ns2d_explicit_terms": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_ns2d_stream_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_ns2d_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "tcfd_irfft2": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
+}
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library (once) and declare every prototype of include/tcfd.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TcfdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). torch-cfd_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name):
+            continue  # optional symbol groups are checked by tests/test_abi.py against the header
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().tcfd_last_error()
+        raise TcfdError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def darray(values) -> ctypes.Array:
+    vals = [float(v) for v in values]
+    return (ctypes.c_double * len(vals))(*vals)
+
+
+def dptr_of_tensor(t: "torch.Tensor"):
+    """Host double pointer of a contiguous float64 CPU tensor."""
+    assert t.dtype == torch.float64 and t.device.type == "cpu" and t.is_contiguous()
+    return ctypes.cast(t.data_ptr(), _dp)
+
+
+def current_stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

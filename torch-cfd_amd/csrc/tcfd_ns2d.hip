@@ -1,0 +1,790 @@
+// tcfd_ns2d.hip -- MI355X (gfx950) kernels + C ABI for the batched 2-D
+// pseudo-spectral RK4-CN vorticity step.  See include/tcfd.h for the boundary
+// and DESIGN.md for the pass model.  Built from scratch; the reference path
+// (torch_cfd/equations.py:328-358, 413-463; torch_cfd/spectral.py:41-115) is a
+// stream of ~200 ATen launches per step, here it is three kernels per RK stage:
+//
+//   k_cols  MODE_A  : u -> {u^,v^,dx w^,dy w^} -> column inverse FFT -> 4 planes
+//   k_rows_advect   : 4 row c2r -> -(dx w * vx + dy w * vy) -> row r2c
+//   k_cols  MODE_CA : column FFT -> mask, forcing, h <- F + beta h,
+//                     u <- (u + g h + mu L u)/(1 - mu L) -> (MODE_A of next stage)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tcfd.h"
+#include "tcfd_fft.hpp"
+
+using namespace tcfd;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(TCFD_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* tcfd_last_error(void) { return g_err; }
+extern "C" int tcfd_version(void) { return 1; }
+
+// ------------------------------------------------------------------ per-size configuration
+// EPT = elements per lane of one transform, COLS = columns per tile of the column kernels.
+template <typename T, int N> struct Cfg;
+#define TCFD_CFG(T, N, EPT_, COLS_)                      \
+    template <> struct Cfg<T, N> {                       \
+        static constexpr int EPT = EPT_, COLS = COLS_;   \
+        static constexpr int G = N / EPT_;               \
+    };
+TCFD_CFG(double, 8, 8, 64)
+TCFD_CFG(double, 16, 4, 16)
+TCFD_CFG(double, 32, 8, 32)
+TCFD_CFG(double, 64, 8, 32)
+TCFD_CFG(double, 128, 8, 16)
+TCFD_CFG(double, 256, 16, 16)
+TCFD_CFG(double, 512, 8, 8)
+TCFD_CFG(double, 1024, 16, 8)
+TCFD_CFG(double, 2048, 16, 4)
+TCFD_CFG(float, 8, 8, 64)
+TCFD_CFG(float, 16, 4, 16)
+TCFD_CFG(float, 32, 8, 32)
+TCFD_CFG(float, 64, 8, 32)
+TCFD_CFG(float, 128, 8, 16)
+TCFD_CFG(float, 256, 16, 16)
+TCFD_CFG(float, 512, 8, 16)
+TCFD_CFG(float, 1024, 16, 8)
+TCFD_CFG(float, 2048, 16, 8)
+
+// ------------------------------------------------------------------ column kernels
+enum ColMode {
+    MODE_A = 0,     // u_in -> 4 planes
+    MODE_CA = 1,    // adv -> FFT -> RK update (h, u_out) -> 4 planes
+    MODE_C = 2,     // adv -> FFT -> RK update (h, u_out)
+    MODE_F = 3,     // adv -> FFT -> out = mask*x + forcing
+    MODE_RES = 4,   // adv -> FFT -> residual = wt - F - L w ; psi = -w/lap
+    MODE_FWD = 5,   // generic column forward c2c:  in -> out * scale
+    MODE_INV = 6    // generic column inverse c2c:  in -> out * scale
+};
+
+template <typename T>
+struct ColArgs {
+    const cx<T>* in;      // adv (MODE_CA/C/F/RES) or generic input
+    const cx<T>* u_in;    // state read  (w for MODE_RES)
+    const cx<T>* wt;      // MODE_RES only
+    cx<T>* u_out;         // state write
+    cx<T>* h;             // RK accumulator (read unless load_h == 0, written)
+    cx<T>* planes;        // 4 output planes (MODE_A/CA)
+    cx<T>* out;           // MODE_F / FWD / INV output ; MODE_RES residual
+    cx<T>* psi;           // MODE_RES
+    const T* kx;          // [n]
+    const T* ky;          // [m]
+    const T* lin;         // [n*m]
+    const T* mask;        // [n*m]
+    const cx<T>* forcing; // [n*m] or null
+    const cx<T>* tw;      // [n]
+    size_t plane_stride;  // elements between planes
+    T beta, gdt, mu, scale;
+    int m;
+    int ntiles;
+    int load_h;
+};
+
+template <typename T, int N, int EPT, int C>
+__device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, size_t colbase,
+                                            int j, int c, int jc, bool valid) {
+    constexpr int G = N / EPT;
+    constexpr T TWO_PI = (T)6.283185307179586476925286766559;
+    constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
+    const T inv_n2 = (T)1 / ((T)N * (T)N);
+    const T ky = valid ? a.ky[jc] : (T)0;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+        cx<T> x[EPT];
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const int i = j + t * G;
+            const T kx = a.kx[i];
+            cx<T> us = cscale(u[t], inv_n2);
+            if (f < 2) {  // stream function: psi = -w / lap, lap(0,0) patched to 1
+                T lap = M4PI2 * (kx * kx + ky * ky);
+                if (i == 0 && jc == 0) lap = (T)1;
+                us = cscale(us, (T)-1 / lap);
+            }
+            // f=0: u^ = 2 pi i ky psi   f=1: v^ = -2 pi i kx psi
+            // f=2: dx w^ = 2 pi i kx w  f=3: dy w^ = 2 pi i ky w
+            const T kk = (f == 0 || f == 3) ? ky : kx;
+            cx<T> v = mul_i(cscale(us, TWO_PI * kk));
+            if (f == 1) v = mk<T>(-v.x, -v.y);
+            x[t] = valid ? v : mk<T>((T)0, (T)0);
+        }
+        tile_fft<T, N, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
+        if (valid) {
+            cx<T>* dst = a.planes + (size_t)f * a.plane_stride + colbase;
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.m] = x[t];
+        }
+    }
+}
+
+template <typename T, int N, int EPT, int C, int MODE>
+__global__ __launch_bounds__(C*(N / EPT)) void k_cols(ColArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+    constexpr int G = N / EPT;
+    const int c = threadIdx.x % C;
+    const int j = threadIdx.x / C;
+    const int tile = blockIdx.x % a.ntiles;
+    const long b = blockIdx.x / a.ntiles;
+    const int jc = tile * C + c;
+    const bool valid = jc < a.m;
+    const size_t colbase = (size_t)b * N * a.m + jc;  // element (b, 0, jc)
+
+    cx<T> x[EPT];
+    if constexpr (MODE == MODE_A) {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t)
+            x[t] = valid ? a.u_in[colbase + (size_t)(j + t * G) * a.m] : mk<T>((T)0, (T)0);
+        emit_planes<T, N, EPT, C>(a, x, lds, colbase, j, c, jc, valid);
+        return;
+    } else {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t)
+            x[t] = valid ? a.in[colbase + (size_t)(j + t * G) * a.m] : mk<T>((T)0, (T)0);
+        constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
+        tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+
+        if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) a.out[colbase + (size_t)(j + t * G) * a.m] = cscale(x[t], a.scale);
+            }
+            return;
+        } else if constexpr (MODE == MODE_F) {
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) {
+                    const size_t tab = (size_t)(j + t * G) * a.m + jc;
+                    cx<T> F = cscale(x[t], a.mask[tab]);
+                    if (a.forcing) F = F + a.forcing[tab];
+                    a.out[colbase + (size_t)(j + t * G) * a.m] = F;
+                }
+            }
+            return;
+        } else if constexpr (MODE == MODE_RES) {
+            if (valid) {
+                constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
+                const T ky = a.ky[jc];
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) {
+                    const int i = j + t * G;
+                    const size_t tab = (size_t)i * a.m + jc;
+                    const size_t g = colbase + (size_t)i * a.m;
+                    cx<T> F = cscale(x[t], a.mask[tab]);
+                    if (a.forcing) F = F + a.forcing[tab];
+                    const cx<T> w = a.u_in[g];
+                    if (a.out) {
+                        const cx<T> wt = a.wt[g];
+                        a.out[g] = wt - F - cscale(w, a.lin[tab]);
+                    }
+                    if (a.psi) {
+                        const T kx = a.kx[i];
+                        T lap = M4PI2 * (kx * kx + ky * ky);
+                        if (i == 0 && jc == 0) lap = (T)1;
+                        a.psi[g] = cscale(w, (T)-1 / lap);
+                    }
+                }
+            }
+            return;
+        } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) {
+                    const int i = j + t * G;
+                    const size_t tab = (size_t)i * a.m + jc;
+                    const size_t g = colbase + (size_t)i * a.m;
+                    cx<T> hn = cscale(x[t], a.mask[tab]);
+                    if (a.forcing) hn = hn + a.forcing[tab];
+                    if (a.load_h) hn = hn + cscale(a.h[g], a.beta);
+                    a.h[g] = hn;
+                    const T L = a.lin[tab];
+                    const cx<T> u = a.u_in[g];
+                    // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
+                    cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
+                    const T den = (T)1 / ((T)1 - a.mu * L);
+                    x[t] = cscale(rhs, den);
+                    a.u_out[g] = x[t];
+                }
+            }
+            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C>(a, x, lds, colbase, j, c, jc, valid);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ row kernels
+// One group of G lanes owns one PAIR of adjacent rows: two real rows ride through
+// one complex transform (x0 + i x1), so c2r/r2c cost one complex FFT per two rows.
+
+// Hermitian-extended load of the pair (A row, B row): sequence Z[e] = A~[e] + i B~[e]
+// where A~ is the Hermitian completion of the half row with Im(DC), Im(Nyquist)
+// dropped -- exactly what a c2r transform consumes (SURVEY note N2).
+template <typename T, int N, int EPT>
+__device__ __forceinline__ void load_herm_pair(cx<T> (&x)[EPT], const cx<T>* __restrict__ rowA,
+                                               const cx<T>* __restrict__ rowB, int j) {
+    constexpr int G = N / EPT;
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int e = j + t * G;
+        if (t < EPT / 2) {
+            cx<T> pa = rowA[e], pb = rowB[e];
+            if (e == 0) { pa.y = 0; pb.y = 0; }
+            x[t] = mk<T>(pa.x - pb.y, pa.y + pb.x);
+        } else {
+            const int k = N - e;  // 1 .. N/2
+            cx<T> pa = rowA[k], pb = rowB[k];
+            if (k == N / 2) { pa.y = 0; pb.y = 0; }
+            // conj(a) + i conj(b)
+            x[t] = mk<T>(pa.x + pb.y, pb.x - pa.y);
+        }
+    }
+}
+
+// x holds Z = FFT(r0 + i r1) distributed j + t*G; writes the half spectra of r0, r1.
+template <typename T, int N, int EPT>
+__device__ __forceinline__ void unpack_store_pair(const cx<T> (&x)[EPT], cx<T>* lds, cx<T>* __restrict__ out0,
+                                                  cx<T>* __restrict__ out1, int j, bool valid) {
+    constexpr int G = N / EPT;
+    constexpr bool WG = (G > 64);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(j + t * G, 0)] = x[t];
+    group_sync<WG>();
+    const T half = (T)0.5;
+#pragma unroll
+    for (int t = 0; t < EPT / 2; ++t) {
+        const int k = j + t * G;
+        const cx<T> A = x[t];
+        const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
+        const cx<T> S = mk<T>(A.x + Bm.x, A.y - Bm.y);  // A + conj(B) = 2 X0
+        const cx<T> D = mk<T>(A.x - Bm.x, A.y + Bm.y);  // A - conj(B) = 2 i X1
+        if (valid) {
+            out0[k] = cscale(S, half);
+            out1[k] = mk<T>(D.y * half, -D.x * half);
+        }
+    }
+    if (j == 0) {
+        const cx<T> A = x[EPT / 2];  // element N/2
+        if (valid) {
+            out0[N / 2] = mk<T>(A.x, (T)0);
+            out1[N / 2] = mk<T>(A.y, (T)0);
+        }
+    }
+    group_sync<WG>();
+}
+
+template <typename T, int N, int EPT>
+struct RowGeom {
+    static constexpr int G = N / EPT;
+    static constexpr int THREADS = G >= 256 ? G : 256;
+    static constexpr int GROUPS = THREADS / G;
+    static constexpr int LDS_PER_GROUP = lds_elems<N, EPT, 1, true>();
+    static constexpr size_t LDS_BYTES = (size_t)GROUPS * LDS_PER_GROUP * sizeof(cx<T>);
+};
+
+template <typename T, int N, int EPT>
+__global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_advect(
+    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
+    long npairs, int m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const bool valid = pair < npairs;
+    if (!valid) pair = npairs - 1;  // keep the barriers uniform; results discarded
+    const size_t row0 = (size_t)pair * 2;
+
+    cx<T> p[EPT];  // advection of (row0, row0+1) packed as re / im
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const size_t off = (row0 + r) * (size_t)m;
+        cx<T> z1[EPT], z2[EPT];
+        load_herm_pair<T, N, EPT>(z1, planes + off, planes + plane_stride + off, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(z1, lds, tw, j, 0);  // vx + i vy
+        load_herm_pair<T, N, EPT>(z2, planes + 2 * plane_stride + off, planes + 3 * plane_stride + off, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(z2, lds, tw, j, 0);  // dx w + i dy w
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const T adv_t = -(z2[t].x * z1[t].x + z2[t].y * z1[t].y);
+            if (r == 0) p[t].x = adv_t; else p[t].y = adv_t;
+        }
+    }
+    tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
+    unpack_store_pair<T, N, EPT>(p, lds, adv + row0 * (size_t)m, adv + (row0 + 1) * (size_t)m, j, valid);
+}
+
+// real (rows, N) -> half spectrum (rows, m): first half of rfft2
+template <typename T, int N, int EPT>
+__global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_r2c(const T* __restrict__ in,
+                                                                             cx<T>* __restrict__ out,
+                                                                             const cx<T>* __restrict__ tw, long npairs,
+                                                                             int m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const bool valid = pair < npairs;
+    if (!valid) pair = npairs - 1;
+    const size_t row0 = (size_t)pair * 2;
+    cx<T> p[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int e = j + t * G;
+        p[t] = mk<T>(in[row0 * N + e], in[(row0 + 1) * N + e]);
+    }
+    tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
+    unpack_store_pair<T, N, EPT>(p, lds, out + row0 * (size_t)m, out + (row0 + 1) * (size_t)m, j, valid);
+}
+
+// half spectrum (rows, m) -> real (rows, N): second half of irfft2 (scale applied by the column pass)
+template <typename T, int N, int EPT>
+__global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_c2r(const cx<T>* __restrict__ in,
+                                                                             T* __restrict__ out,
+                                                                             const cx<T>* __restrict__ tw, long npairs,
+                                                                             int m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const bool valid = pair < npairs;
+    if (!valid) pair = npairs - 1;
+    const size_t row0 = (size_t)pair * 2;
+    cx<T> z[EPT];
+    load_herm_pair<T, N, EPT>(z, in + row0 * (size_t)m, in + (row0 + 1) * (size_t)m, j);
+    tile_fft<T, N, EPT, +1, 1, true, WG>(z, lds, tw, j, 0);
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const int e = j + t * G;
+            out[row0 * N + e] = z[t].x;
+            out[(row0 + 1) * N + e] = z[t].y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ small elementwise kernels
+template <typename T>
+__global__ void k_dwdt(const cx<T>* __restrict__ w_new, const cx<T>* __restrict__ w_old, cx<T>* __restrict__ out,
+                       T s, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const cx<T> a = w_new[i], b = w_old[i];
+        out[i] = mk<T>((a.x - b.x) * s, (a.y - b.y) * s);
+    }
+}
+
+template <typename T>
+__global__ void k_velocity(const cx<T>* __restrict__ w, cx<T>* __restrict__ uh, cx<T>* __restrict__ vh,
+                           cx<T>* __restrict__ psi, const T* __restrict__ kxs, const T* __restrict__ kys, int n,
+                           int m, size_t count) {
+    constexpr T TWO_PI = (T)6.283185307179586476925286766559;
+    constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < count;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int jc = (int)(idx % m);
+        const int i = (int)((idx / m) % n);
+        const T kx = kxs[i], ky = kys[jc];
+        T lap = M4PI2 * (kx * kx + ky * ky);
+        if (i == 0 && jc == 0) lap = (T)1;
+        const cx<T> p = cscale(w[idx], (T)-1 / lap);
+        if (psi) psi[idx] = p;
+        if (uh) uh[idx] = mul_i(cscale(p, TWO_PI * ky));
+        if (vh) vh[idx] = mul_mi(cscale(p, TWO_PI * kx));
+    }
+}
+
+// ------------------------------------------------------------------ plan
+struct tcfd_ns2d_plan {
+    int n, m, dtype;
+    void* tw;       // cx<T>[n]
+    void* kx;       // T[n]
+    void* ky;       // T[m]
+    void* lin;      // T[n*m]
+    void* mask;     // T[n*m]
+    void* forcing;  // cx<T>[n*m] or null
+};
+
+static bool supported_n(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 0; }
+
+template <typename T>
+static int upload(void** dst, const std::vector<T>& host) {
+    HIP_TRY(hipMalloc(dst, host.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T>
+static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, const double* lin, const double* mask,
+                     const double* forcing) {
+    const int n = p->n, m = p->m;
+    std::vector<T> tw(2 * (size_t)n), a(n), b(m), l((size_t)n * m), k((size_t)n * m);
+    for (int t = 0; t < n; ++t) {
+        // long-double evaluation, rounded once to the working type
+        const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)t / (long double)n;
+        tw[2 * t] = (T)cosl(ang);
+        tw[2 * t + 1] = (T)sinl(ang);
+    }
+    // exact values at the quadrant points
+    tw[0] = 1; tw[1] = 0;
+    tw[2 * (n / 4)] = 0; tw[2 * (n / 4) + 1] = -1;
+    tw[2 * (n / 2)] = -1; tw[2 * (n / 2) + 1] = 0;
+    tw[2 * (3 * n / 4)] = 0; tw[2 * (3 * n / 4) + 1] = 1;
+    for (int i = 0; i < n; ++i) a[i] = (T)kx[i];
+    for (int i = 0; i < m; ++i) b[i] = (T)ky[i];
+    for (size_t i = 0; i < (size_t)n * m; ++i) { l[i] = (T)lin[i]; k[i] = (T)mask[i]; }
+    int rc;
+    if ((rc = upload(&p->tw, tw))) return rc;
+    if ((rc = upload(&p->kx, a))) return rc;
+    if ((rc = upload(&p->ky, b))) return rc;
+    if ((rc = upload(&p->lin, l))) return rc;
+    if ((rc = upload(&p->mask, k))) return rc;
+    if (forcing) {
+        std::vector<T> f(2 * (size_t)n * m);
+        for (size_t i = 0; i < f.size(); ++i) f[i] = (T)forcing[i];
+        if ((rc = upload(&p->forcing, f))) return rc;
+    }
+    return 0;
+}
+
+extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
+    if (!p) return;
+    void* ptrs[] = {p->tw, p->kx, p->ky, p->lin, p->mask, p->forcing};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+}
+
+extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
+                                     const double* linear_term, const double* mask, const double* forcing_hat) {
+    if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
+    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048]", n);
+    if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "plan_create: bad dtype %d", dtype);
+    tcfd_ns2d_plan* p = new tcfd_ns2d_plan();
+    memset(p, 0, sizeof(*p));
+    p->n = n;
+    p->m = n / 2 + 1;
+    p->dtype = dtype;
+    int rc = dtype == TCFD_C128 ? plan_fill<double>(p, kx, ky, linear_term, mask, forcing_hat)
+                                : plan_fill<float>(p, kx, ky, linear_term, mask, forcing_hat);
+    if (rc) {
+        tcfd_ns2d_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return 0;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t field_bytes(const tcfd_ns2d_plan* p, long batch) {
+    const size_t esz = p->dtype == TCFD_C128 ? 16 : 8;
+    return align256((size_t)batch * p->n * p->m * esz);
+}
+
+extern "C" size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
+    if (!p || batch <= 0) return 0;
+    return 6 * field_bytes(p, batch);  // h, adv, 4 planes
+}
+
+// ------------------------------------------------------------------ launch helpers
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    return 0;
+}
+
+template <typename T, int N, int MODE>
+static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
+    constexpr int EPT = Cfg<T, N>::EPT, C = Cfg<T, N>::COLS, G = Cfg<T, N>::G;
+    constexpr size_t lds = (size_t)lds_elems<N, EPT, C, false>() * sizeof(cx<T>);
+    a.m = p->m;
+    a.ntiles = (p->m + C - 1) / C;
+    a.kx = (const T*)p->kx;
+    a.ky = (const T*)p->ky;
+    a.lin = (const T*)p->lin;
+    a.mask = (const T*)p->mask;
+    a.forcing = (const cx<T>*)p->forcing;
+    a.tw = (const cx<T>*)p->tw;
+    auto kern = k_cols<T, N, EPT, C, MODE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(kern, lds);
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const long blocks = batch * a.ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C * G), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int N>
+static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
+                              hipStream_t st) {
+    using Gm = RowGeom<T, N, Cfg<T, N>::EPT>;
+    auto kern = k_rows_advect<T, N, Cfg<T, N>::EPT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(kern, Gm::LDS_BYTES);
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const long npairs = batch * (N / 2);
+    const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
+                       (const cx<T>*)p->tw, npairs, p->m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+struct Ws {
+    cx<T>* h;
+    cx<T>* adv;
+    cx<T>* planes;
+    size_t plane_stride;  // elements
+};
+template <typename T>
+static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
+    const size_t fb = field_bytes(p, batch);
+    unsigned char* base = (unsigned char*)ws;
+    Ws<T> w;
+    w.h = (cx<T>*)base;
+    w.adv = (cx<T>*)(base + fb);
+    w.planes = (cx<T>*)(base + 2 * fb);
+    w.plane_stride = fb / sizeof(cx<T>);
+    return w;
+}
+
+// ------------------------------------------------------------------ step driver
+template <typename T, int N>
+static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
+                     const double* beta, const double* gdt, const double* mu, int steps, double inv_total_dt, void* ws,
+                     hipStream_t st) {
+    Ws<T> W = carve<T>(p, ws, batch);
+    int rc;
+    ColArgs<T> a{};
+    a.planes = W.planes;
+    a.plane_stride = W.plane_stride;
+    a.h = W.h;
+    a.in = W.adv;
+    a.u_in = (const cx<T>*)w_in;
+    if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
+    const cx<T>* u_src = (const cx<T>*)w_in;
+    for (int s = 0; s < steps; ++s) {
+        for (int k = 0; k < nstages; ++k) {
+            if ((rc = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, st))) return rc;
+            a.u_in = u_src;
+            a.u_out = (cx<T>*)w_out;
+            a.beta = (T)beta[k];
+            a.gdt = (T)gdt[k];
+            a.mu = (T)mu[k];
+            a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
+            const bool last = (s == steps - 1) && (k == nstages - 1);
+            rc = last ? launch_cols<T, N, MODE_C>(p, a, batch, st) : launch_cols<T, N, MODE_CA>(p, a, batch, st);
+            if (rc) return rc;
+            u_src = (const cx<T>*)w_out;
+        }
+    }
+    if (dwdt) {
+        const size_t count = (size_t)batch * N * p->m;
+        const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_dwdt<T>, dim3(blocks), dim3(256), 0, st, (const cx<T>*)w_out, (const cx<T>*)w_in,
+                           (cx<T>*)dwdt, (T)inv_total_dt, count);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+template <typename T, int N>
+static int explicit_impl(const tcfd_ns2d_plan* p, const void* w, void* out, const void* wt, void* psi, bool residual,
+                         long batch, void* ws, hipStream_t st) {
+    Ws<T> W = carve<T>(p, ws, batch);
+    int rc;
+    ColArgs<T> a{};
+    a.planes = W.planes;
+    a.plane_stride = W.plane_stride;
+    a.u_in = (const cx<T>*)w;
+    if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
+    if ((rc = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, st))) return rc;
+    a.in = W.adv;
+    a.out = (cx<T>*)out;
+    if (residual) {
+        a.wt = (const cx<T>*)wt;
+        a.psi = (cx<T>*)psi;
+        return launch_cols<T, N, MODE_RES>(p, a, batch, st);
+    }
+    return launch_cols<T, N, MODE_F>(p, a, batch, st);
+}
+
+template <typename T, int N>
+static int rfft2_impl(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, hipStream_t st) {
+    using Gm = RowGeom<T, N, Cfg<T, N>::EPT>;
+    auto kern = k_rows_r2c<T, N, Cfg<T, N>::EPT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(kern, Gm::LDS_BYTES);
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const long npairs = batch * (N / 2);
+    const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, (const T*)x, (cx<T>*)out,
+                       (const cx<T>*)p->tw, npairs, p->m);
+    HIP_TRY(hipGetLastError());
+    ColArgs<T> a{};
+    a.in = (const cx<T>*)out;
+    a.out = (cx<T>*)out;
+    a.scale = (T)1;
+    return launch_cols<T, N, MODE_FWD>(p, a, batch, st);
+}
+
+template <typename T, int N>
+static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, hipStream_t st) {
+    ColArgs<T> a{};
+    a.in = (const cx<T>*)xh;
+    a.out = (cx<T>*)ws;
+    a.scale = (T)1 / ((T)N * (T)N);
+    int rc;
+    if ((rc = launch_cols<T, N, MODE_INV>(p, a, batch, st))) return rc;
+    using Gm = RowGeom<T, N, Cfg<T, N>::EPT>;
+    auto kern = k_rows_c2r<T, N, Cfg<T, N>::EPT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        rc = set_lds(kern, Gm::LDS_BYTES);
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const long npairs = batch * (N / 2);
+    const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, (const cx<T>*)ws, (T*)out,
+                       (const cx<T>*)p->tw, npairs, p->m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ (dtype, n) dispatch
+#define TCFD_DISPATCH_N(T, n, CALL)                                       \
+    switch (n) {                                                          \
+        case 8: { constexpr int N_ = 8; return CALL; }                    \
+        case 16: { constexpr int N_ = 16; return CALL; }                  \
+        case 32: { constexpr int N_ = 32; return CALL; }                  \
+        case 64: { constexpr int N_ = 64; return CALL; }                  \
+        case 128: { constexpr int N_ = 128; return CALL; }                \
+        case 256: { constexpr int N_ = 256; return CALL; }                \
+        case 512: { constexpr int N_ = 512; return CALL; }                \
+        case 1024: { constexpr int N_ = 1024; return CALL; }              \
+        case 2048: { constexpr int N_ = 2048; return CALL; }              \
+        default: return fail(TCFD_EINVAL, "unsupported n=%d", n);         \
+    }
+#define TCFD_DISPATCH(p, CALL)                                            \
+    do {                                                                  \
+        if ((p)->dtype == TCFD_C128) {                                    \
+            using T_ = double;                                            \
+            TCFD_DISPATCH_N(T_, (p)->n, CALL)                             \
+        } else {                                                          \
+            using T_ = float;                                             \
+            TCFD_DISPATCH_N(T_, (p)->n, CALL)                             \
+        }                                                                 \
+    } while (0)
+
+static int check_ws(const tcfd_ns2d_plan* p, long batch, void* ws, size_t bytes, size_t need) {
+    if (!ws || bytes < need) return fail(TCFD_EWORKSPACE, "workspace %zu B < required %zu B", bytes, need);
+    return 0;
+}
+
+extern "C" int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
+                              int nstages, const double* beta, const double* gdt, const double* mu, int steps,
+                              double inv_total_dt, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !w_in || !w_out || !beta || !gdt || !mu) return fail(TCFD_EINVAL, "step: null argument");
+    if (batch <= 0 || steps <= 0 || nstages <= 0) return fail(TCFD_EINVAL, "step: batch/steps/nstages must be > 0");
+    if (dwdt && w_in == w_out) return fail(TCFD_EINVAL, "step: w_out may alias w_in only when dwdt is NULL");
+    int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TCFD_DISPATCH(p, (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu, steps, inv_total_dt, ws,
+                                         st)));
+}
+
+extern "C" int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* p, const void* w, void* out, long batch, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if (!p || !w || !out || batch <= 0) return fail(TCFD_EINVAL, "explicit_terms: bad argument");
+    int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TCFD_DISPATCH(p, (explicit_impl<T_, N_>(p, w, out, nullptr, nullptr, false, batch, ws, st)));
+}
+
+extern "C" int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* p, const void* w, const void* wt, void* psi,
+                                         void* residual, long batch, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !w || batch <= 0 || (residual && !wt)) return fail(TCFD_EINVAL, "stream_residual: bad argument");
+    int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TCFD_DISPATCH(p, (explicit_impl<T_, N_>(p, w, residual, wt, psi, true, batch, ws, st)));
+}
+
+template <typename T>
+static int velocity_impl(const tcfd_ns2d_plan* p, const void* w, void* uh, void* vh, void* psi, long batch,
+                         hipStream_t st) {
+    const size_t count = (size_t)batch * p->n * p->m;
+    const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_velocity<T>, dim3(blocks), dim3(256), 0, st, (const cx<T>*)w, (cx<T>*)uh, (cx<T>*)vh,
+                       (cx<T>*)psi, (const T*)p->kx, (const T*)p->ky, p->n, p->m, count);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tcfd_ns2d_velocity(const tcfd_ns2d_plan* p, const void* w, void* uh, void* vh, void* psi, long batch,
+                                  void* stream) {
+    if (!p || !w || batch <= 0) return fail(TCFD_EINVAL, "velocity: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    return p->dtype == TCFD_C128 ? velocity_impl<double>(p, w, uh, vh, psi, batch, st)
+                                 : velocity_impl<float>(p, w, uh, vh, psi, batch, st);
+}
+
+extern "C" int tcfd_rfft2(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, void* stream) {
+    if (!p || !x || !out || batch <= 0) return fail(TCFD_EINVAL, "rfft2: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TCFD_DISPATCH(p, (rfft2_impl<T_, N_>(p, x, out, batch, st)));
+}
+
+extern "C" int tcfd_irfft2(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, size_t ws_bytes,
+                           void* stream) {
+    if (!p || !xh || !out || batch <= 0) return fail(TCFD_EINVAL, "irfft2: bad argument");
+    int rc = check_ws(p, batch, ws, ws_bytes, field_bytes(p, batch));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TCFD_DISPATCH(p, (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)));
+}
