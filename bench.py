@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- RK4-CN pseudo-spectral steps/s on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2], "C3" in SURVEY.md 8d): Kolmogorov-forced 2-D
+turbulence, 1024^2 grid, batch 64, complex128, nu=1e-3, drag 0.1, forcing
+sin(4y), dt = stable_time_step(dx, max_velocity 5) = 6.136e-4, McWilliams random
+initial vorticity (seeds 0..63) generated on the device.  One "step" = one
+NavierStokes2DSpectral.forward(w, dt) call = one full RK4-CN step of all 64 fields
+(5 stages, dw/dt included), input resident in HBM.
+
+N > 1 (launched by torch.distributed.run): every rank owns its own batch of 64
+independent trajectories (weak scaling, no data-path collective); value is the
+aggregate batch-64 steps/s over all ranks; the barrier / max-over-ranks timing
+uses RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, measured
+with HIP events recorded by the library on the launch stream during the timed
+steps; `cpu_baseline` times the CPU oracle (a torch-CPU restatement of the
+reference's op sequence) on this host.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+KIND_NAMES = {0: "k_cols<MODE_A>", 1: "k_rows_advect", 2: "k_cols<MODE_CA>", 3: "k_cols<MODE_C>", 4: "k_dwdt", 5: "other"}
+# algorithmic bytes per launch in units of S = B*n*m*sizeof(complex)  (SURVEY 8d pass model)
+KIND_ALGO_S = {0: 5.0, 1: 5.0, 2: 9.0, 3: 5.0, 4: 3.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=64, help="fields per GPU")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--fused-steps", action="store_true",
+                    help="advance all K steps in ONE forward(steps=K) call (amortises the per-call prologue)")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, real, dt, seconds):
+    """CPU oracle on the host cores: same workload at B=2, linearly extrapolated to B=64."""
+    from oracle import ns2d as O
+
+    L = 2 * math.pi
+    t = O.make_tables(n, L, 1e-3, 0.1, True, None, real)
+    t.forcing_hat = O.kolmogorov_forcing_hat(n, L, t.kx, t.ky, 1.0, 4, real=real)
+    Bs = 2
+    w = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, real)) for s in range(Bs)])
+    with torch.no_grad():
+        # pick the thread count that is fastest on this host (all cores is NOT: a 256-thread
+        # MKL/OpenMP team on 1024^2 x 2 fields is ~100x slower than 16-32 threads)
+        cands = sorted({c for c in (8, 16, 32, 64) if c <= (os.cpu_count() or 1)} or {1})
+        best = None
+        for c in cands:
+            torch.set_num_threads(c)
+            O.advance(w, dt, t)  # warm-up (MKL plans, thread team)
+            t1 = time.perf_counter()
+            O.advance(w, dt, t)
+            el1 = time.perf_counter() - t1
+            if best is None or el1 < best[1]:
+                best = (c, el1)
+            if el1 > seconds / 2:
+                break
+        torch.set_num_threads(best[0])
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            w, _ = O.advance(w, dt, t)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > seconds or steps >= 200:
+                break
+    per_step_b2 = el / steps
+    return {
+        "value": 1.0 / (per_step_b2 * 64 / Bs),
+        "unit": "steps/s (batch 64)",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle/ns2d.py (torch-CPU restatement of the reference op sequence), {n}^2 {str(real)[6:]}, "
+                  f"B={Bs}, {steps} steps in {el:.1f}s ({per_step_b2*1e3:.0f} ms/step), extrapolated linearly to B=64",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    real, cdt = (torch.float64, torch.complex128) if args.dtype == "f64" else (torch.float32, torch.complex64)
+    torch.set_default_dtype(real)
+    n, B, L = args.n, args.batch, 2 * math.pi
+    m = n // 2 + 1
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    dt = tc.stable_time_step(dx=L / n, dt=None, max_velocity=5.0, max_courant_number=0.5, viscosity=1e-3)
+    forcing = tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4)
+    op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, smooth=True, forcing_fn=forcing,
+                                   solver=tc.RK4CrankNicolsonStepper()).to(dev)
+    with torch.no_grad():
+        seeds = [rank * B + i for i in range(B)]
+        plan_fft = tc.fft_plan(n, cdt, dev)
+        w_phys = torch.cat([vorticity_field(grid, 4, batch_seeds=seeds[i:i + 8], device=dev)
+                            for i in range(0, B, 8)])
+        w = plan_fft.rfft2(w_phys)
+        del w_phys
+    S = B * n * m * (16 if real == torch.float64 else 8)
+
+    plan = op._plan(w)
+    lib = tc._lib.load()
+
+    def advance(w, k):
+        if args.fused_steps:
+            out, _ = op(w, dt, steps=k)
+            return out
+        for _ in range(k):
+            w, _ = op(w, dt)
+        return w
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        w = advance(w, args.warmup)
+        fence()
+        max_rec = args.steps * 16 + 16
+        tc._lib.check(lib.tcfd_ns2d_profile_begin(plan.handle, max_rec), "profile_begin")
+        t0 = time.perf_counter()
+        w = advance(w, args.steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        cnt = ctypes.c_int(0)
+        kinds = (ctypes.c_int * max_rec)()
+        ms = (ctypes.c_float * max_rec)()
+        tc._lib.check(lib.tcfd_ns2d_profile_end(plan.handle, max_rec, ctypes.byref(cnt), kinds, ms), "profile_end")
+    assert torch.isfinite(torch.view_as_real(w)).all().item(), "solution blew up"
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    per_kind = {}
+    for i in range(min(cnt.value, max_rec)):
+        per_kind.setdefault(kinds[i], []).append(ms[i])
+    kern = {}
+    for k, v in per_kind.items():
+        avg = sum(v) / len(v)
+        ent = {"launches": len(v), "avg_ms": round(avg, 4), "total_ms": round(sum(v), 2)}
+        if k in KIND_ALGO_S:
+            ent["algo_GBps"] = round(KIND_ALGO_S[k] * S / (avg * 1e-3) / 1e9, 1)
+        kern[KIND_NAMES[k]] = ent
+    dom = max((k for k in per_kind if k in KIND_ALGO_S), key=lambda k: sum(per_kind[k]))
+    dom_avg_ms = sum(per_kind[dom]) / len(per_kind[dom])
+    achieved = KIND_ALGO_S[dom] * S / (dom_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"{KIND_NAMES[dom]}|n{n}|B{B}|{args.dtype}")
+        except Exception:
+            traffic = None
+
+    steps_per_s = world * args.steps / elapsed
+    out = {
+        "metric": "RK4-CN spectral steps/s at 1024^2 batch64; achieved HBM GB/s vs peak",
+        "value": round(steps_per_s, 3),
+        "unit": "steps/s (one step = all 64 fields of a GPU's batch advance one RK4-CN step)",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if real == torch.float64 else "f32",
+        "data": "synthetic (McWilliams random vorticity, seeds rank*B..rank*B+B-1, generated on device)",
+        "config": {"workload": f"Kolmogorov-forced 2D turbulence, {n}^2 grid, batch {B}/GPU, RK4-CN pseudo-spectral, "
+                               f"nu=1e-3 drag=0.1 sin(4y) forcing dt={dt:.4e}",
+                   "n": n, "batch_per_gpu": B, "api": "forward(w,dt,steps=K)" if args.fused_steps else "K x forward(w,dt)",
+                   "parallelism": f"batch-sharded x{world}, no data-path collective"},
+        "sample_steps_per_s": round(steps_per_s * B, 1),
+        "step_algo_GBps": round(70.0 * S * args.steps / elapsed / 1e9, 1),
+        "step_algo_frac_of_peak": round(70.0 * S * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": {"kernel": KIND_NAMES[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algo_bytes_per_launch": KIND_ALGO_S[dom] * S, "avg_launch_ms": round(dom_avg_ms, 4)},
+        "kernels": kern,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(n, real, dt, args.cpu_seconds)
+        except Exception as e:  # the GPU number stands even if the host leg fails
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,16 @@ int tcfd_rfft2(const tcfd_ns2d_plan* plan, const void* x_real, void* out_hat, lo
 int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ---- per-launch event timing (measurement aid; no reference counterpart) -------
+ * Between profile_begin and profile_end every kernel the plan launches is
+ * bracketed by a pair of HIP events recorded on the launch stream (up to
+ * max_records launches).  profile_end synchronises on them and returns, per
+ * launch, the kernel kind (0 column pass A, 1 row pass, 2 column pass C+A,
+ * 3 column pass C, 4 dw/dt, 5 other) and its duration in milliseconds.
+ * Mutates the plan: not to be used concurrently with other calls on it. */
+int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* plan, int max_records);
+int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* kinds, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,311 @@
+"""GPU parity tests of the fused RK4-CN spectral path (through the C ABI) against
+(a) the committed reference-generated golden vectors, (b) the CPU oracle on the
+same seeded inputs, (c) size-independent properties at BASELINE sizes.
+
+Tolerances (rel-L2): fp64 <= 1e-10 per call (north_star bar: 1e-6); fp32 vs the
+reference's own fp32 results <= 2e-6 @1 step, <= 1e-5 @10 steps, <= 5e-4 @1000
+(SURVEY note N5).
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+L = 2 * math.pi
+REAL = {"f64": torch.float64, "f32": torch.float32}
+CPLX = {"f64": torch.complex128, "f32": torch.complex64}
+DRAG = {None: 0.0, "kolmogorov": 0.1, "sincos": 0.0, "kolmogorov_vort": 0.05}
+
+
+@pytest.fixture(autouse=True)
+def _restore_default_dtype():
+    old = torch.get_default_dtype()
+    yield
+    torch.set_default_dtype(old)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def build_op(n, tag, forcing, dev, drag=None, smooth=True, nu=1e-3):
+    import torch_cfd_amd as tc
+
+    torch.set_default_dtype(REAL[tag])
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    fn = {None: None,
+          "kolmogorov": lambda: tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4, swap_xy=False),
+          "kolmogorov_vort": lambda: tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=2, vorticity=True),
+          "sincos": lambda: tc.SinCosForcing(grid=grid, scale=0.1, k=1.0, diam=L)}[forcing]
+    fn = fn() if fn else None
+    op = tc.NavierStokes2DSpectral(nu, grid, drag=DRAG[forcing] if drag is None else drag, smooth=smooth,
+                                   forcing_fn=fn, solver=tc.RK4CrankNicolsonStepper()).to(dev)
+    return grid, op
+
+
+def oracle_tables(n, tag, forcing, drag=None, smooth=True, nu=1e-3):
+    from oracle import ns2d as O
+
+    real = REAL[tag]
+    t = O.make_tables(n, L, nu, DRAG[forcing] if drag is None else drag, smooth, None, real)
+    if forcing == "kolmogorov":
+        t.forcing_hat = O.kolmogorov_forcing_hat(n, L, t.kx, t.ky, 1.0, 4, False, False, real=real)
+    elif forcing == "kolmogorov_vort":
+        t.forcing_hat = O.kolmogorov_forcing_hat(n, L, t.kx, t.ky, 1.0, 2, False, True, real=real)
+    elif forcing == "sincos":
+        t.forcing_hat = O.sincos_forcing_hat(n, L, 0.1, 1.0, diam=L, real=real)
+    return t
+
+
+# ----------------------------------------------------------------------------- golden vectors
+STEP_CASES = [(16, f, B) for f in (None, "kolmogorov", "sincos", "kolmogorov_vort") for B in (1, 3)] + \
+             [(64, f, 2) for f in (None, "kolmogorov")]
+
+
+@pytest.mark.parametrize("n,forcing,B", STEP_CASES)
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_golden_steps(n, forcing, B, tag, dev):
+    import torch_cfd_amd as tc
+
+    g = load_golden("ns2d_steps.npz")
+    key = f"n{n}_{tag}_{forcing}_B{B}"
+    grid, op = build_op(n, tag, forcing, dev)
+    w0 = torch.from_numpy(g[key + "_w0"]).to(dev)
+    t1, t10 = (1e-10, 1e-10) if tag == "f64" else (2e-6, 1e-5)
+    F = op.explicit_terms(w0)
+    assert F.dtype == CPLX[tag] and F.shape == w0.shape
+    assert rel_l2(F, g[key + "_F"]) < (1e-10 if tag == "f64" else 2e-6)
+    w1, d1 = op(w0, 1e-3)
+    assert w1.dtype == CPLX[tag] and w1.is_cuda
+    assert rel_l2(w1, g[key + "_w1"]) < t1
+    assert rel_l2(d1, g[key + "_dwdt1"]) < (1e-8 if tag == "f64" else 5e-3)
+    w10, d10 = op(w0, 1e-3, steps=10)
+    assert rel_l2(w10, g[key + "_w10"]) < t10
+    assert rel_l2(d10, g[key + "_dwdt10"]) < (1e-8 if tag == "f64" else 5e-3)
+    assert rel_l2(op.residual(w1, d1), g[key + "_res1"]) < (1e-6 if tag == "f64" else 5e-2)
+    (uh, vh), psi = tc.vorticity_to_velocity(grid, w0, (op.kx, op.ky))
+    assert rel_l2(psi, g[key + "_psi"]) < (1e-13 if tag == "f64" else 1e-6)
+    if n == 16:
+        assert rel_l2(uh, g[key + "_uh"]) < (1e-13 if tag == "f64" else 1e-6)
+        assert rel_l2(vh, g[key + "_vh"]) < (1e-13 if tag == "f64" else 1e-6)
+    # stepping one call at a time equals steps=10 in one call
+    w = w0
+    for _ in range(10):
+        w, _ = op(w, 1e-3)
+    assert rel_l2(w, w10) < (1e-14 if tag == "f64" else 1e-6)
+
+
+def test_golden_4d_input(dev):
+    g = load_golden("ns2d_steps.npz")
+    _, op = build_op(16, "f64", "kolmogorov", dev)
+    w1, d1 = op(torch.from_numpy(g["n16_f64_4d_w0"]).to(dev), 1e-3)
+    assert w1.shape == (2, 3, 16, 9) and d1.shape == (2, 3, 16, 9)
+    assert rel_l2(w1, g["n16_f64_4d_w1"]) < 1e-10
+    assert rel_l2(d1, g["n16_f64_4d_dwdt1"]) < 1e-8
+
+
+def test_unbatched_input(dev):
+    g = load_golden("ns2d_steps.npz")
+    _, op = build_op(16, "f64", "kolmogorov", dev)
+    w0 = torch.from_numpy(g["n16_f64_kolmogorov_B1_w0"]).to(dev)[0]
+    w1, d1 = op(w0, 1e-3)
+    assert w1.shape == (16, 9)
+    assert rel_l2(w1, g["n16_f64_kolmogorov_B1_w1"][0]) < 1e-10
+
+
+def test_config1_kolmogorov128_200_steps(dev):
+    """BASELINE configs[0] on the reference's own IC: 128^2, B=1, fp64, 200 steps."""
+    g = load_golden("ns2d_c1_kolmogorov128.npz")
+    _, op = build_op(128, "f64", "kolmogorov", dev)
+    w = torch.from_numpy(g["w0"]).to(dev)
+    w1, _ = op(w, 1e-3)
+    assert rel_l2(w1, g["w1"]) < 1e-10
+    w10, _ = op(w, 1e-3, steps=10)
+    assert rel_l2(w10, g["w10"]) < 1e-10
+    w200 = w
+    for _ in range(200):
+        w200, _ = op(w200, 1e-3)
+    assert rel_l2(w200, g["w200"]) < 1e-9
+
+
+@pytest.mark.parametrize("n", [64, 128])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("seed", [0, 7])
+def test_mcwilliams_ic_and_100_steps(n, tag, seed, dev):
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    g = load_golden("ns2d_mcwilliams.npz")
+    key = f"n{n}_{tag}_s{seed}"
+    grid, op = build_op(n, tag, None, dev)
+    ic = vorticity_field(grid, 4, seed, device=dev)
+    assert ic.dtype == REAL[tag] and ic.shape == (n, n)
+    assert rel_l2(ic, g[key + "_ic"]) < (1e-12 if tag == "f64" else 2e-4)  # two fp32 pipelines; k^2 amplifies high-k round-off
+    if key + "_w100" in g.files:
+        plan = tc.fft_plan(n, CPLX[tag], dev)
+        w = plan.rfft2(torch.from_numpy(g[key + "_ic"]).to(dev))[None]
+        w1, _ = op(w, 1e-3)
+        assert rel_l2(w1, g[key + "_w1"]) < (1e-10 if tag == "f64" else 2e-6)
+        w100, _ = op(w, 1e-3, steps=100)
+        # fp32: reference-fp32 vs reference-fp64 is 8.7e-6 after 100 steps
+        assert rel_l2(w100, g[key + "_w100"]) < (1e-9 if tag == "f64" else 5e-5)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_trajectory_matches_reference(tag, dev):
+    import torch_cfd_amd as tc
+
+    g = load_golden("ns2d_trajectory.npz")
+    _, op = build_op(32, tag, "kolmogorov", dev)
+    out = tc.get_trajectory_imex(op, torch.from_numpy(g[f"{tag}_w0"]).to(dev), 1e-3, num_steps=7,
+                                 record_every_steps=3, dtype=CPLX[tag])
+    tol = {"vorticity": 1e-10, "stream": 1e-10, "vort_t": 1e-8, "residual": 1e-6} if tag == "f64" else \
+          {"vorticity": 5e-6, "stream": 5e-6, "vort_t": 2e-2, "residual": 0.5}
+    for k in ("vorticity", "stream", "vort_t", "residual"):
+        ref = g[f"{tag}_{k}"]
+        assert tuple(out[k].shape) == ref.shape and out[k].dtype == CPLX[tag] and out[k].device.type == "cpu"
+        assert rel_l2(out[k], ref) < tol[k], k
+
+
+def test_fft_semantics_golden(dev):
+    import torch_cfd_amd as tc
+
+    g = load_golden("fft_semantics.npz")
+    for n in (8, 16, 32):
+        plan = tc.fft_plan(n, torch.complex128, dev)
+        assert rel_l2(plan.irfft2(torch.from_numpy(g[f"x_{n}"]).to(dev)), g[f"irfft2_{n}"]) < 1e-14
+        assert rel_l2(plan.rfft2(torch.from_numpy(g[f"r_{n}"]).to(dev)), g[f"rfft2_{n}"]) < 1e-14
+
+
+# ----------------------------------------------------------------------------- oracle, larger sizes
+@pytest.mark.parametrize("n,B", [(8, 5), (32, 4), (256, 4), (512, 2), (1024, 2), (2048, 1)])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_against_oracle(n, B, tag, dev):
+    from oracle import ns2d as O
+
+    forcing = "kolmogorov" if n >= 16 else None
+    _, op = build_op(n, tag, forcing, dev)
+    t = oracle_tables(n, tag, forcing)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 100 + s, REAL[tag])) for s in range(B)])
+    steps = 3 if n <= 512 else 1
+    ref, ref_dt = O.advance(w0, 1e-3, t, steps=steps)
+    out, out_dt = op(w0.to(dev), 1e-3, steps=steps)
+    assert rel_l2(out, ref) < (1e-10 if tag == "f64" else 4e-6)
+    assert rel_l2(out_dt, ref_dt) < (1e-8 if tag == "f64" else 1e-2)
+    assert rel_l2(op.explicit_terms(w0.to(dev)), O.explicit_terms(w0, t)) < (1e-10 if tag == "f64" else 4e-6)
+
+
+def test_smooth_false_and_no_drag(dev):
+    from oracle import ns2d as O
+
+    _, op = build_op(64, "f64", None, dev, drag=0.0, smooth=False)
+    t = oracle_tables(64, "f64", None, drag=0.0, smooth=False)
+    w0 = torch.fft.rfft2(O.mcwilliams_vorticity(64, L, 4, 3, torch.float64))[None]
+    out, _ = op(w0.to(dev), 1e-3, steps=2)
+    ref, _ = O.advance(w0, 1e-3, t, steps=2)
+    assert rel_l2(out, ref) < 1e-10
+    # drag = 0: the mean mode is conserved exactly
+    assert out[0, 0, 0].item() == pytest.approx(w0[0, 0, 0].item(), abs=1e-12)
+
+
+def test_config2_mcwilliams256_b16_fp32_long_run(dev):
+    """BASELINE configs[1] shape (256^2, B=16, fp32): 200 steps against the fp32 oracle."""
+    from oracle import ns2d as O
+
+    n, B = 256, 16
+    _, op = build_op(n, "f32", None, dev)
+    t = oracle_tables(n, "f32", None)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64).float()) for s in range(B)])
+    ref, _ = O.advance(w0, 1e-3, t, steps=200)
+    out, _ = op(w0.to(dev), 1e-3, steps=200)
+    # two fp32 evaluations of a chaotic flow: the reference's own fp32-vs-fp64 drift is 2e-5 here
+    assert rel_l2(out, ref) < 1e-4
+
+
+# ----------------------------------------------------------------------------- properties at full size
+def test_taylor_green_analytic_decay(dev):
+    """omega0 = 2k cos(kx) cos(ky) is an exact solution decaying like exp(-2 nu k^2 t);
+    the oracle reproduces it to 2.9e-10."""
+    import torch_cfd_amd as tc
+
+    n, k, nu, dt, steps = 64, 2, 1e-2, 1e-2, 100
+    _, op = build_op(n, "f64", None, dev, drag=0.0, nu=nu)
+    x = torch.arange(n, dtype=torch.float64) * (L / n)
+    X, Y = torch.meshgrid(x, x, indexing="ij")
+    w0 = 2 * k * torch.cos(k * X) * torch.cos(k * Y)
+    plan = tc.fft_plan(n, torch.complex128, dev)
+    wh = plan.rfft2(w0.to(dev))[None]
+    # F vanishes identically for a single Fourier mode pair
+    assert torch.linalg.norm(op.explicit_terms(wh)).item() < 1e-9 * torch.linalg.norm(wh).item()
+    out, _ = op(wh, dt, steps=steps)
+    exact = w0 * math.exp(-2 * nu * k * k * dt * steps)
+    assert rel_l2(plan.irfft2(out)[0], exact) < 1e-9
+
+
+def test_config3_full_size_batch_consistency(dev):
+    """BASELINE configs[2] size (1024^2, B=64, fp64): every field of the batch must
+    evolve exactly as it does alone (independent trajectories), the first two are
+    checked against the oracle, the mask is idempotent and the result finite."""
+    from oracle import ns2d as O
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    n, B = 1024, 64
+    grid, op = build_op(n, "f64", "kolmogorov", dev)
+    plan = tc.fft_plan(n, torch.complex128, dev)
+    w0 = torch.cat([plan.rfft2(vorticity_field(grid, 4, batch_seeds=list(range(i, i + 8)), device=dev))
+                    for i in range(0, B, 8)])
+    dt = 6.136e-4
+    out, dwdt = op(w0, dt)
+    assert torch.isfinite(torch.view_as_real(out)).all()
+    for idx in (0, 37, 63):
+        alone, _ = op(w0[idx:idx + 1].clone(), dt)
+        assert torch.equal(alone[0], out[idx])
+    t = oracle_tables(n, "f64", "kolmogorov")
+    ref, ref_dt = O.advance(w0[:2].cpu(), dt, t)
+    assert rel_l2(out[:2], ref) < 1e-10
+    assert rel_l2(dwdt[:2], ref_dt) < 1e-8
+    # F is exactly band-limited: masking it again changes nothing
+    F = op.explicit_terms(w0[:4]) - op.forcing_hat().to(dev)
+    assert torch.equal(F * op.filter, F)
+
+
+def test_linearity_of_transforms_and_roundtrip(dev):
+    import torch_cfd_amd as tc
+
+    for n, cdt in ((1024, torch.complex128), (512, torch.complex64)):
+        plan = tc.fft_plan(n, cdt, dev)
+        g = torch.Generator(device="cpu").manual_seed(n)
+        real = torch.float64 if cdt == torch.complex128 else torch.float32
+        a = torch.randn(3, n, n, generator=g, dtype=real).to(dev)
+        b = torch.randn(3, n, n, generator=g, dtype=real).to(dev)
+        tol = 1e-13 if real == torch.float64 else 2e-6
+        assert rel_l2(plan.rfft2(2 * a - 3 * b), 2 * plan.rfft2(a) - 3 * plan.rfft2(b)) < tol
+        assert rel_l2(plan.irfft2(plan.rfft2(a)), a) < tol
+        # Parseval with Hermitian weights
+        ah = plan.rfft2(a)
+        wts = torch.full((n // 2 + 1,), 2.0, dtype=real, device=dev)
+        wts[0] = wts[-1] = 1.0
+        lhs = (ah.abs() ** 2 * wts).sum().item() / (n * n)
+        assert lhs == pytest.approx((a.double() ** 2).sum().item(), rel=1e-12 if real == torch.float64 else 1e-5)
+
+
+def test_errors_are_loud(dev):
+    import torch_cfd_amd as tc
+
+    _, op = build_op(16, "f64", None, dev)
+    with pytest.raises(ValueError):
+        op(torch.zeros(2, 16, 8, dtype=torch.complex128, device=dev), 1e-3)  # wrong m
+    with pytest.raises(tc._lib.TcfdError):
+        w = torch.zeros(1, 16, 9, dtype=torch.complex128, device=dev, requires_grad=True)
+        op(w, 1e-3)
+    torch.set_default_dtype(torch.float64)
+    grid = tc.Grid(shape=(24, 24), domain=((0, L), (0, L)))
+    bad = tc.NavierStokes2DSpectral(1e-3, grid, solver=tc.RK4CrankNicolsonStepper()).to(dev)
+    with pytest.raises(tc._lib.TcfdError, match="power of two"):
+        bad(torch.zeros(1, 24, 13, dtype=torch.complex128, device=dev), 1e-3)

@@ -89,6 +89,8 @@ SIGNATURES = {
     "tcfd_ns2d_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),
     "tcfd_irfft2": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
+    "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
 }
 
 

@@ -424,7 +424,15 @@ __global__ void k_velocity(const cx<T>* __restrict__ w, cx<T>* __restrict__ uh, 
 }
 
 // ------------------------------------------------------------------ plan
+struct ProfRec { int kind; hipEvent_t e0, e1; };
+struct ProfState {
+    bool on = false;
+    int max_records = 0;
+    std::vector<ProfRec> recs;
+};
+
 struct tcfd_ns2d_plan {
+    ProfState* prof;  // mutable side-car (tcfd_ns2d_profile_begin/end); null until first use
     int n, m, dtype;
     void* tw;       // cx<T>[n]
     void* kx;       // T[n]
@@ -481,6 +489,10 @@ extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     void* ptrs[] = {p->tw, p->kx, p->ky, p->lin, p->mask, p->forcing};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
+    if (p->prof) {
+        for (auto& r : p->prof->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        delete p->prof;
+    }
     delete p;
 }
 
@@ -515,6 +527,26 @@ extern "C" size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch)
     return 6 * field_bytes(p, batch);  // h, adv, 4 planes
 }
 
+// ------------------------------------------------------------------ optional per-launch event timing
+// kinds: 0 cols MODE_A, 1 rows_advect, 2 cols MODE_CA, 3 cols MODE_C, 4 dwdt, 5 other
+struct ProfScope {
+    ProfState* ps;
+    hipStream_t st;
+    int idx = -1;
+    ProfScope(const tcfd_ns2d_plan* p, int kind, hipStream_t s) : ps(p->prof), st(s) {
+        if (!ps || !ps->on || (int)ps->recs.size() >= ps->max_records) { ps = nullptr; return; }
+        ProfRec r;
+        r.kind = kind;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { ps = nullptr; return; }
+        (void)hipEventRecord(r.e0, st);
+        ps->recs.push_back(r);
+        idx = (int)ps->recs.size() - 1;
+    }
+    ~ProfScope() {
+        if (ps) (void)hipEventRecord(ps->recs[idx].e1, st);
+    }
+};
+
 // ------------------------------------------------------------------ launch helpers
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
@@ -544,6 +576,7 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
         attr_done = true;
     }
     const long blocks = batch * a.ntiles;
+    ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C * G), lds, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -562,6 +595,7 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
     }
     const long npairs = batch * (N / 2);
     const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
+    ProfScope prof(p, 1, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
                        (const cx<T>*)p->tw, npairs, p->m);
     HIP_TRY(hipGetLastError());
@@ -620,6 +654,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     if (dwdt) {
         const size_t count = (size_t)batch * N * p->m;
         const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
+        ProfScope prof(p, 4, st);
         hipLaunchKernelGGL(k_dwdt<T>, dim3(blocks), dim3(256), 0, st, (const cx<T>*)w_out, (const cx<T>*)w_in,
                            (cx<T>*)dwdt, (T)inv_total_dt, count);
         HIP_TRY(hipGetLastError());
@@ -787,4 +822,35 @@ extern "C" int tcfd_irfft2(const tcfd_ns2d_plan* p, const void* xh, void* out, l
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     TCFD_DISPATCH(p, (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)));
+}
+
+// ------------------------------------------------------------------ profiling side-car
+extern "C" int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* p, int max_records) {
+    if (!p || max_records <= 0) return fail(TCFD_EINVAL, "profile_begin: bad argument");
+    if (!p->prof) p->prof = new ProfState();
+    for (auto& r : p->prof->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    p->prof->recs.clear();
+    p->prof->recs.reserve(max_records);
+    p->prof->max_records = max_records;
+    p->prof->on = true;
+    return 0;
+}
+
+extern "C" int tcfd_ns2d_profile_end(tcfd_ns2d_plan* p, int capacity, int* count, int* kinds, float* ms) {
+    if (!p || !p->prof || !count) return fail(TCFD_EINVAL, "profile_end: profiling was not started");
+    ProfState* ps = p->prof;
+    ps->on = false;
+    int n = 0;
+    for (auto& r : ps->recs) {
+        HIP_TRY(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+        if (n < capacity && kinds && ms) { kinds[n] = r.kind; ms[n] = t; }
+        ++n;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    ps->recs.clear();
+    *count = n;
+    return 0;
 }

@@ -195,7 +195,7 @@ def _plan_for_mesh(kx: torch.Tensor, ky: torch.Tensor, like: torch.Tensor) -> _H
 
 def fft_plan(n: int, cdtype: torch.dtype, device, diam: float = 2 * torch.pi) -> _HipPlan:
     """Plan for plain rfft2/irfft2 of (*, n, n) fields on ``device``."""
-    k = torch.fft.fftfreq(n, d=diam / n, dtype=torch.float64)
+    k = torch.fft.fftfreq(n, d=diam / n, dtype=_REAL_OF[cdtype])
     kx, ky = torch.meshgrid(k, k, indexing="ij")
     like = torch.empty(0, dtype=cdtype, device=device)
     return _plan_for_mesh(kx[:, : n // 2 + 1], ky[:, : n // 2 + 1], like)
