@@ -192,7 +192,61 @@ def gen_irfft2():
     save("fft_semantics.npz", **out)
 
 
+def gen_fno():
+    """SpectralConv3d / SpectralConvS / SpectralConvT / SobolevLoss of the reference (fp32)."""
+    torch.set_default_dtype(torch.float32)
+    from fno.fno3d import SpectralConv3d
+    from fno.sfno import SpectralConvS, SpectralConvT
+    from fno.losses import SobolevLoss
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+
+    def sd(mod, key):
+        for k, v in mod.state_dict().items():
+            out[f"{key}_sd_{k}"] = npy(v)
+
+    with torch.no_grad():
+        # (b, Ci, X, Y, T) = (2, 3, 16, 12, 10), Co = 4, modes (4, 3, 3): X != Y and Ci != Co catch transposes
+        x = torch.randn(2, 3, 16, 12, 10, generator=g)
+        torch.manual_seed(0)
+        m = SpectralConv3d(3, 4, 4, 3, 3)
+        out["conv3d_x"] = npy(x); sd(m, "conv3d"); out["conv3d_y"] = npy(m(x))
+
+        for bias in (False, True):
+            torch.manual_seed(1)
+            m = SpectralConvS(3, 4, 4, 3, 3, bias=bias, delta=0.5)
+            if bias:
+                for b_ in m.bias:
+                    b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+            key = f"convS_bias{int(bias)}"
+            out[key + "_x"] = npy(x); sd(m, key); out[key + "_y"] = npy(m(x))
+
+        for pad in (False, True):
+            for steps in (10, 20, 40):
+                torch.manual_seed(2)
+                m = SpectralConvT(3, 4, 4, 3, 3, delta=0.1, bias=True, temporal_padding=pad)
+                for b_ in m.bias:
+                    b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+                key = f"convT_pad{int(pad)}_s{steps}"
+                out[key + "_x"] = npy(x); sd(m, key); out[key + "_y"] = npy(m(x, out_steps=steps))
+
+        # a BASELINE-config-5 shaped layer at reduced batch/width: (1, 4, 64, 64, 10), modes 24/24/5
+        x5 = torch.randn(1, 4, 64, 64, 10, generator=g)
+        torch.manual_seed(3)
+        m = SpectralConvS(4, 4, 24, 24, 5)
+        out["convS_c5_x"] = npy(x5); sd(m, "convS_c5"); out["convS_c5_y"] = npy(m(x5))
+
+        a = torch.randn(2, 16, 16, 10, generator=g)
+        b = torch.randn(2, 16, 16, 10, generator=g)
+        out["sob_x"], out["sob_y"] = npy(a), npy(b)
+        for order in (0, -1, 1):
+            for rel in (True, False):
+                out[f"sob_o{order}_r{int(rel)}"] = npy(SobolevLoss(n_grid=16, norm_order=order, relative=rel)(a, b))
+    save("fno_layers.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2"]
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno"]
     for w in which:
         globals()["gen_" + w]()

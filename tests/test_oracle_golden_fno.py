@@ -1,0 +1,62 @@
+"""Pin oracle/fno.py against reference-generated vectors (tests/golden/fno_layers.npz). CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import fno as OF
+
+
+def weights_from_sd(g, key, complex_params=False):
+    if complex_params:  # SpectralConv3d: weights1..4 complex (fno3d.py:36-79)
+        return [torch.from_numpy(g[f"{key}_sd_weights{i}"]) for i in (1, 2, 3, 4)], None
+    w = [torch.view_as_complex(torch.from_numpy(g[f"{key}_sd_weight.{i}"]).contiguous()) for i in range(4)]
+    b = None
+    if f"{key}_sd_bias.0" in g.files:
+        b = [torch.view_as_complex(torch.from_numpy(g[f"{key}_sd_bias.{i}"]).contiguous()) for i in range(4)]
+    return w, b
+
+
+def test_spectral_conv3d():
+    g = load_golden("fno_layers.npz")
+    w, _ = weights_from_sd(g, "conv3d", complex_params=True)
+    y = OF.spectral_conv(torch.from_numpy(g["conv3d_x"]), w, (4, 3, 3))
+    assert rel_l2(y, g["conv3d_y"]) < 1e-6
+
+
+@pytest.mark.parametrize("bias", [0, 1])
+def test_spectral_conv_s(bias):
+    g = load_golden("fno_layers.npz")
+    key = f"convS_bias{bias}"
+    w, b = weights_from_sd(g, key)
+    assert (b is not None) == bool(bias)
+    y = OF.spectral_conv(torch.from_numpy(g[key + "_x"]), w, (4, 3, 3), b, delta=0.5)
+    assert rel_l2(y, g[key + "_y"]) < 1e-6
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+@pytest.mark.parametrize("steps", [10, 20, 40])
+def test_spectral_conv_t(pad, steps):
+    g = load_golden("fno_layers.npz")
+    key = f"convT_pad{pad}_s{steps}"
+    w, b = weights_from_sd(g, key)
+    y = OF.spectral_conv_t(torch.from_numpy(g[key + "_x"]), w, (4, 3, 3), b, delta=0.1, out_steps=steps,
+                           temporal_padding=bool(pad))
+    assert tuple(y.shape) == g[key + "_y"].shape == (2, 4, 16, 12, steps)
+    assert rel_l2(y, g[key + "_y"]) < 1e-6
+
+
+def test_config5_shaped_layer():
+    g = load_golden("fno_layers.npz")
+    w, _ = weights_from_sd(g, "convS_c5")
+    y = OF.spectral_conv(torch.from_numpy(g["convS_c5_x"]), w, (24, 24, 5))
+    assert rel_l2(y, g["convS_c5_y"]) < 1e-6
+
+
+@pytest.mark.parametrize("order", [0, -1, 1])
+@pytest.mark.parametrize("rel", [0, 1])
+def test_sobolev_loss(order, rel):
+    g = load_golden("fno_layers.npz")
+    val = OF.sobolev_loss(torch.from_numpy(g["sob_x"]), torch.from_numpy(g["sob_y"]), 16, norm_order=order,
+                          relative=bool(rel))
+    assert float(val) == pytest.approx(float(g[f"sob_o{order}_r{rel}"]), rel=1e-5)

@@ -140,20 +140,15 @@ struct Passes {
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = x[s + Q * r];
             if constexpr (Ns > 1) {
-                // w[r] = W^(r * k * N/(Ns*R)); powers of two are loaded, the rest multiplied up
+                // v[r] *= W^(r*base): only the log2(R) powers W^(base*2^b) are loaded; every v[r]
+                // is multiplied by the ones whose bit is set in r (keeps 1 twiddle live instead of R)
                 const int base = k * (N / (Ns * R));
-                cx<T> w[R];
 #pragma unroll
-                for (int r = 1; r < R; ++r) {
-                    if ((r & (r - 1)) == 0) {
-                        w[r] = ldtw<DIR, T>(tw, base * r);
-                    } else {
-                        int hb = r;  // highest set bit of r
-                        hb |= hb >> 1; hb |= hb >> 2; hb |= hb >> 4;
-                        hb = (hb + 1) >> 1;
-                        w[r] = cmul(w[hb], w[r - hb]);
-                    }
-                    v[r] = cmul(v[r], w[r]);
+                for (int bit = 1; bit < R; bit <<= 1) {
+                    const cx<T> w = ldtw<DIR, T>(tw, base * bit);
+#pragma unroll
+                    for (int r = 1; r < R; ++r)
+                        if (r & bit) v[r] = cmul(v[r], w);
                 }
             }
             Dft<R, DIR, T>::run(v);

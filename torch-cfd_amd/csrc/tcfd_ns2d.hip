@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,31 +42,37 @@ extern "C" const char* tcfd_last_error(void) { return g_err; }
 extern "C" int tcfd_version(void) { return 1; }
 
 // ------------------------------------------------------------------ per-size configuration
-// EPT = elements per lane of one transform, COLS = columns per tile of the column kernels.
+// COL_EPT / ROW_EPT = elements per lane of one transform in the column / row kernels,
+// COLS = columns per tile of the column kernels, ROW_THREADS = workgroup size of the row kernels.
 template <typename T, int N> struct Cfg;
-#define TCFD_CFG(T, N, EPT_, COLS_)                      \
-    template <> struct Cfg<T, N> {                       \
-        static constexpr int EPT = EPT_, COLS = COLS_;   \
-        static constexpr int G = N / EPT_;               \
+#define TCFD_CFG(T, N, CEPT_, COLS_, REPT_, RTHR_)                                     \
+    template <> struct Cfg<T, N> {                                                     \
+        static constexpr int COL_EPT = CEPT_, COLS = COLS_, ROW_EPT = REPT_, ROW_THREADS = RTHR_; \
     };
-TCFD_CFG(double, 8, 8, 64)
-TCFD_CFG(double, 16, 4, 16)
-TCFD_CFG(double, 32, 8, 32)
-TCFD_CFG(double, 64, 8, 32)
-TCFD_CFG(double, 128, 8, 16)
-TCFD_CFG(double, 256, 16, 16)
-TCFD_CFG(double, 512, 8, 8)
-TCFD_CFG(double, 1024, 16, 8)
-TCFD_CFG(double, 2048, 16, 4)
-TCFD_CFG(float, 8, 8, 64)
-TCFD_CFG(float, 16, 4, 16)
-TCFD_CFG(float, 32, 8, 32)
-TCFD_CFG(float, 64, 8, 32)
-TCFD_CFG(float, 128, 8, 16)
-TCFD_CFG(float, 256, 16, 16)
-TCFD_CFG(float, 512, 8, 16)
-TCFD_CFG(float, 1024, 16, 8)
-TCFD_CFG(float, 2048, 16, 8)
+TCFD_CFG(double, 8, 8, 64, 8, 256)
+TCFD_CFG(double, 16, 4, 16, 4, 256)
+TCFD_CFG(double, 32, 8, 32, 8, 256)
+TCFD_CFG(double, 64, 8, 32, 8, 256)
+TCFD_CFG(double, 128, 8, 16, 8, 256)
+TCFD_CFG(double, 256, 16, 16, 16, 256)
+TCFD_CFG(double, 512, 8, 8, 8, 256)
+TCFD_CFG(double, 1024, 16, 8, 8, 128)
+TCFD_CFG(double, 2048, 16, 4, 16, 256)
+TCFD_CFG(float, 8, 8, 64, 8, 256)
+TCFD_CFG(float, 16, 4, 16, 4, 256)
+TCFD_CFG(float, 32, 8, 32, 8, 256)
+TCFD_CFG(float, 64, 8, 32, 8, 256)
+TCFD_CFG(float, 128, 8, 16, 8, 256)
+TCFD_CFG(float, 256, 16, 16, 16, 256)
+TCFD_CFG(float, 512, 8, 16, 8, 256)
+TCFD_CFG(float, 1024, 16, 8, 16, 256)
+TCFD_CFG(float, 2048, 16, 8, 16, 256)
+
+// run-time variant override for tuning sweeps (TCFD_VARIANT_COLS / TCFD_VARIANT_ROWS, n=1024 fp64 only)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 
 // ------------------------------------------------------------------ column kernels
 enum ColMode {
@@ -96,13 +103,20 @@ struct ColArgs {
     const cx<T>* tw;      // [n]
     size_t plane_stride;  // elements between planes
     T beta, gdt, mu, scale;
-    int m;
+    int m;        // row pitch (elements) of caller-layout arrays: u_in, u_out, wt, out, psi
+    int ldw;      // row pitch of workspace arrays (adv, h, planes): m rounded up to a 128-byte multiple
+    int in_ld;    // MODE_FWD / MODE_INV: pitch of `in`
+    int out_ld;   // MODE_FWD / MODE_INV: pitch of `out`
+    int u_in_ld;  // MODE_A / CA / C: pitch of u_in (m for the caller's array, ldw for the internal state copy)
+    int u_out_ld; // MODE_CA / C: pitch of u_out
     int ntiles;
+    int batch;
     int load_h;
+    int pair_xcd;  // block->tile map: 0 = batch fastest; 1 = adjacent half-line tiles paired on one XCD
 };
 
 template <typename T, int N, int EPT, int C>
-__device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, size_t colbase,
+__device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, size_t wbase,
                                             int j, int c, int jc, bool valid) {
     constexpr int G = N / EPT;
     constexpr T TWO_PI = (T)6.283185307179586476925286766559;
@@ -131,44 +145,66 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
         }
         tile_fft<T, N, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
         if (valid) {
-            cx<T>* dst = a.planes + (size_t)f * a.plane_stride + colbase;
+            cx<T>* dst = a.planes + (size_t)f * a.plane_stride + wbase;
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.m] = x[t];
+            for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.ldw] = x[t];
         }
     }
 }
 
-template <typename T, int N, int EPT, int C, int MODE>
-__global__ __launch_bounds__(C*(N / EPT)) void k_cols(ColArgs<T> a) {
+template <typename T, int N, int EPT, int C, int MODE, int MINW>
+__global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
     constexpr int G = N / EPT;
     const int c = threadIdx.x % C;
     const int j = threadIdx.x / C;
-    const int tile = blockIdx.x % a.ntiles;
-    const long b = blockIdx.x / a.ntiles;
+    // batch is the fastest block index: the blocks that share one tile of the (n, m) tables
+    // (linear term, mask, forcing) run together and hit them in L2
+    int tile;
+    long b;
+    if (a.pair_xcd) {
+        // tiles narrower than a 128-byte line: the two tiles that share a line are issued 8 block
+        // ids apart, i.e. back to back on the SAME XCD (block id % 8), so the second one hits in L2
+        const unsigned q = blockIdx.x / 16, r = blockIdx.x % 16;
+        const unsigned unit = q * 8 + (r % 8);
+        if (unit >= (unsigned)(((a.ntiles + 1) / 2) * a.batch)) return;
+        tile = 2 * (int)(unit / a.batch) + (int)(r / 8);
+        b = unit % a.batch;
+    } else {
+        tile = blockIdx.x / a.batch;
+        b = blockIdx.x % a.batch;
+    }
     const int jc = tile * C + c;
     const bool valid = jc < a.m;
-    const size_t colbase = (size_t)b * N * a.m + jc;  // element (b, 0, jc)
+    const size_t colbase = (size_t)b * N * a.m + jc;   // element (b, 0, jc) of a caller-layout array
+    const size_t wbase = (size_t)b * N * a.ldw + jc;   // same element of a workspace array
 
     cx<T> x[EPT];
     if constexpr (MODE == MODE_A) {
+        {
+            const size_t ub = (size_t)b * N * a.u_in_ld + jc;
 #pragma unroll
-        for (int t = 0; t < EPT; ++t)
-            x[t] = valid ? a.u_in[colbase + (size_t)(j + t * G) * a.m] : mk<T>((T)0, (T)0);
-        emit_planes<T, N, EPT, C>(a, x, lds, colbase, j, c, jc, valid);
+            for (int t = 0; t < EPT; ++t)
+                x[t] = valid ? a.u_in[ub + (size_t)(j + t * G) * a.u_in_ld] : mk<T>((T)0, (T)0);
+        }
+        emit_planes<T, N, EPT, C>(a, x, lds, wbase, j, c, jc, valid);
         return;
     } else {
+        constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
+        const int in_ld = GENERIC ? a.in_ld : a.ldw;
+        const size_t inbase = (size_t)b * N * in_ld + jc;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            x[t] = valid ? a.in[colbase + (size_t)(j + t * G) * a.m] : mk<T>((T)0, (T)0);
+            x[t] = valid ? a.in[inbase + (size_t)(j + t * G) * in_ld] : mk<T>((T)0, (T)0);
         constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
         tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
             if (valid) {
+                const size_t outbase = (size_t)b * N * a.out_ld + jc;
 #pragma unroll
-                for (int t = 0; t < EPT; ++t) a.out[colbase + (size_t)(j + t * G) * a.m] = cscale(x[t], a.scale);
+                for (int t = 0; t < EPT; ++t) a.out[outbase + (size_t)(j + t * G) * a.out_ld] = cscale(x[t], a.scale);
             }
             return;
         } else if constexpr (MODE == MODE_F) {
@@ -214,20 +250,21 @@ __global__ __launch_bounds__(C*(N / EPT)) void k_cols(ColArgs<T> a) {
                     const int i = j + t * G;
                     const size_t tab = (size_t)i * a.m + jc;
                     const size_t g = colbase + (size_t)i * a.m;
+                    const size_t gw = wbase + (size_t)i * a.ldw;
                     cx<T> hn = cscale(x[t], a.mask[tab]);
                     if (a.forcing) hn = hn + a.forcing[tab];
-                    if (a.load_h) hn = hn + cscale(a.h[g], a.beta);
-                    a.h[g] = hn;
+                    if (a.load_h) hn = hn + cscale(a.h[gw], a.beta);
+                    a.h[gw] = hn;
                     const T L = a.lin[tab];
-                    const cx<T> u = a.u_in[g];
+                    const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                     cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
                     const T den = (T)1 / ((T)1 - a.mu * L);
                     x[t] = cscale(rhs, den);
-                    a.u_out[g] = x[t];
+                    a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                 }
             }
-            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C>(a, x, lds, colbase, j, c, jc, valid);
+            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C>(a, x, lds, wbase, j, c, jc, valid);
         }
     }
 }
@@ -292,21 +329,21 @@ __device__ __forceinline__ void unpack_store_pair(const cx<T> (&x)[EPT], cx<T>* 
     group_sync<WG>();
 }
 
-template <typename T, int N, int EPT>
+template <typename T, int N, int EPT, int THREADS_ = 256>
 struct RowGeom {
     static constexpr int G = N / EPT;
-    static constexpr int THREADS = G >= 256 ? G : 256;
+    static constexpr int THREADS = G >= THREADS_ ? G : THREADS_;
     static constexpr int GROUPS = THREADS / G;
     static constexpr int LDS_PER_GROUP = lds_elems<N, EPT, 1, true>();
     static constexpr size_t LDS_BYTES = (size_t)GROUPS * LDS_PER_GROUP * sizeof(cx<T>);
 };
 
-template <typename T, int N, int EPT>
-__global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_advect(
+template <typename T, int N, int EPT, int THR>
+__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect(
     const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
     long npairs, int m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using Gm = RowGeom<T, N, EPT>;
+    using Gm = RowGeom<T, N, EPT, THR>;
     constexpr int G = Gm::G;
     constexpr bool WG = (G > 64);
     const int grp = threadIdx.x / G;
@@ -336,12 +373,115 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_advect(
     unpack_store_pair<T, N, EPT>(p, lds, adv + row0 * (size_t)m, adv + (row0 + 1) * (size_t)m, j, valid);
 }
 
+// ---- row pass, software-pipelined ("v3") -------------------------------------------------
+// The un-mirrored half rows of two planes as they come from HBM: k = j + G*t, t < EPT/2, plus the
+// Nyquist element.  A group keeps TWO of these in registers: the one being consumed and the one in
+// flight, so a load phase is never exposed (the plain kernel above alternates load and transform
+// phases and reaches only ~3 TB/s at 1024^2).
+template <typename T, int EPT>
+struct RawPair {
+    cx<T> a[EPT / 2], b[EPT / 2];
+    cx<T> an, bn;  // element N/2 of both rows (only lane 0 of the group uses it)
+};
+
+template <typename T, int N, int EPT>
+__device__ __forceinline__ void load_raw(RawPair<T, EPT>& r, const cx<T>* __restrict__ rowA,
+                                         const cx<T>* __restrict__ rowB, int j) {
+    constexpr int G = N / EPT;
+#pragma unroll
+    for (int t = 0; t < EPT / 2; ++t) {
+        r.a[t] = rowA[j + t * G];
+        r.b[t] = rowB[j + t * G];
+    }
+    r.an = rowA[N / 2];
+    r.bn = rowB[N / 2];
+}
+
+// Z[e] = A~[e] + i B~[e] (Hermitian completions, Im of DC / Nyquist dropped) in the j + t*G
+// distribution.  The upper half is the mirror image of data owned by OTHER lanes: it goes through
+// the group's LDS buffer (half an exchange) instead of being loaded from HBM a second time.
+template <typename T, int N, int EPT, bool WG>
+__device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>& r, cx<T>* lds, int j) {
+    constexpr int G = N / EPT;
+#pragma unroll
+    for (int t = 0; t < EPT / 2; ++t) {
+        const int k = j + t * G;
+        cx<T> pa = r.a[t], pb = r.b[t];
+        if (k == 0) { pa.y = 0; pb.y = 0; }
+        x[t] = mk<T>(pa.x - pb.y, pa.y + pb.x);
+        if (k >= 1) lds[lds_addr<EPT, 1, true>(N - k, 0)] = mk<T>(pa.x + pb.y, pb.x - pa.y);
+    }
+    if (j == 0) lds[lds_addr<EPT, 1, true>(N / 2, 0)] = mk<T>(r.an.x, r.bn.x);
+    group_sync<WG>();
+#pragma unroll
+    for (int t = EPT / 2; t < EPT; ++t) x[t] = lds[lds_addr<EPT, 1, true>(j + t * G, 0)];
+    group_sync<WG>();
+}
+
+template <typename T, int N, int EPT, int THR>
+__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect3(
+    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
+    long npairs, int ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT, THR>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    const long stride = (long)gridDim.x * Gm::GROUPS;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    // every group runs the same number of iterations (the barriers are workgroup wide);
+    // out-of-range iterations recompute the last pair and skip the store
+    const long iters = (npairs + stride - 1) / stride;
+    const cx<T>* P0 = planes;
+    const cx<T>* P1 = planes + plane_stride;
+    const cx<T>* P2 = planes + 2 * plane_stride;
+    const cx<T>* P3 = planes + 3 * plane_stride;
+
+    RawPair<T, EPT> ra, rb;
+    {
+        const size_t off = (size_t)(pair < npairs ? pair : npairs - 1) * 2 * (size_t)ld;
+        load_raw<T, N, EPT>(ra, P0 + off, P1 + off, j);
+        load_raw<T, N, EPT>(rb, P2 + off, P3 + off, j);
+    }
+    for (long it = 0; it < iters; ++it, pair += stride) {
+        const bool valid = pair < npairs;
+        const long cur = valid ? pair : npairs - 1;
+        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
+        const size_t off1 = ((size_t)cur * 2 + 1) * (size_t)ld;  // second row of this pair
+        const size_t offn = (size_t)nxt * 2 * (size_t)ld;        // first row of the next pair
+        cx<T> x[EPT], z1[EPT], p[EPT];
+
+        pack_herm<T, N, EPT, WG>(z1, ra, lds, j);
+        load_raw<T, N, EPT>(ra, P0 + off1, P1 + off1, j);             // in flight during the transform
+        tile_fft<T, N, EPT, +1, 1, true, WG>(z1, lds, tw, j, 0);      // vx + i vy   (row 0)
+        pack_herm<T, N, EPT, WG>(x, rb, lds, j);
+        load_raw<T, N, EPT>(rb, P2 + off1, P3 + off1, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);       // dx w + i dy w
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t].x = -(x[t].x * z1[t].x + x[t].y * z1[t].y);
+
+        pack_herm<T, N, EPT, WG>(z1, ra, lds, j);
+        load_raw<T, N, EPT>(ra, P0 + offn, P1 + offn, j);             // next pair, row 0
+        tile_fft<T, N, EPT, +1, 1, true, WG>(z1, lds, tw, j, 0);
+        pack_herm<T, N, EPT, WG>(x, rb, lds, j);
+        load_raw<T, N, EPT>(rb, P2 + offn, P3 + offn, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t].y = -(x[t].x * z1[t].x + x[t].y * z1[t].y);
+
+        tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
+        unpack_store_pair<T, N, EPT>(p, lds, adv + (size_t)cur * 2 * ld, adv + ((size_t)cur * 2 + 1) * ld, j, valid);
+    }
+}
+
 // real (rows, N) -> half spectrum (rows, m): first half of rfft2
 template <typename T, int N, int EPT>
 __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_r2c(const T* __restrict__ in,
                                                                              cx<T>* __restrict__ out,
                                                                              const cx<T>* __restrict__ tw, long npairs,
-                                                                             int m) {
+                                                                             int m /* pitch of out */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using Gm = RowGeom<T, N, EPT>;
     constexpr int G = Gm::G;
@@ -368,7 +508,7 @@ template <typename T, int N, int EPT>
 __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_c2r(const cx<T>* __restrict__ in,
                                                                              T* __restrict__ out,
                                                                              const cx<T>* __restrict__ tw, long npairs,
-                                                                             int m) {
+                                                                             int m /* pitch of in */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using Gm = RowGeom<T, N, EPT>;
     constexpr int G = Gm::G;
@@ -434,6 +574,7 @@ struct ProfState {
 struct tcfd_ns2d_plan {
     ProfState* prof;  // mutable side-car (tcfd_ns2d_profile_begin/end); null until first use
     int n, m, dtype;
+    int ldw;        // workspace row pitch in elements: m rounded up so that a row is a multiple of 128 bytes
     void* tw;       // cx<T>[n]
     void* kx;       // T[n]
     void* ky;       // T[m]
@@ -506,6 +647,10 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->n = n;
     p->m = n / 2 + 1;
     p->dtype = dtype;
+    {
+        const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
+        p->ldw = (p->m + per_line - 1) / per_line * per_line;
+    }
     int rc = dtype == TCFD_C128 ? plan_fill<double>(p, kx, ky, linear_term, mask, forcing_hat)
                                 : plan_fill<float>(p, kx, ky, linear_term, mask, forcing_hat);
     if (rc) {
@@ -519,12 +664,12 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t field_bytes(const tcfd_ns2d_plan* p, long batch) {
     const size_t esz = p->dtype == TCFD_C128 ? 16 : 8;
-    return align256((size_t)batch * p->n * p->m * esz);
+    return align256((size_t)batch * p->n * p->ldw * esz);
 }
 
 extern "C" size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
     if (!p || batch <= 0) return 0;
-    return 6 * field_bytes(p, batch);  // h, adv, 4 planes
+    return 7 * field_bytes(p, batch);  // h, adv, 4 planes, line-aligned copy of the state
 }
 
 // ------------------------------------------------------------------ optional per-launch event timing
@@ -556,37 +701,64 @@ static int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
-template <typename T, int N, int MODE>
-static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
-    constexpr int EPT = Cfg<T, N>::EPT, C = Cfg<T, N>::COLS, G = Cfg<T, N>::G;
+template <typename T, int N, int MODE, int EPT, int C, int MINW = 1>
+static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
+    constexpr int G = N / EPT;
     constexpr size_t lds = (size_t)lds_elems<N, EPT, C, false>() * sizeof(cx<T>);
     a.m = p->m;
+    a.ldw = p->ldw;
     a.ntiles = (p->m + C - 1) / C;
+    a.batch = (int)batch;
     a.kx = (const T*)p->kx;
     a.ky = (const T*)p->ky;
     a.lin = (const T*)p->lin;
     a.mask = (const T*)p->mask;
     a.forcing = (const cx<T>*)p->forcing;
     a.tw = (const cx<T>*)p->tw;
-    auto kern = k_cols<T, N, EPT, C, MODE>;
+    auto kern = k_cols<T, N, EPT, C, MODE, MINW>;
     static bool attr_done = false;
     if (!attr_done) {
         int rc = set_lds(kern, lds);
         if (rc) return rc;
         attr_done = true;
     }
-    const long blocks = batch * a.ntiles;
+    long blocks = batch * a.ntiles;
+    a.pair_xcd = (C * sizeof(cx<T>) < 128) ? env_int("TCFD_PAIR_XCD", 1) : 0;
+    if (a.pair_xcd) blocks = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
     ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C * G), lds, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <typename T, int N>
-static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
-                              hipStream_t st) {
-    using Gm = RowGeom<T, N, Cfg<T, N>::EPT>;
-    auto kern = k_rows_advect<T, N, Cfg<T, N>::EPT>;
+template <typename T, int N, int MODE>
+static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
+    if constexpr (N == 512 && sizeof(T) == 8 && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
+        static const int variant = env_int("TCFD_VARIANT_COLS", 0);
+        switch (variant) {
+            case 1: return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);   // 512 thr, <=128 VGPR: 2 WG/CU
+            case 2: return launch_cols_v<T, N, MODE, 16, 8, 2>(p, a, batch, st);  // 256 thr, <=256 VGPR: 2 WG/CU
+            case 3: return launch_cols_v<T, N, MODE, 16, 8, 4>(p, a, batch, st);  // 256 thr, <=128 VGPR: 4 WG/CU (LDS: 2)
+            default: break;
+        }
+    }
+    if constexpr (N == 1024 && sizeof(T) == 8 && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
+        static const int variant = env_int("TCFD_VARIANT_COLS", 0);
+        switch (variant) {
+            case 1: return launch_cols_v<T, N, MODE, 8, 8>(p, a, batch, st);    // 1024 threads, <=128 VGPR
+            case 2: return launch_cols_v<T, N, MODE, 16, 4>(p, a, batch, st);   // 256 threads, 64 KB LDS
+            case 3: return launch_cols_v<T, N, MODE, 8, 4>(p, a, batch, st);    // 512 threads, 64 KB LDS
+            default: break;
+        }
+    }
+    return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
+}
+
+template <typename T, int N, int EPT, int THR>
+static int launch_rows_advect_v(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
+                                long batch, hipStream_t st) {
+    using Gm = RowGeom<T, N, EPT, THR>;
+    auto kern = k_rows_advect<T, N, EPT, THR>;
     static bool attr_done = false;
     if (!attr_done) {
         int rc = set_lds(kern, Gm::LDS_BYTES);
@@ -597,9 +769,52 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
     const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
     ProfScope prof(p, 1, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
-                       (const cx<T>*)p->tw, npairs, p->m);
+                       (const cx<T>*)p->tw, npairs, p->ldw);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <typename T, int N, int EPT, int THR>
+static int launch_rows_advect3(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
+                               long batch, hipStream_t st) {
+    using Gm = RowGeom<T, N, EPT, THR>;
+    auto kern = k_rows_advect3<T, N, EPT, THR>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(kern, Gm::LDS_BYTES);
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const long npairs = batch * (N / 2);
+    const long want = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
+    static const int per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 8);
+    const long blocks = std::min<long>(want, 256L * per_cu);  // persistent groups, grid-stride over row pairs
+    ProfScope prof(p, 1, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
+                       (const cx<T>*)p->tw, npairs, p->ldw);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int N>
+static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
+                              hipStream_t st) {
+    if constexpr (N == 1024 && sizeof(T) == 8) {
+        static const int variant = env_int("TCFD_VARIANT_ROWS", 0);
+        switch (variant) {
+            case 5: return launch_rows_advect3<T, N, 8, 128>(p, planes, plane_stride, adv, batch, st);
+            case 6: return launch_rows_advect3<T, N, 8, 256>(p, planes, plane_stride, adv, batch, st);
+            case 7: return launch_rows_advect3<T, N, 4, 256>(p, planes, plane_stride, adv, batch, st);
+            case 8: return launch_rows_advect3<T, N, 16, 64>(p, planes, plane_stride, adv, batch, st);
+            case 1: return launch_rows_advect_v<T, N, 16, 256>(p, planes, plane_stride, adv, batch, st);  // 1 wave / pair
+            case 2: return launch_rows_advect_v<T, N, 16, 64>(p, planes, plane_stride, adv, batch, st);
+            case 3: return launch_rows_advect_v<T, N, 8, 256>(p, planes, plane_stride, adv, batch, st);   // 2 pairs / WG
+            case 4: return launch_rows_advect_v<T, N, 4, 256>(p, planes, plane_stride, adv, batch, st);   // 4 waves / pair
+            default: break;
+        }
+    }
+    return launch_rows_advect_v<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch,
+                                                                                   st);
 }
 
 template <typename T>
@@ -607,6 +822,7 @@ struct Ws {
     cx<T>* h;
     cx<T>* adv;
     cx<T>* planes;
+    cx<T>* upad;          // state in the line-aligned internal pitch (stages 1.. of a call)
     size_t plane_stride;  // elements
 };
 template <typename T>
@@ -617,6 +833,7 @@ static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
     w.h = (cx<T>*)base;
     w.adv = (cx<T>*)(base + fb);
     w.planes = (cx<T>*)(base + 2 * fb);
+    w.upad = (cx<T>*)(base + 6 * fb);
     w.plane_stride = fb / sizeof(cx<T>);
     return w;
 }
@@ -634,21 +851,28 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     a.h = W.h;
     a.in = W.adv;
     a.u_in = (const cx<T>*)w_in;
+    a.u_in_ld = p->m;
     if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
+    // the caller's (n, m) rows are not 128-byte aligned (m is odd): only the first read and the last
+    // write of a call touch that layout, every stage in between uses the aligned copy `upad`
     const cx<T>* u_src = (const cx<T>*)w_in;
+    int u_src_ld = p->m;
     for (int s = 0; s < steps; ++s) {
         for (int k = 0; k < nstages; ++k) {
             if ((rc = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, st))) return rc;
+            const bool last = (s == steps - 1) && (k == nstages - 1);
             a.u_in = u_src;
-            a.u_out = (cx<T>*)w_out;
+            a.u_in_ld = u_src_ld;
+            a.u_out = last ? (cx<T>*)w_out : W.upad;
+            a.u_out_ld = last ? p->m : p->ldw;
             a.beta = (T)beta[k];
             a.gdt = (T)gdt[k];
             a.mu = (T)mu[k];
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
-            const bool last = (s == steps - 1) && (k == nstages - 1);
             rc = last ? launch_cols<T, N, MODE_C>(p, a, batch, st) : launch_cols<T, N, MODE_CA>(p, a, batch, st);
             if (rc) return rc;
-            u_src = (const cx<T>*)w_out;
+            u_src = a.u_out;
+            u_src_ld = a.u_out_ld;
         }
     }
     if (dwdt) {
@@ -671,6 +895,7 @@ static int explicit_impl(const tcfd_ns2d_plan* p, const void* w, void* out, cons
     a.planes = W.planes;
     a.plane_stride = W.plane_stride;
     a.u_in = (const cx<T>*)w;
+    a.u_in_ld = p->m;
     if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
     if ((rc = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, st))) return rc;
     a.in = W.adv;
@@ -685,8 +910,8 @@ static int explicit_impl(const tcfd_ns2d_plan* p, const void* w, void* out, cons
 
 template <typename T, int N>
 static int rfft2_impl(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, hipStream_t st) {
-    using Gm = RowGeom<T, N, Cfg<T, N>::EPT>;
-    auto kern = k_rows_r2c<T, N, Cfg<T, N>::EPT>;
+    using Gm = RowGeom<T, N, Cfg<T, N>::ROW_EPT>;
+    auto kern = k_rows_r2c<T, N, Cfg<T, N>::ROW_EPT>;
     static bool attr_done = false;
     if (!attr_done) {
         int rc = set_lds(kern, Gm::LDS_BYTES);
@@ -701,6 +926,7 @@ static int rfft2_impl(const tcfd_ns2d_plan* p, const void* x, void* out, long ba
     ColArgs<T> a{};
     a.in = (const cx<T>*)out;
     a.out = (cx<T>*)out;
+    a.in_ld = a.out_ld = p->m;
     a.scale = (T)1;
     return launch_cols<T, N, MODE_FWD>(p, a, batch, st);
 }
@@ -710,11 +936,13 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
     ColArgs<T> a{};
     a.in = (const cx<T>*)xh;
     a.out = (cx<T>*)ws;
+    a.in_ld = p->m;
+    a.out_ld = p->ldw;
     a.scale = (T)1 / ((T)N * (T)N);
     int rc;
     if ((rc = launch_cols<T, N, MODE_INV>(p, a, batch, st))) return rc;
-    using Gm = RowGeom<T, N, Cfg<T, N>::EPT>;
-    auto kern = k_rows_c2r<T, N, Cfg<T, N>::EPT>;
+    using Gm = RowGeom<T, N, Cfg<T, N>::ROW_EPT>;
+    auto kern = k_rows_c2r<T, N, Cfg<T, N>::ROW_EPT>;
     static bool attr_done = false;
     if (!attr_done) {
         rc = set_lds(kern, Gm::LDS_BYTES);
@@ -724,7 +952,7 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
     const long npairs = batch * (N / 2);
     const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, (const cx<T>*)ws, (T*)out,
-                       (const cx<T>*)p->tw, npairs, p->m);
+                       (const cx<T>*)p->tw, npairs, p->ldw);
     HIP_TRY(hipGetLastError());
     return 0;
 }
