@@ -102,6 +102,34 @@ int tcfd_rfft2(const tcfd_ns2d_plan* plan, const void* x_real, void* out_hat, lo
 int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ---- FNO / SFNO spectral convolution (fp32) ---------------------------------------
+ * Replaces SpectralConv.forward (fno/base.py:229-237) with SpectralConvS.spectral_conv
+ * (fno/sfno.py:364-391), SpectralConvT.forward (fno/sfno.py:433-457) and
+ * SpectralConv3d.forward (fno/fno3d.py:86-116):
+ *     out = irfftn( contract( rfftn(pad_t(v)) ), s = (X, Y, T_out) )[..., -t_keep:]
+ * with pruned transforms (only the 2mx x 2my x mt kept modes are produced / consumed).
+ *   plan: grid (X, Y) powers of two in [8, 1024]; T_in input steps, t_pad zeros prepended
+ *         (SpectralConvT temporal_padding), T_out = irfftn length in t, modes (mx, my, mt).
+ *   v        (batch, cin, X, Y, T_in) fp32         out (batch, cout, X, Y, t_keep) fp32
+ *   weights  4 pointers, each (cin, cout, mx, my, mt) interleaved complex64, block order
+ *            ix + 2*iy = [lo-x lo-y, hi-x lo-y, lo-x hi-y, hi-x hi-y]  (sfno.py:374-386; the
+ *            complex weights1..4 of fno3d.py:36-79 have the same memory layout)
+ *   bias     NULL or 4 pointers (mx, my, mt) complex64, added as delta * bias (sfno.py:388-390)
+ *   fwd_scale / inv_scale   norm="backward": 1 and 1/(X*Y*T_out)
+ *   use_mfma 1: per-mode products on v_mfma_f32_16x16x4_f32; 0: plain VALU kernel */
+typedef struct tcfd_fno_plan tcfd_fno_plan;
+int tcfd_fno_plan_create(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt);
+void tcfd_fno_plan_destroy(tcfd_fno_plan* plan);
+size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* plan, int batch, int cin, int cout);
+int tcfd_fno_spectral_conv(const tcfd_fno_plan* plan, const void* v, const void* const* weights,
+                           const void* const* bias, float delta, void* out, int batch, int cin, int cout,
+                           int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* The contraction alone on truncated spectra (batch, c, 2mx, 2my, mt) complex64 (tests). */
+int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, float delta,
+                      void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,
+                      void* stream);
+
 /* ---- per-launch event timing (measurement aid; no reference counterpart) -------
  * Between profile_begin and profile_end every kernel the plan launches is
  * bracketed by a pair of HIP events recorded on the launch stream (up to

@@ -89,6 +89,13 @@ SIGNATURES = {
     "tcfd_ns2d_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),
     "tcfd_irfft2": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_fno_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i]),
+    "tcfd_fno_plan_destroy": (None, [_vp]),
+    "tcfd_fno_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "tcfd_fno_spectral_conv": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i,
+                                    _i, _i, ctypes.c_float, ctypes.c_float, _i, _vp, _sz, _vp]),
+    "tcfd_fno_contract": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i, _i, _i, _i,
+                               _i, _i, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
 }

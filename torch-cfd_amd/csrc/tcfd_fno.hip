@@ -1,0 +1,539 @@
+// tcfd_fno.hip -- MI355X (gfx950) kernels + C ABI for the FNO / SFNO spectral convolution
+//   y = irfftn( W (.) rfftn(v)[kept modes] , s = out size )
+// reference: fno/base.py:229-237 (forward), fno/sfno.py:364-391 (4-corner contraction + bias),
+// fno/sfno.py:433-457 (time padding / resampling variant), fno/fno3d.py:86-116 (SpectralConv3d).
+//
+// The reference transforms the FULL (b, C, X, Y, T/2+1) spectrum both ways and zero-fills a full
+// output spectrum although only 2mx x 2my x mt modes are ever read or written.  Here the transforms
+// are pruned: five kernels, the big activation tensors are read / written exactly once,
+//
+//   k_fwd_ty   per (b,c,x) slab [Y][T]: real DFT in t (mt outputs) + Y-point FFT per kept kt,
+//              store only the 2my kept ky                         -> W1 (b,C,X,Q)   Q = 2my*mt
+//   k_fwd_x    X-point FFT down the columns of W1, store only the 2mx kept kx -> V (b,C,2mx,Q)
+//   k_contract per-mode (b x Ci)(Ci x Co) complex products on MFMA (f32 16x16x4), + delta*bias
+//   k_inv_x    zero-padded X-point inverse FFT                     -> W2 (b,C,X,Q)
+//   k_inv_ty   zero-padded Y-point inverse FFT per kt + inverse real DFT in t -> (b,C,X,Y,T_keep)
+//
+// fp32 only (SpectralConv3d is cfloat-only in the reference).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tcfd.h"
+#include "tcfd_fft.hpp"
+
+using namespace tcfd;
+typedef cx<float> cf;
+
+extern "C" const char* tcfd_last_error(void);
+int tcfd_set_error(int code, const char* fmt, ...);  // defined in tcfd_ns2d.hip
+#define FAIL(...) tcfd_set_error(__VA_ARGS__)
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return FAIL(TCFD_EHIP, "%s: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------ plan
+struct tcfd_fno_plan {
+    int X, Y, T_in, t_pad, T_out, mx, my, mt;
+    int Tp;        // padded input length  T_in + t_pad (the rfft length in t)
+    cf* tw_x;      // [X]   exp(-2 pi i k / X)
+    cf* tw_y;      // [Y]
+    cf* tw_tf;     // [mt][Tp]   forward:  exp(-2 pi i kt t / Tp)
+    cf* tw_ti;     // [T_out][mt] inverse: c_kt * exp(+2 pi i kt t / T_out), c = 1 (kt = 0 or Nyquist) else 2
+};
+
+static bool pow2(int n) { return n >= 8 && n <= 1024 && (n & (n - 1)) == 0; }
+
+template <typename V>
+static int upload_vec(void** dst, const std::vector<V>& h) {
+    HIP_TRY(hipMalloc(dst, h.size() * sizeof(V)));
+    HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static std::vector<cf> unit_roots(int n) {
+    std::vector<cf> w(n);
+    for (int t = 0; t < n; ++t) {
+        const long double a = -2.0L * 3.141592653589793238462643383279502884L * t / n;
+        w[t].x = (float)cosl(a);
+        w[t].y = (float)sinl(a);
+    }
+    return w;
+}
+
+extern "C" void tcfd_fno_plan_destroy(tcfd_fno_plan* p) {
+    if (!p) return;
+    void* ptrs[] = {p->tw_x, p->tw_y, p->tw_tf, p->tw_ti};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+}
+
+extern "C" int tcfd_fno_plan_create(tcfd_fno_plan** out, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my,
+                                    int mt) {
+    if (!out) return FAIL(TCFD_EINVAL, "fno_plan_create: null argument");
+    if (!pow2(X) || !pow2(Y)) return FAIL(TCFD_EINVAL, "fno_plan_create: X=%d, Y=%d must be powers of two in [8, 1024]", X, Y);
+    if (T_in < 1 || t_pad < 0 || T_out < 1 || mx < 1 || my < 1 || mt < 1)
+        return FAIL(TCFD_EINVAL, "fno_plan_create: bad sizes");
+    const int Tp = T_in + t_pad;
+    if (2 * mx > X || 2 * my > Y) return FAIL(TCFD_EINVAL, "fno_plan_create: 2*modes exceed the grid (%d,%d vs %d,%d)", mx, my, X, Y);
+    if (mt > Tp / 2 + 1 || mt > T_out / 2 + 1 || mt > 16)
+        return FAIL(TCFD_EINVAL, "fno_plan_create: modes_t=%d exceeds the half spectrum of T=%d / T_out=%d (or 16)", mt, Tp, T_out);
+    tcfd_fno_plan* p = new tcfd_fno_plan();
+    memset(p, 0, sizeof(*p));
+    p->X = X; p->Y = Y; p->T_in = T_in; p->t_pad = t_pad; p->T_out = T_out;
+    p->mx = mx; p->my = my; p->mt = mt; p->Tp = Tp;
+    std::vector<cf> tf((size_t)mt * Tp), ti((size_t)T_out * mt);
+    const long double PI2 = 2.0L * 3.141592653589793238462643383279502884L;
+    for (int k = 0; k < mt; ++k)
+        for (int t = 0; t < Tp; ++t) {
+            const long double a = -PI2 * (long double)((long)k * t % Tp) / Tp;
+            tf[(size_t)k * Tp + t].x = (float)cosl(a);
+            tf[(size_t)k * Tp + t].y = (float)sinl(a);
+        }
+    for (int t = 0; t < T_out; ++t)
+        for (int k = 0; k < mt; ++k) {
+            // c2r: x[t] = sum_k c_k Re( X_k e^{+2 pi i k t / T} ), Im(X_0) and Im(X_Nyquist) ignored
+            const bool edge = (k == 0) || (2 * k == T_out);
+            const long double a = PI2 * (long double)((long)k * t % T_out) / T_out;
+            const float c = edge ? 1.f : 2.f;
+            ti[(size_t)t * mt + k].x = c * (float)cosl(a);
+            ti[(size_t)t * mt + k].y = edge ? 0.f : c * (float)sinl(a);
+        }
+    int rc;
+    if ((rc = upload_vec((void**)&p->tw_x, unit_roots(X))) || (rc = upload_vec((void**)&p->tw_y, unit_roots(Y))) ||
+        (rc = upload_vec((void**)&p->tw_tf, tf)) || (rc = upload_vec((void**)&p->tw_ti, ti))) {
+        tcfd_fno_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return 0;
+}
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ constexpr size_t al16c(size_t x) { return (x + 15) & ~(size_t)15; }
+
+extern "C" size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* p, int batch, int cin, int cout) {
+    if (!p) return 0;
+    const size_t Q = (size_t)2 * p->my * p->mt;
+    const int cmax = std::max(cin, cout);
+    const size_t w = al256((size_t)batch * cmax * p->X * Q * sizeof(cf));        // W1 / W2 (shared)
+    const size_t v = al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf));    // truncated input spectrum
+    const size_t o = al256((size_t)batch * cout * 2 * p->mx * Q * sizeof(cf));   // truncated output spectrum
+    return w + v + o;
+}
+
+// ------------------------------------------------------------------ forward: t DFT + y FFT, pruned
+// block = one (b, c, x) slab; thread = (kt, j): kt-th time mode, lane j of the G-lane Y-point transform.
+template <int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_fwd_ty(const float* __restrict__ v, cf* __restrict__ w1,
+                                                 const cf* __restrict__ tw_y, const cf* __restrict__ tw_tf, int T_in,
+                                                 int t_pad, int mt, int my, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int G = Y / EPT;
+    constexpr bool WG = (G > 64);
+    const int Tp = T_in + t_pad;
+    float* slab = reinterpret_cast<float*>(smem_raw);                               // [Y][T_in]
+    cf* twt = reinterpret_cast<cf*>(smem_raw + al16c((size_t)Y * T_in * 4));          // [mt][Tp]
+    cf* ex = twt + (size_t)mt * Tp;                                                  // exchange: mt * lds_elems
+    const int kt = threadIdx.x / G, j = threadIdx.x % G;
+    const size_t slab_elems = (size_t)Y * T_in;
+    const float* src = v + (size_t)blockIdx.x * slab_elems;
+    for (size_t i = threadIdx.x; i < slab_elems; i += blockDim.x) slab[i] = src[i];
+    for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
+    __syncthreads();
+    cf x[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int y = j + t * G;
+        float re = 0.f, im = 0.f;
+        const float* row = slab + (size_t)y * T_in;
+        const cf* w = twt + (size_t)kt * Tp + t_pad;  // the first t_pad samples are zeros (left padding)
+        for (int s = 0; s < T_in; ++s) {
+            re += row[s] * w[s].x;
+            im += row[s] * w[s].y;
+        }
+        x[t] = mk<float>(re * scale, im * scale);
+    }
+    cf* lds = ex + (size_t)kt * lds_elems<Y, EPT, 1, true>();
+    tile_fft<float, Y, EPT, -1, 1, true, WG>(x, lds, tw_y, j, 0);
+    const int Q = 2 * my * mt;
+    cf* dst = w1 + (size_t)blockIdx.x * Q;
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int ky = j + t * G;
+        int kyi = -1;
+        if (ky < my) kyi = ky;
+        else if (ky >= Y - my) kyi = ky - (Y - 2 * my);
+        if (kyi >= 0) dst[kyi * mt + kt] = x[t];
+    }
+}
+
+// ------------------------------------------------------------------ inverse: y IFFT + t inverse real DFT
+template <int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_inv_ty(const cf* __restrict__ w2, float* __restrict__ out,
+                                                 const cf* __restrict__ tw_y, const cf* __restrict__ tw_ti, int T_out,
+                                                 int t_keep, int mt, int my, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int G = Y / EPT;
+    constexpr bool WG = (G > 64);
+    cf* spec = reinterpret_cast<cf*>(smem_raw);                  // [Y][mt] physical-y, spectral-t
+    cf* twt = spec + (size_t)Y * mt;                             // [T_out][mt]
+    cf* ex = twt + (size_t)T_out * mt;                           // exchange
+    const int kt = threadIdx.x / G, j = threadIdx.x % G;
+    const int Q = 2 * my * mt;
+    const cf* src = w2 + (size_t)blockIdx.x * Q;
+    for (int i = threadIdx.x; i < T_out * mt; i += blockDim.x) twt[i] = tw_ti[i];
+    cf x[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int ky = j + t * G;
+        int kyi = -1;
+        if (ky < my) kyi = ky;
+        else if (ky >= Y - my) kyi = ky - (Y - 2 * my);
+        x[t] = kyi >= 0 ? src[kyi * mt + kt] : mk<float>(0.f, 0.f);
+    }
+    cf* lds = ex + (size_t)kt * lds_elems<Y, EPT, 1, true>();
+    tile_fft<float, Y, EPT, +1, 1, true, WG>(x, lds, tw_y, j, 0);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) spec[(size_t)(j + t * G) * mt + kt] = x[t];
+    __syncthreads();
+    // out[y][t] = scale * sum_k Re( spec[y][k] * twi[t][k] ),   t in the kept tail of [0, T_out)
+    const int t0 = T_out - t_keep;
+    float* dst = out + (size_t)blockIdx.x * Y * t_keep;
+    for (int i = threadIdx.x; i < Y * t_keep; i += blockDim.x) {
+        const int y = i / t_keep, tt = i % t_keep;
+        const cf* s = spec + (size_t)y * mt;
+        const cf* w = twt + (size_t)(t0 + tt) * mt;
+        float acc = 0.f;
+        for (int k = 0; k < mt; ++k) acc += s[k].x * w[k].x - s[k].y * w[k].y;
+        dst[i] = acc * scale;
+    }
+}
+
+// ------------------------------------------------------------------ x transforms on (X, Q) column tiles
+// FWD: in (b*c, X, Q) -> out (b*c, 2mx, Q) kept rows;  INV: in (b*c, 2mx, Q) -> out (b*c, X, Q)
+template <int X, int EPT, int C, bool FWD>
+__global__ __launch_bounds__(C*(X / EPT)) void k_x(const cf* __restrict__ in, cf* __restrict__ out,
+                                                   const cf* __restrict__ tw_x, int Q, int mx, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    constexpr int G = X / EPT;
+    const int c = threadIdx.x % C, j = threadIdx.x / C;
+    const int tile = blockIdx.x % ntiles;
+    const size_t bc = blockIdx.x / ntiles;
+    const int q = tile * C + c;
+    const bool valid = q < Q;
+    cf x[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int kx = j + t * G;
+        if constexpr (FWD) {
+            x[t] = valid ? in[(bc * X + kx) * Q + q] : mk<float>(0.f, 0.f);
+        } else {
+            int kxi = -1;
+            if (kx < mx) kxi = kx;
+            else if (kx >= X - mx) kxi = kx - (X - 2 * mx);
+            x[t] = (valid && kxi >= 0) ? in[(bc * 2 * mx + kxi) * Q + q] : mk<float>(0.f, 0.f);
+        }
+    }
+    tile_fft<float, X, EPT, FWD ? -1 : +1, C, false, true>(x, lds, tw_x, j, c);
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const int kx = j + t * G;
+            if constexpr (FWD) {
+                int kxi = -1;
+                if (kx < mx) kxi = kx;
+                else if (kx >= X - mx) kxi = kx - (X - 2 * mx);
+                if (kxi >= 0) out[(bc * 2 * mx + kxi) * Q + q] = x[t];
+            } else {
+                out[(bc * X + kx) * Q + q] = x[t];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ contraction
+struct ContractArgs {
+    const cf* vin;        // (b, ci, 2mx, 2my, mt)
+    cf* vout;             // (b, co, 2mx, 2my, mt)
+    const cf* w[4];       // (ci, co, mx, my, mt)  block index ix + 2*iy
+    const cf* bias[4];    // (mx, my, mt) or null
+    float delta;
+    int b, ci, co, mx, my, mt;
+};
+
+// Plain VALU form: one thread per (batch, out channel, mode); lanes run along the modes so both the
+// spectrum and the weight reads are contiguous.  Used for shapes the MFMA kernel does not cover and
+// as its cross-check.
+__global__ void k_contract_valu(ContractArgs a) {
+    const int M = 4 * a.mx * a.my * a.mt;  // kept modes per (b, channel)
+    const long total = (long)a.b * a.co * M;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int mode = (int)(idx % M);
+        const int o = (int)((idx / M) % a.co);
+        const int bb = (int)(idx / ((long)M * a.co));
+        const int kt = mode % a.mt;
+        const int kyi = (mode / a.mt) % (2 * a.my);
+        const int kxi = mode / (a.mt * 2 * a.my);
+        const int ix = kxi >= a.mx, iy = kyi >= a.my;
+        const int blk = ix + 2 * iy;
+        const int wm = ((kxi - ix * a.mx) * a.my + (kyi - iy * a.my)) * a.mt + kt;  // mode inside the block
+        const int MB = a.mx * a.my * a.mt;
+        const cf* w = a.w[blk];
+        float re = 0.f, im = 0.f;
+        for (int i = 0; i < a.ci; ++i) {
+            const cf xv = a.vin[((long)bb * a.ci + i) * M + mode];
+            const cf wv = w[((long)i * a.co + o) * MB + wm];
+            re += xv.x * wv.x - xv.y * wv.y;
+            im += xv.x * wv.y + xv.y * wv.x;
+        }
+        if (a.bias[blk]) {
+            const cf bv = a.bias[blk][wm];
+            re += a.delta * bv.x;
+            im += a.delta * bv.y;
+        }
+        a.vout[idx] = mk<float>(re, im);
+    }
+}
+
+// MFMA form (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain at the fp32 vector rate).
+// One wave owns one mode at a time: C[16 b x 16 o] += A[16 b x 4 i] * B[4 i x 16 o], complex product as
+// four real MFMA chains (rr, ii, ri, ir).  A workgroup stages, for NM consecutive modes of one
+// (block, kx, ky-run), the spectrum slice [b][ci][NM] and the weight slice [ci][co][NM] in LDS with
+// coalesced loads (lanes along the contiguous mode axis), then its waves sweep the modes.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NM>
+__global__ __launch_bounds__(256) void k_contract_mfma(ContractArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = 4 * a.mx * a.my * a.mt;
+    const int MB = a.mx * a.my * a.mt;
+    const int cip = (a.ci + 3) & ~3;        // K padded to a multiple of 4
+    const int bp = (a.b + 15) & ~15;        // M padded to a multiple of 16
+    const int cop = (a.co + 15) & ~15;      // N padded to a multiple of 16
+    // LDS: A[mode][bp][cip] complex, B[mode][cip][cop] complex (zero padded)
+    cf* As = reinterpret_cast<cf*>(smem_raw);
+    cf* Bs = As + (size_t)NM * bp * cip;
+    // this block's run of NM modes: runs never straddle a corner block (MB % NM == 0 is checked by the host)
+    const int run = blockIdx.x;
+    const int runs_per_blk = MB / NM;
+    const int blk = run / runs_per_blk;
+    const int wm0 = (run % runs_per_blk) * NM;               // first mode inside the weight block
+    const int ix = blk & 1, iy = blk >> 1;
+    const cf* w = a.w[blk];
+    // zero fill (padding) then stage
+    for (int i = threadIdx.x; i < NM * (bp * cip + cip * cop); i += blockDim.x) As[i] = mk<float>(0.f, 0.f);
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.b * a.ci * NM; i += blockDim.x) {
+        const int mm = i % NM, rest = i / NM;
+        const int wm = wm0 + mm;
+        const int kt = wm % a.mt, ky = (wm / a.mt) % a.my, kx = wm / (a.mt * a.my);
+        const int mode = ((kx + ix * a.mx) * 2 * a.my + (ky + iy * a.my)) * a.mt + kt;
+        const int ic = rest % a.ci, bb = rest / a.ci;
+        As[((size_t)mm * bp + bb) * cip + ic] = a.vin[((long)bb * a.ci + ic) * M + mode];
+    }
+    for (int i = threadIdx.x; i < a.ci * a.co * NM; i += blockDim.x) {
+        const int mm = i % NM, rest = i / NM;
+        const int o = rest % a.co, ic = rest / a.co;
+        Bs[((size_t)mm * cip + ic) * cop + o] = w[((long)ic * a.co + o) * MB + wm0 + mm];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    const int nwaves = blockDim.x / 64;
+    const int mt_tiles = bp / 16, nt_tiles = cop / 16;
+    for (int work = wave; work < NM * mt_tiles * nt_tiles; work += nwaves) {
+        const int mm = work / (mt_tiles * nt_tiles);
+        const int mtile = (work / nt_tiles) % mt_tiles, ntile = work % nt_tiles;
+        f32x4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0}, ir = {0, 0, 0, 0};
+        const cf* Am = As + (size_t)mm * bp * cip;
+        const cf* Bm = Bs + (size_t)mm * cip * cop;
+        for (int k0 = 0; k0 < cip; k0 += 4) {
+            // A operand: lane l holds A[m = l & 15][k = l >> 4];  B operand: B[k = l >> 4][n = l & 15]
+            const cf av = Am[(size_t)(mtile * 16 + (lane & 15)) * cip + k0 + (lane >> 4)];
+            const cf bv = Bm[(size_t)(k0 + (lane >> 4)) * cop + ntile * 16 + (lane & 15)];
+            rr = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, rr, 0, 0, 0);
+            ii = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, ii, 0, 0, 0);
+            ri = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.y, ri, 0, 0, 0);
+            ir = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.x, ir, 0, 0, 0);
+        }
+        // C/D layout: col n = lane & 15, row m = (lane >> 4) * 4 + r
+        const int wm = wm0 + mm;
+        const int kt = wm % a.mt, ky = (wm / a.mt) % a.my, kx = wm / (a.mt * a.my);
+        const int mode = ((kx + ix * a.mx) * 2 * a.my + (ky + iy * a.my)) * a.mt + kt;
+        const int o = ntile * 16 + (lane & 15);
+        cf bias = mk<float>(0.f, 0.f);
+        if (a.bias[blk]) bias = cscale(a.bias[blk][wm], a.delta);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bb = mtile * 16 + (lane >> 4) * 4 + r;
+            if (bb < a.b && o < a.co)
+                a.vout[((long)bb * a.co + o) * M + mode] = mk<float>(rr[r] - ii[r] + bias.x, ri[r] + ir[r] + bias.y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <typename K>
+static int set_lds_attr(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    return 0;
+}
+
+template <int Y>
+struct TyCfg {
+    static constexpr int EPT = Y >= 256 ? Y / 64 : (Y >= 32 ? 4 : 2);  // 64 lanes per transform when possible
+    static constexpr int G = Y / EPT;
+};
+
+template <int Y>
+static int launch_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float scale, hipStream_t st) {
+    constexpr int EPT = TyCfg<Y>::EPT, G = TyCfg<Y>::G;
+    const size_t lds = al16c((size_t)Y * p->T_in * 4) + ((size_t)p->mt * p->Tp + (size_t)p->mt * lds_elems<Y, EPT, 1, true>()) * sizeof(cf);
+    if (p->mt * G > 1024) return FAIL(TCFD_EINVAL, "fno: modes_t * %d lanes exceed a workgroup", G);
+    if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T=%d)", Y, p->T_in);
+    auto kern = k_fwd_ty<Y, EPT>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)slabs), dim3(p->mt * G), lds, st, v, w1, (const cf*)p->tw_y,
+                       (const cf*)p->tw_tf, p->T_in, p->t_pad, p->mt, p->my, scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int Y>
+static int launch_inv_ty(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float scale,
+                         hipStream_t st) {
+    constexpr int EPT = TyCfg<Y>::EPT, G = TyCfg<Y>::G;
+    const size_t lds = ((size_t)Y * p->mt + (size_t)p->T_out * p->mt + (size_t)p->mt * lds_elems<Y, EPT, 1, true>()) * sizeof(cf);
+    if (p->mt * G > 1024) return FAIL(TCFD_EINVAL, "fno: modes_t * %d lanes exceed a workgroup", G);
+    if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T_out=%d)", Y, p->T_out);
+    auto kern = k_inv_ty<Y, EPT>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)slabs), dim3(p->mt * G), lds, st, w2, out, (const cf*)p->tw_y,
+                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int X, bool FWD>
+static int launch_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
+    constexpr int EPT = X >= 512 ? 16 : (X >= 64 ? 8 : 4);
+    constexpr int C = 16;  // 16 complex64 = one 128-byte line
+    const int Q = 2 * p->my * p->mt;
+    const int ntiles = (Q + C - 1) / C;
+    constexpr size_t lds = (size_t)lds_elems<X, EPT, C, false>() * sizeof(cf);
+    auto kern = k_x<X, EPT, C, FWD>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(bc * ntiles)), dim3(C * (X / EPT)), lds, st, in, out, (const cf*)p->tw_x, Q,
+                       p->mx, ntiles);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+#define DISPATCH_POW2(n, CALL)                                              \
+    switch (n) {                                                            \
+        case 8: { constexpr int N_ = 8; return CALL; }                      \
+        case 16: { constexpr int N_ = 16; return CALL; }                    \
+        case 32: { constexpr int N_ = 32; return CALL; }                    \
+        case 64: { constexpr int N_ = 64; return CALL; }                    \
+        case 128: { constexpr int N_ = 128; return CALL; }                  \
+        case 256: { constexpr int N_ = 256; return CALL; }                  \
+        case 512: { constexpr int N_ = 512; return CALL; }                  \
+        case 1024: { constexpr int N_ = 1024; return CALL; }                \
+        default: return FAIL(TCFD_EINVAL, "unsupported transform length %d", n); \
+    }
+
+static int do_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float s, hipStream_t st) {
+    DISPATCH_POW2(p->Y, (launch_fwd_ty<N_>(p, v, w1, slabs, s, st)));
+}
+static int do_inv_ty(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float s, hipStream_t st) {
+    DISPATCH_POW2(p->Y, (launch_inv_ty<N_>(p, w2, out, slabs, t_keep, s, st)));
+}
+static int do_fwd_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
+    DISPATCH_POW2(p->X, (launch_x<N_, true>(p, in, out, bc, st)));
+}
+static int do_inv_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
+    DISPATCH_POW2(p->X, (launch_x<N_, false>(p, in, out, bc, st)));
+}
+
+static int do_contract(const tcfd_fno_plan* p, ContractArgs a, int use_mfma, hipStream_t st) {
+    const int MB = a.mx * a.my * a.mt;
+    constexpr int NM = 8;
+    const int cip = (a.ci + 3) & ~3, bp = (a.b + 15) & ~15, cop = (a.co + 15) & ~15;
+    const size_t lds = (size_t)NM * ((size_t)bp * cip + (size_t)cip * cop) * sizeof(cf);
+    if (use_mfma && MB % NM == 0 && lds <= 150 * 1024) {
+        auto kern = k_contract_mfma<NM>;
+        int rc = set_lds_attr(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(4 * MB / NM)), dim3(256), lds, st, a);
+    } else {
+        const long total = (long)a.b * a.co * 4 * MB;
+        const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_contract_valu, dim3(blocks), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Full spectral convolution.  v (b, ci, X, Y, T_in) fp32 -> out (b, co, X, Y, t_keep) fp32 (the last t_keep of
+// the T_out reconstructed steps).  weights[k] (ci, co, mx, my, mt, 2) fp32, bias[k] (mx, my, mt, 2) or NULL.
+// fwd_scale / inv_scale: normalisation of rfftn / irfftn ("backward": 1 and 1/(X*Y*T_out)).
+extern "C" int tcfd_fno_spectral_conv(const tcfd_fno_plan* p, const void* v, const void* const* weights,
+                                      const void* const* bias, float delta, void* out, int batch, int cin, int cout,
+                                      int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    if (!p || !v || !weights || !out) return FAIL(TCFD_EINVAL, "fno_spectral_conv: null argument");
+    if (batch <= 0 || cin <= 0 || cout <= 0 || t_keep <= 0 || t_keep > p->T_out)
+        return FAIL(TCFD_EINVAL, "fno_spectral_conv: bad sizes");
+    const size_t need = tcfd_fno_workspace_bytes(p, batch, cin, cout);
+    if (!ws || ws_bytes < need) return FAIL(TCFD_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t Q = (size_t)2 * p->my * p->mt;
+    const int cmax = std::max(cin, cout);
+    unsigned char* base = (unsigned char*)ws;
+    cf* W = (cf*)base;
+    cf* V = (cf*)(base + al256((size_t)batch * cmax * p->X * Q * sizeof(cf)));
+    cf* O = (cf*)((unsigned char*)V + al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf)));
+    int rc;
+    if ((rc = do_fwd_ty(p, (const float*)v, W, (long)batch * cin * p->X, fwd_scale, st))) return rc;
+    if ((rc = do_fwd_x(p, W, V, (long)batch * cin, st))) return rc;
+    ContractArgs a;
+    a.vin = V; a.vout = O;
+    for (int k = 0; k < 4; ++k) {
+        a.w[k] = (const cf*)weights[k];
+        a.bias[k] = bias ? (const cf*)bias[k] : nullptr;
+    }
+    a.delta = delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = p->mx; a.my = p->my; a.mt = p->mt;
+    if ((rc = do_contract(p, a, use_mfma, st))) return rc;
+    if ((rc = do_inv_x(p, O, W, (long)batch * cout, st))) return rc;
+    return do_inv_ty(p, W, (float*)out, (long)batch * cout * p->X, t_keep, inv_scale, st);
+}
+
+// Contraction alone on caller-provided truncated spectra (tests, MFMA vs VALU cross-check).
+extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, float delta,
+                                 void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,
+                                 void* stream) {
+    if (!vin || !weights || !vout) return FAIL(TCFD_EINVAL, "fno_contract: null argument");
+    ContractArgs a;
+    a.vin = (const cf*)vin; a.vout = (cf*)vout;
+    for (int k = 0; k < 4; ++k) {
+        a.w[k] = (const cf*)weights[k];
+        a.bias[k] = bias ? (const cf*)bias[k] : nullptr;
+    }
+    a.delta = delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
+    return do_contract(nullptr, a, use_mfma, (hipStream_t)stream);
+}

@@ -25,13 +25,14 @@ using namespace tcfd;
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int tcfd_set_error(int code, const char* fmt, ...) {  // shared with tcfd_fno.hip
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
+#define fail(...) tcfd_set_error(__VA_ARGS__)
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -112,6 +113,8 @@ struct ColArgs {
     int ntiles;
     int batch;
     int load_h;
+    int ablate;    // timing ablations (TCFD_ABLATE bit mask; results are WRONG when non-zero): 1 skip the
+                   // transforms, 2 skip the plane stores, 4 skip the table reads, 8 skip the h traffic
     int pair_xcd;  // block->tile map: 0 = batch fastest; 1 = adjacent half-line tiles paired on one XCD
 };
 
@@ -143,8 +146,8 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             if (f == 1) v = mk<T>(-v.x, -v.y);
             x[t] = valid ? v : mk<T>((T)0, (T)0);
         }
-        tile_fft<T, N, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
-        if (valid) {
+        if (!(a.ablate & 1)) tile_fft<T, N, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
+        if (valid && !(a.ablate & 2)) {
             cx<T>* dst = a.planes + (size_t)f * a.plane_stride + wbase;
 #pragma unroll
             for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.ldw] = x[t];
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
         for (int t = 0; t < EPT; ++t)
             x[t] = valid ? a.in[inbase + (size_t)(j + t * G) * in_ld] : mk<T>((T)0, (T)0);
         constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
-        tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+        if (!(a.ablate & 1)) tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
             if (valid) {
@@ -251,11 +254,12 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
                     const size_t tab = (size_t)i * a.m + jc;
                     const size_t g = colbase + (size_t)i * a.m;
                     const size_t gw = wbase + (size_t)i * a.ldw;
-                    cx<T> hn = cscale(x[t], a.mask[tab]);
-                    if (a.forcing) hn = hn + a.forcing[tab];
-                    if (a.load_h) hn = hn + cscale(a.h[gw], a.beta);
-                    a.h[gw] = hn;
-                    const T L = a.lin[tab];
+                    const bool tabs = !(a.ablate & 4);
+                    cx<T> hn = cscale(x[t], tabs ? a.mask[tab] : (T)1);
+                    if (a.forcing && tabs) hn = hn + a.forcing[tab];
+                    if (a.load_h && !(a.ablate & 8)) hn = hn + cscale(a.h[gw], a.beta);
+                    if (!(a.ablate & 8)) a.h[gw] = hn;
+                    const T L = tabs ? a.lin[tab] : (T)-0.5;
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                     cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
@@ -724,6 +728,8 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     }
     long blocks = batch * a.ntiles;
     a.pair_xcd = (C * sizeof(cx<T>) < 128) ? env_int("TCFD_PAIR_XCD", 1) : 0;
+    static const int ablate = env_int("TCFD_ABLATE", 0);
+    a.ablate = ablate;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
     ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C * G), lds, st, a);
@@ -813,8 +819,11 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
             default: break;
         }
     }
-    return launch_rows_advect_v<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch,
-                                                                                   st);
+    static const int legacy = env_int("TCFD_ROWS_LEGACY", 0);
+    if (legacy)
+        return launch_rows_advect_v<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv,
+                                                                                       batch, st);
+    return launch_rows_advect3<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch, st);
 }
 
 template <typename T>

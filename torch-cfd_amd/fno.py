@@ -1,0 +1,484 @@
+"""FNO / SFNO spectral layers on the HIP pruned-transform + MFMA-contraction kernels.
+
+Drop-in operator API for (same class names, constructor arguments, parameter
+names / shapes and ``state_dict`` keys):
+
+  * ``SpectralConv``      fno/base.py:114-237   (template: rfftn -> spectral_conv -> irfftn)
+  * ``SpectralConvS``     fno/sfno.py:331-394
+  * ``SpectralConvT``     fno/sfno.py:397-457   (time padding / arbitrary output steps)
+  * ``SpectralConv3d``    fno/fno3d.py:19-116   (4 complex ``weights1..4`` parameters)
+  * ``LayerNormnd``, ``PointwiseFFN``, ``SpaceTimePositionalEncoding``, ``HelmholtzProjection``,
+    ``LiftingOperator``, ``OutConv``, ``SFNO``   fno/base.py:61-111, fno/sfno.py:25-328, 460-620
+
+The spectral convolutions call ``tcfd_fno_spectral_conv`` (include/tcfd.h): five
+kernels that read and write the (b, C, X, Y, T) activations exactly once instead
+of the reference's full rfftn / zero-filled spectrum / irfftn.  Forward only, fp32,
+HIP device tensors, X and Y powers of two; anything else raises (no fallback).
+The pointwise layers around them (1x1x1 convolutions, GroupNorm, activations) are
+ordinary torch modules running on the same device.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import weakref
+from copy import deepcopy
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+conv_dict = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
+ActivationType = Union[str]
+
+
+# ----------------------------------------------------------------------------- HIP plan cache
+class _FnoPlan:
+    def __init__(self, key, device):
+        X, Y, T_in, t_pad, T_out, mx, my, mt = key
+        self.lib = _lib.load()
+        self.key = key
+        self.device = torch.device(device)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.tcfd_fno_plan_create(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt)
+        _lib.check(rc, "tcfd_fno_plan_create")
+        self.handle = handle
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._fin = weakref.finalize(self, self.lib.tcfd_fno_plan_destroy, handle)
+
+    def workspace(self, b, ci, co):
+        k = (b, ci, co)
+        ws = self._ws.get(k)
+        if ws is None:
+            n = self.lib.tcfd_fno_workspace_bytes(self.handle, b, ci, co)
+            self._ws = {k: torch.empty(n, dtype=torch.uint8, device=self.device)}
+            ws = self._ws[k]
+        return ws
+
+
+_PLANS: Dict[tuple, _FnoPlan] = {}
+
+
+def _plan(key, device) -> _FnoPlan:
+    full = key + (torch.device(device),)
+    p = _PLANS.get(full)
+    if p is None:
+        p = _FnoPlan(key, device)
+        _PLANS[full] = p
+    return p
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * 4)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _norm_scales(norm: str, n_in: int, n_out: int) -> Tuple[float, float]:
+    if norm in (None, "backward"):
+        return 1.0, 1.0 / n_out
+    if norm == "ortho":
+        return 1.0 / math.sqrt(n_in), 1.0 / math.sqrt(n_out)
+    if norm == "forward":
+        return 1.0 / n_in, 1.0
+    raise ValueError(f"unknown fft norm {norm!r}")
+
+
+def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad: int = 0,
+                      t_out: Optional[int] = None, t_keep: Optional[int] = None, norm: str = "backward",
+                      use_mfma: bool = True) -> torch.Tensor:
+    """irfftn(contract(rfftn(left_pad_t(v, t_pad))), s=(X, Y, t_out))[..., -t_keep:] on the HIP kernels.
+
+    v (b, Ci, X, Y, T) fp32 HIP tensor; weights: 4 tensors (Ci, Co, mx, my, mt) complex64 or
+    (Ci, Co, mx, my, mt, 2) fp32; bias: None or 4 tensors (mx, my, mt[, 2])."""
+    if not v.is_cuda:
+        raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+    if v.dtype != torch.float32:
+        raise TypeError(f"the HIP spectral convolution is fp32 only, got {v.dtype}")
+    if torch.is_grad_enabled() and (v.requires_grad or any(w.requires_grad for w in weights)):
+        raise _lib.TcfdError("the HIP spectral convolution is forward-only: call it under torch.no_grad()")
+    if v.dim() != 5:
+        raise ValueError(f"expected (b, C, X, Y, T), got {tuple(v.shape)}")
+    b, ci, X, Y, T = v.shape
+    mx, my, mt = modes
+    co = weights[0].shape[1]
+    t_out = T + t_pad if t_out is None else t_out
+    t_keep = t_out if t_keep is None else t_keep
+    v = v.detach().contiguous()
+
+    def as_real(w, shape):
+        w = w.detach()
+        if w.is_complex():
+            w = torch.view_as_real(w)
+        w = w.to(torch.float32).contiguous()
+        if tuple(w.shape) != shape:
+            raise ValueError(f"weight/bias shape {tuple(w.shape)} != {shape}")
+        return w
+
+    ws_ = [as_real(w, (ci, co, mx, my, mt, 2)) for w in weights]
+    bs_ = [as_real(x, (mx, my, mt, 2)) for x in bias] if bias is not None else None
+    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device)
+    out = torch.empty(b, co, X, Y, t_keep, dtype=torch.float32, device=v.device)
+    ws = plan.workspace(b, ci, co)
+    fs, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    with torch.cuda.device(v.device):
+        rc = plan.lib.tcfd_fno_spectral_conv(
+            plan.handle, v.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None,
+            float(delta), out.data_ptr(), b, ci, co, t_keep, fs, is_, 1 if use_mfma else 0,
+            ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+    _lib.check(rc, "tcfd_fno_spectral_conv")
+    return out
+
+
+def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -> torch.Tensor:
+    """The 4-corner contraction alone on truncated spectra (b, Ci, 2mx, 2my, mt) complex64."""
+    b, ci = vh.shape[:2]
+    mx, my, mt = modes
+    co = weights[0].shape[1]
+    vh = vh.contiguous()
+    ws_ = [torch.view_as_real(w).contiguous() if w.is_complex() else w.contiguous() for w in weights]
+    bs_ = None
+    if bias is not None:
+        bs_ = [torch.view_as_real(x).contiguous() if x.is_complex() else x.contiguous() for x in bias]
+    out = torch.empty(b, co, 2 * mx, 2 * my, mt, dtype=torch.complex64, device=vh.device)
+    lib = _lib.load()
+    with torch.cuda.device(vh.device):
+        rc = lib.tcfd_fno_contract(vh.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None,
+                                   float(delta), out.data_ptr(), b, ci, co, mx, my, mt, 1 if use_mfma else 0,
+                                   ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
+    _lib.check(rc, "tcfd_fno_contract")
+    return out
+
+
+# ----------------------------------------------------------------------------- pointwise helpers
+class LayerNormnd(nn.GroupNorm):
+    """GroupNorm with one group used as a LayerNorm over (C, *spatial)."""
+
+    def __init__(self, num_channels, eps=1e-07, elementwise_affine=True, device=None, dtype=None):
+        super().__init__(num_groups=1, num_channels=num_channels, eps=eps, affine=elementwise_affine,
+                         device=device, dtype=dtype)
+
+
+class PointwiseFFN(nn.Module):
+    """Two 1x1 convolutions with a channel expansion and an activation in between."""
+
+    def __init__(self, in_channels: int, out_channels: int, mid_channels: int, activation: ActivationType = "ReLU",
+                 dim: int = 3):
+        super().__init__()
+        if dim not in conv_dict:
+            raise ValueError(f"Unsupported dimension: {dim}, expected 1, 2, or 3")
+        Conv = conv_dict[dim]
+        self.linear1 = Conv(in_channels, mid_channels, 1)
+        self.linear2 = Conv(mid_channels, out_channels, 1)
+        self.activation = getattr(nn, activation)()
+
+    def forward(self, v):
+        return self.linear2(self.activation(self.linear1(v)))
+
+
+# ----------------------------------------------------------------------------- spectral convolutions
+class SpectralConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, modes: List[int], dim: int, bias: bool = False,
+                 norm: str = "backward") -> None:
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.dim = dim
+        self.bias = bias
+        self.norm = norm
+        assert len(modes) == dim, "modes should match the dimension"
+        if dim != 3:
+            raise NotImplementedError("the HIP spectral convolution covers the (2+1)-D layer (dim=3)")
+        size = [in_channels, out_channels, *modes, 2]
+        gain = 0.5 / (in_channels * out_channels)
+        self._initialize_weights(size, gain)
+
+    def _initialize_weights(self, size, gain=1e-4):
+        n_blocks = 2 * (self.dim - 1)
+        self.weight = nn.ParameterList([nn.Parameter(gain * torch.rand(*size)) for _ in range(n_blocks)])
+        if self.bias:
+            self.bias = nn.ParameterList([nn.Parameter(gain * torch.zeros(*size[2:])) for _ in range(n_blocks)])
+
+    def _bias_list(self):
+        return list(self.bias) if isinstance(self.bias, nn.ParameterList) else None
+
+
+class SpectralConvS(SpectralConv):
+    def __init__(self, in_channels: int, out_channels: int, modes_x: int, modes_y: int, modes_t: int, dim: int = 3,
+                 bias: bool = False, delta: float = 1, norm="backward") -> None:
+        super().__init__(in_channels=in_channels, out_channels=out_channels, modes=(modes_x, modes_y, modes_t),
+                         dim=dim, bias=bias, norm=norm)
+        self.modes_x, self.modes_y, self.modes_t = modes_x, modes_y, modes_t
+        self.delta = delta
+
+    @property
+    def modes(self):
+        return (self.modes_x, self.modes_y, self.modes_t)
+
+    def spectral_conv(self, vh, kx: int = None, ky: int = None, kt: int = None):
+        """Contraction on an ALREADY TRUNCATED spectrum (b, Ci, 2mx, 2my, mt) -> (b, Co, 2mx, 2my, mt)."""
+        return hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
+
+    def forward(self, v, out_mesh_size=None, **kwargs):
+        t_out = None
+        if out_mesh_size is not None:
+            if tuple(out_mesh_size[:2]) != tuple(v.shape[-3:-1]):
+                raise NotImplementedError("spatial resampling in SpectralConv.forward is not supported on the HIP path")
+            t_out = out_mesh_size[-1]
+        return hip_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_out=t_out,
+                                 norm=self.norm)
+
+
+class SpectralConvT(SpectralConvS):
+    def __init__(self, in_channels: int, out_channels: int, modes_x: int, modes_y: int, modes_t: int,
+                 delta: float = 1e-1, out_steps: int = None, norm: str = "backward", bias: bool = True,
+                 temporal_padding: bool = False, postprocess: nn.Module = nn.Identity(), **kwargs) -> None:
+        super().__init__(in_channels, out_channels, modes_x, modes_y, modes_t, norm=norm, delta=delta, bias=bias)
+        self.out_steps = out_steps
+        self.temporal_padding = temporal_padding
+        self.postprocess = postprocess
+
+    def forward(self, v, out_steps: int = None):
+        if not isinstance(self.postprocess, nn.Identity):
+            raise NotImplementedError("spectral post-processing (Helmholtz projection, out_dim=2) is not on the HIP path yet")
+        if out_steps is None and self.out_steps is not None:
+            out_steps = self.out_steps
+        t_pad = v.size(-1) if self.temporal_padding else 0
+        return hip_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad=t_pad,
+                                 t_out=out_steps + t_pad, t_keep=out_steps, norm=self.norm)
+
+
+class SpectralConv3d(nn.Module):
+    """The original FNO3d Fourier layer: 4 complex weight blocks ``weights1..4``."""
+
+    def __init__(self, in_channels, out_channels, modes1, modes2, modes3):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.modes1, self.modes2, self.modes3 = modes1, modes2, modes3
+        self.scale = 1 / (in_channels * out_channels)
+        shape = (in_channels, out_channels, modes1, modes2, modes3)
+        for k in (1, 2, 3, 4):
+            setattr(self, f"weights{k}", nn.Parameter(self.scale * torch.rand(*shape, dtype=torch.cfloat)))
+
+    def forward(self, x):
+        w = [self.weights1, self.weights2, self.weights3, self.weights4]
+        return hip_spectral_conv(x, w, None, 1.0, (self.modes1, self.modes2, self.modes3))
+
+
+# ----------------------------------------------------------------------------- SFNO
+class SpaceTimePositionalEncoding(nn.Module):
+    """Channels [x, y, t, e^{beta t} sin/cos(pi (k+1) t) ...] added to the single input channel
+    (fno/sfno.py:25-113; the random-feature variant :62-88 is supported too)."""
+
+    def __init__(self, modes_x: int = 16, modes_y: int = 16, modes_t: int = 5, num_channels: int = 20,
+                 input_shape=(64, 64, 10), spatial_random_feats: bool = False, max_time_steps: int = 100,
+                 time_exponential_scale: float = 1e-2, **kwargs):
+        super().__init__()
+        assert num_channels % 2 == 0 and num_channels > 3
+        self.num_channels = num_channels
+        self.max_time_steps = max_time_steps
+        self.time_exponential_scale = time_exponential_scale
+        self.modes_x, self.modes_y, self.modes_t = modes_x, modes_y, modes_t
+        self.spatial_random_feats = spatial_random_feats
+        self._build(*input_shape)
+        if spatial_random_feats:
+            self.proj = nn.Conv3d(modes_x * modes_y * modes_t + 3, num_channels, kernel_size=1)
+        else:
+            self.proj = nn.Identity()
+
+    def _build(self, nx, ny, nt):
+        gx = torch.linspace(0, 1, nx)
+        gy = torch.linspace(0, 1, ny)
+        gt = torch.linspace(0, 1, self.max_time_steps + 1)[1: nt + 1]
+        X, Y, Tt = torch.meshgrid(gx, gy, gt, indexing="ij")
+        pe = [X, Y, Tt]
+        if self.spatial_random_feats:
+            for i in range(1, self.modes_x + 1):
+                bx = torch.sin if i % 2 == 0 else torch.cos
+                for j in range(1, self.modes_y + 1):
+                    by = torch.sin if j % 2 == 0 else torch.cos
+                    for k in range(1, self.modes_t + 1):
+                        bt = torch.sin if k % 2 == 0 else torch.cos
+                        pe.append(1 / (i * j * k) * torch.exp(self.time_exponential_scale * Tt)
+                                  * bx(torch.pi * i * X) * by(torch.pi * j * Y) * bt(torch.pi * k * Tt))
+        else:
+            for k in range(self.num_channels - 3):
+                basis = torch.sin if k % 2 == 0 else torch.cos
+                col = torch.exp(self.time_exponential_scale * gt) * basis(torch.pi * (k + 1) * gt)
+                pe.append(col.reshape(1, 1, nt).repeat(nx, ny, 1))
+        self.pe = torch.stack(pe).unsqueeze(0)
+
+    def forward(self, v):
+        if self.pe is None or self.pe.shape[-3:] != v.shape[-3:]:
+            self._build(*v.shape[-3:])
+        if self.pe.device != v.device or self.pe.dtype != v.dtype:
+            self.pe = self.pe.to(device=v.device, dtype=v.dtype)  # keep the table resident on the device
+        return v + self.proj(self.pe)
+
+
+class HelmholtzProjection(nn.Module):
+    """Divergence-free projection in Fourier space, w^ = u^ - grad div u^ / lap (fno/sfno.py:116-193);
+    element-wise device ops."""
+
+    def __init__(self, n_grid: int = 64, diam: float = 2 * torch.pi, dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.n_grid, self.diam = n_grid, diam
+        self._update_fft_mesh(n_grid, diam, dtype)
+
+    def _update_fft_mesh(self, n, diam=None, dtype=torch.float32):
+        diam = diam if diam is not None else self.diam
+        k = torch.fft.fftfreq(n, d=diam / n)
+        kx, ky = torch.meshgrid([k, k], indexing="ij")
+        lap = -4 * (torch.pi**2) * (abs(kx) ** 2 + abs(ky) ** 2)
+        lap[..., 0, 0] = 1
+        dev = self.lap.device if hasattr(self, "lap") else None
+        for name, val in (("lap", lap), ("kx", kx), ("ky", ky)):
+            val = val.to(dtype).to(dev) if dev is not None else val.to(dtype)
+            if hasattr(self, name):
+                setattr(self, name, val)
+            else:
+                self.register_buffer(name, val)
+
+    @staticmethod
+    def div(uhat, fft_mesh):
+        kx, ky = (z[None, :, :, None] for z in fft_mesh)
+        return 2j * torch.pi * (uhat[:, 0] * kx + uhat[:, 1] * ky)
+
+    @staticmethod
+    def grad(uhat, fft_mesh):
+        kx, ky = (z[None, :, :, None] for z in fft_mesh)
+        return torch.stack((2j * torch.pi * kx * uhat, 2j * torch.pi * ky * uhat), dim=1)
+
+    def forward(self, uhat):
+        nx = uhat.shape[2]
+        mesh = (self.kx, self.ky)
+        if nx != self.n_grid:
+            self._update_fft_mesh(nx)
+        g = self.grad(self.div(uhat, mesh), mesh)
+        return uhat - g / self.lap[None, None, :, :, None]
+
+
+class LiftingOperator(nn.Module):
+    def __init__(self, width: int, modes_x: int, modes_y: int, modes_t: int, latent_steps: int = 10,
+                 norm: str = "backward", activation: ActivationType = "GELU", beta: float = 0.1,
+                 spatial_random_feats: bool = False, channel_expansion: int = 4, nonlinear: bool = True, **kwargs):
+        super().__init__()
+        pe_modes_t = modes_t - 1 if modes_t % 2 != 0 else modes_t
+        self.pe = SpaceTimePositionalEncoding(modes_x // 2, modes_y // 2, pe_modes_t // 2, num_channels=width,
+                                              time_exponential_scale=beta,
+                                              spatial_random_feats=spatial_random_feats)
+        in_channels = self.pe.num_channels
+        self.norm = LayerNormnd(in_channels)
+        self.proj = nn.Conv3d(in_channels, width, kernel_size=1)
+        self.sconv = SpectralConvT(width, width, modes_x, modes_y, modes_t, out_steps=latent_steps, norm=norm,
+                                   bias=False)
+        self.latent_steps = latent_steps
+        if nonlinear:
+            self.activation = getattr(nn, activation)()
+            self.mlp = PointwiseFFN(width, width, channel_expansion * width, activation)
+        else:
+            self.activation = nn.Identity()
+            self.mlp = nn.Conv3d(width, width, kernel_size=1)
+
+    def forward(self, v):
+        assert self.latent_steps <= v.size(-1)
+        v = self.proj(self.norm(self.pe(v)))
+        w = self.mlp(self.sconv(v))
+        return self.activation(v[..., -1:] + w)
+
+
+class OutConv(nn.Module):
+    def __init__(self, modes_x: int, modes_y: int, modes_t: int, delta: float = 0.1, out_dim: int = 1,
+                 diam: float = 1, n_grid: int = 64, out_steps: int = None, spatial_padding: int = 0,
+                 temporal_padding: bool = True, norm: str = "backward", **kwargs):
+        super().__init__()
+        self.size = [out_dim, out_dim, modes_x, modes_y, modes_t]
+        postprocess = HelmholtzProjection(n_grid=n_grid, diam=diam) if out_dim == 2 else nn.Identity()
+        self.conv = SpectralConvT(*self.size, norm=norm, delta=delta, out_steps=out_steps, bias=True,
+                                  temporal_padding=temporal_padding, postprocess=postprocess)
+        self.n_grid, self.norm, self.delta = n_grid, norm, delta
+        self.spatial_padding, self.temporal_padding = spatial_padding, temporal_padding
+
+    def forward(self, v, v_res, out_steps: int, **kwargs):
+        v_res = v_res.unsqueeze(1).expand(-1, v.size(1), -1, -1, -1)
+        v = torch.cat([v_res[..., -1:], v], dim=-1)
+        sp = self.spatial_padding
+        if sp > 0:
+            v = F.pad(v, pad=(0, 0, sp, sp, sp, sp), mode="constant")
+        v = self.conv(v, out_steps=out_steps + 1)
+        if sp > 0:
+            v = v[..., sp:-sp, sp:-sp, :]
+        v = v_res[..., -1:] + v[..., -out_steps:]
+        return v.squeeze(1)
+
+
+class FNOBase(nn.Module):
+    def __init__(self, *, num_spectral_layers: int = 4, fft_norm="backward", activation: ActivationType = "ReLU",
+                 spatial_padding: int = 0, channel_expansion: int = 4, spatial_random_feats: bool = False,
+                 lift_activation: bool = False, debug=False, **kwargs):
+        super().__init__()
+        self.spatial_padding = spatial_padding
+        self.fft_norm = fft_norm
+        self.activation = activation
+        self.spatial_random_feats = spatial_random_feats
+        self.lift_activation = lift_activation
+        self.channel_expansion = channel_expansion
+        self.debug = debug
+        self.num_spectral_layers = num_spectral_layers
+
+    @staticmethod
+    def _set_modulelist(module, num_layers, *args):
+        return nn.ModuleList([deepcopy(module(*args)) for _ in range(num_layers)])
+
+    def _set_spectral_layers(self, num_layers, modes, width, activation, spectral_conv, mlp, linear,
+                             channel_expansion: int = 4):
+        act = getattr(nn, activation)
+        for attr, module, args in zip(
+            ["spectral_conv", "mlp", "w", "activations"], [spectral_conv, mlp, linear, act],
+            [(width, width, *modes), (width, width, channel_expansion * width, activation), (width, width, 1), ()],
+        ):
+            setattr(self, attr, self._set_modulelist(module, num_layers, *args))
+
+
+class SFNO(FNOBase):
+    """Spectral-refiner FNO for (2+1)-D fields: (b, x, y, t_in) -> (b, x, y, out_steps)."""
+
+    def __init__(self, modes_x: int, modes_y: int, modes_t: int, width: int, out_dim: int = 1, beta: float = -1e-2,
+                 delta: float = 1e-1, num_spectral_layers: int = 4, fft_norm: str = "backward",
+                 activation: ActivationType = "ReLU", spatial_padding: int = 0, temporal_padding: bool = True,
+                 channel_expansion: int = 4, spatial_random_feats: bool = False, lift_activation: bool = True,
+                 latent_steps: int = 10, output_steps: int = None, debug=False, **kwargs):
+        super().__init__(num_spectral_layers=num_spectral_layers, fft_norm=fft_norm, activation=activation,
+                         spatial_padding=spatial_padding, channel_expansion=channel_expansion,
+                         spatial_random_feats=spatial_random_feats, lift_activation=lift_activation, debug=debug,
+                         **kwargs)
+        self.modes_x, self.modes_y, self.modes_t, self.width = modes_x, modes_y, modes_t, width
+        assert num_spectral_layers > 1
+        num_spectral_layers -= 1  # the lifting operator holds the first spectral convolution
+        self._set_spectral_layers(num_spectral_layers, [modes_x, modes_y, modes_t], width, spectral_conv=SpectralConvS,
+                                  mlp=PointwiseFFN, linear=nn.Conv3d, activation=activation,
+                                  channel_expansion=channel_expansion)
+        self.lifting_operator = LiftingOperator(width, modes_x, modes_y, modes_t, latent_steps=latent_steps,
+                                                norm=fft_norm, beta=beta, activation=activation,
+                                                spatial_random_feats=spatial_random_feats,
+                                                channel_expansion=channel_expansion, nonlinear=lift_activation)
+        self.output_operator = OutConv(modes_x, modes_y, modes_t, out_dim=out_dim, delta=delta,
+                                       out_steps=output_steps, spatial_padding=spatial_padding,
+                                       temporal_padding=temporal_padding, norm=fft_norm)
+        self.reduction = nn.Conv3d(width, 1, kernel_size=1)
+        self.out_steps = output_steps
+
+    def forward(self, v, out_steps=None):
+        if out_steps is None:
+            out_steps = self.out_steps if self.out_steps is not None else v.size(-1)
+        v_res = v
+        v = self.lifting_operator(v.unsqueeze(1))
+        for conv, mlp, w, act in zip(self.spectral_conv, self.mlp, self.w, self.activations):
+            v = act(mlp(conv(v)) + w(v))
+        v = self.reduction(v)
+        return self.output_operator(v, v_res, out_steps=out_steps)
