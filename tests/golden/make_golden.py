@@ -207,8 +207,8 @@ def gen_fno():
             out[f"{key}_sd_{k}"] = npy(v)
 
     with torch.no_grad():
-        # (b, Ci, X, Y, T) = (2, 3, 16, 12, 10), Co = 4, modes (4, 3, 3): X != Y and Ci != Co catch transposes
-        x = torch.randn(2, 3, 16, 12, 10, generator=g)
+        # (b, Ci, X, Y, T) = (2, 3, 16, 8, 10), Co = 4, modes (4, 3, 3): X != Y and Ci != Co catch transposes
+        x = torch.randn(2, 3, 16, 8, 10, generator=g)
         torch.manual_seed(0)
         m = SpectralConv3d(3, 4, 4, 3, 3)
         out["conv3d_x"] = npy(x); sd(m, "conv3d"); out["conv3d_y"] = npy(m(x))

@@ -1,0 +1,155 @@
+"""GPU parity tests of the HIP spectral convolution (pruned transforms + MFMA contraction) against
+reference-generated golden vectors and the CPU oracle.  Tolerance: rel-L2 <= 1e-5 (north_star: FNO
+forward within 1e-5), fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def load_sd(mod, g, key, dev):
+    sd = {k: torch.from_numpy(g[f"{key}_sd_{k}"]) for k in mod.state_dict().keys()}
+    mod.load_state_dict(sd)
+    return mod.to(dev)
+
+
+def test_state_dict_layout_matches_reference():
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_layers.npz")
+    for key, mod in (("conv3d", fno.SpectralConv3d(3, 4, 4, 3, 3)),
+                     ("convS_bias1", fno.SpectralConvS(3, 4, 4, 3, 3, bias=True)),
+                     ("convT_pad1_s20", fno.SpectralConvT(3, 4, 4, 3, 3, bias=True, temporal_padding=True))):
+        ref_keys = sorted(k[len(key) + 4:] for k in g.files if k.startswith(key + "_sd_"))
+        assert sorted(mod.state_dict().keys()) == ref_keys
+        for k, v in mod.state_dict().items():
+            assert tuple(v.shape) == g[f"{key}_sd_{k}"].shape and str(v.dtype).endswith(str(g[f"{key}_sd_{k}"].dtype))
+
+
+def test_spectral_conv3d_golden(dev):
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_layers.npz")
+    m = load_sd(fno.SpectralConv3d(3, 4, 4, 3, 3), g, "conv3d", dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["conv3d_x"]).to(dev))
+    assert y.shape == (2, 4, 16, 8, 10) and y.dtype == torch.float32
+    assert rel_l2(y, g["conv3d_y"]) < TOL
+
+
+@pytest.mark.parametrize("bias", [0, 1])
+def test_spectral_conv_s_golden(bias, dev):
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_layers.npz")
+    key = f"convS_bias{bias}"
+    m = load_sd(fno.SpectralConvS(3, 4, 4, 3, 3, bias=bool(bias), delta=0.5), g, key, dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g[key + "_x"]).to(dev))
+    assert rel_l2(y, g[key + "_y"]) < TOL
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+@pytest.mark.parametrize("steps", [10, 20, 40])
+def test_spectral_conv_t_golden(pad, steps, dev):
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_layers.npz")
+    key = f"convT_pad{pad}_s{steps}"
+    m = load_sd(fno.SpectralConvT(3, 4, 4, 3, 3, delta=0.1, bias=True, temporal_padding=bool(pad)), g, key, dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g[key + "_x"]).to(dev), out_steps=steps)
+    assert y.shape == (2, 4, 16, 8, steps)
+    assert rel_l2(y, g[key + "_y"]) < TOL
+
+
+def test_config5_shaped_layer_golden(dev):
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_layers.npz")
+    m = load_sd(fno.SpectralConvS(4, 4, 24, 24, 5), g, "convS_c5", dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["convS_c5_x"]).to(dev))
+    assert rel_l2(y, g["convS_c5_y"]) < TOL
+
+
+@pytest.mark.parametrize("b,ci,co,X,Y,T,modes", [
+    (3, 5, 7, 32, 64, 10, (6, 9, 4)),       # odd channel counts, X != Y
+    (32, 10, 10, 64, 64, 10, (24, 24, 5)),  # BASELINE config 5 channel/mode shape on a 64^2 grid
+    (2, 1, 1, 128, 128, 22, (24, 24, 5)),   # OutConv shape: one channel, T = 2*(10+1)
+    (1, 17, 3, 16, 16, 7, (8, 8, 4)),       # 2*modes == grid, ci > 16
+])
+def test_against_oracle(b, ci, co, X, Y, T, modes, dev):
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    g = torch.Generator().manual_seed(b * 1000 + ci)
+    v = torch.randn(b, ci, X, Y, T, generator=g)
+    w = [torch.view_as_complex(torch.rand(ci, co, *modes, 2, generator=g) / (ci * co)) for _ in range(4)]
+    bias = [torch.view_as_complex(torch.randn(*modes, 2, generator=g) * 0.1) for _ in range(4)]
+    ref = OF.spectral_conv(v, w, modes, bias, delta=0.3)
+    with torch.no_grad():
+        for mfma in (True, False):
+            y = fno.hip_spectral_conv(v.to(dev), [x.to(dev) for x in w], [x.to(dev) for x in bias], 0.3, modes,
+                                      use_mfma=mfma)
+            assert rel_l2(y, ref) < TOL, mfma
+        # time resampling with left padding (SpectralConvT / OutConv path)
+        ref_t = OF.spectral_conv_t(v, w, modes, bias, delta=0.3, out_steps=T + 3, temporal_padding=True)
+        y = fno.hip_spectral_conv(v.to(dev), [x.to(dev) for x in w], [x.to(dev) for x in bias], 0.3, modes,
+                                  t_pad=T, t_out=2 * T + 3, t_keep=T + 3)
+        assert rel_l2(y, ref_t) < TOL
+
+
+def test_contraction_mfma_equals_valu_and_oracle(dev):
+    """Transpose-detecting check of the MFMA fragment layout: asymmetric sizes and weights."""
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    g = torch.Generator().manual_seed(5)
+    b, ci, co, modes = 19, 6, 11, (4, 6, 4)
+    mx, my, mt = modes
+    vh = torch.view_as_complex(torch.randn(b, ci, 2 * mx, 2 * my, mt, 2, generator=g))
+    w = [torch.view_as_complex(torch.randn(ci, co, *modes, 2, generator=g)) for _ in range(4)]
+    # oracle on a "full" spectrum whose kept corners are vh
+    X, Y = 2 * mx, 2 * my
+    ref = OF.spectral_contract(vh, w, modes)
+    a = fno.hip_contract(vh.to(dev), [x.to(dev) for x in w], None, 1.0, modes, use_mfma=True)
+    c = fno.hip_contract(vh.to(dev), [x.to(dev) for x in w], None, 1.0, modes, use_mfma=False)
+    assert rel_l2(c, ref) < 1e-6
+    assert rel_l2(a, ref) < 1e-6
+
+
+def test_linearity_and_zero_input(dev):
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(0)
+    m = fno.SpectralConvS(4, 4, 12, 12, 5).to(dev)
+    with torch.no_grad():
+        a = torch.randn(2, 4, 256, 256, 10, device=dev)
+        b = torch.randn(2, 4, 256, 256, 10, device=dev)
+        assert rel_l2(m(2 * a - b), 2 * m(a) - m(b)) < 1e-5
+        assert m(torch.zeros_like(a)).abs().max().item() == 0.0
+
+
+def test_errors_are_loud(dev):
+    from torch_cfd_amd import _lib, fno
+
+    m = fno.SpectralConvS(2, 2, 4, 4, 3).to(dev)
+    with pytest.raises(_lib.TcfdError):
+        m(torch.randn(1, 2, 16, 16, 10))  # CPU tensor
+    with pytest.raises(_lib.TcfdError):
+        m(torch.randn(1, 2, 16, 16, 10, device=dev))  # grad enabled + parameters require grad
+    with torch.no_grad():
+        with pytest.raises(_lib.TcfdError, match="powers of two"):
+            m(torch.randn(1, 2, 24, 16, 10, device=dev))
+        with pytest.raises(TypeError):
+            m(torch.randn(1, 2, 16, 16, 10, device=dev, dtype=torch.float64))

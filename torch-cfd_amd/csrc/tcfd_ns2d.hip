@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../include/tcfd.h"
@@ -100,7 +101,16 @@ struct ColArgs {
     const T* ky;          // [m]
     const T* lin;         // [n*m]
     const T* mask;        // [n*m]
-    const cx<T>* forcing; // [n*m] or null
+    const cx<T>* forcing; // [n*m] or null (dense form)
+    // separable / sparse forms of the same tables (chosen at plan creation when they are exact):
+    const T* mask_r;      // [n], mask = mask_r[i] * mask_c[j]
+    const T* mask_c;      // [m]
+    const T* lin_r;       // [n], linear_term = lin_r[i] + lin_c[j]
+    const T* lin_c;       // [m]
+    const int* f_ptr;     // [m+1] CSC column pointers of the non-zero forcing entries, or null
+    const int* f_row;     // [nnz]
+    const cx<T>* f_val;   // [nnz]
+    int sep;              // 1: use the separable mask / linear term
     const cx<T>* tw;      // [n]
     size_t plane_stride;  // elements between planes
     T beta, gdt, mu, scale;
@@ -137,7 +147,7 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             if (f < 2) {  // stream function: psi = -w / lap, lap(0,0) patched to 1
                 T lap = M4PI2 * (kx * kx + ky * ky);
                 if (i == 0 && jc == 0) lap = (T)1;
-                us = cscale(us, (T)-1 / lap);
+                us = cscale(us, -fast_rcp(lap));
             }
             // f=0: u^ = 2 pi i ky psi   f=1: v^ = -2 pi i kx psi
             // f=2: dx w^ = 2 pi i kx w  f=3: dy w^ = 2 pi i ky w
@@ -152,6 +162,33 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
 #pragma unroll
             for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.ldw] = x[t];
         }
+    }
+}
+
+// x[t] (column FFT of the advection) -> F = mask * x + forcing, in place (equations.py:424-437)
+template <typename T, int N, int EPT>
+__device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&x)[EPT], int j, int jc) {
+    constexpr int G = N / EPT;
+    if (a.ablate & 4) return;
+    if (a.sep) {
+        const T cm = a.mask_c[jc];
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask_r[j + t * G] * cm);
+    } else {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask[(size_t)(j + t * G) * a.m + jc]);
+    }
+    if (a.f_ptr) {  // a handful of entries per column at most (e.g. 2 in total for Kolmogorov forcing)
+        for (int e = a.f_ptr[jc]; e < a.f_ptr[jc + 1]; ++e) {
+            const int r = a.f_row[e];
+            const cx<T> v = a.f_val[e];
+#pragma unroll
+            for (int t = 0; t < EPT; ++t)
+                if (r == j + t * G) x[t] = x[t] + v;
+        }
+    } else if (a.forcing) {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) x[t] = x[t] + a.forcing[(size_t)(j + t * G) * a.m + jc];
     }
 }
 
@@ -212,30 +249,27 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             return;
         } else if constexpr (MODE == MODE_F) {
             if (valid) {
+                apply_mask_forcing<T, N, EPT>(a, x, j, jc);
 #pragma unroll
-                for (int t = 0; t < EPT; ++t) {
-                    const size_t tab = (size_t)(j + t * G) * a.m + jc;
-                    cx<T> F = cscale(x[t], a.mask[tab]);
-                    if (a.forcing) F = F + a.forcing[tab];
-                    a.out[colbase + (size_t)(j + t * G) * a.m] = F;
-                }
+                for (int t = 0; t < EPT; ++t) a.out[colbase + (size_t)(j + t * G) * a.m] = x[t];
             }
             return;
         } else if constexpr (MODE == MODE_RES) {
             if (valid) {
                 constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
                 const T ky = a.ky[jc];
+                apply_mask_forcing<T, N, EPT>(a, x, j, jc);
+                const T lc = a.sep ? a.lin_c[jc] : (T)0;
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) {
                     const int i = j + t * G;
-                    const size_t tab = (size_t)i * a.m + jc;
                     const size_t g = colbase + (size_t)i * a.m;
-                    cx<T> F = cscale(x[t], a.mask[tab]);
-                    if (a.forcing) F = F + a.forcing[tab];
+                    const cx<T> F = x[t];
                     const cx<T> w = a.u_in[g];
                     if (a.out) {
                         const cx<T> wt = a.wt[g];
-                        a.out[g] = wt - F - cscale(w, a.lin[tab]);
+                        const T L = a.sep ? a.lin_r[i] + lc : a.lin[(size_t)i * a.m + jc];
+                        a.out[g] = wt - F - cscale(w, L);
                     }
                     if (a.psi) {
                         const T kx = a.kx[i];
@@ -248,22 +282,20 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
             if (valid) {
+                apply_mask_forcing<T, N, EPT>(a, x, j, jc);
+                const T lc = a.sep ? a.lin_c[jc] : (T)0;
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) {
                     const int i = j + t * G;
-                    const size_t tab = (size_t)i * a.m + jc;
-                    const size_t g = colbase + (size_t)i * a.m;
                     const size_t gw = wbase + (size_t)i * a.ldw;
-                    const bool tabs = !(a.ablate & 4);
-                    cx<T> hn = cscale(x[t], tabs ? a.mask[tab] : (T)1);
-                    if (a.forcing && tabs) hn = hn + a.forcing[tab];
+                    cx<T> hn = x[t];
                     if (a.load_h && !(a.ablate & 8)) hn = hn + cscale(a.h[gw], a.beta);
                     if (!(a.ablate & 8)) a.h[gw] = hn;
-                    const T L = tabs ? a.lin[tab] : (T)-0.5;
+                    const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? a.lin_r[i] + lc : a.lin[(size_t)i * a.m + jc]);
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                     cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
-                    const T den = (T)1 / ((T)1 - a.mu * L);
+                    const T den = fast_rcp((T)1 - a.mu * L);
                     x[t] = cscale(rhs, den);
                     a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                 }
@@ -584,7 +616,13 @@ struct tcfd_ns2d_plan {
     void* ky;       // T[m]
     void* lin;      // T[n*m]
     void* mask;     // T[n*m]
-    void* forcing;  // cx<T>[n*m] or null
+    void* forcing;  // cx<T>[n*m] or null (dense form, used when the forcing is not sparse)
+    // exact compact forms found at plan creation (the (n, m) tables cost ~2x the state's bytes per
+    // column tile in L2 traffic; the reference's own tables are separable / sparse by construction)
+    void* mask_r; void* mask_c; void* lin_r; void* lin_c;  // T[n], T[m], T[n], T[m]
+    void* f_ptr; void* f_row; void* f_val;                 // int[m+1], int[nnz], cx<T>[nnz]
+    int sep;        // mask and linear term are separable
+    int f_sparse;   // forcing stored as CSC
 };
 
 static bool supported_n(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 0; }
@@ -621,17 +659,69 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
     if ((rc = upload(&p->ky, b))) return rc;
     if ((rc = upload(&p->lin, l))) return rc;
     if ((rc = upload(&p->mask, k))) return rc;
+    const bool force_tables = env_int("TCFD_FORCE_TABLES", 0) != 0;
+    // --- separable forms: mask = r[i]*c[j] (exact for 0/1 brick walls), lin = a[i] + b[j]
+    {
+        std::vector<T> mr(n, 0), mc(m, 0), lr(n), lc(m);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < m; ++j) {
+                mr[i] = std::max(mr[i], k[(size_t)i * m + j]);
+                mc[j] = std::max(mc[j], k[(size_t)i * m + j]);
+            }
+        bool ok = true;
+        T lmax = 0;
+        for (int j = 0; j < m; ++j) lc[j] = l[j];
+        for (int i = 0; i < n; ++i) lr[i] = l[(size_t)i * m] - l[0];
+        for (size_t i = 0; i < (size_t)n * m; ++i) lmax = std::max(lmax, (T)std::fabs(l[i]));
+        const T tol = (T)8 * std::numeric_limits<T>::epsilon() * lmax;
+        for (int i = 0; i < n && ok; ++i)
+            for (int j = 0; j < m; ++j) {
+                if (k[(size_t)i * m + j] != mr[i] * mc[j]) { ok = false; break; }
+                if (std::fabs(l[(size_t)i * m + j] - (lr[i] + lc[j])) > tol) { ok = false; break; }
+            }
+        p->sep = (ok && !force_tables) ? 1 : 0;
+        if (p->sep) {
+            if ((rc = upload(&p->mask_r, mr))) return rc;
+            if ((rc = upload(&p->mask_c, mc))) return rc;
+            if ((rc = upload(&p->lin_r, lr))) return rc;
+            if ((rc = upload(&p->lin_c, lc))) return rc;
+        }
+    }
     if (forcing) {
         std::vector<T> f(2 * (size_t)n * m);
         for (size_t i = 0; i < f.size(); ++i) f[i] = (T)forcing[i];
-        if ((rc = upload(&p->forcing, f))) return rc;
+        size_t nnz = 0;
+        for (size_t i = 0; i < (size_t)n * m; ++i) nnz += (f[2 * i] != 0 || f[2 * i + 1] != 0);
+        if (nnz * 64 <= (size_t)n * m && !force_tables) {  // sparse: column-compressed list
+            std::vector<int> ptr(m + 1, 0), row;
+            std::vector<T> val;
+            for (int j = 0; j < m; ++j) {
+                for (int i = 0; i < n; ++i) {
+                    const size_t e = (size_t)i * m + j;
+                    if (f[2 * e] != 0 || f[2 * e + 1] != 0) {
+                        row.push_back(i);
+                        val.push_back(f[2 * e]);
+                        val.push_back(f[2 * e + 1]);
+                    }
+                }
+                ptr[j + 1] = (int)row.size();
+            }
+            if (row.empty()) { row.push_back(0); val.push_back(0); val.push_back(0); }
+            p->f_sparse = 1;
+            if ((rc = upload(&p->f_ptr, ptr))) return rc;
+            if ((rc = upload(&p->f_row, row))) return rc;
+            if ((rc = upload(&p->f_val, val))) return rc;
+        } else if ((rc = upload(&p->forcing, f))) {
+            return rc;
+        }
     }
     return 0;
 }
 
 extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     if (!p) return;
-    void* ptrs[] = {p->tw, p->kx, p->ky, p->lin, p->mask, p->forcing};
+    void* ptrs[] = {p->tw, p->kx, p->ky, p->lin, p->mask, p->forcing, p->mask_r, p->mask_c,
+                    p->lin_r, p->lin_c, p->f_ptr, p->f_row, p->f_val};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->prof) {
@@ -718,6 +808,14 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.lin = (const T*)p->lin;
     a.mask = (const T*)p->mask;
     a.forcing = (const cx<T>*)p->forcing;
+    a.mask_r = (const T*)p->mask_r;
+    a.mask_c = (const T*)p->mask_c;
+    a.lin_r = (const T*)p->lin_r;
+    a.lin_c = (const T*)p->lin_c;
+    a.f_ptr = p->f_sparse ? (const int*)p->f_ptr : nullptr;
+    a.f_row = (const int*)p->f_row;
+    a.f_val = (const cx<T>*)p->f_val;
+    a.sep = p->sep;
     a.tw = (const cx<T>*)p->tw;
     auto kern = k_cols<T, N, EPT, C, MODE, MINW>;
     static bool attr_done = false;
