@@ -59,7 +59,7 @@ TCFD_CFG(double, 128, 8, 16, 8, 256)
 TCFD_CFG(double, 256, 16, 16, 16, 256)
 TCFD_CFG(double, 512, 8, 8, 8, 256)
 TCFD_CFG(double, 1024, 16, 8, 8, 128)
-TCFD_CFG(double, 2048, 16, 4, 16, 256)
+TCFD_CFG(double, 2048, 16, 2, 16, 256)
 TCFD_CFG(float, 8, 8, 64, 8, 256)
 TCFD_CFG(float, 16, 4, 16, 4, 256)
 TCFD_CFG(float, 32, 8, 32, 8, 256)
@@ -129,8 +129,8 @@ struct ColArgs {
 };
 
 template <typename T, int N, int EPT, int C>
-__device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, size_t wbase,
-                                            int j, int c, int jc, bool valid) {
+__device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, const T* rt_kx,
+                                            size_t wbase, int j, int c, int jc, bool valid) {
     constexpr int G = N / EPT;
     constexpr T TWO_PI = (T)6.283185307179586476925286766559;
     constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
@@ -142,7 +142,7 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
             const int i = j + t * G;
-            const T kx = a.kx[i];
+            const T kx = rt_kx[i];
             cx<T> us = cscale(u[t], inv_n2);
             if (f < 2) {  // stream function: psi = -w / lap, lap(0,0) patched to 1
                 T lap = M4PI2 * (kx * kx + ky * ky);
@@ -167,19 +167,19 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
 
 // x[t] (column FFT of the advection) -> F = mask * x + forcing, in place (equations.py:424-437)
 template <typename T, int N, int EPT>
-__device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&x)[EPT], int j, int jc) {
+__device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&x)[EPT], int j, int jc,
+                                                   const T* rt_mask, T cm, int f_lo, int f_hi) {
     constexpr int G = N / EPT;
     if (a.ablate & 4) return;
     if (a.sep) {
-        const T cm = a.mask_c[jc];
 #pragma unroll
-        for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask_r[j + t * G] * cm);
+        for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], rt_mask[j + t * G] * cm);
     } else {
 #pragma unroll
         for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask[(size_t)(j + t * G) * a.m + jc]);
     }
     if (a.f_ptr) {  // a handful of entries per column at most (e.g. 2 in total for Kolmogorov forcing)
-        for (int e = a.f_ptr[jc]; e < a.f_ptr[jc + 1]; ++e) {
+        for (int e = f_lo; e < f_hi; ++e) {
             const int r = a.f_row[e];
             const cx<T> v = a.f_val[e];
 #pragma unroll
@@ -220,6 +220,28 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
     const size_t colbase = (size_t)b * N * a.m + jc;   // element (b, 0, jc) of a caller-layout array
     const size_t wbase = (size_t)b * N * a.ldw + jc;   // same element of a workspace array
 
+    // per-row constants (kx, separable parts of the linear term and of the mask) live in LDS behind the
+    // exchange tile: every later use is an LDS read instead of a dependent global load; per-column
+    // constants and the forcing column range are fetched up front, before the transform needs them
+    T* rt_kx = reinterpret_cast<T*>(lds + lds_elems<N, EPT, C, false>());
+    T* rt_lin = rt_kx + N;
+    T* rt_mask = rt_lin + N;
+    constexpr bool NEEDS_TABLES = (MODE != MODE_FWD && MODE != MODE_INV);
+    T col_ky = 0, col_lin = 0, col_mask = 1;
+    int f_lo = 0, f_hi = 0;
+    if constexpr (NEEDS_TABLES) {
+        for (int i = threadIdx.x; i < N; i += C * G) {
+            rt_kx[i] = a.kx[i];
+            rt_lin[i] = a.sep ? a.lin_r[i] : (T)0;
+            rt_mask[i] = a.sep ? a.mask_r[i] : (T)1;
+        }
+        if (valid) {
+            col_ky = a.ky[jc];
+            if (a.sep) { col_lin = a.lin_c[jc]; col_mask = a.mask_c[jc]; }
+            if (a.f_ptr) { f_lo = a.f_ptr[jc]; f_hi = a.f_ptr[jc + 1]; }
+        }
+    }
+
     cx<T> x[EPT];
     if constexpr (MODE == MODE_A) {
         {
@@ -228,7 +250,8 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             for (int t = 0; t < EPT; ++t)
                 x[t] = valid ? a.u_in[ub + (size_t)(j + t * G) * a.u_in_ld] : mk<T>((T)0, (T)0);
         }
-        emit_planes<T, N, EPT, C>(a, x, lds, wbase, j, c, jc, valid);
+        __syncthreads();  // row tables visible
+        emit_planes<T, N, EPT, C>(a, x, lds, rt_kx, wbase, j, c, jc, valid);
         return;
     } else {
         constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
@@ -239,6 +262,7 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             x[t] = valid ? a.in[inbase + (size_t)(j + t * G) * in_ld] : mk<T>((T)0, (T)0);
         constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
         if (!(a.ablate & 1)) tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+        if constexpr (NEEDS_TABLES) __syncthreads();  // row tables visible (a one-pass transform has no barrier)
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
             if (valid) {
@@ -249,7 +273,7 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             return;
         } else if constexpr (MODE == MODE_F) {
             if (valid) {
-                apply_mask_forcing<T, N, EPT>(a, x, j, jc);
+                apply_mask_forcing<T, N, EPT>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi);
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) a.out[colbase + (size_t)(j + t * G) * a.m] = x[t];
             }
@@ -257,9 +281,9 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
         } else if constexpr (MODE == MODE_RES) {
             if (valid) {
                 constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
-                const T ky = a.ky[jc];
-                apply_mask_forcing<T, N, EPT>(a, x, j, jc);
-                const T lc = a.sep ? a.lin_c[jc] : (T)0;
+                const T ky = col_ky;
+                apply_mask_forcing<T, N, EPT>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi);
+                const T lc = col_lin;
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) {
                     const int i = j + t * G;
@@ -268,11 +292,11 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
                     const cx<T> w = a.u_in[g];
                     if (a.out) {
                         const cx<T> wt = a.wt[g];
-                        const T L = a.sep ? a.lin_r[i] + lc : a.lin[(size_t)i * a.m + jc];
+                        const T L = a.sep ? rt_lin[i] + lc : a.lin[(size_t)i * a.m + jc];
                         a.out[g] = wt - F - cscale(w, L);
                     }
                     if (a.psi) {
-                        const T kx = a.kx[i];
+                        const T kx = rt_kx[i];
                         T lap = M4PI2 * (kx * kx + ky * ky);
                         if (i == 0 && jc == 0) lap = (T)1;
                         a.psi[g] = cscale(w, (T)-1 / lap);
@@ -282,8 +306,8 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
             if (valid) {
-                apply_mask_forcing<T, N, EPT>(a, x, j, jc);
-                const T lc = a.sep ? a.lin_c[jc] : (T)0;
+                apply_mask_forcing<T, N, EPT>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi);
+                const T lc = col_lin;
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) {
                     const int i = j + t * G;
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
                     cx<T> hn = x[t];
                     if (a.load_h && !(a.ablate & 8)) hn = hn + cscale(a.h[gw], a.beta);
                     if (!(a.ablate & 8)) a.h[gw] = hn;
-                    const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? a.lin_r[i] + lc : a.lin[(size_t)i * a.m + jc]);
+                    const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[i] + lc : a.lin[(size_t)i * a.m + jc]);
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                     cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
                     a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                 }
             }
-            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C>(a, x, lds, wbase, j, c, jc, valid);
+            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C>(a, x, lds, rt_kx, wbase, j, c, jc, valid);
         }
     }
 }
@@ -798,7 +822,7 @@ static int set_lds(K kernel, size_t bytes) {
 template <typename T, int N, int MODE, int EPT, int C, int MINW = 1>
 static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
     constexpr int G = N / EPT;
-    constexpr size_t lds = (size_t)lds_elems<N, EPT, C, false>() * sizeof(cx<T>);
+    constexpr size_t lds = (size_t)lds_elems<N, EPT, C, false>() * sizeof(cx<T>) + 3 * (size_t)N * sizeof(T);
     a.m = p->m;
     a.ldw = p->ldw;
     a.ntiles = (p->m + C - 1) / C;
