@@ -60,6 +60,11 @@ int tcfd_ns2d_plan_create(tcfd_ns2d_plan** plan, int n, int dtype, const double*
                           const double* linear_term, const double* mask, const double* forcing_hat);
 void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* plan);
 
+/* Which exact compact forms the plan found in its tables: separable mask / linear term (1-D vectors
+ * instead of (n, m) tables), sparse forcing (CSC list), and keep_cols > 0 when F and the RK
+ * accumulator are identically zero outside the 2/3-rule mask so those entries are never stored. */
+int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* plan, int* separable, int* sparse_forcing, int* keep_cols);
+
 /* Bytes of caller-owned scratch needed by the calls below for `batch` fields. */
 size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* plan, long batch);
 

@@ -109,8 +109,11 @@ struct ColArgs {
     const T* lin_c;       // [m]
     const int* f_ptr;     // [m+1] CSC column pointers of the non-zero forcing entries, or null
     const int* f_row;     // [nnz]
+    const int* f_col;     // [nnz]
     const cx<T>* f_val;   // [nnz]
+    int f_nnz;            // > 0: so few entries that every lane scans the whole list (uniform scalar loads)
     int sep;              // 1: use the separable mask / linear term
+    int keep_cols;        // > 0: columns >= keep_cols and rows with mask_r == 0 carry F = h = 0 (pruned)
     const cx<T>* tw;      // [n]
     size_t plane_stride;  // elements between planes
     T beta, gdt, mu, scale;
@@ -178,7 +181,17 @@ __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&
 #pragma unroll
         for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask[(size_t)(j + t * G) * a.m + jc]);
     }
-    if (a.f_ptr) {  // a handful of entries per column at most (e.g. 2 in total for Kolmogorov forcing)
+    if (a.f_nnz > 0) {  // a handful of entries in total (1 for Kolmogorov forcing): uniform loop
+        for (int e = 0; e < a.f_nnz; ++e) {
+            const int r = a.f_row[e];
+            const cx<T> v = a.f_val[e];
+            if (a.f_col[e] == jc) {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t)
+                    if (r == j + t * G) x[t] = x[t] + v;
+            }
+        }
+    } else if (a.f_ptr) {  // sparse, many entries: this column's slice of the CSC list
         for (int e = f_lo; e < f_hi; ++e) {
             const int r = a.f_row[e];
             const cx<T> v = a.f_val[e];
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
         if (valid) {
             col_ky = a.ky[jc];
             if (a.sep) { col_lin = a.lin_c[jc]; col_mask = a.mask_c[jc]; }
-            if (a.f_ptr) { f_lo = a.f_ptr[jc]; f_hi = a.f_ptr[jc + 1]; }
+            if (a.f_ptr && a.f_nnz == 0) { f_lo = a.f_ptr[jc]; f_hi = a.f_ptr[jc + 1]; }
         }
     }
 
@@ -257,11 +270,14 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
         constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
         const int in_ld = GENERIC ? a.in_ld : a.ldw;
         const size_t inbase = (size_t)b * N * in_ld + jc;
+        // pruned plans never write the advection for columns >= keep_cols: they are exact zeros
+        const bool col_live = valid && (GENERIC || a.keep_cols == 0 || jc < a.keep_cols);
+        const bool tile_live = GENERIC || a.keep_cols == 0 || tile * C < a.keep_cols;  // block-uniform
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            x[t] = valid ? a.in[inbase + (size_t)(j + t * G) * in_ld] : mk<T>((T)0, (T)0);
+            x[t] = col_live ? a.in[inbase + (size_t)(j + t * G) * in_ld] : mk<T>((T)0, (T)0);
         constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
-        if (!(a.ablate & 1)) tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+        if (!(a.ablate & 1) && tile_live) tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
         if constexpr (NEEDS_TABLES) __syncthreads();  // row tables visible (a one-pass transform has no barrier)
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
@@ -313,8 +329,12 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
                     const int i = j + t * G;
                     const size_t gw = wbase + (size_t)i * a.ldw;
                     cx<T> hn = x[t];
-                    if (a.load_h && !(a.ablate & 8)) hn = hn + cscale(a.h[gw], a.beta);
-                    if (!(a.ablate & 8)) a.h[gw] = hn;
+                    // pruned entries: F = 0 at every stage, so h stays 0 and is not stored at all
+                    const bool h_live = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[i] != (T)0));
+                    if (h_live) {
+                        if (a.load_h) hn = hn + cscale(a.h[gw], a.beta);
+                        a.h[gw] = hn;
+                    }
                     const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[i] + lc : a.lin[(size_t)i * a.m + jc]);
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
@@ -360,7 +380,7 @@ __device__ __forceinline__ void load_herm_pair(cx<T> (&x)[EPT], const cx<T>* __r
 // x holds Z = FFT(r0 + i r1) distributed j + t*G; writes the half spectra of r0, r1.
 template <typename T, int N, int EPT>
 __device__ __forceinline__ void unpack_store_pair(const cx<T> (&x)[EPT], cx<T>* lds, cx<T>* __restrict__ out0,
-                                                  cx<T>* __restrict__ out1, int j, bool valid) {
+                                                  cx<T>* __restrict__ out1, int j, bool valid, int kc = N) {
     constexpr int G = N / EPT;
     constexpr bool WG = (G > 64);
 #pragma unroll
@@ -374,14 +394,14 @@ __device__ __forceinline__ void unpack_store_pair(const cx<T> (&x)[EPT], cx<T>* 
         const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
         const cx<T> S = mk<T>(A.x + Bm.x, A.y - Bm.y);  // A + conj(B) = 2 X0
         const cx<T> D = mk<T>(A.x - Bm.x, A.y + Bm.y);  // A - conj(B) = 2 i X1
-        if (valid) {
+        if (valid && k < kc) {  // kc: columns the consumer reads (2/3-rule pruning)
             out0[k] = cscale(S, half);
             out1[k] = mk<T>(D.y * half, -D.x * half);
         }
     }
     if (j == 0) {
         const cx<T> A = x[EPT / 2];  // element N/2
-        if (valid) {
+        if (valid && N / 2 < kc) {
             out0[N / 2] = mk<T>(A.x, (T)0);
             out1[N / 2] = mk<T>(A.y, (T)0);
         }
@@ -481,7 +501,7 @@ __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>
 template <typename T, int N, int EPT, int THR>
 __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect3(
     const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
-    long npairs, int ld) {
+    long npairs, int ld, int kc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using Gm = RowGeom<T, N, EPT, THR>;
     constexpr int G = Gm::G;
@@ -532,7 +552,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
         for (int t = 0; t < EPT; ++t) p[t].y = -(x[t].x * z1[t].x + x[t].y * z1[t].y);
 
         tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
-        unpack_store_pair<T, N, EPT>(p, lds, adv + (size_t)cur * 2 * ld, adv + ((size_t)cur * 2 + 1) * ld, j, valid);
+        unpack_store_pair<T, N, EPT>(p, lds, adv + (size_t)cur * 2 * ld, adv + ((size_t)cur * 2 + 1) * ld, j, valid, kc);
     }
 }
 
@@ -644,9 +664,13 @@ struct tcfd_ns2d_plan {
     // exact compact forms found at plan creation (the (n, m) tables cost ~2x the state's bytes per
     // column tile in L2 traffic; the reference's own tables are separable / sparse by construction)
     void* mask_r; void* mask_c; void* lin_r; void* lin_c;  // T[n], T[m], T[n], T[m]
-    void* f_ptr; void* f_row; void* f_val;                 // int[m+1], int[nnz], cx<T>[nnz]
+    void* f_ptr; void* f_row; void* f_val; void* f_col;    // int[m+1], int[nnz], cx<T>[nnz], int[nnz]
+    int f_nnz;
     int sep;        // mask and linear term are separable
     int f_sparse;   // forcing stored as CSC
+    int keep_cols;  // > 0: F (hence the RK accumulator h) is identically zero for columns >= keep_cols and for
+                    // rows with mask_r == 0 (2/3-rule mask, forcing inside the mask): those entries of the
+                    // advection / h arrays are neither written nor read.  0: no pruning.
 };
 
 static bool supported_n(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 0; }
@@ -704,6 +728,16 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
                 if (std::fabs(l[(size_t)i * m + j] - (lr[i] + lc[j])) > tol) { ok = false; break; }
             }
         p->sep = (ok && !force_tables) ? 1 : 0;
+        // prunable: mask_c is a 1...1 0...0 prefix pattern and every forcing entry sits where the mask is 1
+        int kc = 0;
+        while (kc < m && mc[kc] == (T)1) ++kc;
+        bool prefix = p->sep && kc < m;
+        for (int j = kc; j < m && prefix; ++j) prefix = (mc[j] == (T)0);
+        for (int i = 0; i < n && prefix; ++i) prefix = (mr[i] == (T)0 || mr[i] == (T)1);
+        if (prefix && forcing)
+            for (size_t e = 0; e < (size_t)n * m && prefix; ++e)
+                if ((forcing[2 * e] != 0 || forcing[2 * e + 1] != 0) && k[e] == (T)0) prefix = false;
+        p->keep_cols = (prefix && !env_int("TCFD_NO_PRUNE", 0)) ? kc : 0;
         if (p->sep) {
             if ((rc = upload(&p->mask_r, mr))) return rc;
             if ((rc = upload(&p->mask_c, mc))) return rc;
@@ -717,21 +751,24 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
         size_t nnz = 0;
         for (size_t i = 0; i < (size_t)n * m; ++i) nnz += (f[2 * i] != 0 || f[2 * i + 1] != 0);
         if (nnz * 64 <= (size_t)n * m && !force_tables) {  // sparse: column-compressed list
-            std::vector<int> ptr(m + 1, 0), row;
+            std::vector<int> ptr(m + 1, 0), row, col;
             std::vector<T> val;
             for (int j = 0; j < m; ++j) {
                 for (int i = 0; i < n; ++i) {
                     const size_t e = (size_t)i * m + j;
                     if (f[2 * e] != 0 || f[2 * e + 1] != 0) {
                         row.push_back(i);
+                        col.push_back(j);
                         val.push_back(f[2 * e]);
                         val.push_back(f[2 * e + 1]);
                     }
                 }
                 ptr[j + 1] = (int)row.size();
             }
-            if (row.empty()) { row.push_back(0); val.push_back(0); val.push_back(0); }
+            p->f_nnz = (int)row.size();
+            if (row.empty()) { row.push_back(0); col.push_back(0); val.push_back(0); val.push_back(0); }
             p->f_sparse = 1;
+            if ((rc = upload(&p->f_col, col))) return rc;
             if ((rc = upload(&p->f_ptr, ptr))) return rc;
             if ((rc = upload(&p->f_row, row))) return rc;
             if ((rc = upload(&p->f_val, val))) return rc;
@@ -745,7 +782,7 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
 extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     if (!p) return;
     void* ptrs[] = {p->tw, p->kx, p->ky, p->lin, p->mask, p->forcing, p->mask_r, p->mask_c,
-                    p->lin_r, p->lin_c, p->f_ptr, p->f_row, p->f_val};
+                    p->lin_r, p->lin_c, p->f_ptr, p->f_row, p->f_val, p->f_col};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->prof) {
@@ -776,6 +813,14 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
         return rc;
     }
     *out = p;
+    return 0;
+}
+
+extern "C" int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* p, int* separable, int* sparse_forcing, int* keep_cols) {
+    if (!p) return fail(TCFD_EINVAL, "plan_info: null plan");
+    if (separable) *separable = p->sep;
+    if (sparse_forcing) *sparse_forcing = p->f_sparse;
+    if (keep_cols) *keep_cols = p->keep_cols;
     return 0;
 }
 
@@ -837,9 +882,12 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.lin_r = (const T*)p->lin_r;
     a.lin_c = (const T*)p->lin_c;
     a.f_ptr = p->f_sparse ? (const int*)p->f_ptr : nullptr;
+    a.f_col = (const int*)p->f_col;
+    a.f_nnz = (p->f_sparse && p->f_nnz <= 32) ? p->f_nnz : 0;
     a.f_row = (const int*)p->f_row;
     a.f_val = (const cx<T>*)p->f_val;
     a.sep = p->sep;
+    a.keep_cols = p->keep_cols;
     a.tw = (const cx<T>*)p->tw;
     auto kern = k_cols<T, N, EPT, C, MODE, MINW>;
     static bool attr_done = false;
@@ -919,7 +967,7 @@ static int launch_rows_advect3(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     const long blocks = std::min<long>(want, 256L * per_cu);  // persistent groups, grid-stride over row pairs
     ProfScope prof(p, 1, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
-                       (const cx<T>*)p->tw, npairs, p->ldw);
+                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
     HIP_TRY(hipGetLastError());
     return 0;
 }
