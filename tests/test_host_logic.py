@@ -77,9 +77,14 @@ def test_forcing_table_matches_oracle():
         _, op = make(32, real, forcing=True)
         t = O.make_tables(32, L, 1e-3, 0.1, True, None, real)
         ref = O.kolmogorov_forcing_hat(32, L, t.kx, t.ky, 1.0, 4, real=real)
+        op.forcing_noise_floor = 0  # keep every entry: equals the reference's table
         fh = op.forcing_hat()
         assert fh.dtype == ref.dtype
         assert torch.allclose(fh, ref, rtol=0, atol=1e-12 if real == torch.float64 else 1e-4)
+        op.forcing_noise_floor = None  # default: transform round-off (< n*eps*max) becomes exact zeros
+        clean = op.forcing_hat()
+        assert int((clean != 0).sum()) == 1  # sin(4y): one half-spectrum mode
+        assert (clean - ref).abs().max() <= 32 * torch.finfo(real).eps * ref.abs().max()
 
 
 def test_cpu_tensor_fails_loudly_no_fallback():
