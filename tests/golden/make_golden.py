@@ -246,7 +246,28 @@ def gen_fno():
     save("fno_layers.npz", **out)
 
 
+def gen_sfno():
+    """Tiny SFNO end to end (fp32): state_dict + input + outputs for two out_steps."""
+    torch.set_default_dtype(torch.float32)
+    from fno.sfno import SFNO
+
+    out = {}
+    torch.manual_seed(0)
+    model = SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for b_ in model.output_operator.conv.bias:
+            b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+        x = torch.randn(2, 16, 16, 10, generator=g)
+        out["x"] = npy(x)
+        for k, v in model.state_dict().items():
+            out["sd_" + k] = npy(v)
+        out["y10"] = npy(model(x))
+        out["y20"] = npy(model(x, out_steps=20))
+    save("fno_sfno_tiny.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno"]
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno"]
     for w in which:
         globals()["gen_" + w]()

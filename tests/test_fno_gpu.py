@@ -153,3 +153,22 @@ def test_errors_are_loud(dev):
             m(torch.randn(1, 2, 24, 16, 10, device=dev))
         with pytest.raises(TypeError):
             m(torch.randn(1, 2, 16, 16, 10, device=dev, dtype=torch.float64))
+
+
+def test_sfno_tiny_end_to_end_golden(dev):
+    """Whole SFNO forward (lifting + 2 spectral layers + OutConv) with the reference's weights."""
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_sfno_tiny.npz")
+    model = fno.SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).eval()
+    ref_keys = sorted(k[3:] for k in g.files if k.startswith("sd_"))
+    assert sorted(model.state_dict().keys()) == ref_keys
+    model.load_state_dict({k: torch.from_numpy(g["sd_" + k]) for k in ref_keys})
+    model = model.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.no_grad():
+        y10 = model(x)
+        y20 = model(x, out_steps=20)
+    assert y10.shape == (2, 16, 16, 10) and y20.shape == (2, 16, 16, 20)
+    assert rel_l2(y10, g["y10"]) < 1e-5
+    assert rel_l2(y20, g["y20"]) < 1e-5
