@@ -141,40 +141,55 @@ __global__ __launch_bounds__(1024) void k_fwd_ty(const float* __restrict__ v, cf
     constexpr int G = Y / EPT;
     constexpr bool WG = (G > 64);
     const int Tp = T_in + t_pad;
-    float* slab = reinterpret_cast<float*>(smem_raw);                               // [Y][T_in]
-    cf* twt = reinterpret_cast<cf*>(smem_raw + al16c((size_t)Y * T_in * 4));          // [mt][Tp]
-    cf* ex = twt + (size_t)mt * Tp;                                                  // exchange: mt * lds_elems
+    float* slab = reinterpret_cast<float*>(smem_raw);                            // [Y][T_in]
+    const size_t head = (size_t)Y * T_in * 4 > (size_t)2 * my * mt * sizeof(cf) ? (size_t)Y * T_in * 4
+                                                                                 : (size_t)2 * my * mt * sizeof(cf);
+    cf* ex = reinterpret_cast<cf*>(smem_raw + al16c(head));                       // exchange: mt * lds_elems
     const int kt = threadIdx.x / G, j = threadIdx.x % G;
     const size_t slab_elems = (size_t)Y * T_in;
     const float* src = v + (size_t)blockIdx.x * slab_elems;
-    for (size_t i = threadIdx.x; i < slab_elems; i += blockDim.x) slab[i] = src[i];
-    for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
+    // the slab is one contiguous, 16-byte aligned run (Y is a multiple of 8): 16-byte loads
+    {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(slab);
+        for (int i = threadIdx.x; i < (int)(slab_elems / 4); i += blockDim.x) d4[i] = s4[i];
+    }
     __syncthreads();
+    // real DFT in t for this lane's EPT rows.  With 64 lanes per transform the time mode is wave uniform, so the
+    // twiddles come through the scalar unit straight from the table (no LDS traffic for them).
+    const int kt_u = (G >= 64) ? __builtin_amdgcn_readfirstlane(kt) : kt;
+    const cf* w = tw_tf + (size_t)kt_u * Tp + t_pad;  // the first t_pad samples are the zero padding
     cf x[EPT];
 #pragma unroll
-    for (int t = 0; t < EPT; ++t) {
-        const int y = j + t * G;
-        float re = 0.f, im = 0.f;
-        const float* row = slab + (size_t)y * T_in;
-        const cf* w = twt + (size_t)kt * Tp + t_pad;  // the first t_pad samples are zeros (left padding)
-        for (int s = 0; s < T_in; ++s) {
-            re += row[s] * w[s].x;
-            im += row[s] * w[s].y;
+    for (int t = 0; t < EPT; ++t) x[t] = mk<float>(0.f, 0.f);
+    for (int s = 0; s < T_in; ++s) {
+        const cf ws = w[s];
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const float r = slab[(size_t)(j + t * G) * T_in + s];
+            x[t].x += r * ws.x;
+            x[t].y += r * ws.y;
         }
-        x[t] = mk<float>(re * scale, im * scale);
     }
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], scale);
     cf* lds = ex + (size_t)kt * lds_elems<Y, EPT, 1, true>();
     tile_fft<float, Y, EPT, -1, 1, true, WG>(x, lds, tw_y, j, 0);
+    // kept ky of all time modes -> one contiguous (2my, mt) block: stage in LDS, store coalesced
+    __syncthreads();
+    cf* stage = reinterpret_cast<cf*>(slab);  // the slab is dead
     const int Q = 2 * my * mt;
-    cf* dst = w1 + (size_t)blockIdx.x * Q;
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const int ky = j + t * G;
         int kyi = -1;
         if (ky < my) kyi = ky;
         else if (ky >= Y - my) kyi = ky - (Y - 2 * my);
-        if (kyi >= 0) dst[kyi * mt + kt] = x[t];
+        if (kyi >= 0) stage[kyi * mt + kt] = x[t];
     }
+    __syncthreads();
+    cf* dst = w1 + (size_t)blockIdx.x * Q;
+    for (int i = threadIdx.x; i < Q; i += blockDim.x) dst[i] = stage[i];
 }
 
 // ------------------------------------------------------------------ inverse: y IFFT + t inverse real DFT
@@ -208,14 +223,23 @@ __global__ __launch_bounds__(1024) void k_inv_ty(const cf* __restrict__ w2, floa
     __syncthreads();
     // out[y][t] = scale * sum_k Re( spec[y][k] * twi[t][k] ),   t in the kept tail of [0, T_out)
     const int t0 = T_out - t_keep;
-    float* dst = out + (size_t)blockIdx.x * Y * t_keep;
-    for (int i = threadIdx.x; i < Y * t_keep; i += blockDim.x) {
+    const int total = Y * t_keep;
+    float* oslab = reinterpret_cast<float*>(ex);  // the exchange buffers are free again: reuse as [Y][t_keep]
+    float* dst = out + (size_t)blockIdx.x * total;
+    const bool stage = (size_t)total * 4 <= (size_t)mt * lds_elems<Y, EPT, 1, true>() * sizeof(cf) && (total & 3) == 0;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int y = i / t_keep, tt = i % t_keep;
         const cf* s = spec + (size_t)y * mt;
         const cf* w = twt + (size_t)(t0 + tt) * mt;
         float acc = 0.f;
         for (int k = 0; k < mt; ++k) acc += s[k].x * w[k].x - s[k].y * w[k].y;
-        dst[i] = acc * scale;
+        if (stage) oslab[i] = acc * scale; else dst[i] = acc * scale;
+    }
+    if (stage) {
+        __syncthreads();
+        const float4* s4 = reinterpret_cast<const float4*>(oslab);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = threadIdx.x; i < total / 4; i += blockDim.x) d4[i] = s4[i];
     }
 }
 
@@ -400,7 +424,8 @@ struct TyCfg {
 template <int Y>
 static int launch_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float scale, hipStream_t st) {
     constexpr int EPT = TyCfg<Y>::EPT, G = TyCfg<Y>::G;
-    const size_t lds = al16c((size_t)Y * p->T_in * 4) + ((size_t)p->mt * p->Tp + (size_t)p->mt * lds_elems<Y, EPT, 1, true>()) * sizeof(cf);
+    const size_t lds = al16c(std::max((size_t)Y * p->T_in * 4, (size_t)2 * p->my * p->mt * sizeof(cf))) +
+                       (size_t)p->mt * lds_elems<Y, EPT, 1, true>() * sizeof(cf);
     if (p->mt * G > 1024) return FAIL(TCFD_EINVAL, "fno: modes_t * %d lanes exceed a workgroup", G);
     if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T=%d)", Y, p->T_in);
     auto kern = k_fwd_ty<Y, EPT>;
