@@ -172,3 +172,14 @@ def test_sfno_tiny_end_to_end_golden(dev):
     assert y10.shape == (2, 16, 16, 10) and y20.shape == (2, 16, 16, 20)
     assert rel_l2(y10, g["y10"]) < 1e-5
     assert rel_l2(y20, g["y20"]) < 1e-5
+
+
+@pytest.mark.parametrize("order", [0, -1, 1])
+@pytest.mark.parametrize("rel", [0, 1])
+def test_sobolev_loss_golden(order, rel, dev):
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_layers.npz")
+    loss = fno.SobolevLoss(n_grid=16, norm_order=order, relative=bool(rel)).to(dev)
+    val = loss(torch.from_numpy(g["sob_x"]).to(dev), torch.from_numpy(g["sob_y"]).to(dev))
+    assert float(val) == pytest.approx(float(g[f"sob_o{order}_r{rel}"]), rel=2e-5)

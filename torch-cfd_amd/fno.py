@@ -482,3 +482,71 @@ class SFNO(FNOBase):
             v = act(mlp(conv(v)) + w(v))
         v = self.reduction(v)
         return self.output_operator(v, v_res, out_steps=out_steps)
+
+
+# ----------------------------------------------------------------------------- loss (config 5 "forward + loss")
+class SobolevLoss(nn.Module):
+    """Fourier-domain weighted norm of (x - y), fno/losses.py:199-315 (freq_cutoff=None).
+
+    Copies the code's behaviour, not its comment: for ``norm_order == 0`` the multiplier is
+    sqrt(alpha + 4 pi^2 |k|^2) itself, not 1.  The 2-D transforms over dims (1, 2) of the
+    time-last tensors run on the HIP rfft2 kernels (one Hermitian-weighted half spectrum per time slice
+    instead of the reference's full complex fftn); everything else is a handful of device reductions."""
+
+    def __init__(self, n_grid: int = 256, time_average: bool = True, reduction: bool = True, mesh_weighted: bool = True,
+                 relative: bool = False, inp_time_last: bool = True, freq_cutoff: int = None, norm_order: float = -1,
+                 alpha: float = 0.1, fft_norm: str = "backward", diam: float = 1, debug: bool = False):
+        super().__init__()
+        if fft_norm not in (None, "backward"):
+            raise NotImplementedError("SobolevLoss on the HIP path supports fft_norm='backward'")
+        self.relative, self.time_average, self.reduction = relative, time_average, reduction
+        self.mesh_weighted, self.norm_order, self.alpha = mesh_weighted, norm_order, alpha
+        self.inp_time_last, self.n_grid, self.diam = inp_time_last, n_grid, diam
+        n = n_grid
+        k = torch.fft.fftfreq(n, d=diam / n)
+        kx, ky = torch.meshgrid([k, k], indexing="ij")
+        cutoff = (n // 2 + 1 if freq_cutoff is None else freq_cutoff) / diam
+        fill = math.inf if norm_order < 0 else 0.0
+        kx = kx.clone().masked_fill(kx.abs() > cutoff, fill)
+        ky = ky.clone().masked_fill(ky.abs() > cutoff, fill)
+        weight = alpha + 4 * (torch.pi) ** 2 * (kx**2 + ky**2)
+        self.register_buffer("kx", kx[None, :, :, None])
+        self.register_buffer("ky", ky[None, :, :, None])
+        self.register_buffer("weight", weight[None, :, :, None])
+
+    def _half_spectrum_weights(self, device, dtype):
+        n = self.n_grid
+        w = torch.sqrt(self.weight[0, :, : n // 2 + 1, 0].to(device=device, dtype=dtype))
+        w = w ** (self.norm_order / 2) if self.norm_order != 0 else w
+        herm = torch.full((n // 2 + 1,), 2.0, dtype=dtype, device=device)  # |X[k]|^2 counted twice except DC/Nyquist
+        herm[0] = 1.0
+        herm[-1] = 1.0
+        return w**2 * herm
+
+    def forward(self, x, y=None):
+        from .equations import fft_plan
+
+        if not self.inp_time_last:
+            x = x.permute(0, 2, 3, 1)
+            y = y.permute(0, 2, 3, 1) if y is not None else None
+        bsz, n, _, nt = x.shape
+        if n != self.n_grid:
+            raise ValueError(f"grid {n} != n_grid {self.n_grid}")
+        plan = fft_plan(n, torch.complex64 if x.dtype == torch.float32 else torch.complex128, x.device, self.diam)
+        w2 = self._half_spectrum_weights(x.device, x.dtype)
+
+        def sq_norms(z):  # (b, n, n, t) -> (b, t): || w * fft2(z_t) ||_F^2 via the half spectrum
+            zh = plan.rfft2(z.permute(0, 3, 1, 2).contiguous())
+            return (zh.real**2 + zh.imag**2).mul_(w2).sum(dim=(-2, -1))
+
+        diff = sq_norms(x if y is None else x - y)  # the transform is linear: one rfft2 of the difference
+        loss = diff.sum(dim=-1).sqrt()
+        if self.relative and y is not None:
+            yn = sq_norms(y).sum(dim=-1).sqrt()
+        else:
+            yn = torch.ones(bsz, device=x.device, dtype=x.dtype)
+        yn = yn / n if self.mesh_weighted else yn
+        loss = loss / yn
+        loss = loss / math.sqrt(nt) if self.time_average else loss
+        loss = loss.mean(0) if self.reduction else loss.sum(0)
+        return loss / n if self.mesh_weighted else loss
