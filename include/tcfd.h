@@ -135,6 +135,18 @@ int tcfd_fno_contract(const void* vin, const void* const* weights, const void* c
                       void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,
                       void* stream);
 
+/* Fused pointwise block of an SFNO layer (fp32, channel-major (batch, C, P) tensors, P = X*Y*T):
+ *     out = act2( W2.act1(W1.x + b1) + b2  [+ Ws.skip + bs  |  + skip[..., -1:]] )
+ * = PointwiseFFN (fno/base.py:86-111) + the 1x1x1 skip convolution + sum + activation of one layer
+ * (fno/sfno.py:607-614), the lifting tail act(v[..., -1:] + mlp(.)) (fno/sfno.py:258-259), or a single 1x1x1
+ * convolution when w1 is NULL.  w2t / wst are the TRANSPOSED weight matrices ((cm, co) and (ci, co)).
+ * act: 0 none, 1 ReLU, 2 GELU(erf), 3 SiLU, 4 tanh.  skip_mode: 0 none, 1 convolution of `skip` (batch, ci, P),
+ * 2 broadcast of the last time slice of `skip` (batch, co, P/T*skip_T).
+ * Returns TCFD_EINVAL for channel combinations that are not instantiated. */
+int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w1, const void* b1, const void* w2t,
+                       const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
+                       int T, int skip_T, int act1, int act2, int skip_mode, void* stream);
+
 /* ---- per-launch event timing (measurement aid; no reference counterpart) -------
  * Between profile_begin and profile_end every kernel the plan launches is
  * bracketed by a pair of HIP events recorded on the launch stream (up to

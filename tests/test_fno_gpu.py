@@ -183,3 +183,33 @@ def test_sobolev_loss_golden(order, rel, dev):
     loss = fno.SobolevLoss(n_grid=16, norm_order=order, relative=bool(rel)).to(dev)
     val = loss(torch.from_numpy(g["sob_x"]).to(dev), torch.from_numpy(g["sob_y"]).to(dev))
     assert float(val) == pytest.approx(float(g[f"sob_o{order}_r{rel}"]), rel=2e-5)
+
+
+@pytest.mark.parametrize("width,act", [(10, "ReLU"), (32, "GELU"), (8, "SiLU"), (20, "Tanh")])
+def test_fused_pointwise_block_matches_torch_modules(width, act, dev):
+    """tcfd_fno_pointwise vs the same layer evaluated with torch modules (PointwiseFFN + skip conv + act),
+    the lifting tail (last-slice broadcast) and the single-convolution forms."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(width)
+    mlp = fno.PointwiseFFN(width, width, 4 * width, act).to(dev)
+    w = torch.nn.Conv3d(width, width, 1).to(dev)
+    red = torch.nn.Conv3d(width, 1, 1).to(dev)
+    a2 = getattr(torch.nn, act)()
+    x1 = torch.randn(2, width, 16, 8, 10, device=dev)
+    v = torch.randn(2, width, 16, 8, 10, device=dev)
+    vin = torch.randn(2, width, 16, 8, 13, device=dev)
+    with torch.no_grad():
+        ref = a2(mlp.linear2(mlp.activation(mlp.linear1(x1))) + w(v))
+        out = fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=a2)
+        assert out is not None and rel_l2(out, ref) < 2e-6
+        ref = a2(vin[..., -1:] + mlp.linear2(mlp.activation(mlp.linear1(x1))))
+        out = fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=vin, act2=a2, skip_last_slice=True)
+        assert out is not None and rel_l2(out, ref) < 2e-6
+        out = fno.hip_pointwise(v, None, None, red)
+        assert out is not None and rel_l2(out, red(v)) < 2e-6
+        out = fno.hip_pointwise(v, None, None, w)
+        assert out is not None and rel_l2(out, w(v)) < 2e-6
+        # not instantiated -> None (the caller keeps its torch modules)
+        odd = torch.nn.Conv3d(7, 7, 1).to(dev)
+        assert fno.hip_pointwise(torch.randn(1, 7, 8, 8, 4, device=dev), None, None, odd) is None

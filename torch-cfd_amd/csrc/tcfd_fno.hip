@@ -562,3 +562,129 @@ extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, co
     a.delta = delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
     return do_contract(nullptr, a, use_mfma, (hipStream_t)stream);
 }
+
+
+// ------------------------------------------------------------------ fused pointwise block of the SFNO layer
+//   out = act2( W2 . act1( W1 . x + b1 ) + b2  [+ Ws . s + bs | + s[..., -1:]] )
+// i.e. PointwiseFFN (two 1x1x1 convolutions, fno/base.py:86-111) + the 1x1x1 skip convolution + sum + activation
+// of one SFNO layer (fno/sfno.py:607-614), or the lifting operator's tail act(v[..., -1:] + mlp(.)) (:258-259),
+// or a single 1x1x1 convolution (W1 absent).  One lane per point, channels in registers, weights through the
+// scalar unit (they are lane uniform): the (b, C, P) activations are read once and written once, where the
+// reference-style op stream makes ~6 passes and materialises the 4x wider hidden tensor.
+struct PwArgs {
+    const float* x;     // (b, CI, P)
+    const float* s;     // skip input or null: mode 1 (b, CI, P); mode 2 (b, CO, P / T * sT), last time slice is added
+    float* out;         // (b, CO, P)
+    const float* w1;    // (CM, CI) or null (then CM == CI and the hidden vector is x itself)
+    const float* b1;    // (CM) or null
+    const float* w2t;   // (CM, CO)  = W2 transposed
+    const float* b2;    // (CO) or null
+    const float* wst;   // (CI, CO)  = Ws transposed (mode 1)
+    const float* bs;    // (CO) or null
+    long P;
+    int T, sT, act1, act2, skip_mode;
+};
+
+__device__ __forceinline__ float pw_act(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.f;                                  // ReLU
+        case 2: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // GELU (exact, torch default)
+        case 3: return v / (1.f + __expf(-v));                             // SiLU
+        case 4: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <int CI, int CM, int CO, bool HAS_L1>
+__global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= a.P) return;
+    float x[CI], o[CO];
+    const float* xb = a.x + (size_t)b * CI * a.P + p;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) o[c] = a.b2 ? a.b2[c] : 0.f;
+    if constexpr (HAS_L1) {
+#pragma unroll 4
+        for (int m = 0; m < CM; ++m) {
+            float h = a.b1 ? a.b1[m] : 0.f;
+            const float* w1 = a.w1 + m * CI;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) h += w1[i] * x[i];
+            h = pw_act(h, a.act1);
+            const float* w2 = a.w2t + m * CO;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] += w2[c] * h;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < CI; ++m) {
+            const float* w2 = a.w2t + m * CO;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] += w2[c] * x[m];
+        }
+    }
+    if (a.skip_mode == 1) {
+        const float* sb = a.s + (size_t)b * CI * a.P + p;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const float sv = sb[(size_t)i * a.P];
+            const float* ws = a.wst + i * CO;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] += ws[c] * sv;
+        }
+        if (a.bs) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] += a.bs[c];
+        }
+    } else if (a.skip_mode == 2) {
+        const long xy = p / a.T;
+        const long sP = (a.P / a.T) * a.sT;
+        const float* sb = a.s + (size_t)b * CO * sP + xy * a.sT + (a.sT - 1);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) o[c] += sb[(size_t)c * sP];
+    }
+    float* ob = a.out + (size_t)b * CO * a.P + p;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) ob[(size_t)c * a.P] = pw_act(o[c], a.act2);
+}
+
+template <int CI, int CM, int CO, bool HAS_L1>
+static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
+    dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1>), grid, dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Returns TCFD_EINVAL (with a message) for channel combinations that are not instantiated; the caller then
+// uses its own pointwise modules.
+extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w1, const void* b1,
+                                  const void* w2t, const void* b2, const void* wst, const void* bs, int batch, int ci,
+                                  int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
+                                  void* stream) {
+    if (!x || !out || !w2t || batch <= 0 || P <= 0) return FAIL(TCFD_EINVAL, "fno_pointwise: bad argument");
+    if (skip_mode && !skip) return FAIL(TCFD_EINVAL, "fno_pointwise: skip input missing");
+    if (skip_mode == 2 && (T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise: bad T");
+    PwArgs a;
+    a.x = (const float*)x; a.s = (const float*)skip; a.out = (float*)out;
+    a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
+    a.wst = (const float*)wst; a.bs = (const float*)bs;
+    a.P = P; a.T = T; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
+    hipStream_t st = (hipStream_t)stream;
+    const bool l1 = w1 != nullptr;
+#define PW_CASE(CI_, CM_, CO_)                                                             \
+    if (ci == CI_ && cm == CM_ && co == CO_)                                                \
+        return l1 ? launch_pw<CI_, CM_, CO_, true>(a, batch, st) : launch_pw<CI_, CM_, CO_, false>(a, batch, st);
+    if (l1) {
+        PW_CASE(4, 16, 4) PW_CASE(8, 32, 8) PW_CASE(10, 40, 10) PW_CASE(16, 64, 16) PW_CASE(20, 80, 20) PW_CASE(32, 128, 32)
+    } else {
+        if (cm != ci) return FAIL(TCFD_EINVAL, "fno_pointwise: single layer needs cm == ci");
+        PW_CASE(4, 4, 4) PW_CASE(4, 4, 1) PW_CASE(8, 8, 8) PW_CASE(8, 8, 1) PW_CASE(10, 10, 10) PW_CASE(10, 10, 1)
+        PW_CASE(16, 16, 16) PW_CASE(16, 16, 1) PW_CASE(20, 20, 20) PW_CASE(20, 20, 1) PW_CASE(32, 32, 32) PW_CASE(32, 32, 1)
+    }
+#undef PW_CASE
+    return FAIL(TCFD_EINVAL, "fno_pointwise: channels (%d -> %d -> %d) not instantiated", ci, cm, co);
+}

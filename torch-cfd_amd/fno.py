@@ -178,7 +178,76 @@ class PointwiseFFN(nn.Module):
         self.activation = getattr(nn, activation)()
 
     def forward(self, v):
-        return self.linear2(self.activation(self.linear1(v)))
+        out = hip_pointwise(v, self.linear1, self.activation, self.linear2)
+        return out if out is not None else self.linear2(self.activation(self.linear1(v)))
+
+
+_ACT_CODES = {nn.Identity: 0, nn.ReLU: 1, nn.GELU: 2, nn.SiLU: 3, nn.Tanh: 4}
+
+
+def _act_code(mod) -> Optional[int]:
+    if mod is None:
+        return 0
+    code = _ACT_CODES.get(type(mod))
+    if code == 2 and getattr(mod, "approximate", "none") != "none":
+        return None
+    return code
+
+
+def _is_pointwise(conv) -> bool:
+    return (isinstance(conv, (nn.Conv1d, nn.Conv2d, nn.Conv3d)) and all(k == 1 for k in conv.kernel_size)
+            and conv.groups == 1 and all(s_ == 1 for s_ in conv.stride) and all(p_ == 0 for p_ in conv.padding))
+
+
+def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, act2=None,
+                  skip_last_slice: bool = False) -> Optional[torch.Tensor]:
+    """out = act2( lin2(act1(lin1(x))) [+ skip_conv(skip) | + skip[..., -1:]] ) in ONE fused HIP kernel
+    (``tcfd_fno_pointwise``); ``lin1=None`` makes it a single 1x1x1 convolution.  Returns ``None`` when the
+    combination is not covered (channel counts, activation type, dtype, autograd) -- the caller then runs its
+    torch modules."""
+    c1, c2 = _act_code(act1), _act_code(act2)
+    if (c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32 or not _is_pointwise(lin2)
+            or (lin1 is not None and not _is_pointwise(lin1)) or (skip_conv is not None and not _is_pointwise(skip_conv))
+            or (torch.is_grad_enabled() and (x.requires_grad or lin2.weight.requires_grad))):
+        return None
+    b, ci = x.shape[:2]
+    co = lin2.out_channels
+    cm = lin1.out_channels if lin1 is not None else ci
+    if lin2.in_channels != cm or (lin1 is not None and lin1.in_channels != ci):
+        return None
+    P = x[0, 0].numel()
+    T = x.shape[-1]
+    mode, s_t, sT = 0, None, 0
+    if skip_conv is not None:
+        if skip is None or skip.shape != x.shape or skip_conv.in_channels != ci or skip_conv.out_channels != co:
+            return None
+        mode, s_t = 1, skip.contiguous()
+    elif skip_last_slice:
+        if skip is None or skip.shape[1] != co or skip.shape[2:-1] != x.shape[2:-1]:
+            return None
+        mode, s_t, sT = 2, skip.contiguous(), skip.shape[-1]
+    x = x.contiguous()
+    out = torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=x.device)
+
+    def mat(conv, transpose):
+        w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
+        return (w.t() if transpose else w).contiguous()
+
+    w1 = mat(lin1, False) if lin1 is not None else None
+    w2t = mat(lin2, True)
+    wst = mat(skip_conv, True) if skip_conv is not None else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    bias = lambda c: c.bias.detach().contiguous() if (c is not None and c.bias is not None) else None
+    b1, b2, bs = bias(lin1), bias(lin2), bias(skip_conv)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.tcfd_fno_pointwise(x.data_ptr(), ptr(s_t), out.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst),
+                                    ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode,
+                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+        return None
+    _lib.check(rc, "tcfd_fno_pointwise")
+    return out
 
 
 # ----------------------------------------------------------------------------- spectral convolutions
@@ -387,9 +456,19 @@ class LiftingOperator(nn.Module):
 
     def forward(self, v):
         assert self.latent_steps <= v.size(-1)
-        v = self.proj(self.norm(self.pe(v)))
-        w = self.mlp(self.sconv(v))
-        return self.activation(v[..., -1:] + w)
+        vn = self.norm(self.pe(v))
+        v = hip_pointwise(vn, None, None, self.proj)
+        if v is None:
+            v = self.proj(vn)
+        x1 = self.sconv(v)
+        if isinstance(self.mlp, PointwiseFFN):
+            out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=v,
+                                act2=self.activation, skip_last_slice=True)
+        else:
+            out = hip_pointwise(x1, None, None, self.mlp, skip=v, act2=self.activation, skip_last_slice=True)
+        if out is not None:
+            return out
+        return self.activation(v[..., -1:] + self.mlp(x1))
 
 
 class OutConv(nn.Module):
@@ -479,8 +558,11 @@ class SFNO(FNOBase):
         v_res = v
         v = self.lifting_operator(v.unsqueeze(1))
         for conv, mlp, w, act in zip(self.spectral_conv, self.mlp, self.w, self.activations):
-            v = act(mlp(conv(v)) + w(v))
-        v = self.reduction(v)
+            x1 = conv(v)
+            fused = hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
+            v = fused if fused is not None else act(mlp(x1) + w(v))
+        red = hip_pointwise(v, None, None, self.reduction)
+        v = red if red is not None else self.reduction(v)
         return self.output_operator(v, v_res, out_steps=out_steps)
 
 
