@@ -97,7 +97,9 @@ SIGNATURES = {
                                     _i, _i, ctypes.c_float, ctypes.c_float, _i, _vp, _sz, _vp]),
     "tcfd_fno_contract": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                _i, _i, _vp]),
-    "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
+    "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
+                                _l, _vp]),
+    "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
 }

@@ -582,6 +582,8 @@ struct PwArgs {
     const float* wst;   // (CI, CO)  = Ws transposed (mode 1)
     const float* bs;    // (CO) or null
     long P;
+    long w2_bstride, b2_bstride;  // per-batch-element offsets of w2t / b2 (0: shared) -- lets a per-sample
+                                  // affine map (e.g. a folded LayerNorm) ride in the single-layer form
     int T, sT, act1, act2, skip_mode;
 };
 
@@ -604,8 +606,10 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     const float* xb = a.x + (size_t)b * CI * a.P + p;
 #pragma unroll
     for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+    const float* w2t_b = a.w2t + (size_t)b * a.w2_bstride;
+    const float* b2_b = a.b2 ? a.b2 + (size_t)b * a.b2_bstride : nullptr;
 #pragma unroll
-    for (int c = 0; c < CO; ++c) o[c] = a.b2 ? a.b2[c] : 0.f;
+    for (int c = 0; c < CO; ++c) o[c] = b2_b ? b2_b[c] : 0.f;
     if constexpr (HAS_L1) {
 #pragma unroll 4
         for (int m = 0; m < CM; ++m) {
@@ -614,14 +618,14 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
 #pragma unroll
             for (int i = 0; i < CI; ++i) h += w1[i] * x[i];
             h = pw_act(h, a.act1);
-            const float* w2 = a.w2t + m * CO;
+            const float* w2 = w2t_b + m * CO;
 #pragma unroll
             for (int c = 0; c < CO; ++c) o[c] += w2[c] * h;
         }
     } else {
 #pragma unroll
         for (int m = 0; m < CI; ++m) {
-            const float* w2 = a.w2t + m * CO;
+            const float* w2 = w2t_b + m * CO;
 #pragma unroll
             for (int c = 0; c < CO; ++c) o[c] += w2[c] * x[m];
         }
@@ -664,7 +668,7 @@ static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
 extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w1, const void* b1,
                                   const void* w2t, const void* b2, const void* wst, const void* bs, int batch, int ci,
                                   int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
-                                  void* stream) {
+                                  long w2_bstride, long b2_bstride, void* stream) {
     if (!x || !out || !w2t || batch <= 0 || P <= 0) return FAIL(TCFD_EINVAL, "fno_pointwise: bad argument");
     if (skip_mode && !skip) return FAIL(TCFD_EINVAL, "fno_pointwise: skip input missing");
     if (skip_mode == 2 && (T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise: bad T");
@@ -673,6 +677,7 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
     a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
     a.wst = (const float*)wst; a.bs = (const float*)bs;
     a.P = P; a.T = T; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
+    a.w2_bstride = w2_bstride; a.b2_bstride = b2_bstride;
     hipStream_t st = (hipStream_t)stream;
     const bool l1 = w1 != nullptr;
 #define PW_CASE(CI_, CM_, CO_)                                                             \
@@ -687,4 +692,63 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
     }
 #undef PW_CASE
     return FAIL(TCFD_EINVAL, "fno_pointwise: channels (%d -> %d -> %d) not instantiated", ci, cm, co);
+}
+
+
+// ------------------------------------------------------------------ LayerNormnd statistics
+// sum and sum of squares of every row of a (rows, L) fp32 matrix (one row = one sample's (C, X, Y, T) block),
+// accumulated in double.  torch's GroupNorm moments kernel runs ONE workgroup per row (6 ms for 32 rows of
+// 6.5 M elements on MI355X); here every row is cut into chunks reduced by different workgroups.
+__global__ __launch_bounds__(256) void k_row_moments(const float* __restrict__ x, double* __restrict__ stats, long L,
+                                                     int chunks) {
+    __shared__ double sh[2][4];
+    const int row = blockIdx.y, chunk = blockIdx.x;
+    const long per = ((L + chunks - 1) / chunks + 3) & ~3L;
+    const long lo = (long)chunk * per, hi = lo + per < L ? lo + per : L;
+    const float* r = x + (size_t)row * L;
+    double s1 = 0.0, s2 = 0.0;
+    float a1 = 0.f, a2 = 0.f;
+    int cnt = 0;
+    const bool vec = ((L & 3) == 0);
+    if (vec) {
+        for (long i = lo + (long)threadIdx.x * 4; i < hi; i += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(r + i);
+            a1 += (v.x + v.y) + (v.z + v.w);
+            a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            if (++cnt == 16) { s1 += a1; s2 += a2; a1 = a2 = 0.f; cnt = 0; }  // short fp32 runs, double totals
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = r[i];
+            a1 += v;
+            a2 += v * v;
+            if (++cnt == 64) { s1 += a1; s2 += a2; a1 = a2 = 0.f; cnt = 0; }
+        }
+    }
+    s1 += a1;
+    s2 += a2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+    }
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * row], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&stats[2 * row + 1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    }
+}
+
+// stats (rows, 2) double, zeroed by this call (memset node on the stream) before the accumulation.
+extern "C" int tcfd_row_moments(const void* x, void* stats, int rows, long L, void* stream) {
+    if (!x || !stats || rows <= 0 || L <= 0) return FAIL(TCFD_EINVAL, "row_moments: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(stats, 0, (size_t)rows * 2 * sizeof(double), st));
+    int chunks = (int)std::min<long>(std::max<long>(L / (256 * 4 * 8), 1), 2048 / std::max(rows, 1) + 1);
+    hipLaunchKernelGGL(k_row_moments, dim3((unsigned)chunks, (unsigned)rows), dim3(256), 0, st, (const float*)x,
+                       (double*)stats, L, chunks);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }

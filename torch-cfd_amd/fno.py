@@ -200,7 +200,7 @@ def _is_pointwise(conv) -> bool:
 
 
 def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, act2=None,
-                  skip_last_slice: bool = False) -> Optional[torch.Tensor]:
+                  skip_last_slice: bool = False, norm: Optional[nn.GroupNorm] = None) -> Optional[torch.Tensor]:
     """out = act2( lin2(act1(lin1(x))) [+ skip_conv(skip) | + skip[..., -1:]] ) in ONE fused HIP kernel
     (``tcfd_fno_pointwise``); ``lin1=None`` makes it a single 1x1x1 convolution.  Returns ``None`` when the
     combination is not covered (channel counts, activation type, dtype, autograd) -- the caller then runs its
@@ -235,14 +235,41 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
 
     w1 = mat(lin1, False) if lin1 is not None else None
     w2t = mat(lin2, True)
+    w2_bs = b2_bs = 0
+    folded_bias = None
+    if norm is not None:
+        # LayerNormnd (GroupNorm, one group) followed by a 1x1x1 convolution: the statistics come from the
+        # many-workgroup moments kernel, the normalisation + affine is folded into per-sample weights
+        #   W'_b[c, o] = W[o, c] gamma_c rstd_b ,  b'_b[o] = bias[o] + sum_c W[o, c] (beta_c - gamma_c mu_b rstd_b)
+        if lin1 is not None or norm.num_groups != 1 or norm.num_channels != ci:
+            return None
+        L = ci * P
+        stats = torch.empty(b, 2, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().tcfd_row_moments(x.data_ptr(), stats.data_ptr(), b, L, ctypes.c_void_p(
+                torch.cuda.current_stream(x.device).cuda_stream)), "tcfd_row_moments")
+        mu = stats[:, 0] / L
+        rstd = torch.rsqrt((stats[:, 1] / L - mu * mu).clamp_min(0) + norm.eps)
+        gamma = norm.weight.detach().double() if norm.weight is not None else torch.ones(ci, dtype=torch.float64, device=x.device)
+        beta = norm.bias.detach().double() if norm.bias is not None else torch.zeros(ci, dtype=torch.float64, device=x.device)
+        W = lin2.weight.detach().reshape(co, ci).double()
+        w2t = (W.t()[None] * (gamma[None, :, None] * rstd[:, None, None])).float().contiguous()      # (b, ci, co)
+        shift = beta[None, :] - gamma[None, :] * (mu * rstd)[:, None]                               # (b, ci)
+        folded_bias = shift @ W.t()
+        if lin2.bias is not None:
+            folded_bias = folded_bias + lin2.bias.detach().double()[None]
+        folded_bias = folded_bias.float().contiguous()                                              # (b, co)
+        w2_bs, b2_bs = ci * co, co
     wst = mat(skip_conv, True) if skip_conv is not None else None
     ptr = lambda t: t.data_ptr() if t is not None else None
     bias = lambda c: c.bias.detach().contiguous() if (c is not None and c.bias is not None) else None
     b1, b2, bs = bias(lin1), bias(lin2), bias(skip_conv)
+    if folded_bias is not None:
+        b2 = folded_bias
     lib = _lib.load()
     with torch.cuda.device(x.device):
         rc = lib.tcfd_fno_pointwise(x.data_ptr(), ptr(s_t), out.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst),
-                                    ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode,
+                                    ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs,
                                     ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
         return None
@@ -456,10 +483,10 @@ class LiftingOperator(nn.Module):
 
     def forward(self, v):
         assert self.latent_steps <= v.size(-1)
-        vn = self.norm(self.pe(v))
-        v = hip_pointwise(vn, None, None, self.proj)
+        vp = self.pe(v)
+        v = hip_pointwise(vp, None, None, self.proj, norm=self.norm)  # LayerNormnd folded into the projection
         if v is None:
-            v = self.proj(vn)
+            v = self.proj(self.norm(vp))
         x1 = self.sconv(v)
         if isinstance(self.mlp, PointwiseFFN):
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=v,
