@@ -366,3 +366,35 @@ def test_compact_and_general_paths_agree(dev, monkeypatch):
         slow, _ = op2(w0, 1e-3, steps=4)
         monkeypatch.delenv(var)
         assert rel_l2(slow, fast) < 1e-13, var
+
+
+def test_trajectory_fuses_steps_between_records(dev):
+    """record_every_steps > 1: the unrecorded steps run as one multi-step call; results equal the oracle's
+    step-by-step loop, and a 1000-step fp32 run (BASELINE configs[1] length) stays within the stated drift."""
+    import torch_cfd_amd as tc
+    from oracle import ns2d as O
+
+    n, B = 64, 3
+    _, op = build_op(n, "f64", "kolmogorov", dev)
+    t = oracle_tables(n, "f64", "kolmogorov")
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64)) for s in range(B)])
+    ref = O.trajectory(w0, 1e-3, t, num_steps=23, record_every_steps=5, dtype=torch.complex128)
+    out = tc.get_trajectory_imex(op, w0.to(dev), 1e-3, num_steps=23, record_every_steps=5, dtype=torch.complex128)
+    for k in ("vorticity", "stream", "vort_t", "residual"):
+        assert out[k].shape == ref[k].shape == (B, 5, n, n // 2 + 1)
+        assert rel_l2(out[k], ref[k]) < (1e-10 if k in ("vorticity", "stream") else 1e-6), k
+
+
+def test_config2_1000_steps_fp32(dev):
+    """BASELINE configs[1]: McWilliams 256^2, B=16, fp32, 1000 RK4-CN steps; stated tolerance 5e-4 vs the
+    reference-equivalent fp32 run."""
+    from oracle import ns2d as O
+
+    n, B = 256, 16
+    _, op = build_op(n, "f32", None, dev)
+    t = oracle_tables(n, "f32", None)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64).float()) for s in range(B)])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref, _ = O.advance(w0, 1e-3, t, steps=1000)
+    out, _ = op(w0.to(dev), 1e-3, steps=1000)
+    assert rel_l2(out, ref) < 5e-4
