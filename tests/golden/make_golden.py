@@ -267,7 +267,28 @@ def gen_sfno():
     save("fno_sfno_tiny.npz", **out)
 
 
+def gen_imex():
+    """IMEXStepper orders 1 / 1.5 / 2 (equations.py:110-246) on the spectral operator, 3 steps, fp64."""
+    from torch_cfd.equations import IMEXStepper
+
+    torch.set_default_dtype(torch.float64)
+    out = {}
+    n = 32
+    grid = Grid(shape=(n, n), domain=((0, L), (0, L)))
+    w0 = ic_batch(grid, [0, 1], torch.float64)
+    out["w0"] = npy(w0)
+    for order, alpha, beta in ((1, 1.0, 1.0), (1.5, 0.5, 0.5), (2, 0.5, 0.5), (2, 2 / 3, 0.5)):
+        fn = KolmogorovForcing(grid=grid, scale=1.0, wave_number=4, swap_xy=False)
+        op = NavierStokes2DSpectral(viscosity=1e-3, grid=grid, drag=0.1, smooth=True, forcing_fn=fn,
+                                    solver=IMEXStepper(order=order, alpha=alpha, beta=beta))
+        with torch.no_grad():
+            w, d = op(w0, 1e-3, steps=3)
+        out[f"o{order}_a{alpha:.3f}_w"] = npy(w)
+        out[f"o{order}_a{alpha:.3f}_dwdt"] = npy(d)
+    save("ns2d_imex.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno"]
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno", "imex"]
     for w in which:
         globals()["gen_" + w]()

@@ -398,3 +398,20 @@ def test_config2_1000_steps_fp32(dev):
     ref, _ = O.advance(w0, 1e-3, t, steps=1000)
     out, _ = op(w0.to(dev), 1e-3, steps=1000)
     assert rel_l2(out, ref) < 5e-4
+
+
+@pytest.mark.parametrize("order,alpha,beta", [(1, 1.0, 1.0), (1.5, 0.5, 0.5), (2, 0.5, 0.5), (2, 2 / 3, 0.5)])
+def test_imex_steppers_golden(order, alpha, beta, dev):
+    """IMEXStepper orders 1 / 1.5 / 2 (equations.py:174-228) behind the same operator: the
+    explicit term runs on the HIP kernels, the few combinations around it are device tensor ops."""
+    import torch_cfd_amd as tc
+
+    g = load_golden("ns2d_imex.npz")
+    torch.set_default_dtype(torch.float64)
+    grid = tc.Grid(shape=(32, 32), domain=((0, L), (0, L)))
+    fn = tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4)
+    op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, forcing_fn=fn,
+                                   solver=tc.IMEXStepper(order=order, alpha=alpha, beta=beta)).to(dev)
+    w, d = op(torch.from_numpy(g["w0"]).to(dev), 1e-3, steps=3)
+    assert rel_l2(w, g[f"o{order}_a{alpha:.3f}_w"]) < 1e-10
+    assert rel_l2(d, g[f"o{order}_a{alpha:.3f}_dwdt"]) < 1e-8

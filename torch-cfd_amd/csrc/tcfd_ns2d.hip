@@ -916,14 +916,11 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
         const long tiles = batch * ((p->m + Cfg<T, N>::COLS - 1) / Cfg<T, N>::COLS);
         if (force == 1 || (force != 0 && tiles < 2 * 256)) return launch_cols_v<T, N, MODE, 4, 4>(p, a, batch, st);
     }
-    if constexpr (N == 512 && sizeof(T) == 8 && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
-        static const int variant = env_int("TCFD_VARIANT_COLS", 0);
-        switch (variant) {
-            case 1: return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);   // 512 thr, <=128 VGPR: 2 WG/CU
-            case 2: return launch_cols_v<T, N, MODE, 16, 8, 2>(p, a, batch, st);  // 256 thr, <=256 VGPR: 2 WG/CU
-            case 3: return launch_cols_v<T, N, MODE, 16, 8, 4>(p, a, batch, st);  // 256 thr, <=128 VGPR: 4 WG/CU (LDS: 2)
-            default: break;
-        }
+    // 512-point fp64 tiles are 64 KB: capping the update kernels at 128 VGPRs lets TWO workgroups share a CU,
+    // so one tile's memory phases overlap the other's transforms (measured at 512^2 x 256: CA 1.05 -> 0.87 ms)
+    if constexpr (N == 512 && sizeof(T) == 8 && (MODE == MODE_CA || MODE == MODE_C)) {
+        static const int two = env_int("TCFD_TWO_WG", 1);
+        if (two) return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);
     }
     if constexpr (N == 1024 && sizeof(T) == 8 && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
         static const int variant = env_int("TCFD_VARIANT_COLS", 0);
