@@ -415,3 +415,23 @@ def test_imex_steppers_golden(order, alpha, beta, dev):
     w, d = op(torch.from_numpy(g["w0"]).to(dev), 1e-3, steps=3)
     assert rel_l2(w, g[f"o{order}_a{alpha:.3f}_w"]) < 1e-10
     assert rel_l2(d, g[f"o{order}_a{alpha:.3f}_dwdt"]) < 1e-8
+
+
+@pytest.mark.parametrize("n,tag", [(16, "f64"), (64, "f32"), (256, "f64"), (512, "f32")])
+def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
+    """The radix-2 split of the column transform (default at 1024^2 fp64) can be forced on or off for any
+    n >= 16; both plans must give the same step and the same explicit terms."""
+    from oracle import ns2d as O
+
+    real = REAL[tag]
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, real)) for s in range(2)]).to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TCFD_SPLIT", flag)
+        _, op = build_op(n, tag, "kolmogorov", dev)
+        out, dwdt = op(w0, 1e-3, steps=3)
+        res[flag] = (out, dwdt, op.explicit_terms(w0), op.residual(out, dwdt))
+    monkeypatch.delenv("TCFD_SPLIT")
+    tol = 1e-12 if tag == "f64" else 2e-6
+    for a, b in zip(res["0"][:3], res["1"][:3]):
+        assert rel_l2(a, b) < tol

@@ -131,10 +131,15 @@ struct ColArgs {
     int pair_xcd;  // block->tile map: 0 = batch fastest; 1 = adjacent half-line tiles paired on one XCD
 };
 
-template <typename T, int N, int EPT, int C>
+// SP = 1 ("split"): the workgroup owns the rows of ONE parity q of the column (i = 2 s + q) and runs N/2-point
+// transforms on them; the radix-2 butterfly that joins the two parities rides in the row kernel, which works
+// on row pairs (r, r + N/2) anyway.  Workspace rows [0, N/2) then hold the even-part transforms E (resp. the
+// folded sums S of the advection), rows [N/2, N) the odd parts O (resp. the twiddled differences D).
+template <typename T, int N, int EPT, int C, int SP>
 __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, const T* rt_kx,
-                                            size_t wbase, int j, int c, int jc, bool valid) {
-    constexpr int G = N / EPT;
+                                            size_t wbase, int j, int c, int jc, bool valid, int q) {
+    constexpr int NT = N >> SP;
+    constexpr int G = NT / EPT;
     constexpr T TWO_PI = (T)6.283185307179586476925286766559;
     constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
     const T inv_n2 = (T)1 / ((T)N * (T)N);
@@ -144,8 +149,9 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
         cx<T> x[EPT];
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            const int i = j + t * G;
-            const T kx = rt_kx[i];
+            const int sl = j + t * G;
+            const int i = SP ? 2 * sl + q : sl;
+            const T kx = rt_kx[sl];
             cx<T> us = cscale(u[t], inv_n2);
             if (f < 2) {  // stream function: psi = -w / lap, lap(0,0) patched to 1
                 T lap = M4PI2 * (kx * kx + ky * ky);
@@ -159,9 +165,9 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             if (f == 1) v = mk<T>(-v.x, -v.y);
             x[t] = valid ? v : mk<T>((T)0, (T)0);
         }
-        if (!(a.ablate & 1)) tile_fft<T, N, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
+        if (!(a.ablate & 1)) tile_fft<T, NT, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
         if (valid && !(a.ablate & 2)) {
-            cx<T>* dst = a.planes + (size_t)f * a.plane_stride + wbase;
+            cx<T>* dst = a.planes + (size_t)f * a.plane_stride + wbase + (size_t)(SP ? q * NT : 0) * a.ldw;
 #pragma unroll
             for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.ldw] = x[t];
         }
@@ -169,17 +175,18 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
 }
 
 // x[t] (column FFT of the advection) -> F = mask * x + forcing, in place (equations.py:424-437)
-template <typename T, int N, int EPT>
+template <typename T, int N, int EPT, int SP>
 __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&x)[EPT], int j, int jc,
-                                                   const T* rt_mask, T cm, int f_lo, int f_hi) {
-    constexpr int G = N / EPT;
+                                                   const T* rt_mask, T cm, int f_lo, int f_hi, int q) {
+    constexpr int G = (N >> SP) / EPT;
+#define TCFD_IROW(t_) (SP ? 2 * (j + (t_) * G) + q : j + (t_) * G)
     if (a.ablate & 4) return;
     if (a.sep) {
 #pragma unroll
         for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], rt_mask[j + t * G] * cm);
     } else {
 #pragma unroll
-        for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask[(size_t)(j + t * G) * a.m + jc]);
+        for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], a.mask[(size_t)TCFD_IROW(t) * a.m + jc]);
     }
     if (a.f_nnz > 0) {  // a handful of entries in total (1 for Kolmogorov forcing): uniform loop
         for (int e = 0; e < a.f_nnz; ++e) {
@@ -188,7 +195,7 @@ __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&
             if (a.f_col[e] == jc) {
 #pragma unroll
                 for (int t = 0; t < EPT; ++t)
-                    if (r == j + t * G) x[t] = x[t] + v;
+                    if (r == TCFD_IROW(t)) x[t] = x[t] + v;
             }
         }
     } else if (a.f_ptr) {  // sparse, many entries: this column's slice of the CSC list
@@ -197,19 +204,25 @@ __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&
             const cx<T> v = a.f_val[e];
 #pragma unroll
             for (int t = 0; t < EPT; ++t)
-                if (r == j + t * G) x[t] = x[t] + v;
+                if (r == TCFD_IROW(t)) x[t] = x[t] + v;
         }
     } else if (a.forcing) {
 #pragma unroll
-        for (int t = 0; t < EPT; ++t) x[t] = x[t] + a.forcing[(size_t)(j + t * G) * a.m + jc];
+        for (int t = 0; t < EPT; ++t) x[t] = x[t] + a.forcing[(size_t)TCFD_IROW(t) * a.m + jc];
     }
+#undef TCFD_IROW
 }
 
-template <typename T, int N, int EPT, int C, int MODE, int MINW>
-__global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
+template <typename T, int N, int EPT, int C, int MODE, int MINW, int SP = 0>
+__global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
-    constexpr int G = N / EPT;
+    constexpr int NT = N >> SP;  // transform length (half the column when the workgroup owns one parity)
+    constexpr int G = NT / EPT;
+    static_assert(!(SP && (MODE == MODE_FWD || MODE == MODE_INV)), "plain transforms are not split");
+    const int q = SP ? (int)blockIdx.y : 0;  // parity of the spectral rows this workgroup owns
+#define TCFD_IROW(s_) (SP ? 2 * (s_) + q : (s_))
+    const size_t wq = (size_t)(SP ? q * NT : 0);  // first workspace row of this parity
     const int c = threadIdx.x % C;
     const int j = threadIdx.x / C;
     // batch is the fastest block index: the blocks that share one tile of the (n, m) tables
@@ -236,17 +249,18 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
     // per-row constants (kx, separable parts of the linear term and of the mask) live in LDS behind the
     // exchange tile: every later use is an LDS read instead of a dependent global load; per-column
     // constants and the forcing column range are fetched up front, before the transform needs them
-    T* rt_kx = reinterpret_cast<T*>(lds + lds_elems<N, EPT, C, false>());
-    T* rt_lin = rt_kx + N;
-    T* rt_mask = rt_lin + N;
+    T* rt_kx = reinterpret_cast<T*>(lds + lds_elems<NT, EPT, C, false>());
+    T* rt_lin = rt_kx + NT;
+    T* rt_mask = rt_lin + NT;
     constexpr bool NEEDS_TABLES = (MODE != MODE_FWD && MODE != MODE_INV);
     T col_ky = 0, col_lin = 0, col_mask = 1;
     int f_lo = 0, f_hi = 0;
     if constexpr (NEEDS_TABLES) {
-        for (int i = threadIdx.x; i < N; i += C * G) {
-            rt_kx[i] = a.kx[i];
-            rt_lin[i] = a.sep ? a.lin_r[i] : (T)0;
-            rt_mask[i] = a.sep ? a.mask_r[i] : (T)1;
+        for (int sl = threadIdx.x; sl < NT; sl += C * G) {  // indexed by the LOCAL row sl, spectral row IROW(sl)
+            const int i = TCFD_IROW(sl);
+            rt_kx[sl] = a.kx[i];
+            rt_lin[sl] = a.sep ? a.lin_r[i] : (T)0;
+            rt_mask[sl] = a.sep ? a.mask_r[i] : (T)1;
         }
         if (valid) {
             col_ky = a.ky[jc];
@@ -261,10 +275,10 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             const size_t ub = (size_t)b * N * a.u_in_ld + jc;
 #pragma unroll
             for (int t = 0; t < EPT; ++t)
-                x[t] = valid ? a.u_in[ub + (size_t)(j + t * G) * a.u_in_ld] : mk<T>((T)0, (T)0);
+                x[t] = valid ? a.u_in[ub + (size_t)TCFD_IROW(j + t * G) * a.u_in_ld] : mk<T>((T)0, (T)0);
         }
         __syncthreads();  // row tables visible
-        emit_planes<T, N, EPT, C>(a, x, lds, rt_kx, wbase, j, c, jc, valid);
+        emit_planes<T, N, EPT, C, SP>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
         return;
     } else {
         constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
@@ -275,9 +289,9 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
         const bool tile_live = GENERIC || a.keep_cols == 0 || tile * C < a.keep_cols;  // block-uniform
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            x[t] = col_live ? a.in[inbase + (size_t)(j + t * G) * in_ld] : mk<T>((T)0, (T)0);
+            x[t] = col_live ? a.in[inbase + (wq + (size_t)(j + t * G)) * in_ld] : mk<T>((T)0, (T)0);
         constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
-        if (!(a.ablate & 1) && tile_live) tile_fft<T, N, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+        if (!(a.ablate & 1) && tile_live) tile_fft<T, NT, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
         if constexpr (NEEDS_TABLES) __syncthreads();  // row tables visible (a one-pass transform has no barrier)
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
@@ -289,30 +303,31 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             return;
         } else if constexpr (MODE == MODE_F) {
             if (valid) {
-                apply_mask_forcing<T, N, EPT>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi);
+                apply_mask_forcing<T, N, EPT, SP>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi, q);
 #pragma unroll
-                for (int t = 0; t < EPT; ++t) a.out[colbase + (size_t)(j + t * G) * a.m] = x[t];
+                for (int t = 0; t < EPT; ++t) a.out[colbase + (size_t)TCFD_IROW(j + t * G) * a.m] = x[t];
             }
             return;
         } else if constexpr (MODE == MODE_RES) {
             if (valid) {
                 constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
                 const T ky = col_ky;
-                apply_mask_forcing<T, N, EPT>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi);
+                apply_mask_forcing<T, N, EPT, SP>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi, q);
                 const T lc = col_lin;
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) {
-                    const int i = j + t * G;
+                    const int sl = j + t * G;
+                    const int i = TCFD_IROW(sl);
                     const size_t g = colbase + (size_t)i * a.m;
                     const cx<T> F = x[t];
                     const cx<T> w = a.u_in[g];
                     if (a.out) {
                         const cx<T> wt = a.wt[g];
-                        const T L = a.sep ? rt_lin[i] + lc : a.lin[(size_t)i * a.m + jc];
+                        const T L = a.sep ? rt_lin[sl] + lc : a.lin[(size_t)i * a.m + jc];
                         a.out[g] = wt - F - cscale(w, L);
                     }
                     if (a.psi) {
-                        const T kx = rt_kx[i];
+                        const T kx = rt_kx[sl];
                         T lap = M4PI2 * (kx * kx + ky * ky);
                         if (i == 0 && jc == 0) lap = (T)1;
                         a.psi[g] = cscale(w, (T)-1 / lap);
@@ -322,20 +337,21 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
             if (valid) {
-                apply_mask_forcing<T, N, EPT>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi);
+                apply_mask_forcing<T, N, EPT, SP>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi, q);
                 const T lc = col_lin;
 #pragma unroll
                 for (int t = 0; t < EPT; ++t) {
-                    const int i = j + t * G;
-                    const size_t gw = wbase + (size_t)i * a.ldw;
+                    const int sl = j + t * G;
+                    const int i = TCFD_IROW(sl);
+                    const size_t gw = wbase + (wq + (size_t)sl) * a.ldw;  // h is stored parity-major when split
                     cx<T> hn = x[t];
                     // pruned entries: F = 0 at every stage, so h stays 0 and is not stored at all
-                    const bool h_live = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[i] != (T)0));
+                    const bool h_live = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[sl] != (T)0));
                     if (h_live) {
                         if (a.load_h) hn = hn + cscale(a.h[gw], a.beta);
                         a.h[gw] = hn;
                     }
-                    const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[i] + lc : a.lin[(size_t)i * a.m + jc]);
+                    const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[sl] + lc : a.lin[(size_t)i * a.m + jc]);
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                     cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
@@ -344,9 +360,10 @@ __global__ __launch_bounds__(C*(N / EPT), MINW) void k_cols(ColArgs<T> a) {
                     a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                 }
             }
-            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C>(a, x, lds, rt_kx, wbase, j, c, jc, valid);
+            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
         }
     }
+#undef TCFD_IROW
 }
 
 // ------------------------------------------------------------------ row kernels
@@ -556,6 +573,147 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
     }
 }
 
+// ---- row pass for the split column transforms ("v4") -----------------------------------------
+// Row pair = (r, r + N/2).  The planes hold, for every field, the N/2-point column transforms of the even
+// spectral rows (E, workspace rows [0, N/2)) and of the odd ones (O, rows [N/2, N)); the column transform is
+// completed here:  x[r] = E[r] + w O[r],  x[r + N/2] = E[r] - w O[r],  w = exp(+2 pi i r / N).
+// Symmetrically the advection spectra A_r, A_{r+N/2} leave as S = A_r + A_{r+N/2} and
+// D = (A_r - A_{r+N/2}) exp(-2 pi i r / N), which the two parity workgroups of the column pass transform
+// with N/2 points each.  Same loads, stores and transforms per pair as k_rows_advect3.
+template <typename T, int EPT>
+struct HalfQuad {  // un-mirrored half rows of E and O of one plane (+ the Nyquist elements)
+    cx<T> e[EPT / 2], o[EPT / 2];
+    cx<T> en, on;
+};
+
+template <typename T, int N, int EPT>
+__device__ __forceinline__ void load_half(HalfQuad<T, EPT>& h, const cx<T>* __restrict__ rowE,
+                                          const cx<T>* __restrict__ rowO, int j) {
+    constexpr int G = N / EPT;
+#pragma unroll
+    for (int t = 0; t < EPT / 2; ++t) {
+        h.e[t] = rowE[j + t * G];
+        h.o[t] = rowO[j + t * G];
+    }
+    h.en = rowE[N / 2];
+    h.on = rowO[N / 2];
+}
+
+// h.o <- w * h.o (done once per pair; both output rows reuse it)
+template <typename T, int EPT>
+__device__ __forceinline__ void twist_half(HalfQuad<T, EPT>& h, cx<T> w) {
+#pragma unroll
+    for (int t = 0; t < EPT / 2; ++t) h.o[t] = cmul(h.o[t], w);
+    h.on = cmul(h.on, w);
+}
+
+// RawPair of output row r (SIGN=+1) or r + N/2 (SIGN=-1) from the twisted half quads of planes (a, b)
+template <typename T, int EPT, int SIGN>
+__device__ __forceinline__ void combine_halves(RawPair<T, EPT>& r, const HalfQuad<T, EPT>& ha,
+                                               const HalfQuad<T, EPT>& hb) {
+#pragma unroll
+    for (int t = 0; t < EPT / 2; ++t) {
+        r.a[t] = SIGN > 0 ? ha.e[t] + ha.o[t] : ha.e[t] - ha.o[t];
+        r.b[t] = SIGN > 0 ? hb.e[t] + hb.o[t] : hb.e[t] - hb.o[t];
+    }
+    r.an = SIGN > 0 ? ha.en + ha.on : ha.en - ha.on;
+    r.bn = SIGN > 0 ? hb.en + hb.on : hb.en - hb.on;
+}
+
+template <typename T, int N, int EPT, int THR>
+__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect4(
+    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
+    long npairs, int ld, int kc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT, THR>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    constexpr int N2 = N / 2;
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    const long stride = (long)gridDim.x * Gm::GROUPS;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const long iters = (npairs + stride - 1) / stride;
+    // pair p -> batch b = p / N2, row r = p % N2; E row = b*N + r, O row = b*N + N2 + r
+    auto erow = [&](long p) { return (size_t)((p / N2) * N + (p % N2)) * (size_t)ld; };
+    const size_t oskip = (size_t)N2 * ld;
+
+    HalfQuad<T, EPT> h0, h1;
+    {
+        const size_t off = erow(pair < npairs ? pair : npairs - 1);
+        load_half<T, N, EPT>(h0, planes + off, planes + off + oskip, j);
+        load_half<T, N, EPT>(h1, planes + plane_stride + off, planes + plane_stride + off + oskip, j);
+    }
+    for (long it = 0; it < iters; ++it, pair += stride) {
+        const bool valid = pair < npairs;
+        const long cur = valid ? pair : npairs - 1;
+        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
+        const size_t off = erow(cur), offn = erow(nxt);
+        const int r = (int)(cur % N2);
+        const cx<T> wf = tw[r];            // exp(-2 pi i r / N)
+        const cx<T> wi = cconj(wf);        // exp(+2 pi i r / N)
+        const cx<T>* P2 = planes + 2 * plane_stride;
+        const cx<T>* P3 = planes + 3 * plane_stride;
+        cx<T> x[EPT], z1r[EPT], z1s[EPT], p[EPT];
+        RawPair<T, EPT> raw;
+
+        twist_half<T, EPT>(h0, wi);
+        twist_half<T, EPT>(h1, wi);
+        combine_halves<T, EPT, +1>(raw, h0, h1);
+        pack_herm<T, N, EPT, WG>(z1r, raw, lds, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(z1r, lds, tw, j, 0);     // vx + i vy, row r
+        combine_halves<T, EPT, -1>(raw, h0, h1);
+        load_half<T, N, EPT>(h0, P2 + off, P2 + off + oskip, j);      // planes 2, 3: in flight during the transform
+        load_half<T, N, EPT>(h1, P3 + off, P3 + off + oskip, j);
+        pack_herm<T, N, EPT, WG>(z1s, raw, lds, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(z1s, lds, tw, j, 0);     // vx + i vy, row r + N/2
+
+        twist_half<T, EPT>(h0, wi);
+        twist_half<T, EPT>(h1, wi);
+        combine_halves<T, EPT, +1>(raw, h0, h1);
+        pack_herm<T, N, EPT, WG>(x, raw, lds, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);       // dx w + i dy w, row r
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t].x = -(x[t].x * z1r[t].x + x[t].y * z1r[t].y);
+        combine_halves<T, EPT, -1>(raw, h0, h1);
+        load_half<T, N, EPT>(h0, planes + offn, planes + offn + oskip, j);  // next pair, planes 0 and 1
+        load_half<T, N, EPT>(h1, planes + plane_stride + offn, planes + plane_stride + offn + oskip, j);
+        pack_herm<T, N, EPT, WG>(x, raw, lds, j);
+        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t].y = -(x[t].x * z1s[t].x + x[t].y * z1s[t].y);
+
+        tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
+        // unpack the two real-row spectra and fold them for the parity workgroups of the column pass
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(j + t * G, 0)] = p[t];
+        group_sync<WG>();
+        const T half = (T)0.5;
+        cx<T>* outS = adv + off;
+        cx<T>* outD = adv + off + oskip;
+#pragma unroll
+        for (int t = 0; t < EPT / 2; ++t) {
+            const int k = j + t * G;
+            const cx<T> A = p[t];
+            const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
+            const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of row r
+            const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of row r + N/2
+            if (valid && k < kc) {
+                outS[k] = X0 + X1;
+                outD[k] = cmul(X0 - X1, wf);
+            }
+        }
+        if (j == 0 && valid && N / 2 < kc) {
+            const cx<T> A = p[EPT / 2];
+            const cx<T> X0 = mk<T>(A.x, (T)0), X1 = mk<T>(A.y, (T)0);
+            outS[N / 2] = X0 + X1;
+            outD[N / 2] = cmul(X0 - X1, wf);
+        }
+        group_sync<WG>();
+    }
+}
+
 // real (rows, N) -> half spectrum (rows, m): first half of rfft2
 template <typename T, int N, int EPT>
 __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_r2c(const T* __restrict__ in,
@@ -656,6 +814,7 @@ struct tcfd_ns2d_plan {
     int n, m, dtype;
     int ldw;        // workspace row pitch in elements: m rounded up so that a row is a multiple of 128 bytes
     void* tw;       // cx<T>[n]
+    void* tw2;      // cx<T>[n/2]: table of the half-length column transforms (split plans)
     void* kx;       // T[n]
     void* ky;       // T[m]
     void* lin;      // T[n*m]
@@ -703,6 +862,11 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
     for (size_t i = 0; i < (size_t)n * m; ++i) { l[i] = (T)lin[i]; k[i] = (T)mask[i]; }
     int rc;
     if ((rc = upload(&p->tw, tw))) return rc;
+    {
+        std::vector<T> t2((size_t)n);  // W_{n/2}^t = W_n^{2t}
+        for (int t = 0; t < n / 2; ++t) { t2[2 * t] = tw[2 * (2 * t)]; t2[2 * t + 1] = tw[2 * (2 * t) + 1]; }
+        if ((rc = upload(&p->tw2, t2))) return rc;
+    }
     if ((rc = upload(&p->kx, a))) return rc;
     if ((rc = upload(&p->ky, b))) return rc;
     if ((rc = upload(&p->lin, l))) return rc;
@@ -781,7 +945,7 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
 
 extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     if (!p) return;
-    void* ptrs[] = {p->tw, p->kx, p->ky, p->lin, p->mask, p->forcing, p->mask_r, p->mask_c,
+    void* ptrs[] = {p->tw, p->tw2, p->kx, p->ky, p->lin, p->mask, p->forcing, p->mask_r, p->mask_c,
                     p->lin_r, p->lin_c, p->f_ptr, p->f_row, p->f_val, p->f_col};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -864,10 +1028,11 @@ static int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
-template <typename T, int N, int MODE, int EPT, int C, int MINW = 1>
+template <typename T, int N, int MODE, int EPT, int C, int MINW = 1, int SP = 0>
 static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
-    constexpr int G = N / EPT;
-    constexpr size_t lds = (size_t)lds_elems<N, EPT, C, false>() * sizeof(cx<T>) + 3 * (size_t)N * sizeof(T);
+    constexpr int NT = N >> SP;
+    constexpr int G = NT / EPT;
+    constexpr size_t lds = (size_t)lds_elems<NT, EPT, C, false>() * sizeof(cx<T>) + 3 * (size_t)NT * sizeof(T);
     a.m = p->m;
     a.ldw = p->ldw;
     a.ntiles = (p->m + C - 1) / C;
@@ -888,8 +1053,8 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.f_val = (const cx<T>*)p->f_val;
     a.sep = p->sep;
     a.keep_cols = p->keep_cols;
-    a.tw = (const cx<T>*)p->tw;
-    auto kern = k_cols<T, N, EPT, C, MODE, MINW>;
+    a.tw = (const cx<T>*)(SP ? p->tw2 : p->tw);
+    auto kern = k_cols<T, N, EPT, C, MODE, MINW, SP>;
     static bool attr_done = false;
     if (!attr_done) {
         int rc = set_lds(kern, lds);
@@ -902,13 +1067,41 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.ablate = ablate;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
     ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C * G), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SP ? 2u : 1u), dim3(C * G), lds, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+#ifndef TCFD_SPLIT_A_MINW4
+#define TCFD_SPLIT_A_MINW4 1
+#endif
+// Split plans: the column transform is cut radix-2 across the row pass so that a column tile is half as big
+// and two workgroups share a CU.  Default: where the full tile would fill the CU's LDS (n = 1024 in fp64).
+template <typename T, int N>
+static bool use_split() {
+    static const int force = env_int("TCFD_SPLIT", -1);
+    if (N < 16) return false;
+    if (force >= 0) return force != 0;
+    return N == 1024 && sizeof(T) == 8;
+}
+
+template <typename T, int N, int MODE>
+static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
+    constexpr int H = N >= 16 ? N / 2 : 8;
+    constexpr int EPT = Cfg<T, H>::COL_EPT, C = Cfg<T, H>::COLS;
+    // 128 VGPRs per lane = two 512-lane workgroups per CU for the half-size fp64 tiles
+    constexpr int MINW = (C * (H / EPT) == 512 && (MODE != MODE_A || TCFD_SPLIT_A_MINW4)) ? 4 : 1;
+    if constexpr (N >= 16 && MODE != MODE_FWD && MODE != MODE_INV)
+        return launch_cols_v<T, N, MODE, EPT, C, MINW, 1>(p, a, batch, st);
+    else
+        return fail(TCFD_EINVAL, "split launch of an unsupported mode");
+}
+
 template <typename T, int N, int MODE>
 static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
+    if constexpr (MODE != MODE_FWD && MODE != MODE_INV) {
+        if (use_split<T, N>()) return launch_cols_split<T, N, MODE>(p, a, batch, st);
+    }
     // small problems (few column tiles for 256 CUs, working set cache resident): narrow 4-column tiles and
     // 4 elements per lane give ~4x more, shorter workgroups (measured at 256^2 x 16 fp32: CA 29 -> 21 us)
     if constexpr ((N == 128 || N == 256) && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
@@ -976,9 +1169,34 @@ static int launch_rows_advect3(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
+template <typename T, int N, int EPT, int THR>
+static int launch_rows_advect4(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
+                               long batch, hipStream_t st) {
+    using Gm = RowGeom<T, N, EPT, THR>;
+    auto kern = k_rows_advect4<T, N, EPT, THR>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(kern, Gm::LDS_BYTES);
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const long npairs = batch * (N / 2);
+    const long want = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
+    static const int per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 8);
+    const long blocks = std::min<long>(want, 256L * per_cu);
+    ProfScope prof(p, 1, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
+                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <typename T, int N>
 static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
                               hipStream_t st) {
+    if (use_split<T, N>())
+        return launch_rows_advect4<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch,
+                                                                                     st);
     if constexpr (N == 128 || N == 256) {
         static const int force = env_int("TCFD_SMALL_TILES", -1);
         if (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256))
