@@ -130,6 +130,14 @@ int tcfd_fno_spectral_conv(const tcfd_fno_plan* plan, const void* v, const void*
                            const void* const* bias, float delta, void* out, int batch, int cin, int cout,
                            int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The two halves of the convolution on their own, for layers that post-process the spectrum between contraction
+ * and inverse transform (SpectralConvT(postprocess=HelmholtzProjection), fno/sfno.py:449):
+ *   forward_trunc: v (batch, c, X, Y, T_in) fp32 -> vh (batch, c, 2mx, 2my, mt) complex64, kept modes only
+ *   inverse_trunc: vh -> out (batch, c, X, Y, t_keep) fp32.  Workspace: tcfd_fno_workspace_bytes(plan, batch, c, c). */
+int tcfd_fno_forward_trunc(const tcfd_fno_plan* plan, const void* v, void* vh, int batch, int c, float fwd_scale,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int tcfd_fno_inverse_trunc(const tcfd_fno_plan* plan, const void* vh, void* out, int batch, int c, int t_keep,
+                           float inv_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* The contraction alone on truncated spectra (batch, c, 2mx, 2my, mt) complex64 (tests). */
 int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, float delta,
                       void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,

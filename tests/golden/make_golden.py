@@ -288,7 +288,30 @@ def gen_imex():
     save("ns2d_imex.npz", **out)
 
 
+def gen_helmholtz():
+    """SpectralConvT with the Helmholtz projection as spectrum post-processing (the out_dim = 2 OutConv core)."""
+    torch.set_default_dtype(torch.float32)
+    from fno.sfno import HelmholtzProjection, SpectralConvT
+
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(4)
+    n = 16
+    m = SpectralConvT(2, 2, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True,
+                      postprocess=HelmholtzProjection(n_grid=n, diam=2 * math.pi))
+    with torch.no_grad():
+        for b_ in m.bias:
+            b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+        x = torch.randn(2, 2, n, n, 6, generator=g)
+        out["x"] = npy(x)
+        for k, v in m.state_dict().items():
+            out["sd_" + k] = npy(v)
+        out["y"] = npy(m(x, out_steps=9))
+    save("fno_helmholtz.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno", "imex"]
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno", "imex",
+                             "helmholtz"]
     for w in which:
         globals()["gen_" + w]()

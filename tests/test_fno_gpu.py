@@ -213,3 +213,29 @@ def test_fused_pointwise_block_matches_torch_modules(width, act, dev):
         # not instantiated -> None (the caller keeps its torch modules)
         odd = torch.nn.Conv3d(7, 7, 1).to(dev)
         assert fno.hip_pointwise(torch.randn(1, 7, 8, 8, 4, device=dev), None, None, odd) is None
+
+
+def test_spectral_conv_t_with_helmholtz_postprocess_golden(dev):
+    """out_dim = 2 path: transform -> contraction -> Helmholtz projection on the kept modes -> inverse; the
+    output velocity field must also be divergence free (fno/sfno_pytest.py:72-129 checks < 1e-5 in fp32)."""
+    from torch_cfd_amd import fno
+    import math
+
+    g = load_golden("fno_helmholtz.npz")
+    n = 16
+    m = fno.SpectralConvT(2, 2, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True,
+                          postprocess=fno.HelmholtzProjection(n_grid=n, diam=2 * math.pi))
+    keys = sorted(k[3:] for k in g.files if k.startswith("sd_"))
+    assert sorted(m.state_dict().keys()) == keys
+    m.load_state_dict({k: torch.from_numpy(g["sd_" + k]) for k in keys})
+    m = m.to(dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]).to(dev), out_steps=9)
+    assert y.shape == (2, 2, n, n, 9)
+    assert rel_l2(y, g["y"]) < 1e-5
+    # divergence of (u, v) in Fourier space
+    k = torch.fft.fftfreq(n, d=2 * math.pi / n)
+    kx, ky = torch.meshgrid(k, k, indexing="ij")
+    yh = torch.fft.fft2(y.cpu().double(), dim=(2, 3))
+    div = 2j * math.pi * (yh[:, 0] * kx[None, :, :, None] + yh[:, 1] * ky[None, :, :, None])
+    assert (div.abs().max() / yh.abs().max()).item() < 1e-5

@@ -95,6 +95,8 @@ SIGNATURES = {
     "tcfd_fno_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "tcfd_fno_spectral_conv": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i,
                                     _i, _i, ctypes.c_float, ctypes.c_float, _i, _vp, _sz, _vp]),
+    "tcfd_fno_forward_trunc": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_float, _vp, _sz, _vp]),
+    "tcfd_fno_inverse_trunc": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp, _sz, _vp]),
     "tcfd_fno_contract": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                _i, _i, _vp]),
     "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,

@@ -548,6 +548,32 @@ extern "C" int tcfd_fno_spectral_conv(const tcfd_fno_plan* p, const void* v, con
     return do_inv_ty(p, W, (float*)out, (long)batch * cout * p->X, t_keep, inv_scale, st);
 }
 
+// The two halves of the spectral convolution on their own, for layers that post-process the spectrum between
+// the contraction and the inverse transform (SpectralConvT(postprocess=HelmholtzProjection), fno/sfno.py:449):
+//   forward_trunc : v (batch, c, X, Y, T_in) fp32  -> vh (batch, c, 2mx, 2my, mt) complex64 (kept modes only)
+//   inverse_trunc : vh (batch, c, 2mx, 2my, mt)    -> out (batch, c, X, Y, t_keep) fp32
+// Workspace: tcfd_fno_workspace_bytes(plan, batch, c, c).
+extern "C" int tcfd_fno_forward_trunc(const tcfd_fno_plan* p, const void* v, void* vh, int batch, int c, float fwd_scale,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !v || !vh || batch <= 0 || c <= 0) return FAIL(TCFD_EINVAL, "fno_forward_trunc: bad argument");
+    if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = do_fwd_ty(p, (const float*)v, (cf*)ws, (long)batch * c * p->X, fwd_scale, st))) return rc;
+    return do_fwd_x(p, (const cf*)ws, (cf*)vh, (long)batch * c, st);
+}
+
+extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
+                                      float inv_scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !vh || !out || batch <= 0 || c <= 0 || t_keep <= 0 || t_keep > p->T_out)
+        return FAIL(TCFD_EINVAL, "fno_inverse_trunc: bad argument");
+    if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = do_inv_x(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
+    return do_inv_ty(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, inv_scale, st);
+}
+
 // Contraction alone on caller-provided truncated spectra (tests, MFMA vs VALU cross-check).
 extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, float delta,
                                  void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,

@@ -135,6 +135,38 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     return out
 
 
+def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward"):
+    """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) fp32 -> (b, C, 2mx, 2my, mt) complex64, plus the plan."""
+    b, c, X, Y, T = v.shape
+    mx, my, mt = modes
+    t_out = T + t_pad if t_out is None else t_out
+    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device)
+    v = v.detach().contiguous()
+    vh = torch.empty(b, c, 2 * mx, 2 * my, mt, dtype=torch.complex64, device=v.device)
+    ws = plan.workspace(b, c, c)
+    fs, _ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    with torch.cuda.device(v.device):
+        rc = plan.lib.tcfd_fno_forward_trunc(plan.handle, v.data_ptr(), vh.data_ptr(), b, c, fs, ws.data_ptr(), ws.numel(),
+                                             ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+    _lib.check(rc, "tcfd_fno_forward_trunc")
+    return vh, plan
+
+
+def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward") -> torch.Tensor:
+    """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep)."""
+    X, Y, T, t_pad, t_out, mx, my, mt = plan.key
+    b, c = vh.shape[:2]
+    vh = vh.contiguous()
+    out = torch.empty(b, c, X, Y, t_keep, dtype=torch.float32, device=vh.device)
+    ws = plan.workspace(b, c, c)
+    _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    with torch.cuda.device(vh.device):
+        rc = plan.lib.tcfd_fno_inverse_trunc(plan.handle, vh.data_ptr(), out.data_ptr(), b, c, t_keep, is_, ws.data_ptr(),
+                                             ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
+    _lib.check(rc, "tcfd_fno_inverse_trunc")
+    return out
+
+
 def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -> torch.Tensor:
     """The 4-corner contraction alone on truncated spectra (b, Ci, 2mx, 2my, mt) complex64."""
     b, ci = vh.shape[:2]
@@ -340,11 +372,19 @@ class SpectralConvT(SpectralConvS):
         self.postprocess = postprocess
 
     def forward(self, v, out_steps: int = None):
-        if not isinstance(self.postprocess, nn.Identity):
-            raise NotImplementedError("spectral post-processing (Helmholtz projection, out_dim=2) is not on the HIP path yet")
         if out_steps is None and self.out_steps is not None:
             out_steps = self.out_steps
         t_pad = v.size(-1) if self.temporal_padding else 0
+        if not isinstance(self.postprocess, nn.Identity):
+            # spectrum post-processing (Helmholtz projection for out_dim = 2): the projection is diagonal in k,
+            # so it acts on the kept modes only -- transform, contract, project, inverse-transform
+            if not v.is_cuda or v.dtype != torch.float32:
+                raise _lib.TcfdError("expected an fp32 HIP device tensor (torch-cfd_amd has no CPU fallback)")
+            vh, plan = hip_truncated_rfftn(v, self.modes, t_pad=t_pad, t_out=out_steps + t_pad, norm=self.norm)
+            oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
+            oh = self.postprocess.forward_truncated(oh, self.modes, v.shape[-3]) if hasattr(
+                self.postprocess, "forward_truncated") else self.postprocess(oh)
+            return hip_truncated_irfftn(oh, plan, out_steps, norm=self.norm)
         return hip_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad=t_pad,
                                  t_out=out_steps + t_pad, t_keep=out_steps, norm=self.norm)
 
@@ -434,7 +474,8 @@ class HelmholtzProjection(nn.Module):
         lap[..., 0, 0] = 1
         dev = self.lap.device if hasattr(self, "lap") else None
         for name, val in (("lap", lap), ("kx", kx), ("ky", ky)):
-            val = val.to(dtype).to(dev) if dev is not None else val.to(dtype)
+            val = val.to(dtype).clone()  # meshgrid returns expanded views; buffers must own their memory
+            val = val.to(dev) if dev is not None else val
             if hasattr(self, name):
                 setattr(self, name, val)
             else:
@@ -452,11 +493,26 @@ class HelmholtzProjection(nn.Module):
 
     def forward(self, uhat):
         nx = uhat.shape[2]
-        mesh = (self.kx, self.ky)
         if nx != self.n_grid:
             self._update_fft_mesh(nx)
+            self.n_grid = nx
+        mesh = (self.kx, self.ky)
         g = self.grad(self.div(uhat, mesh), mesh)
         return uhat - g / self.lap[None, None, :, :, None]
+
+    def forward_truncated(self, uhat, modes, n_grid: int):
+        """The same projection on a spectrum stored only at the kept modes (b, 2, 2mx, 2my, mt): the projection
+        is diagonal in k, so the wavenumber tables are simply restricted to rows [:mx] + [-mx:], cols [:my] + [-my:]."""
+        if n_grid != self.n_grid:
+            self._update_fft_mesh(n_grid)
+            self.n_grid = n_grid
+        mx, my, _ = modes
+        rows = torch.cat([torch.arange(mx), torch.arange(n_grid - mx, n_grid)]).to(uhat.device)
+        cols = torch.cat([torch.arange(my), torch.arange(n_grid - my, n_grid)]).to(uhat.device)
+        sub = lambda z: z.to(uhat.device)[rows][:, cols]
+        kx, ky, lap = sub(self.kx), sub(self.ky), sub(self.lap)
+        g = self.grad(self.div(uhat, (kx, ky)), (kx, ky))
+        return uhat - g / lap[None, None, :, :, None]
 
 
 class LiftingOperator(nn.Module):
