@@ -435,3 +435,29 @@ def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
     tol = 1e-12 if tag == "f64" else 2e-6
     for a, b in zip(res["0"][:3], res["1"][:3]):
         assert rel_l2(a, b) < tol
+
+
+def test_dataset_generation_loop_matches_reference_driver_shape(dev, tmp_path):
+    """IC -> warm-up -> trajectory -> irfft2 -> bilinear subsample -> dict, checked against the
+    oracle running the same loop on the CPU (64^2, 4 samples in 2 batches, 2x subsample)."""
+    from oracle import ns2d as O
+    from torch_cfd_amd.data_gen import generate_mcwilliams_dataset
+
+    torch.set_default_dtype(torch.float64)
+    n, N, bs, dt = 64, 4, 2, 1e-3
+    path = str(tmp_path / "mcw.pt")
+    data = generate_mcwilliams_dataset(n, N, bs, dt, warmup_steps=5, total_steps=7, record_every_steps=3,
+                                       random_state=3, subsample=2, dtype=torch.float32, cdtype=torch.complex128,
+                                       device=dev, path=path)
+    assert sorted(data) == ["random_states", "residual", "stream", "vort_t", "vorticity"]
+    assert data["random_states"].dtype == torch.int32 and data["random_states"].tolist() == [3, 4, 5, 6]
+    t = O.make_tables(n, L, 1e-3, 0.0, True, None, torch.float64)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 3 + s, torch.float64)) for s in range(N)])
+    w0, _ = O.advance(w0, dt, t, steps=5)
+    ref = O.trajectory(w0, dt, t, num_steps=7, record_every_steps=3, dtype=torch.complex128)
+    for k in ("vorticity", "stream", "vort_t", "residual"):
+        phys = torch.fft.irfft2(ref[k]).float()
+        phys = torch.nn.functional.interpolate(phys, size=(32, 32), mode="bilinear")
+        assert data[k].shape == (N, 3, 32, 32) and data[k].dtype == torch.float32 and data[k].device.type == "cpu"
+        assert rel_l2(data[k], phys) < (1e-6 if k != "residual" else 1e-4), k
+    assert sorted(torch.load(path)) == sorted(data)

@@ -1,0 +1,81 @@
+"""Ensemble trajectory generation: the loop of the reference's data-generation drivers, device side only.
+
+Mirrors the batch loop of fno/data_gen/data_gen_McWilliams2d.py:119-171 (IC stack -> rfft2 -> warm-up steps ->
+``get_trajectory_imex`` -> irfft2 -> bilinear subsample -> dtype cast -> dict with ``random_states``) and its
+final on-disk layout (``pickle_to_pt``, fno/data_gen/data_utils.py:309-328: one dict of tensors concatenated
+over the batches: vorticity / stream / vort_t / residual of shape (N, T, ns, ns) + int32 ``random_states``).
+The argparse / logging / dill-append plumbing of the drivers is out of scope.
+
+Everything between the seeded CPU noise and the final ``.cpu()`` runs on the GPU: IC generation, the fused
+RK4-CN steps (the warm-up is ONE multi-step library call), the record sweeps and the c2r of the records (HIP
+irfft2); the bilinear subsample is a torch device op.  With a process group initialised every rank generates a
+contiguous slice of the samples and rank ``dst`` receives the concatenated dict (``distributed.gather_trajectory``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .distributed import gather_trajectory, shard_batch
+from .equations import NavierStokes2DSpectral, RK4CrankNicolsonStepper, fft_plan
+from .grids import Grid
+from .initial_conditions import vorticity_field
+from .solvers import get_trajectory_imex
+
+
+def spectral_to_physical(value_hat: torch.Tensor, out_size: Optional[int] = None,
+                         dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """(..., n, m) half spectra -> (..., ns, ns) real fields: HIP irfft2, then (if ns != n) bilinear
+    interpolation exactly as ``F.interpolate(value, size=(ns, ns), mode='bilinear')`` in the drivers."""
+    n = value_hat.shape[-2]
+    plan = fft_plan(n, torch.promote_types(value_hat.dtype, torch.complex64), value_hat.device)
+    phys = plan.irfft2(value_hat).to(dtype)
+    if out_size is not None and out_size != n:
+        lead = phys.shape[:-2]
+        phys = F.interpolate(phys.reshape(-1, 1, n, n), size=(out_size, out_size), mode="bilinear").reshape(
+            *lead, out_size, out_size)
+    return phys
+
+
+def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt: float, warmup_steps: int,
+                                total_steps: int, record_every_steps: int, viscosity: float = 1e-3,
+                                diam: float = 2 * torch.pi, peak_wavenumber: float = 4, random_state: int = 0,
+                                subsample: int = 1, dtype: torch.dtype = torch.float32,
+                                cdtype: torch.dtype = torch.complex64, device="cuda", dst: int = 0,
+                                path: Optional[str] = None) -> Optional[Dict[str, torch.Tensor]]:
+    """Decaying-turbulence ensemble (McWilliams IC).  Computes in the torch default dtype (the reference driver
+    sets float64), stores ``dtype`` / ``cdtype``.  Returns the dataset dict on rank ``dst`` (saved with
+    ``torch.save`` when ``path`` is given), ``None`` on the other ranks."""
+    import torch.distributed as dist
+
+    device = torch.device(device)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = shard_batch(total_samples, rank, world)
+    grid = Grid(shape=(n, n), domain=((0, diam), (0, diam)), device=device)
+    op = NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=0, smooth=True, forcing_fn=None,
+                                solver=RK4CrankNicolsonStepper()).to(device)
+    real = torch.get_default_dtype()
+    plan = fft_plan(n, torch.complex128 if real == torch.float64 else torch.complex64, device, diam)
+    ns = n // subsample
+    chunks = []
+    for start in range(lo, hi, batch_size):
+        seeds = [random_state + start + k for k in range(min(batch_size, hi - start))]
+        w = plan.rfft2(vorticity_field(grid, peak_wavenumber, batch_seeds=seeds, device=device))
+        if warmup_steps > 0:
+            w, _ = op._fused_steps(w, dt, warmup_steps, want_dwdt=False)
+        result = get_trajectory_imex(op, w, dt, num_steps=total_steps, record_every_steps=record_every_steps,
+                                     dtype=cdtype, to_cpu=False)
+        result = {k: spectral_to_physical(v, ns, dtype) for k, v in result.items()}
+        result["random_states"] = torch.tensor(seeds, dtype=torch.int32, device=device)
+        chunks.append(result)
+    local = {k: torch.cat([c[k] for c in chunks]) for k in chunks[0]} if chunks else {}
+    full = gather_trajectory(local, total_samples, dst=dst) if world > 1 else local
+    if full is None:
+        return None
+    full = {k: v.cpu() for k, v in full.items()}
+    if path is not None:
+        torch.save(full, path)
+    return full
