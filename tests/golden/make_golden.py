@@ -310,8 +310,31 @@ def gen_helmholtz():
     save("fno_helmholtz.npz", **out)
 
 
+def gen_legacy_cn():
+    """Legacy IMEX Crank-Nicolson step + residual (fno/data_gen/solvers.py:49-188), fp64."""
+    import solvers
+
+    torch.set_default_dtype(torch.float64)
+    out = {}
+    n = 32
+    grid = Grid(shape=(n, n), domain=((0, L), (0, L)))
+    w0 = ic_batch(grid, [0, 1, 2], torch.float64)
+    fphys = SinCosForcing(grid=grid, scale=0.1, k=1.0, diam=L)(grid, None)
+    fh = torch.fft.rfft2(fphys)
+    out["w0"], out["f"] = npy(w0), npy(fh)
+    for dealias in (False, True):
+        w_next, dwdt, w, psi, res, (kx, ky), lap, filt = solvers.imex_crank_nicolson_step(
+            w0, fh, 1e-3, 1e-3, diam=L, dealias=dealias, output_rfft=True)
+        tag = f"d{int(dealias)}"
+        for k, v in (("w_next", w_next), ("dwdt", dwdt), ("psi", psi), ("res", res)):
+            out[f"{tag}_{k}"] = npy(v)
+        res2 = solvers.update_residual(w_next, dwdt, fh, 1e-3, (kx, ky), lap, dealias_filter=filt, dealias=dealias)
+        out[f"{tag}_res_update"] = npy(res2)
+    save("ns2d_legacy_cn.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno", "imex",
-                             "helmholtz"]
+                             "helmholtz", "legacy_cn"]
     for w in which:
         globals()["gen_" + w]()

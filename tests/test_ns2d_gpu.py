@@ -461,3 +461,23 @@ def test_dataset_generation_loop_matches_reference_driver_shape(dev, tmp_path):
         assert data[k].shape == (N, 3, 32, 32) and data[k].dtype == torch.float32 and data[k].device.type == "cpu"
         assert rel_l2(data[k], phys) < (1e-6 if k != "residual" else 1e-4), k
     assert sorted(torch.load(path)) == sorted(data)
+
+
+@pytest.mark.parametrize("dealias", [0, 1])
+def test_legacy_crank_nicolson_step_golden(dealias, dev):
+    """imex_crank_nicolson_step / update_residual (fno/data_gen/solvers.py:49-188)."""
+    from torch_cfd_amd import solvers
+
+    torch.set_default_dtype(torch.float64)  # like the reference, the mesh is built in the default dtype
+    g = load_golden("ns2d_legacy_cn.npz")
+    w0 = torch.from_numpy(g["w0"]).to(dev)
+    f = torch.from_numpy(g["f"]).to(dev)
+    w_next, dwdt, w, psi, res, mesh, lap, filt = solvers.imex_crank_nicolson_step(
+        w0, f, 1e-3, 1e-3, diam=L, dealias=bool(dealias), output_rfft=True)
+    tag = f"d{dealias}"
+    assert rel_l2(w_next, g[f"{tag}_w_next"]) < 1e-12
+    assert rel_l2(dwdt, g[f"{tag}_dwdt"]) < 1e-9
+    assert rel_l2(psi, g[f"{tag}_psi"]) < 1e-13
+    assert rel_l2(res, g[f"{tag}_res"]) < 1e-6
+    res2 = solvers.update_residual(w_next, dwdt, f, 1e-3, mesh, lap, dealias_filter=filt, dealias=bool(dealias))
+    assert rel_l2(res2, g[f"{tag}_res_update"]) < 1e-9

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import math
 from datetime import datetime
-from typing import Dict
+from typing import Dict, Tuple
 
 import torch
 
@@ -80,3 +80,76 @@ def get_trajectory_imex(
     if to_cpu:
         out = {k: v.cpu() for k, v in out.items()}
     return out
+
+
+# ----------------------------------------------------------------------------- legacy IMEX Crank-Nicolson step
+_CN_PLANS: Dict[tuple, object] = {}
+
+
+def _convection_hat(w: torch.Tensor, kx: torch.Tensor, ky: torch.Tensor, mask: torch.Tensor):
+    """rfft2(u w_x + v w_y) (times ``mask``) = minus the de-aliased advection term of the RK operator: the same
+    three HIP kernels (column pass, fused row pass, column pass) with a plan that has no linear term / forcing."""
+    from .equations import _COMPLEX_OF, _HipPlan
+
+    n, m = w.shape[-2:]
+    cdtype = torch.promote_types(w.dtype, _COMPLEX_OF.get(kx.dtype, torch.complex64))
+    kx1 = kx.reshape(-1, n, m)[0, :, 0].detach().cpu().double()
+    ky1 = ky.reshape(-1, n, m)[0, 0, :].detach().cpu().double()
+    mk = mask.reshape(-1, n, m)[0].detach().cpu().double()
+    key = (n, cdtype, w.device, float(kx1[1]), float(ky1[1]), float(mk.sum()), int(mk[:, 0].sum()), int(mk[0, :].sum()))
+    plan = _CN_PLANS.get(key)
+    if plan is None:
+        plan = _HipPlan(n, cdtype, w.device, kx1, ky1, torch.zeros(n, m), mk)
+        _CN_PLANS[key] = plan
+    return -plan.explicit_terms(w).reshape(w.shape)
+
+
+def _cn_tables(w, diam, rfftmesh, laplacian, dealias_filter):
+    n = w.shape[-2]
+    k_max = math.floor(n / 2.0)
+    real = torch.float64 if w.dtype == torch.complex128 else torch.float32
+    if rfftmesh is None:
+        k = torch.fft.fftfreq(n, d=diam / n)
+        kx, ky = torch.meshgrid([k, k], indexing="ij")
+        kx, ky = kx[..., : k_max + 1], ky[..., : k_max + 1]
+    else:
+        kx, ky = rfftmesh
+    kx, ky = [z.to(real).to(w.device) for z in (kx, ky)]
+    if laplacian is None:
+        laplacian = -4 * (math.pi**2) * (kx**2 + ky**2)
+        laplacian[..., 0, 0] = 1.0
+    if dealias_filter is None:
+        dealias_filter = torch.logical_and(torch.abs(ky) <= (2.0 / 3.0) * k_max, torch.abs(kx) <= (2.0 / 3.0) * k_max)
+    return kx, ky, laplacian.to(w.device), dealias_filter.to(w.device)
+
+
+def update_residual(w_h, w_h_t, f_h, visc, rfftmesh, laplacian, dealias_filter=None, dealias=True, **kwargs):
+    """Residual  w_t + u.grad(w) - nu lap w - f  in Fourier space (fno/data_gen/solvers.py:49-88)."""
+    kx, ky = rfftmesh
+    use = dealias and dealias_filter is not None
+    mask = dealias_filter.to(kx.dtype) if use else torch.ones_like(kx)
+    conv = _convection_hat(w_h, kx, ky, mask)
+    return w_h_t + conv - visc * laplacian * w_h - f_h
+
+
+def imex_crank_nicolson_step(w, f, visc, delta_t, diam: float = 1, rfftmesh=None, laplacian=None,
+                             dealias_filter=None, dealias: bool = False, output_rfft: bool = False, debug=False,
+                             **kwargs):
+    """One first-order IMEX step with Crank-Nicolson diffusion (fno/data_gen/solvers.py:91-188, the stepper
+    behind the fine-tuning head).  Returns (w_next, dw/dt, w, psi_h, residual[, mesh, laplacian, filter])."""
+    size = w.shape[1:]
+    assert (size[-1] - 1) * 2 == size[-2]  # an rfft2 tensor
+    kx, ky, laplacian, dealias_filter = _cn_tables(w, diam, rfftmesh, laplacian, dealias_filter)
+    if f.ndim < w.ndim:
+        f = f.unsqueeze(0)
+    f = f.to(w.device)
+    psi_h = -w / laplacian
+    mask = dealias_filter.to(kx.dtype) if dealias else torch.ones_like(kx)
+    convection_h = _convection_hat(w, kx, ky, mask)
+    half = 0.5 * delta_t * visc * laplacian
+    w_next = (-delta_t * convection_h + delta_t * f + (1.0 + half) * w) / (1.0 - half)
+    dwdt = (w_next - w) / delta_t
+    res_h = dwdt + convection_h - visc * laplacian * w - f
+    if output_rfft:
+        return w_next, dwdt, w, psi_h, res_h, (kx, ky), laplacian, dealias_filter
+    return w_next, dwdt, w, psi_h, res_h
