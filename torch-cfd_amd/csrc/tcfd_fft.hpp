@@ -118,13 +118,17 @@ __device__ __forceinline__ void group_sync() {
 
 template <int EPT, int C, bool PAD>
 __device__ __forceinline__ int lds_addr(int e, int c) {
-    // PAD: one pad element every EPT elements breaks the stride-R bank pattern
-    // of the first pass when a group owns the buffer alone (C == 1).
-    if constexpr (PAD) e += e / EPT;
+    // PAD (a group owns the buffer alone, C == 1): the first pass stores element EPT*j + r from lane j -- a
+    // stride-EPT pattern that lands every lane of a store group on the same banks.  XOR-ing the low log2(EPT)
+    // index bits with the next ones spreads it over EPT different 16-byte slots, while every later access
+    // (consecutive lanes <-> consecutive elements) only gets permuted inside aligned EPT-element blocks and
+    // stays conflict free.  (A one-element pad per EPT block fixes the stores too, but makes every 16-byte
+    // READ two-way conflicted: measured 28 % LDS conflict cycles in the row kernel.)
+    if constexpr (PAD) e ^= (e / EPT) % EPT;
     return e * C + c;
 }
 template <int N, int EPT, int C, bool PAD>
-__host__ __device__ constexpr int lds_elems() { return (PAD ? N + N / EPT : N) * C; }
+__host__ __device__ constexpr int lds_elems() { return N * C; }
 
 // twiddle: W[t] = exp(-2*pi*i*t/N); DIR > 0 uses the conjugate
 template <int DIR, typename T>
