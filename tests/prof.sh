@@ -6,13 +6,14 @@ export TMPDIR=/tmp
 out=/root/repo/gpurun_out/prof_$tag
 mkdir -p $out
 ARGS="--steps 4 --warmup 1 --no-cpu-baseline $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python bench.py $ARGS > $out/trace.log 2>&1
+CMD=${PROF_CMD:-python bench.py $ARGS}   # PROF_CMD="python tests/bench_fno.py" profiles something else
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- $CMD > $out/trace.log 2>&1
 i=0
 for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --output-format csv -d $out/pmc$i -o pmc -- python bench.py $ARGS > $out/pmc$i.log 2>&1
+  rocprofv3 --pmc $pmc --output-format csv -d $out/pmc$i -o pmc -- $CMD > $out/pmc$i.log 2>&1
 done
 python tests/prof_summarize.py $out > $out/summary.txt 2>&1
 cat $out/summary.txt

@@ -243,6 +243,188 @@ __global__ __launch_bounds__(1024) void k_inv_ty(const cf* __restrict__ w2, floa
     }
 }
 
+// ------------------------------------------------------------------ t/y transforms, packed form
+// The activations are REAL, so the Y-point transforms can run first, two time samples per complex transform
+// (z[y] = v[y][2p] + i v[y][2p+1]); the short real DFT in t then only touches the 2my kept rows instead of all Y.
+// Against the kernels above this removes the mt-fold redundant LDS sweep of the slab (forward) and the
+// Y x t_keep x mt LDS dot products (inverse): both were LDS-bound, not HBM-bound.
+//   forward :  Z_p = FFT_y(z_p);  v^[ky][2p] = (Z_p[ky] + conj Z_p[-ky]) / 2,  v^[ky][2p+1] = (Z_p[ky] - conj Z_p[-ky]) / 2i
+//              out[ky][kt] = sum_t v^[ky][t] w[kt][t]
+//   inverse :  out[y][t] = sum_kt c_k Re(spec[y][kt] E[t][kt])  (c2r semantics, spec = IFFT_y W)
+//                        = IFFT_y G[.][t],  G[ky][t] = 1/2 sum_kt (W[ky][kt] E[t][kt] + conj(W[-ky][kt] E[t][kt]))
+//              and two output steps ride through one complex IFFT:  H_p = G[.][t0+2p] + i G[.][t0+2p+1].
+// A workgroup owns NS consecutive slabs; thread = (transform tr = s*P + p, lane j of its G-lane group), G <= 64 so
+// every transform lives inside one wave and the exchange needs no workgroup barrier.
+template <int Y>
+struct TyCfg2 {
+    static constexpr int EPT = Y >= 256 ? 16 : (Y >= 64 ? 8 : (Y >= 16 ? 4 : 2));
+    static constexpr int G = Y / EPT;
+};
+
+template <int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, cf* __restrict__ w1,
+                                                  const cf* __restrict__ tw_y, const cf* __restrict__ tw_tf, int T_in,
+                                                  int t_pad, int mt, int my, float scale, int P, int NS, long slabs,
+                                                  unsigned mt_magic) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int G = Y / EPT;
+    const int Tp = T_in + t_pad, Q = 2 * my * mt;
+    const size_t per = (size_t)Y * T_in * 4 > (size_t)P * Y * sizeof(cf) ? (size_t)Y * T_in * 4 : (size_t)P * Y * sizeof(cf);
+    unsigned char* slabs_b = smem_raw;                                            // [NS] slab, later [P][Y] spectra
+    cf* twt = reinterpret_cast<cf*>(smem_raw + (size_t)NS * per);                  // [mt][Tp]
+    const int tr = threadIdx.x / G, j = threadIdx.x % G;
+    const int s = tr / P, p = tr - s * P;
+    const long base = (long)blockIdx.x * NS;
+    const int count = (int)(slabs - base < NS ? slabs - base : NS);
+    const size_t slab_elems = (size_t)Y * T_in;
+    {
+        const float4* s4 = reinterpret_cast<const float4*>(v + (size_t)base * slab_elems);
+        const int n4 = (int)(slab_elems / 4);
+        for (int q = 0; q < count; ++q) {
+            float4* d4 = reinterpret_cast<float4*>(slabs_b + (size_t)q * per);
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[(size_t)q * n4 + i];
+        }
+        for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
+    }
+    __syncthreads();
+    cf x[EPT];
+    {   // slabs past the end of the batch (last workgroup only) transform stale LDS; nothing of theirs is stored
+        const float* sl = reinterpret_cast<const float*>(slabs_b + (size_t)s * per) + (size_t)j * T_in + 2 * p;
+        if ((T_in & 1) == 0) {
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) {
+                const float2 r = *reinterpret_cast<const float2*>(sl + (size_t)t * G * T_in);
+                x[t] = mk<float>(r.x, r.y);
+            }
+        } else {
+            const bool pair = 2 * p + 1 < T_in;
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) {
+                const float* r = sl + (size_t)t * G * T_in;
+                x[t] = mk<float>(r[0], pair ? r[1] : 0.f);
+            }
+        }
+    }
+    __syncthreads();  // every transform of the slab has its input: the slab bytes become the exchange buffers
+    cf* lds = reinterpret_cast<cf*>(slabs_b + (size_t)s * per) + (size_t)p * Y;
+    tile_fft<float, Y, EPT, -1, 1, true, false>(x, lds, tw_y, j, 0);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) lds[j + t * G] = x[t];   // Z_p in natural order, read by the whole slab below
+    __syncthreads();
+    // v^[-ky][t] = conj v^[ky][t] (real input): one task (ky in [0, my], kt) produces out[ky][kt] and out[-ky][kt]
+    // from four real sums.  The slab's P*G lanes stride over the (my+1)*mt tasks.
+    if (s < count) {
+        const float hsc = 0.5f * scale;
+        cf* dst = w1 + (size_t)(base + s) * Q;
+        const cf* zbase = reinterpret_cast<const cf*>(slabs_b + (size_t)s * per);
+        const int ntask = (my + 1) * mt;
+        for (int task = p * G + j; task < ntask; task += P * G) {
+            const int ky = mt == 1 ? task : (int)__umulhi((unsigned)task, mt_magic);
+            const int kt = task - ky * mt;
+            const int kyn = (Y - ky) & (Y - 1);
+            const cf* w = twt + (size_t)kt * Tp + t_pad;
+            float sce = 0.f, sdf = 0.f, scf = 0.f, sde = 0.f;
+            for (int pp = 0; pp < P; ++pp) {
+                const cf za = zbase[(size_t)pp * Y + ky], zb = zbase[(size_t)pp * Y + kyn];
+                // 2 v^[ky][2pp] = za + conj zb ;  2 v^[ky][2pp+1] = -i (za - conj zb)
+                const float c0 = za.x + zb.x, d0 = za.y - zb.y;
+                const float c1 = za.y + zb.y, d1 = zb.x - za.x;
+                const cf w0 = w[2 * pp];
+                sce += c0 * w0.x; sdf += d0 * w0.y; scf += c0 * w0.y; sde += d0 * w0.x;
+                if (2 * pp + 1 < T_in) {
+                    const cf w1v = w[2 * pp + 1];
+                    sce += c1 * w1v.x; sdf += d1 * w1v.y; scf += c1 * w1v.y; sde += d1 * w1v.x;
+                }
+            }
+            if (ky < my) dst[(size_t)ky * mt + kt] = mk<float>((sce - sdf) * hsc, (scf + sde) * hsc);
+            if (ky >= 1) dst[(size_t)(2 * my - ky) * mt + kt] = mk<float>((sce + sdf) * hsc, (scf - sde) * hsc);
+        }
+    }
+}
+
+template <int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, float* __restrict__ out,
+                                                  const cf* __restrict__ tw_y, const cf* __restrict__ tw_ti, int T_out,
+                                                  int t_keep, int mt, int my, float scale, int P, int NS, long slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int G = Y / EPT;
+    const int Q = 2 * my * mt, t0 = T_out - t_keep;
+    cf* ex = reinterpret_cast<cf*>(smem_raw);                  // [NS*P][Y] input / exchange, later [NS][Y][t_keep] floats
+    cf* win = ex + (size_t)NS * P * Y;                         // [NS][Q]
+    cf* twt = win + (size_t)NS * Q;                            // [t_keep][mt]
+    const int tr = threadIdx.x / G, j = threadIdx.x % G;
+    const int s = tr / P, p = tr - s * P;
+    const long base = (long)blockIdx.x * NS;
+    const int count = (int)(slabs - base < NS ? slabs - base : NS);
+    cf* lds = ex + (size_t)tr * Y;
+    {
+        const cf* src = w2 + (size_t)base * Q;
+        for (int i = threadIdx.x; i < count * Q; i += blockDim.x) win[i] = src[i];
+        for (int i = threadIdx.x; i < t_keep * mt; i += blockDim.x) twt[i] = tw_ti[(size_t)t0 * mt + i];
+        float4* z4 = reinterpret_cast<float4*>(lds);           // zero this transform's spectrum (the padding)
+#pragma unroll
+        for (int t = 0; t < EPT / 2; ++t) z4[j + t * G] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // G[-ky][t] = conj G[ky][t]: the transform's own lanes stride over ky in [0, my] and fill H_p[ky], H_p[-ky].
+    // With a = W[ky][k], b = W[-ky][k], u = a + b, d = a - b:  a E + conj(b E) = (E.x u.x - E.y u.y) + i (E.y d.x + E.x d.y)
+    if (s < count) {
+        const float hsc = 0.5f * scale;
+        const bool pair = 2 * p + 1 < t_keep;
+        const cf* e0 = twt + (size_t)(2 * p) * mt;
+        const cf* e1 = twt + (size_t)(pair ? 2 * p + 1 : 2 * p) * mt;
+        const cf* wq = win + (size_t)s * Q;
+        for (int ky = j; ky <= my; ky += G) {
+            const int kyn = (Y - ky) & (Y - 1);
+            const bool ha = ky < my || ky >= Y - my;      // W[ky] kept (ky == my only when 2my == Y)
+            const cf* wa = wq + (size_t)(ky < my ? ky : (ha ? ky - (Y - 2 * my) : 0)) * mt;
+            const cf* wb = wq + (size_t)(kyn < my ? kyn : kyn - (Y - 2 * my)) * mt;   // -ky of [0, my] is always kept
+            float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f;
+            for (int k = 0; k < mt; ++k) {
+                cf a = wa[k];
+                if (!ha) a = mk<float>(0.f, 0.f);
+                const cf b = wb[k];
+                const float ux = a.x + b.x, uy = a.y + b.y, dx = a.x - b.x, dy = a.y - b.y;
+                const cf E0 = e0[k], E1 = e1[k];
+                g0x += E0.x * ux - E0.y * uy;  g0y += E0.y * dx + E0.x * dy;
+                g1x += E1.x * ux - E1.y * uy;  g1y += E1.y * dx + E1.x * dy;
+            }
+            if (!pair) { g1x = 0.f; g1y = 0.f; }
+            // H[ky] = G0 + i G1 ;  H[-ky] = conj G0 + i conj G1
+            lds[ky] = mk<float>((g0x - g1y) * hsc, (g0y + g1x) * hsc);
+            if (kyn != ky) lds[kyn] = mk<float>((g0x + g1y) * hsc, (g1x - g0y) * hsc);
+        }
+    }
+    group_sync<false>();
+    cf x[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) x[t] = lds[j + t * G];
+    group_sync<false>();
+    tile_fft<float, Y, EPT, +1, 1, true, false>(x, lds, tw_y, j, 0);
+    __syncthreads();  // all exchanges done: the buffers become the output slabs [y][t_keep]
+    float* oslab = reinterpret_cast<float*>(ex + (size_t)s * P * Y) + (size_t)j * t_keep + 2 * p;
+    if ((t_keep & 1) == 0) {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t)
+            *reinterpret_cast<float2*>(oslab + (size_t)t * G * t_keep) = make_float2(x[t].x, x[t].y);
+    } else {
+        const bool pair = 2 * p + 1 < t_keep;
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            float* o = oslab + (size_t)t * G * t_keep;
+            o[0] = x[t].x;
+            if (pair) o[1] = x[t].y;
+        }
+    }
+    __syncthreads();
+    const int n4 = Y * t_keep / 4;
+    float4* d4 = reinterpret_cast<float4*>(out + (size_t)base * Y * t_keep);
+    for (int q = 0; q < count; ++q) {
+        const float4* s4 = reinterpret_cast<const float4*>(ex + (size_t)q * P * Y);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[(size_t)q * n4 + i] = s4[i];
+    }
+}
+
 // ------------------------------------------------------------------ x transforms on (X, Q) column tiles
 // FWD: in (b*c, X, Q) -> out (b*c, 2mx, Q) kept rows;  INV: in (b*c, 2mx, Q) -> out (b*c, X, Q)
 template <int X, int EPT, int C, bool FWD>
@@ -469,6 +651,65 @@ static int launch_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipS
     return 0;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
+template <int Y>
+static int ty2_geometry(int P, int* NS) {
+    constexpr int G = TyCfg2<Y>::G;
+    if (P * G > 1024) return FAIL(TCFD_EINVAL, "fno: %d packed time pairs x %d lanes exceed a workgroup", P, G);
+    int ns = env_int("TCFD_FNO_NS", 0);
+    if (ns <= 0) ns = std::max(1, std::min(8, 256 / (P * G)));
+    while (ns > 1 && ns * P * G > 1024) --ns;
+    *NS = ns;
+    return 0;
+}
+
+template <int Y>
+static int launch_fwd_ty2(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float scale, hipStream_t st) {
+    constexpr int EPT = TyCfg2<Y>::EPT, G = TyCfg2<Y>::G;
+    const int P = (p->T_in + 1) / 2;
+    int NS, rc;
+    if ((rc = ty2_geometry<Y>(P, &NS))) return rc;
+    const size_t per = std::max((size_t)Y * p->T_in * 4, (size_t)P * Y * sizeof(cf));
+    size_t lds;
+    for (;; --NS) {
+        lds = (size_t)NS * per + (size_t)p->mt * p->Tp * sizeof(cf);
+        if (lds <= 160 * 1024 || NS == 1) break;
+    }
+    if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T=%d)", Y, p->T_in);
+    auto kern = k_fwd_ty2<Y, EPT>;
+    if ((rc = set_lds_attr(kern, lds))) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, v, w1, (const cf*)p->tw_y,
+                       (const cf*)p->tw_tf, p->T_in, p->t_pad, p->mt, p->my, scale, P, NS, slabs,
+                       p->mt > 1 ? (unsigned)(((1ull << 32) + p->mt - 1) / p->mt) : 0u);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int Y>
+static int launch_inv_ty2(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float scale,
+                          hipStream_t st) {
+    constexpr int EPT = TyCfg2<Y>::EPT, G = TyCfg2<Y>::G;
+    const int P = (t_keep + 1) / 2;
+    int NS, rc;
+    if ((rc = ty2_geometry<Y>(P, &NS))) return rc;
+    size_t lds;
+    for (;; --NS) {
+        lds = ((size_t)NS * P * Y + (size_t)NS * 2 * p->my * p->mt + (size_t)t_keep * p->mt) * sizeof(cf);
+        if (lds <= 160 * 1024 || NS == 1) break;
+    }
+    if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T_out=%d)", Y, p->T_out);
+    auto kern = k_inv_ty2<Y, EPT>;
+    if ((rc = set_lds_attr(kern, lds))) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const cf*)p->tw_y,
+                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 #define DISPATCH_POW2(n, CALL)                                              \
     switch (n) {                                                            \
         case 8: { constexpr int N_ = 8; return CALL; }                      \
@@ -483,9 +724,11 @@ static int launch_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipS
     }
 
 static int do_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float s, hipStream_t st) {
+    if (env_int("TCFD_FNO_TY", 2) == 2) { DISPATCH_POW2(p->Y, (launch_fwd_ty2<N_>(p, v, w1, slabs, s, st))); }
     DISPATCH_POW2(p->Y, (launch_fwd_ty<N_>(p, v, w1, slabs, s, st)));
 }
 static int do_inv_ty(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float s, hipStream_t st) {
+    if (env_int("TCFD_FNO_TY", 2) == 2) { DISPATCH_POW2(p->Y, (launch_inv_ty2<N_>(p, w2, out, slabs, t_keep, s, st))); }
     DISPATCH_POW2(p->Y, (launch_inv_ty<N_>(p, w2, out, slabs, t_keep, s, st)));
 }
 static int do_fwd_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
