@@ -163,6 +163,22 @@ def main():
         tc._lib.check(lib.tcfd_ns2d_profile_end(plan.handle, max_rec, ctypes.byref(cnt), kinds, ms), "profile_end")
     assert torch.isfinite(torch.view_as_real(w)).all().item(), "solution blew up"
 
+    # STREAM-style probe of this box: what a plain 16-B/lane copy / read / fill reaches next to the 8 TB/s spec
+    probe = {}
+    try:
+        nbytes = 1 << 30
+        a_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        b_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for mode, name, traffic_x in ((0, "copy_GBps", 2), (1, "read_GBps", 1), (2, "fill_GBps", 1)):
+            t_ms = ctypes.c_float(0)
+            tc._lib.check(lib.tcfd_hbm_probe(a_buf.data_ptr(), b_buf.data_ptr(), nbytes, mode, 10, ctypes.byref(t_ms), st),
+                          "hbm_probe")
+            probe[name] = round(traffic_x * nbytes / (t_ms.value * 1e-3) / 1e9, 1)
+        del a_buf, b_buf
+    except Exception as e:
+        probe = {"error": repr(e)}
+
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,6 +231,7 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algo_bytes_per_launch": KIND_ALGO_S[dom] * S, "avg_launch_ms": round(dom_avg_ms, 4)},
         "kernels": kern,
+        "hbm_probe": probe,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -171,6 +171,13 @@ int tcfd_row_moments(const void* x, void* stats, int rows, long L, void* stream)
 int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* plan, int max_records);
 int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* kinds, float* ms);
 
+/* STREAM-style device probe (measurement aid, SURVEY 8d "verify with a device STREAM-style probe"): `iters`
+ * launches of a 16-byte-per-lane grid-stride kernel over `bytes` (a multiple of 16) of caller-owned device memory,
+ * timed with HIP events on `stream`.  mode 0: copy src -> dst (2*bytes of traffic per launch); 1: read-only
+ * sum of src (dst = 8 bytes of scratch); 2: write-only fill of dst (src unused).  *ms = average launch
+ * duration.  Synchronises the stream (it is a benchmark, not part of the path). */
+int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int iters, float* ms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
