@@ -278,3 +278,52 @@ def mcwilliams_vorticity(n: int, L: float, peak_wavenumber: float = 3.0, seed: i
     ke = (2 * (k * psih).abs() ** 2 / (n * n) ** 2).sum()
     psi = psi / ke.sqrt()
     return torch.fft.ifftn(torch.fft.fftn(psi) * k**2).real
+
+
+def filtered_velocity_field(n: int, L: float, maximum_velocity: float = 1.0, peak_wavenumber: float = 3.0,
+                            iterations: int = 3, seed: int = 0, real: torch.dtype = torch.float64):
+    """Divergence-free random velocity on the staggered (MAC) grid, components (ux, uy) at the cell faces.
+
+    torch_cfd/initial_conditions.py:122-167: per component white noise (seeds ``seed``, ``seed+1``) filtered with a
+    log-normal density / k (:60-66, :89-99), then ``iterations`` x project_and_normalize (:110-119):
+    backward-difference divergence (finite_differences.py:126-135) -> pseudo-inverse of the FINITE-DIFFERENCE
+    Laplacian by circulant rfftn diagonalisation (pressure.py:296-360: eigenvalues = fft / rfft of the first column
+    [-2, 1, 0.., 1]/h^2 of the periodic 1-D Laplacian, finite_differences.py:167-193; inverse where |lambda| >
+    10 eps(float32), the solver's default dtype) -> subtract the forward-difference gradient (:74-83) -> rescale
+    so that max |u| = maximum_velocity.  ``real`` plays the role of the default dtype.
+    """
+    h = L / n
+    om = 2 * torch.pi * torch.fft.fftfreq(n, h, dtype=real)
+    k = torch.linalg.norm(torch.stack(torch.meshgrid(om, om, indexing="ij"), dim=0), dim=0)
+    variance = 0.25
+    mean = math.log(peak_wavenumber) + variance
+    logk = torch.log(k)
+    dens = torch.exp(-((mean - logk) ** 2) / 2 / variance - logk) / k
+    filt = torch.where(k > 0, dens, 0.0)
+    comps = []
+    gen = torch.Generator()
+    for i in range(2):
+        gen.manual_seed(seed + i)
+        noise = torch.randn((n, n), generator=gen, dtype=real)
+        comps.append(torch.fft.ifftn(torch.fft.fftn(noise) * filt).real)
+    ux, uy = comps
+    col = torch.zeros(n, dtype=real)
+    col[0] = -2 / h**2
+    col[1] = col[-1] = 1 / h**2
+    lam = torch.fft.fft(col)[:, None] + torch.fft.rfft(col)[None, :]
+    cutoff = 10 * torch.finfo(torch.float32).eps
+    inv = torch.where(torch.abs(lam) > cutoff, 1 / lam, 0)
+    for _ in range(iterations):
+        div = (ux - torch.roll(ux, 1, 0)) / h + (uy - torch.roll(uy, 1, 1)) / h
+        q = torch.fft.irfftn(inv * torch.fft.rfftn(div), s=(n, n)).real
+        ux = ux - (torch.roll(q, -1, 0) - q) / h
+        uy = uy - (torch.roll(q, -1, 1) - q) / h
+        vmax = torch.linalg.norm(torch.stack([ux, uy]), dim=0).max()
+        ux, uy = maximum_velocity * ux / vmax, maximum_velocity * uy / vmax
+    return ux, uy
+
+
+def curl_2d(ux: torch.Tensor, uy: torch.Tensor, L: float) -> torch.Tensor:
+    """Forward-difference curl of a staggered velocity, torch_cfd/finite_differences.py:412-419."""
+    h = L / ux.shape[-1]
+    return (torch.roll(uy, -1, -2) - uy) / h - (torch.roll(ux, -1, -1) - ux) / h

@@ -160,6 +160,24 @@ def gen_mcwilliams():
     save("ns2d_mcwilliams.npz", **out)
 
 
+def gen_velocity_ic():
+    """filtered_velocity_field + curl_2d (initial_conditions.py:122-167, finite_differences.py:412-419): the staggered
+    velocity components after the 3 project-and-normalise sweeps and the resulting vorticity."""
+    out = {}
+    for n in (32, 64):
+        for real, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            for seed, vmax, peak in ((0, 5.0, 4.0), (3, 1.0, 3.0)):
+                torch.set_default_dtype(real)
+                grid = Grid(shape=(n, n), domain=((0, L), (0, L)))
+                v = filtered_velocity_field(grid, vmax, peak, random_state=seed)
+                key = f"n{n}_{tag}_s{seed}"
+                out[key + "_ux"] = npy(v[0].data)
+                out[key + "_uy"] = npy(v[1].data)
+                out[key + "_w"] = npy(curl_2d(v).data)
+    torch.set_default_dtype(torch.float64)
+    save("ns2d_velocity_ic.npz", **out)
+
+
 def gen_trajectory():
     import tqdm
     import solvers
@@ -334,7 +352,7 @@ def gen_legacy_cn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "trajectory", "irfft2", "fno", "sfno", "imex",
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "imex",
                              "helmholtz", "legacy_cn"]
     for w in which:
         globals()["gen_" + w]()

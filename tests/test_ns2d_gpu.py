@@ -156,6 +156,43 @@ def test_mcwilliams_ic_and_100_steps(n, tag, seed, dev):
         assert rel_l2(w100, g[key + "_w100"]) < (1e-9 if tag == "f64" else 5e-5)
 
 
+@pytest.mark.parametrize("n", [32, 64])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("seed,vmax,peak", [(0, 5.0, 4.0), (3, 1.0, 3.0)])
+def test_filtered_velocity_ic_on_device(n, tag, seed, vmax, peak, dev):
+    """SURVEY 8f rank 1, second half: filtered_velocity_field + curl_2d generated on the device."""
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import filtered_velocity_field, curl_2d
+
+    g = load_golden("ns2d_velocity_ic.npz")
+    torch.set_default_dtype(REAL[tag])
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    ux, uy = filtered_velocity_field(grid, vmax, peak, random_state=seed, device=dev)
+    w = curl_2d((ux, uy), grid)
+    # batched form: sample b uses seeds (s, s + 1) like a single call with random_state = s
+    bx, by = filtered_velocity_field(grid, vmax, peak, batch_seeds=[seed, seed + 5], device=dev)
+    key = f"n{n}_{tag}_s{seed}"
+    tol = 1e-11 if tag == "f64" else 2e-4   # fp32: two different fp32 FFT pipelines through 3 projection sweeps
+    assert ux.dtype == REAL[tag] and ux.shape == (n, n)
+    assert rel_l2(ux, g[key + "_ux"]) < tol and rel_l2(uy, g[key + "_uy"]) < tol
+    assert rel_l2(w, g[key + "_w"]) < tol * 10
+    assert rel_l2(bx[0], g[key + "_ux"]) < tol and rel_l2(by[0], g[key + "_uy"]) < tol and bx.shape == (2, n, n)
+
+
+def test_config1_from_device_initial_condition(dev):
+    """BASELINE configs[0] end to end on the device: IC generator -> rfft2 -> 200 RK4-CN steps."""
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import filtered_velocity_field, curl_2d
+
+    g = load_golden("ns2d_c1_kolmogorov128.npz")
+    grid, op = build_op(128, "f64", "kolmogorov", dev)   # sets the default dtype (the forcing follows it, as in the reference)
+    w_phys = curl_2d(filtered_velocity_field(grid, 5, 4, random_state=0, device=dev), grid)
+    w0 = tc.fft_plan(128, torch.complex128, dev).rfft2(w_phys)[None]
+    assert rel_l2(w0, g["w0"]) < 1e-11
+    w200, _ = op(w0, 1e-3, steps=200)
+    assert rel_l2(w200, g["w200"]) < 1e-8
+
+
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 def test_trajectory_matches_reference(tag, dev):
     import torch_cfd_amd as tc

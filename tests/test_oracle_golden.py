@@ -117,6 +117,31 @@ def test_mcwilliams_ic(n, tag, seed):
         assert rel_l2(w100, g[key + "_w100"]) < (1e-12 if tag == "f64" else 2e-4)
 
 
+@pytest.mark.parametrize("n", [32, 64])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("seed,vmax,peak", [(0, 5.0, 4.0), (3, 1.0, 3.0)])
+def test_filtered_velocity_ic(n, tag, seed, vmax, peak):
+    """filtered_velocity_field + curl_2d (BASELINE config 1's initial condition) against the reference's output."""
+    g = load_golden("ns2d_velocity_ic.npz")
+    ux, uy = O.filtered_velocity_field(n, L, vmax, peak, 3, seed, REAL[tag])
+    key = f"n{n}_{tag}_s{seed}"
+    tol = 1e-13 if tag == "f64" else 1e-6
+    assert rel_l2(ux, g[key + "_ux"]) < tol and rel_l2(uy, g[key + "_uy"]) < tol
+    assert rel_l2(O.curl_2d(ux, uy, L), g[key + "_w"]) < tol
+    # the projection leaves a field whose backward-difference divergence vanishes, at the prescribed max speed
+    h = L / n
+    div = (ux - torch.roll(ux, 1, 0)) / h + (uy - torch.roll(uy, 1, 1)) / h
+    assert div.abs().max() < (1e-10 if tag == "f64" else 2e-3) * vmax / h
+    assert abs(torch.sqrt(ux * ux + uy * uy).max().item() - vmax) < 1e-5 * vmax
+
+
+def test_config1_initial_condition_is_the_velocity_ic():
+    """The 128^2 Kolmogorov run's w0 fixture is rfft2(curl_2d(filtered_velocity_field(grid, 5, 4, seed 0)))."""
+    g = load_golden("ns2d_c1_kolmogorov128.npz")
+    ux, uy = O.filtered_velocity_field(128, L, 5.0, 4.0, 3, 0, torch.float64)
+    assert rel_l2(torch.fft.rfft2(O.curl_2d(ux, uy, L))[None], g["w0"]) < 1e-13
+
+
 @pytest.mark.parametrize("tag,cdt", [("f64", torch.complex128), ("f32", torch.complex64)])
 def test_trajectory(tag, cdt):
     g = load_golden("ns2d_trajectory.npz")
