@@ -25,6 +25,18 @@ with torch.no_grad():
     loss = loss_fn(out, y)
     t_fwd = timeit(lambda: model(x))
     t_all = timeit(lambda: loss_fn(model(x), y))
+# training step: forward + SobolevLoss + backward (HIP spectral convolutions fwd/bwd, torch pointwise modules under autograd)
+model.train()
+def train_step():
+    model.zero_grad(set_to_none=True)
+    loss_fn(model(x), y).backward()
+t_train = None
+if os.environ.get("TRAIN", "1") == "1":
+    torch.cuda.reset_peak_memory_stats()
+    t_train = timeit(train_step, 3)
+    train_mem = torch.cuda.max_memory_allocated() / 1e9
 print(json.dumps({"config": f"SFNO(24,24,5,width={width},layers=4) b={b} 256x256x10 fp32", "forward_ms": round(t_fwd, 2),
                   "forward_plus_loss_ms": round(t_all, 2), "loss": float(loss), "params": sum(p.numel() for p in model.parameters()),
-                  "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}))
+                  "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                  "train_step_ms": round(t_train, 2) if t_train else None,
+                  "train_peak_mem_GB": round(train_mem, 2) if t_train else None}))

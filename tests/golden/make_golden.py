@@ -285,6 +285,54 @@ def gen_sfno():
     save("fno_sfno_tiny.npz", **out)
 
 
+def gen_grads():
+    """Reference gradients (torch autograd through torch.fft on the CPU, fp32): SpectralConvS, SpectralConvT with
+    temporal padding / resampling, and the tiny SFNO of gen_sfno under a SobolevLoss -- parameter and input grads."""
+    torch.set_default_dtype(torch.float32)
+    from fno.sfno import SFNO, SpectralConvS, SpectralConvT
+    from fno.losses import SobolevLoss
+
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    for name, layer, xs, kw in (
+        ("convS", SpectralConvS(3, 5, 4, 3, 3, bias=True, delta=0.3), (2, 3, 16, 8, 10), {}),
+        ("convT_pad", SpectralConvT(4, 4, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True), (2, 4, 16, 16, 6),
+         {"out_steps": 9}),
+        ("convT_plain", SpectralConvT(2, 3, 3, 4, 4, delta=0.1, bias=False, temporal_padding=False), (2, 2, 8, 16, 7),
+         {"out_steps": 12}),
+    ):
+        with torch.no_grad():
+            for p_ in layer.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.2)
+        x = torch.randn(*xs, generator=g).requires_grad_(True)
+        y = layer(x, **kw)
+        t = torch.randn(y.shape, generator=g)
+        ((y * t).sum() + 0.5 * (y ** 2).sum()).backward()
+        out[f"{name}_x"] = npy(x)
+        out[f"{name}_t"] = npy(t)
+        out[f"{name}_y"] = npy(y)
+        out[f"{name}_gx"] = npy(x.grad)
+        for k, v in layer.state_dict().items():
+            out[f"{name}_sd_{k}"] = npy(v)
+        for k, v in layer.named_parameters():
+            out[f"{name}_g_{k}"] = npy(v.grad)
+    torch.manual_seed(0)
+    model = SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).train()
+    with torch.no_grad():
+        for b_ in model.output_operator.conv.bias:
+            b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+    x = torch.randn(2, 16, 16, 10, generator=g).requires_grad_(True)
+    target = torch.randn(2, 16, 16, 10, generator=g)
+    loss = SobolevLoss(n_grid=16, norm_order=0, relative=True)(model(x), target)
+    loss.backward()
+    out["sfno_x"], out["sfno_target"], out["sfno_loss"], out["sfno_gx"] = npy(x), npy(target), npy(loss), npy(x.grad)
+    for k, v in model.state_dict().items():
+        out["sfno_sd_" + k] = npy(v)
+    for k, v in model.named_parameters():
+        out["sfno_g_" + k] = npy(v.grad) if v.grad is not None else np.zeros(0, dtype=np.float32)
+    save("fno_grads.npz", **out)
+
+
 def gen_imex():
     """IMEXStepper orders 1 / 1.5 / 2 (equations.py:110-246) on the spectral operator, 3 steps, fp64."""
     from torch_cfd.equations import IMEXStepper
@@ -352,7 +400,7 @@ def gen_legacy_cn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "imex",
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "grads", "imex",
                              "helmholtz", "legacy_cn"]
     for w in which:
         globals()["gen_" + w]()

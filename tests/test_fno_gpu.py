@@ -146,8 +146,10 @@ def test_errors_are_loud(dev):
     m = fno.SpectralConvS(2, 2, 4, 4, 3).to(dev)
     with pytest.raises(_lib.TcfdError):
         m(torch.randn(1, 2, 16, 16, 10))  # CPU tensor
-    with pytest.raises(_lib.TcfdError):
-        m(torch.randn(1, 2, 16, 16, 10, device=dev))  # grad enabled + parameters require grad
+    assert m(torch.randn(1, 2, 16, 16, 10, device=dev)).grad_fn is not None  # autograd on: differentiable path
+    hp = fno.SpectralConvT(2, 2, 4, 4, 3, postprocess=fno.HelmholtzProjection(n_grid=16, diam=1.0)).to(dev)
+    with pytest.raises(_lib.TcfdError, match="forward-only"):
+        hp(torch.randn(1, 2, 16, 16, 10, device=dev), out_steps=10)  # spectrum post-processing has no backward yet
     with torch.no_grad():
         with pytest.raises(_lib.TcfdError, match="powers of two"):
             m(torch.randn(1, 2, 24, 16, 10, device=dev))
@@ -239,3 +241,102 @@ def test_spectral_conv_t_with_helmholtz_postprocess_golden(dev):
     yh = torch.fft.fft2(y.cpu().double(), dim=(2, 3))
     div = 2j * math.pi * (yh[:, 0] * kx[None, :, :, None] + yh[:, 1] * ky[None, :, :, None])
     assert (div.abs().max() / yh.abs().max()).item() < 1e-5
+
+
+# ----------------------------------------------------------------------------- backward
+GRAD_TOL = 2e-5   # fp32 gradients of two different fp32 FFT pipelines
+
+
+def _load_layer_sd(layer, g, name):
+    keys = sorted(k[len(name) + 4:] for k in g.files if k.startswith(name + "_sd_"))
+    assert sorted(layer.state_dict().keys()) == keys
+    layer.load_state_dict({k: torch.from_numpy(g[f"{name}_sd_{k}"]) for k in keys})
+
+
+@pytest.mark.parametrize("name,ctor,kw", [
+    ("convS", lambda f: f.SpectralConvS(3, 5, 4, 3, 3, bias=True, delta=0.3), {}),
+    ("convT_pad", lambda f: f.SpectralConvT(4, 4, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True), {"out_steps": 9}),
+    ("convT_plain", lambda f: f.SpectralConvT(2, 3, 3, 4, 4, delta=0.1, bias=False, temporal_padding=False), {"out_steps": 12}),
+])
+def test_spectral_conv_backward_golden(name, ctor, kw, dev):
+    """Hand-written backward of the HIP spectral convolution against the reference's autograd (torch.fft, CPU):
+    input gradient, the four weight blocks and the four bias blocks; odd / resampled / left-padded time axes."""
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_grads.npz")
+    layer = ctor(fno)
+    _load_layer_sd(layer, g, name)
+    layer = layer.to(dev)
+    x = torch.from_numpy(g[name + "_x"]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(g[name + "_t"]).to(dev)
+    y = layer(x, **kw)
+    assert rel_l2(y, g[name + "_y"]) < TOL
+    ((y * t).sum() + 0.5 * (y ** 2).sum()).backward()
+    assert rel_l2(x.grad, g[name + "_gx"]) < GRAD_TOL
+    for k, p in layer.named_parameters():
+        assert p.grad is not None and rel_l2(p.grad, g[f"{name}_g_{k}"]) < GRAD_TOL, k
+
+
+def test_spectral_conv_backward_is_the_adjoint(dev):
+    """<G(x), t> = <x, G^T(t)> for the linear map x -> layer(x) (bias off), at BASELINE config 5's mode shape."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(0)
+    layer = fno.SpectralConvS(10, 10, 24, 24, 5).to(dev)
+    x = torch.randn(2, 10, 64, 64, 10, device=dev, requires_grad=True)
+    t = torch.randn(2, 10, 64, 64, 10, device=dev)
+    y = layer(x)
+    (gx,) = torch.autograd.grad((y * t).sum(), x)
+    x2 = torch.randn_like(x)
+    with torch.no_grad():
+        lhs = (layer(x2) * t).sum().double()
+    rhs = (x2 * gx).sum().double()
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1e-3)
+
+
+def test_sfno_training_step_gradients_golden(dev):
+    """Tiny SFNO + SobolevLoss: loss, input gradient and EVERY parameter gradient against the reference's autograd.
+    Under autograd the spectral convolutions run _SpectralConvFn (HIP forward + HIP backward), the loss transform
+    _Rfft2Fn, the pointwise blocks their torch modules."""
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_grads.npz")
+    model = fno.SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).train()
+    keys = sorted(k[8:] for k in g.files if k.startswith("sfno_sd_"))
+    assert sorted(model.state_dict().keys()) == keys
+    model.load_state_dict({k: torch.from_numpy(g["sfno_sd_" + k]) for k in keys})
+    model = model.to(dev)
+    x = torch.from_numpy(g["sfno_x"]).to(dev).requires_grad_(True)
+    target = torch.from_numpy(g["sfno_target"]).to(dev)
+    loss = fno.SobolevLoss(n_grid=16, norm_order=0, relative=True).to(dev)(model(x), target)
+    assert float(loss.detach()) == pytest.approx(float(g["sfno_loss"]), rel=2e-5)
+    loss.backward()
+    assert rel_l2(x.grad, g["sfno_gx"]) < 5e-5
+    checked = 0
+    for k, p in model.named_parameters():
+        ref = g["sfno_g_" + k]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        # (reduction.bias is a 4e-7 sum of O(1e-2) terms: absolute floor for cancelled gradients)
+        err = float((p.grad.detach().cpu() - torch.from_numpy(ref)).norm())
+        assert err < 5e-5 * float(torch.from_numpy(ref).norm()) + 2e-9, k
+        checked += 1
+    assert checked >= 30
+    # the gradient is a descent direction: a backtracking step along -grad lowers the loss
+    with torch.no_grad():
+        params = [p for p in model.parameters() if p.grad is not None]
+        saved = [p.clone() for p in params]
+        g2 = sum(float((p.grad ** 2).sum()) for p in params)
+        lr = 0.01 * float(loss.detach()) / g2
+        loss_fn = fno.SobolevLoss(n_grid=16, norm_order=0, relative=True).to(dev)
+        for _ in range(14):
+            for p, p0 in zip(params, saved):
+                p.copy_(p0 - lr * p.grad)
+            loss2 = float(loss_fn(model(x.detach()), target))
+            if loss2 < float(loss.detach()) * (1 - 1e-5):
+                break
+            lr /= 4
+        else:
+            raise AssertionError("no descent along the negative gradient")

@@ -60,3 +60,32 @@ def test_sobolev_loss(order, rel):
     val = OF.sobolev_loss(torch.from_numpy(g["sob_x"]), torch.from_numpy(g["sob_y"]), 16, norm_order=order,
                           relative=bool(rel))
     assert float(val) == pytest.approx(float(g[f"sob_o{order}_r{rel}"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("name,modes,delta,kw", [
+    ("convS", (4, 3, 3), 0.3, None),
+    ("convT_pad", (4, 4, 3), 0.1, {"out_steps": 9, "temporal_padding": True}),
+    ("convT_plain", (3, 4, 4), 0.1, {"out_steps": 12, "temporal_padding": False}),
+])
+def test_gradients_of_the_oracle_match_the_reference(name, modes, delta, kw):
+    """Pins the gradient fixtures (tests/golden/fno_grads.npz): autograd through the oracle's torch.fft restatement
+    reproduces the reference's input / weight / bias gradients."""
+    g = load_golden("fno_grads.npz")
+    x = torch.from_numpy(g[name + "_x"]).requires_grad_(True)
+    t = torch.from_numpy(g[name + "_t"])
+    wr = [torch.from_numpy(g[f"{name}_sd_weight.{k}"]).requires_grad_(True) for k in range(4)]
+    has_bias = f"{name}_sd_bias.0" in g.files
+    br = [torch.from_numpy(g[f"{name}_sd_bias.{k}"]).requires_grad_(True) for k in range(4)] if has_bias else None
+    w = [torch.view_as_complex(a) for a in wr]
+    b = [torch.view_as_complex(a) for a in br] if br else None
+    if kw is None:
+        y = OF.spectral_conv(x, w, modes, b, delta=delta)
+    else:
+        y = OF.spectral_conv_t(x, w, modes, b, delta=delta, **kw)
+    assert rel_l2(y, g[name + "_y"]) < 1e-6
+    ((y * t).sum() + 0.5 * (y ** 2).sum()).backward()
+    assert rel_l2(x.grad, g[name + "_gx"]) < 1e-6
+    for k in range(4):
+        assert rel_l2(wr[k].grad, g[f"{name}_g_weight.{k}"]) < 1e-6
+        if br:
+            assert rel_l2(br[k].grad, g[f"{name}_g_bias.{k}"]) < 1e-6

@@ -12,8 +12,10 @@ names / shapes and ``state_dict`` keys):
 
 The spectral convolutions call ``tcfd_fno_spectral_conv`` (include/tcfd.h): five
 kernels that read and write the (b, C, X, Y, T) activations exactly once instead
-of the reference's full rfftn / zero-filled spectrum / irfftn.  Forward only, fp32,
-HIP device tensors, X and Y powers of two; anything else raises (no fallback).
+of the reference's full rfftn / zero-filled spectrum / irfftn.  fp32, HIP device
+tensors, X and Y powers of two; anything else raises (no fallback).  Under autograd the
+spectral convolutions run a hand-written backward on the same kernels (``_SpectralConvFn``);
+the pointwise blocks then use their torch modules.
 The pointwise layers around them (1x1x1 convolutions, GroupNorm, activations) are
 ordinary torch modules running on the same device.
 """
@@ -100,8 +102,6 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
         raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
     if v.dtype != torch.float32:
         raise TypeError(f"the HIP spectral convolution is fp32 only, got {v.dtype}")
-    if torch.is_grad_enabled() and (v.requires_grad or any(w.requires_grad for w in weights)):
-        raise _lib.TcfdError("the HIP spectral convolution is forward-only: call it under torch.no_grad()")
     if v.dim() != 5:
         raise ValueError(f"expected (b, C, X, Y, T), got {tuple(v.shape)}")
     b, ci, X, Y, T = v.shape
@@ -109,6 +109,10 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     co = weights[0].shape[1]
     t_out = T + t_pad if t_out is None else t_out
     t_keep = t_out if t_keep is None else t_keep
+    params = list(weights) + (list(bias) if bias is not None else [])
+    if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params)):
+        return _SpectralConvFn.apply(v, (float(delta), tuple(modes), t_pad, t_out, t_keep, norm, bias is not None,
+                                         use_mfma), *params)
     v = v.detach().contiguous()
 
     def as_real(w, shape):
@@ -135,8 +139,10 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     return out
 
 
-def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward"):
-    """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) fp32 -> (b, C, 2mx, 2my, mt) complex64, plus the plan."""
+def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward",
+                        scale: Optional[float] = None):
+    """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) fp32 -> (b, C, 2mx, 2my, mt) complex64, plus the plan.
+    ``scale`` overrides the normalisation factor of ``norm``."""
     b, c, X, Y, T = v.shape
     mx, my, mt = modes
     t_out = T + t_pad if t_out is None else t_out
@@ -145,6 +151,7 @@ def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[
     vh = torch.empty(b, c, 2 * mx, 2 * my, mt, dtype=torch.complex64, device=v.device)
     ws = plan.workspace(b, c, c)
     fs, _ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    fs = fs if scale is None else float(scale)
     with torch.cuda.device(v.device):
         rc = plan.lib.tcfd_fno_forward_trunc(plan.handle, v.data_ptr(), vh.data_ptr(), b, c, fs, ws.data_ptr(), ws.numel(),
                                              ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
@@ -152,7 +159,8 @@ def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[
     return vh, plan
 
 
-def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward") -> torch.Tensor:
+def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward",
+                         scale: Optional[float] = None) -> torch.Tensor:
     """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep)."""
     X, Y, T, t_pad, t_out, mx, my, mt = plan.key
     b, c = vh.shape[:2]
@@ -160,6 +168,7 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
     out = torch.empty(b, c, X, Y, t_keep, dtype=torch.float32, device=vh.device)
     ws = plan.workspace(b, c, c)
     _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    is_ = is_ if scale is None else float(scale)
     with torch.cuda.device(vh.device):
         rc = plan.lib.tcfd_fno_inverse_trunc(plan.handle, vh.data_ptr(), out.data_ptr(), b, c, t_keep, is_, ws.data_ptr(),
                                              ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
@@ -185,6 +194,81 @@ def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -
                                    ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_contract")
     return out
+
+
+def _c2r_weights(mt: int, T: int, device) -> torch.Tensor:
+    """Multiplicity of the kept time modes in a length-T c2r transform: 1 for kt = 0 and the Nyquist mode, else 2."""
+    c = torch.full((mt,), 2.0, dtype=torch.float32, device=device)
+    c[0] = 1.0
+    if T % 2 == 0 and T // 2 < mt:
+        c[T // 2] = 1.0
+    return c
+
+
+def _corner_slices(mx: int, my: int):
+    """Corner block k = ix + 2 iy of the truncated (.., 2mx, 2my, mt) layout (fno/sfno.py:376-389 order)."""
+    sx, sy = (slice(0, mx), slice(mx, 2 * mx)), (slice(0, my), slice(my, 2 * my))
+    return [(sx[k % 2], sy[k // 2]) for k in range(4)]
+
+
+class _SpectralConvFn(torch.autograd.Function):
+    """Spectral convolution with a hand-written backward on the same HIP kernels.
+
+    y = G(W . F(v)): F = truncated rfftn of the left-padded input (an R-linear map real -> complex), G = zero-padded
+    irfftn with c2r semantics.  With complex cotangents in torch's convention (dL/dRe + i dL/dIm):
+      G^T(dy)  = c_out * F'(dy)        F' = the forward transform of the plan with (T_in, t_pad) := (t_keep, t_out - t_keep)
+      grad W   = conj(v^) (x) G^T(dy)  summed over the batch,   grad bias = delta * sum_{b, o} G^T(dy)
+      grad v^  = conj(W)^T . G^T(dy)   (the MFMA contraction kernel with transposed, conjugated weights)
+      F^T(z)   = G'(z / c_in)          G' = the inverse transform of that plan, output length T_in + t_pad, kept tail T_in
+    c_out / c_in are the c2r multiplicities (1 for DC / Nyquist in t, else 2) of the two time lengths: the inverse
+    kernel doubles the interior modes, the adjoint of an r2c transform does not."""
+
+    @staticmethod
+    def forward(ctx, v, cfg, *params):
+        delta, modes, t_pad, t_out, t_keep, norm, has_bias, use_mfma = cfg
+        weights, bias = list(params[:4]), (list(params[4:8]) if has_bias else None)
+        with torch.no_grad():
+            vh, plan = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
+            oh = hip_contract(vh, [w.detach() for w in weights], [x.detach() for x in bias] if bias else None, delta, modes,
+                              use_mfma=use_mfma)
+            out = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
+        ctx.cfg, ctx.in_shape = cfg, tuple(v.shape)
+        ctx.save_for_backward(vh, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        delta, modes, t_pad, t_out, t_keep, norm, has_bias, use_mfma = ctx.cfg
+        vh, *params = ctx.saved_tensors
+        weights = params[:4]
+        b, ci, X, Y, T = ctx.in_shape
+        mx, my, mt = modes
+        Tp = T + t_pad
+        fs, is_ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
+        dev = dy.device
+        with torch.no_grad():
+            gh, plan_b = hip_truncated_rfftn(dy.contiguous(), modes, t_pad=t_out - t_keep, t_out=Tp, scale=is_)
+            gh = gh * _c2r_weights(mt, t_out, dev)                                  # G^T(dy)
+            grads = [None] * len(params)
+            need_w = [ctx.needs_input_grad[2 + k] for k in range(len(params))]
+            for k, (sx, sy) in enumerate(_corner_slices(mx, my)):
+                if need_w[k]:
+                    gw = torch.einsum("bixyt,boxyt->ioxyt", vh[:, :, sx, sy].conj(), gh[:, :, sx, sy])
+                    grads[k] = gw if weights[k].is_complex() else torch.view_as_real(gw.contiguous())
+                if has_bias and need_w[4 + k]:
+                    gb = delta * gh[:, :, sx, sy].sum(dim=(0, 1))
+                    grads[4 + k] = gb if params[4 + k].is_complex() else torch.view_as_real(gb.contiguous())
+            gv = None
+            if ctx.needs_input_grad[0]:
+                wh = []
+                for w in weights:
+                    w = w.detach()
+                    w = w if w.is_complex() else torch.view_as_complex(w.contiguous())
+                    wh.append(w.conj().transpose(0, 1).resolve_conj().contiguous())   # (Co, Ci, mx, my, mt)
+                zh = hip_contract(gh, wh, None, 0.0, modes, use_mfma=use_mfma)
+                zh = zh / _c2r_weights(mt, Tp, dev)
+                gv = hip_truncated_irfftn(zh, plan_b, T, scale=fs)
+        return (gv, None, *grads)
 
 
 # ----------------------------------------------------------------------------- pointwise helpers
@@ -380,6 +464,8 @@ class SpectralConvT(SpectralConvS):
             # so it acts on the kept modes only -- transform, contract, project, inverse-transform
             if not v.is_cuda or v.dtype != torch.float32:
                 raise _lib.TcfdError("expected an fp32 HIP device tensor (torch-cfd_amd has no CPU fallback)")
+            if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
+                raise _lib.TcfdError("SpectralConvT with a spectrum post-processor is forward-only: use torch.no_grad()")
             vh, plan = hip_truncated_rfftn(v, self.modes, t_pad=t_pad, t_out=out_steps + t_pad, norm=self.norm)
             oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
             oh = self.postprocess.forward_truncated(oh, self.modes, v.shape[-3]) if hasattr(
@@ -650,6 +736,25 @@ class SFNO(FNOBase):
 
 
 # ----------------------------------------------------------------------------- loss (config 5 "forward + loss")
+class _Rfft2Fn(torch.autograd.Function):
+    """rfft2 on the HIP kernels with its adjoint: for a cotangent g (dL/dRe + i dL/dIm of the half spectrum)
+    grad z = Re sum_{kx, ky <= n/2} g e^{+i(kx x + ky y)} = n^2 irfft2(g / c), c = 2 on the interior columns
+    (the c2r transform counts them twice, the adjoint of an r2c transform does not)."""
+
+    @staticmethod
+    def forward(ctx, z, plan):
+        ctx.plan = plan
+        return plan.rfft2(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        n = plan.n
+        c = torch.full((n // 2 + 1,), 0.5 * n * n, dtype=plan.rdtype, device=g.device)
+        c[0] = c[-1] = float(n * n)
+        return plan.irfft2(g * c), None
+
+
 class SobolevLoss(nn.Module):
     """Fourier-domain weighted norm of (x - y), fno/losses.py:199-315 (freq_cutoff=None).
 
@@ -701,7 +806,11 @@ class SobolevLoss(nn.Module):
         w2 = self._half_spectrum_weights(x.device, x.dtype)
 
         def sq_norms(z):  # (b, n, n, t) -> (b, t): || w * fft2(z_t) ||_F^2 via the half spectrum
-            zh = plan.rfft2(z.permute(0, 3, 1, 2).contiguous())
+            zt = z.permute(0, 3, 1, 2).contiguous()
+            if torch.is_grad_enabled() and zt.requires_grad:
+                zh = _Rfft2Fn.apply(zt, plan)
+                return ((zh.real**2 + zh.imag**2) * w2).sum(dim=(-2, -1))
+            zh = plan.rfft2(zt)
             return (zh.real**2 + zh.imag**2).mul_(w2).sum(dim=(-2, -1))
 
         diff = sq_norms(x if y is None else x - y)  # the transform is linear: one rfft2 of the difference
