@@ -15,7 +15,8 @@ kernels that read and write the (b, C, X, Y, T) activations exactly once instead
 of the reference's full rfftn / zero-filled spectrum / irfftn.  fp32, HIP device
 tensors, X and Y powers of two; anything else raises (no fallback).  Under autograd the
 spectral convolutions run a hand-written backward on the same kernels (``_SpectralConvFn``);
-the pointwise blocks then use their torch modules.
+the pointwise blocks keep their HIP forward and recompute the block with torch einsums in the
+backward (``_PointwiseFn``).
 The pointwise layers around them (1x1x1 convolutions, GroupNorm, activations) are
 ordinary torch modules running on the same device.
 """
@@ -298,6 +299,52 @@ class PointwiseFFN(nn.Module):
         return out if out is not None else self.linear2(self.activation(self.linear1(v)))
 
 
+def _pointwise_reference(spec, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
+    """The fused block written with channel einsums (differentiable torch ops) -- used for the backward recompute."""
+    has_l1, act1, act2, mode, eps = spec
+    b, ci = x.shape[:2]
+    tail = x.shape[2:]
+    h = x if eps is None else F.group_norm(x, 1, gamma, beta, eps)
+    h = h.reshape(b, ci, -1)
+    bias = lambda t: 0 if t is None else t[None, :, None]
+    if has_l1:
+        h = torch.einsum("mc,bcp->bmp", w1.reshape(w1.shape[0], -1), h) + bias(b1)
+        h = act1(h) if act1 is not None else h
+    o = torch.einsum("om,bmp->bop", w2.reshape(w2.shape[0], -1), h) + bias(b2)
+    if mode == 1:
+        o = o + torch.einsum("oc,bcp->bop", ws.reshape(ws.shape[0], -1), skip.reshape(b, skip.shape[1], -1)) + bias(bs)
+    o = o.reshape(b, o.shape[1], *tail)
+    if mode == 2:
+        o = o + skip[..., -1:]
+    return act2(o) if act2 is not None else o
+
+
+class _PointwiseFn(torch.autograd.Function):
+    """Fused pointwise block under autograd: the forward value comes from the HIP kernel (passed in), the backward
+    recomputes the block from its inputs (nothing but the inputs is kept alive between forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, out, spec, *tensors):
+        ctx.spec = spec
+        ctx.present = [t is not None for t in tensors]
+        ctx.save_for_backward(*[t for t in tensors if t is not None])
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        it = iter(ctx.saved_tensors)
+        tensors = [next(it) if p else None for p in ctx.present]
+        need = ctx.needs_input_grad[2:]
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(True) if (t is not None and n) else (t.detach() if t is not None else None)
+                      for t, n in zip(tensors, need)]
+            out = _pointwise_reference(ctx.spec, *leaves)
+            wanted = [l for l, n in zip(leaves, need) if l is not None and n]
+            got = iter(torch.autograd.grad(out, wanted, dout, allow_unused=True))
+        grads = [next(got) if (l is not None and n) else None for l, n in zip(leaves, need)]
+        return (None, None, *grads)
+
+
 _ACT_CODES = {nn.Identity: 0, nn.ReLU: 1, nn.GELU: 2, nn.SiLU: 3, nn.Tanh: 4}
 
 
@@ -323,9 +370,24 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     torch modules."""
     c1, c2 = _act_code(act1), _act_code(act2)
     if (c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32 or not _is_pointwise(lin2)
-            or (lin1 is not None and not _is_pointwise(lin1)) or (skip_conv is not None and not _is_pointwise(skip_conv))
-            or (torch.is_grad_enabled() and (x.requires_grad or lin2.weight.requires_grad))):
+            or (lin1 is not None and not _is_pointwise(lin1)) or (skip_conv is not None and not _is_pointwise(skip_conv))):
         return None
+    if torch.is_grad_enabled():
+        mods = [m for m in (lin1, lin2, skip_conv, norm) if m is not None]
+        tensors = [x, skip] + [p for m in mods for p in m.parameters()]
+        if any(t is not None and t.requires_grad for t in tensors):
+            # training: HIP forward, backward by recomputing the block with channel einsums under autograd
+            # (torch's own Conv3d 1x1x1 backward takes SECONDS per layer at this size on ROCm)
+            with torch.no_grad():
+                out = hip_pointwise(x, lin1, act1, lin2, skip=skip, skip_conv=skip_conv, act2=act2,
+                                    skip_last_slice=skip_last_slice, norm=norm)
+            if out is None:
+                return None
+            spec = (lin1 is not None, act1, act2, 1 if skip_conv is not None else (2 if skip_last_slice else 0),
+                    norm.eps if norm is not None else None)
+            pw = lambda m, a: getattr(m, a) if m is not None else None
+            return _PointwiseFn.apply(out, spec, x, skip, pw(lin1, "weight"), pw(lin1, "bias"), lin2.weight, lin2.bias,
+                                      pw(skip_conv, "weight"), pw(skip_conv, "bias"), pw(norm, "weight"), pw(norm, "bias"))
     b, ci = x.shape[:2]
     co = lin2.out_channels
     cm = lin1.out_channels if lin1 is not None else ci
