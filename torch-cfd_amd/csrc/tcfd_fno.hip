@@ -986,6 +986,292 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
 }
 
 
+// ------------------------------------------------------------------ backward of the fused pointwise block
+// Given dL/dout, ONE pass recomputes the block per point (hidden vector in registers, as the forward does) and
+// produces dL/dx, dL/dskip and the weight / bias gradients.  The weight gradients are sums over ALL points of
+// outer products (dW2 = sum g2 (x) h, dW1 = sum g1 (x) x, dWs = sum g2 (x) s): a GEMM whose K axis is the points
+// of a wave.  Each wave stages its 64 points channel-major in its own LDS slice ([channel][point], row pitch 66
+// floats: lane-consecutive conflict-free stores, conflict-free operand fetches) and accumulates on
+// v_mfma_f32_16x16x4_f32 (A lane l -> [row l&15][k l>>4], B -> [k l>>4][col l&15], D -> [row 4(l>>4)+r][col l&15]);
+// a constant-1 channel appended to h / x makes the bias gradients fall out of the same products.  The accumulators
+// (28 registers at width 10) live across the wave's whole grid-stride loop; every wave writes its partial sums
+// once, the caller adds the partials (deterministic, no atomics).
+struct PwBwdArgs {
+    const float* x;      // (b, CI, P)
+    const float* s;      // (b, CI, P) skip input (skip_mode 1) or null
+    const float* dout;   // (b, CO, P)
+    float* dx;           // (b, CI, P)
+    float* ds;           // (b, CI, P) or null
+    const float* w1;     // (CM, CI) or null
+    const float* b1;
+    const float* w2t;    // (CM, CO)
+    const float* b2;
+    const float* wst;    // (CI, CO)
+    const float* bs;
+    float* partials;     // (waves, PW_FLOATS) padded tiles, see pw_bwd_layout
+    long P;
+    long chunks_per_batch, total_chunks;
+    int act1, act2, skip_mode;
+};
+
+__device__ __forceinline__ float pw_dact(float z, int act) {   // d act / dz
+    switch (act) {
+        case 1: return z > 0.f ? 1.f : 0.f;
+        case 2: {
+            const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+            return cdf + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+        }
+        case 3: { const float sg = 1.f / (1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }
+        case 4: { const float t = tanhf(z); return 1.f - t * t; }
+        default: return 1.f;
+    }
+}
+
+template <int CI, int CM, int CO, bool HAS_L1>
+struct PwBwdGeom {
+    static constexpr int COP = (CO + 15) / 16 * 16;
+    static constexpr int CIP = (CI + 1 + 15) / 16 * 16;                   // [x, 1]
+    static constexpr int CB = ((HAS_L1 ? CM : CI) + 1 + CI + 15) / 16 * 16; // [h, 1, s]   (single layer: [x, 1, s])
+    static constexpr int CM1 = HAS_L1 ? (CM + 15) / 16 * 16 : 0;           // g1 rows (in place over h)
+    static constexpr int PITCH = 66;
+    static constexpr int R0 = COP > CIP ? COP : CIP;                       // rows of the first operand slot: g2, later [x, 1]
+    static constexpr int ROWS = R0 + CB;
+    static constexpr int N_A = COP * CB;                                   // g2 (x) [h, 1, s]
+    static constexpr int N_B = CM1 * CIP;                                  // g1 (x) [x, 1]
+    static constexpr int TOTAL = N_A + N_B;
+    static constexpr int WAVES = 2;                                        // per workgroup (21 KB of LDS per wave at width 10)
+};
+
+template <int CI, int CM, int CO, bool HAS_L1>
+__global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
+    using Gm = PwBwdGeom<CI, CM, CO, HAS_L1>;
+    constexpr int PITCH = Gm::PITCH, CH = HAS_L1 ? CM : CI;   // channels of the second operand's first block
+    constexpr int TO = Gm::COP / 16, TB = Gm::CB / 16, TI = Gm::CIP / 16, TM = Gm::CM1 / 16;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* L0 = reinterpret_cast<float*>(smem_raw) + (size_t)wave * Gm::ROWS * PITCH;   // g2, later [x, 1]
+    float* L1 = L0 + Gm::R0 * PITCH;                                                     // [h, 1, s], later g1 over h
+    const int kq = lane >> 4, kc = lane & 15;
+    f4 accA[TO * TB];
+    f4 accB[HAS_L1 ? TM * TI : 1];
+#pragma unroll
+    for (auto& v : accA) v = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (auto& v : accB) v = f4{0.f, 0.f, 0.f, 0.f};
+    const long wstride = (long)gridDim.x * Gm::WAVES;
+    for (long chunk = (long)blockIdx.x * Gm::WAVES + wave; chunk < a.total_chunks; chunk += wstride) {
+        const long b = chunk / a.chunks_per_batch;
+        const long p = (chunk - b * a.chunks_per_batch) * 64 + lane;
+        const bool live = p < a.P;
+        const long pc = live ? p : a.P - 1;
+        float x[CI], g2[CO], z2[CO], dx[CI];
+        const float* xb = a.x + (size_t)b * CI * a.P + pc;
+        const float* db = a.dout + (size_t)b * CO * a.P + pc;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) g2[c] = live ? db[(size_t)c * a.P] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) z2[c] = (a.b2 ? a.b2[c] : 0.f) + ((a.skip_mode == 1 && a.bs) ? a.bs[c] : 0.f);
+#pragma unroll
+        for (int i = 0; i < CI; ++i) dx[i] = 0.f;
+        // second operand rows [CH] = 1, [CH+1, CH+1+CI) = skip input (zero without a skip convolution)
+        L1[CH * PITCH + lane] = live ? 1.f : 0.f;
+        if (a.skip_mode == 1) {
+            const float* sb = a.s + (size_t)b * CI * a.P + pc;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) {
+                const float sv = live ? sb[(size_t)i * a.P] : 0.f;
+                L1[(CH + 1 + i) * PITCH + lane] = sv;
+                const float* ws = a.wst + i * CO;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) z2[c] = fmaf(ws[c], sv, z2[c]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) L1[(CH + 1 + i) * PITCH + lane] = 0.f;
+        }
+        if constexpr (HAS_L1) {
+#pragma unroll 4
+            for (int m = 0; m < CM; ++m) {   // hidden vector: kept in this lane's LDS column, not in registers
+                float z = a.b1 ? a.b1[m] : 0.f;
+                const float* w1 = a.w1 + m * CI;
+#pragma unroll
+                for (int i = 0; i < CI; ++i) z = fmaf(w1[i], x[i], z);
+                const float h = live ? pw_act(z, a.act1) : 0.f;
+                L1[m * PITCH + lane] = h;
+                const float* w2 = a.w2t + m * CO;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) z2[c] = fmaf(w2[c], h, z2[c]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < CI; ++m) {
+                L1[m * PITCH + lane] = live ? x[m] : 0.f;
+                const float* w2 = a.w2t + m * CO;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) z2[c] = fmaf(w2[c], x[m], z2[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            g2[c] *= pw_dact(z2[c], a.act2);
+            L0[c * PITCH + lane] = g2[c];
+        }
+        group_sync<false>();
+#pragma unroll 2
+        for (int q = 0; q < 16; ++q) {   // [dW2 | db2 | dWs][o][.] += g2[o] [h, 1, s][.] over the 4 points of the k-step
+            float av[TO];
+#pragma unroll
+            for (int to = 0; to < TO; ++to) av[to] = L0[(16 * to + kc) * PITCH + 4 * q + kq];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const float bv = L1[(16 * tb + kc) * PITCH + 4 * q + kq];
+#pragma unroll
+                for (int to = 0; to < TO; ++to)
+                    accA[to * TB + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[to], bv, accA[to * TB + tb], 0, 0, 0);
+            }
+        }
+        group_sync<false>();
+        if constexpr (HAS_L1) {
+            // g1 = (W2^T g2) act1'(z1) written over h;  dx = W1^T g1
+            const bool from_h = a.act1 == 0 || a.act1 == 1 || a.act1 == 4;   // act1' is a function of h itself
+#pragma unroll 4
+            for (int m = 0; m < CM; ++m) {
+                const float* w1 = a.w1 + m * CI;
+                const float h = L1[m * PITCH + lane];
+                float d1;
+                if (from_h) {
+                    d1 = a.act1 == 1 ? (h > 0.f ? 1.f : 0.f) : (a.act1 == 4 ? 1.f - h * h : 1.f);
+                } else {
+                    float z = a.b1 ? a.b1[m] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < CI; ++i) z = fmaf(w1[i], x[i], z);
+                    d1 = pw_dact(z, a.act1);
+                }
+                const float* w2 = a.w2t + m * CO;
+                float dh = 0.f;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) dh = fmaf(w2[c], g2[c], dh);
+                const float g1 = dh * d1;      // g2 = 0 on dead lanes, so g1 is too
+                L1[m * PITCH + lane] = g1;
+#pragma unroll
+                for (int i = 0; i < CI; ++i) dx[i] = fmaf(w1[i], g1, dx[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < CI; ++i) L0[i * PITCH + lane] = live ? x[i] : 0.f;
+            L0[CI * PITCH + lane] = live ? 1.f : 0.f;
+            group_sync<false>();
+#pragma unroll 2
+            for (int q = 0; q < 16; ++q) {   // [dW1 | db1][m][.] += g1[m] [x, 1][.]
+                float bv[TI];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) bv[ti] = L0[(16 * ti + kc) * PITCH + 4 * q + kq];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = L1[(16 * tm + kc) * PITCH + 4 * q + kq];
+#pragma unroll
+                    for (int ti = 0; ti < TI; ++ti)
+                        accB[tm * TI + ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ti], accB[tm * TI + ti], 0, 0, 0);
+                }
+            }
+            group_sync<false>();
+        } else {
+#pragma unroll
+            for (int m = 0; m < CI; ++m) {
+                const float* w2 = a.w2t + m * CO;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) dx[m] = fmaf(w2[c], g2[c], dx[m]);
+            }
+        }
+        if (live) {
+            float* dxb = a.dx + (size_t)b * CI * a.P + p;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) dxb[(size_t)i * a.P] = dx[i];
+            if (a.skip_mode == 1 && a.ds) {
+                float* dsb = a.ds + (size_t)b * CI * a.P + p;
+#pragma unroll
+                for (int i = 0; i < CI; ++i) {
+                    const float* ws = a.wst + i * CO;
+                    float v = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) v = fmaf(ws[c], g2[c], v);
+                    dsb[(size_t)i * a.P] = v;
+                }
+            }
+        }
+    }
+    // this wave's partial sums as row-major padded tiles:  A (COP x CB) | B (CM1 x CIP)
+    float* out = a.partials + ((size_t)blockIdx.x * Gm::WAVES + wave) * Gm::TOTAL;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * to + 4 * kq + r) * Gm::CB + 16 * tb + kc] = accA[to * TB + tb][r];
+    if constexpr (HAS_L1) {
+        float* o1 = out + Gm::N_A;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o1[(16 * tm + 4 * kq + r) * Gm::CIP + 16 * ti + kc] = accB[tm * TI + ti][r];
+    }
+}
+
+template <int CI, int CM, int CO, bool HAS_L1>
+static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipStream_t st) {
+    using Gm = PwBwdGeom<CI, CM, CO, HAS_L1>;
+    dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
+    if (!a.x) return 0;   // layout query
+    a.chunks_per_batch = (a.P + 63) / 64;
+    a.total_chunks = a.chunks_per_batch * batch;
+    int blocks = (int)std::min<long>((a.total_chunks + Gm::WAVES - 1) / Gm::WAVES, max_waves / Gm::WAVES);
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)Gm::WAVES * Gm::ROWS * Gm::PITCH * sizeof(float);
+    auto kern = k_pointwise_bwd<CI, CM, CO, HAS_L1>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * Gm::WAVES), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    dims[5] = blocks * Gm::WAVES;
+    return 0;
+}
+
+// Backward of tcfd_fno_pointwise for skip_mode 0 / 1 (shared weights).  `partials` holds `max_waves` rows of
+// dims[4] floats; on return dims = {COP, CB, CM1, CIP, floats per row, rows written}: row-major padded tiles
+//   A (COP x CB):  A[o][0:ch] = dW2[o][.] (ch = cm, single layer: ci),  A[o][ch] = db2[o] (= dbs),  A[o][ch+1 : ch+1+ci] = dWs[o][.]
+//   B (CM1 x CIP): B[m][0:ci] = dW1[m][.],  B[m][ci] = db1[m]            (two-layer form only)
+// The caller sums the rows.  Passing x == NULL only fills dims (layout query).
+extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, void* dx, void* dskip,
+                                      const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
+                                      const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
+                                      int cm, int co, long P, int act1, int act2, int skip_mode, void* stream) {
+    if (!dims) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: null dims");
+    if (x && (!dout || !dx || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
+        return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad argument");
+    if (skip_mode != 0 && skip_mode != 1) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode %d not supported", skip_mode);
+    if (x && skip_mode == 1 && (!skip || !wst)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip input missing");
+    PwBwdArgs a;
+    a.x = (const float*)x; a.s = (const float*)skip; a.dout = (const float*)dout; a.dx = (float*)dx; a.ds = (float*)dskip;
+    a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
+    a.wst = (const float*)wst; a.bs = (const float*)bs; a.partials = (float*)partials;
+    a.P = P; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
+    a.chunks_per_batch = a.total_chunks = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool l1 = cm != ci || w1 != nullptr;
+#define PWB_CASE(CI_, CM_, CO_, L1_) \
+    if (ci == CI_ && cm == CM_ && co == CO_ && l1 == L1_) return launch_pw_bwd<CI_, CM_, CO_, L1_>(a, batch, max_waves, dims, st);
+    PWB_CASE(4, 16, 4, true) PWB_CASE(8, 32, 8, true) PWB_CASE(10, 40, 10, true)
+    PWB_CASE(4, 4, 4, false) PWB_CASE(4, 4, 1, false) PWB_CASE(8, 8, 8, false) PWB_CASE(8, 8, 1, false)
+    PWB_CASE(10, 10, 10, false) PWB_CASE(10, 10, 1, false)
+#undef PWB_CASE
+    return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: channels (%d -> %d -> %d) not instantiated", ci, cm, co);
+}
+
+
 // ------------------------------------------------------------------ LayerNormnd statistics
 // sum and sum of squares of every row of a (rows, L) fp32 matrix (one row = one sample's (C, X, Y, T) block),
 // accumulated in double.  torch's GroupNorm moments kernel runs ONE workgroup per row (6 ms for 32 rows of
