@@ -171,8 +171,9 @@ int tcfd_row_moments(const void* x, void* stats, int rows, long L, void* stream)
 int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* plan, int max_records);
 int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* kinds, float* ms);
 
-/* Backward of tcfd_fno_pointwise (skip_mode 0 or 1, shared weights): one pass over x / skip / dout recomputes the
- * block per point and writes dx (batch, ci, P), dskip (batch, ci, P; may be NULL) and per-wave partial weight
+/* Backward of tcfd_fno_pointwise (shared weights): one pass over x / skip / dout recomputes the
+ * block per point and writes dx (batch, ci, P), dskip (skip_mode 1: (batch, ci, P), may be NULL; skip_mode 2:
+ * dL/d(pre-activation) (batch, co, P), which the caller sums over t into the skip's last time slice) and per-wave partial weight
  * gradients into `partials` (max_waves rows).  On return dims[6] = {COP, CB, CM1, CIP, floats per row, rows
  * written}; a row holds two row-major zero-padded tiles, A (COP x CB) then B (CM1 x CIP), with ch = cm (single
  * layer: ci):  A[o][0:ch] = dW2[o][.],  A[o][ch] = db2[o] = dbs[o],  A[o][ch+1 : ch+1+ci] = dWs[o][.];
@@ -181,8 +182,8 @@ int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* k
  * fno/sfno.py:607-614.  TCFD_EINVAL for channel combinations that are not instantiated. */
 int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, void* dx, void* dskip, const void* w1,
                            const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
-                           void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int act1,
-                           int act2, int skip_mode, void* stream);
+                           void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
+                           int skip_T, int act1, int act2, int skip_mode, void* stream);
 
 /* STREAM-style device probe (measurement aid, SURVEY 8d "verify with a device STREAM-style probe"): `iters`
  * launches of a 16-byte-per-lane grid-stride kernel over `bytes` (a multiple of 16) of caller-owned device memory,

@@ -345,6 +345,7 @@ def test_sfno_training_step_gradients_golden(dev):
 @pytest.mark.parametrize("ci,cm,co,two,mode,act", [
     (10, 40, 10, True, 1, "ReLU"), (10, 40, 10, True, 1, "GELU"), (10, 40, 10, True, 0, "SiLU"), (8, 32, 8, True, 1, "Tanh"),
     (10, 10, 1, False, 0, None), (10, 10, 10, False, 1, "ReLU"), (4, 16, 4, True, 1, "ReLU"),
+    (10, 40, 10, True, 2, "GELU"), (4, 16, 4, True, 2, "ReLU"),
 ])
 def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, dev):
     """tcfd_fno_pointwise_bwd (input / skip gradients + MFMA-accumulated weight and bias gradients) against torch
@@ -361,7 +362,9 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
     a2 = getattr(nn, act)() if act else None
     x = torch.randn(*shape, device=dev, requires_grad=True)
     s = torch.randn(*shape, device=dev, requires_grad=True) if mode == 1 else None
-    out = fno.hip_pointwise(x, lin1, a1, lin2, skip=s, skip_conv=skc, act2=a2)
+    if mode == 2:   # lifting tail: the last time slice of a (b, co, X, Y, 6) tensor is broadcast over t
+        s = torch.randn(3, co, 7, 9, 6, device=dev, requires_grad=True)
+    out = fno.hip_pointwise(x, lin1, a1, lin2, skip=s, skip_conv=skc, act2=a2, skip_last_slice=(mode == 2))
     assert out is not None and out.grad_fn is not None
     t = torch.randn_like(out)
     (out * t).sum().backward()

@@ -1012,6 +1012,7 @@ struct PwBwdArgs {
     long P;
     long chunks_per_batch, total_chunks;
     int act1, act2, skip_mode;
+    int T, sT;           // skip_mode 2: s is (b, CO, P / T * sT), its last time slice is added; ds receives dL/dz2 (b, CO, P)
 };
 
 __device__ __forceinline__ float pw_dact(float z, int act) {   // d act / dz
@@ -1042,16 +1043,44 @@ struct PwBwdGeom {
     static constexpr int WAVES = 2;                                        // per workgroup (21 KB of LDS per wave at width 10)
 };
 
+// weights of the block, staged once per workgroup in LDS (rows padded to 4 floats): with ~1.5 waves per SIMD the
+// scalar-cache latency of per-row s_loads is exposed (measured 8x slower); uniform-address ds_reads pipeline.
+template <int CI, int CM, int CO, bool HAS_L1>
+struct PwBwdW {
+    static constexpr int RI = (CI + 3) & ~3, RO = (CO + 3) & ~3;
+    static constexpr int W1 = 0;                                   // (CM, RI)
+    static constexpr int B1 = W1 + (HAS_L1 ? CM * RI : 0);         // (CM)
+    static constexpr int W2 = B1 + (HAS_L1 ? ((CM + 3) & ~3) : 0); // (CH, RO)   CH = CM or CI
+    static constexpr int B2 = W2 + (HAS_L1 ? CM : CI) * RO;        // (RO)  b2 + bs
+    static constexpr int WS = B2 + RO;                             // (CI, RO)
+    static constexpr int TOTAL = WS + CI * RO;
+};
+
 template <int CI, int CM, int CO, bool HAS_L1>
 __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
     using Gm = PwBwdGeom<CI, CM, CO, HAS_L1>;
+    using Wm = PwBwdW<CI, CM, CO, HAS_L1>;
     constexpr int PITCH = Gm::PITCH, CH = HAS_L1 ? CM : CI;   // channels of the second operand's first block
     constexpr int TO = Gm::COP / 16, TB = Gm::CB / 16, TI = Gm::CIP / 16, TM = Gm::CM1 / 16;
+    constexpr int RI = Wm::RI, RO = Wm::RO;
     typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* L0 = reinterpret_cast<float*>(smem_raw) + (size_t)wave * Gm::ROWS * PITCH;   // g2, later [x, 1]
-    float* L1 = L0 + Gm::R0 * PITCH;                                                     // [h, 1, s], later g1 over h
+    float* Wl = reinterpret_cast<float*>(smem_raw);
+    float* L0 = Wl + ((Wm::TOTAL + 3) & ~3) + (size_t)wave * Gm::ROWS * PITCH;   // g2, later [x, 1]
+    float* L1 = L0 + Gm::R0 * PITCH;                                              // [h, 1, s], later g1 over h
+    for (int i = threadIdx.x; i < Wm::TOTAL; i += blockDim.x) Wl[i] = 0.f;
+    __syncthreads();
+    if constexpr (HAS_L1) {
+        for (int i = threadIdx.x; i < CM * CI; i += blockDim.x) Wl[Wm::W1 + (i / CI) * RI + i % CI] = a.w1[i];
+        if (a.b1) for (int i = threadIdx.x; i < CM; i += blockDim.x) Wl[Wm::B1 + i] = a.b1[i];
+    }
+    for (int i = threadIdx.x; i < CH * CO; i += blockDim.x) Wl[Wm::W2 + (i / CO) * RO + i % CO] = a.w2t[i];
+    for (int i = threadIdx.x; i < CO; i += blockDim.x)
+        Wl[Wm::B2 + i] = (a.b2 ? a.b2[i] : 0.f) + ((a.skip_mode == 1 && a.bs) ? a.bs[i] : 0.f);
+    if (a.skip_mode == 1)
+        for (int i = threadIdx.x; i < CI * CO; i += blockDim.x) Wl[Wm::WS + (i / CO) * RO + i % CO] = a.wst[i];
+    __syncthreads();
     const int kq = lane >> 4, kc = lane & 15;
     f4 accA[TO * TB];
     f4 accB[HAS_L1 ? TM * TI : 1];
@@ -1073,9 +1102,16 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) g2[c] = live ? db[(size_t)c * a.P] : 0.f;
 #pragma unroll
-        for (int c = 0; c < CO; ++c) z2[c] = (a.b2 ? a.b2[c] : 0.f) + ((a.skip_mode == 1 && a.bs) ? a.bs[c] : 0.f);
+        for (int c = 0; c < CO; ++c) z2[c] = Wl[Wm::B2 + c];
 #pragma unroll
         for (int i = 0; i < CI; ++i) dx[i] = 0.f;
+        if (a.skip_mode == 2) {
+            const long xy = pc / a.T;
+            const long sP = (a.P / a.T) * a.sT;
+            const float* sb = a.s + (size_t)b * CO * sP + xy * a.sT + (a.sT - 1);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) z2[c] += sb[(size_t)c * sP];
+        }
         // second operand rows [CH] = 1, [CH+1, CH+1+CI) = skip input (zero without a skip convolution)
         L1[CH * PITCH + lane] = live ? 1.f : 0.f;
         if (a.skip_mode == 1) {
@@ -1084,7 +1120,7 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
             for (int i = 0; i < CI; ++i) {
                 const float sv = live ? sb[(size_t)i * a.P] : 0.f;
                 L1[(CH + 1 + i) * PITCH + lane] = sv;
-                const float* ws = a.wst + i * CO;
+                const float* ws = Wl + Wm::WS + i * RO;
 #pragma unroll
                 for (int c = 0; c < CO; ++c) z2[c] = fmaf(ws[c], sv, z2[c]);
             }
@@ -1095,13 +1131,13 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
         if constexpr (HAS_L1) {
 #pragma unroll 4
             for (int m = 0; m < CM; ++m) {   // hidden vector: kept in this lane's LDS column, not in registers
-                float z = a.b1 ? a.b1[m] : 0.f;
-                const float* w1 = a.w1 + m * CI;
+                float z = Wl[Wm::B1 + m];
+                const float* w1 = Wl + Wm::W1 + m * RI;
 #pragma unroll
                 for (int i = 0; i < CI; ++i) z = fmaf(w1[i], x[i], z);
                 const float h = live ? pw_act(z, a.act1) : 0.f;
                 L1[m * PITCH + lane] = h;
-                const float* w2 = a.w2t + m * CO;
+                const float* w2 = Wl + Wm::W2 + m * RO;
 #pragma unroll
                 for (int c = 0; c < CO; ++c) z2[c] = fmaf(w2[c], h, z2[c]);
             }
@@ -1109,7 +1145,7 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
 #pragma unroll
             for (int m = 0; m < CI; ++m) {
                 L1[m * PITCH + lane] = live ? x[m] : 0.f;
-                const float* w2 = a.w2t + m * CO;
+                const float* w2 = Wl + Wm::W2 + m * RO;
 #pragma unroll
                 for (int c = 0; c < CO; ++c) z2[c] = fmaf(w2[c], x[m], z2[c]);
             }
@@ -1139,18 +1175,18 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
             const bool from_h = a.act1 == 0 || a.act1 == 1 || a.act1 == 4;   // act1' is a function of h itself
 #pragma unroll 4
             for (int m = 0; m < CM; ++m) {
-                const float* w1 = a.w1 + m * CI;
+                const float* w1 = Wl + Wm::W1 + m * RI;
                 const float h = L1[m * PITCH + lane];
                 float d1;
                 if (from_h) {
                     d1 = a.act1 == 1 ? (h > 0.f ? 1.f : 0.f) : (a.act1 == 4 ? 1.f - h * h : 1.f);
                 } else {
-                    float z = a.b1 ? a.b1[m] : 0.f;
+                    float z = Wl[Wm::B1 + m];
 #pragma unroll
                     for (int i = 0; i < CI; ++i) z = fmaf(w1[i], x[i], z);
                     d1 = pw_dact(z, a.act1);
                 }
-                const float* w2 = a.w2t + m * CO;
+                const float* w2 = Wl + Wm::W2 + m * RO;
                 float dh = 0.f;
 #pragma unroll
                 for (int c = 0; c < CO; ++c) dh = fmaf(w2[c], g2[c], dh);
@@ -1180,7 +1216,7 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
         } else {
 #pragma unroll
             for (int m = 0; m < CI; ++m) {
-                const float* w2 = a.w2t + m * CO;
+                const float* w2 = Wl + Wm::W2 + m * RO;
 #pragma unroll
                 for (int c = 0; c < CO; ++c) dx[m] = fmaf(w2[c], g2[c], dx[m]);
             }
@@ -1193,12 +1229,16 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
                 float* dsb = a.ds + (size_t)b * CI * a.P + p;
 #pragma unroll
                 for (int i = 0; i < CI; ++i) {
-                    const float* ws = a.wst + i * CO;
+                    const float* ws = Wl + Wm::WS + i * RO;
                     float v = 0.f;
 #pragma unroll
                     for (int c = 0; c < CO; ++c) v = fmaf(ws[c], g2[c], v);
                     dsb[(size_t)i * a.P] = v;
                 }
+            } else if (a.skip_mode == 2 && a.ds) {   // dL/dz2: the caller sums it over t into the skip's last slice
+                float* dsb = a.ds + (size_t)b * CO * a.P + p;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) dsb[(size_t)c * a.P] = g2[c];
             }
         }
     }
@@ -1228,19 +1268,26 @@ static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipSt
     if (!a.x) return 0;   // layout query
     a.chunks_per_batch = (a.P + 63) / 64;
     a.total_chunks = a.chunks_per_batch * batch;
-    int blocks = (int)std::min<long>((a.total_chunks + Gm::WAVES - 1) / Gm::WAVES, max_waves / Gm::WAVES);
-    if (blocks < 1) blocks = 1;
-    const size_t lds = (size_t)Gm::WAVES * Gm::ROWS * Gm::PITCH * sizeof(float);
+    using Wm = PwBwdW<CI, CM, CO, HAS_L1>;
+    const size_t lds = ((size_t)((Wm::TOTAL + 3) & ~3) + (size_t)Gm::WAVES * Gm::ROWS * Gm::PITCH) * sizeof(float);
     auto kern = k_pointwise_bwd<CI, CM, CO, HAS_L1>;
     int rc = set_lds_attr(kern, lds);
     if (rc) return rc;
+    // persistent grid: exactly the resident workgroups (a second, partial round would double the run time)
+    int per_cu = 0, dev = 0, cus = 256;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * Gm::WAVES, lds));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    long resident = (long)std::max(per_cu, 1) * cus;
+    int blocks = (int)std::min<long>({(a.total_chunks + Gm::WAVES - 1) / Gm::WAVES, (long)(max_waves / Gm::WAVES), resident});
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * Gm::WAVES), lds, st, a);
     HIP_TRY(hipGetLastError());
     dims[5] = blocks * Gm::WAVES;
     return 0;
 }
 
-// Backward of tcfd_fno_pointwise for skip_mode 0 / 1 (shared weights).  `partials` holds `max_waves` rows of
+// Backward of tcfd_fno_pointwise (shared weights; skip_mode 2 writes dL/dz2 (b, co, P) into dskip).  `partials` holds `max_waves` rows of
 // dims[4] floats; on return dims = {COP, CB, CM1, CIP, floats per row, rows written}: row-major padded tiles
 //   A (COP x CB):  A[o][0:ch] = dW2[o][.] (ch = cm, single layer: ci),  A[o][ch] = db2[o] (= dbs),  A[o][ch+1 : ch+1+ci] = dWs[o][.]
 //   B (CM1 x CIP): B[m][0:ci] = dW1[m][.],  B[m][ci] = db1[m]            (two-layer form only)
@@ -1248,17 +1295,19 @@ static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipSt
 extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, void* dx, void* dskip,
                                       const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
                                       const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
-                                      int cm, int co, long P, int act1, int act2, int skip_mode, void* stream) {
+                                      int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
+                                      void* stream) {
     if (!dims) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: null dims");
     if (x && (!dout || !dx || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
         return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad argument");
-    if (skip_mode != 0 && skip_mode != 1) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode %d not supported", skip_mode);
+    if (skip_mode < 0 || skip_mode > 2) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode %d not supported", skip_mode);
     if (x && skip_mode == 1 && (!skip || !wst)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip input missing");
+    if (x && skip_mode == 2 && (!skip || T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad T");
     PwBwdArgs a;
     a.x = (const float*)x; a.s = (const float*)skip; a.dout = (const float*)dout; a.dx = (float*)dx; a.ds = (float*)dskip;
     a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
     a.wst = (const float*)wst; a.bs = (const float*)bs; a.partials = (float*)partials;
-    a.P = P; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
+    a.P = P; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode; a.T = T; a.sT = skip_T;
     a.chunks_per_batch = a.total_chunks = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool l1 = cm != ci || w1 != nullptr;

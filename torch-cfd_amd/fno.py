@@ -321,12 +321,12 @@ def _pointwise_reference(spec, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
 
 def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
     """Gradients of the fused block from ``tcfd_fno_pointwise_bwd`` (one pass; weight gradients accumulated on MFMA,
-    per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm, the
-    last-slice skip of the lifting operator, a width that is not instantiated -- the caller then recomputes the
+    per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm or a width
+    that is not instantiated -- the caller then recomputes the
     block with torch einsums."""
     has_l1, act1, act2, mode, eps = spec
     c1, c2 = _act_code(act1), _act_code(act2)
-    if eps is not None or mode == 2 or c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
+    if eps is not None or c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
         return None
     b, ci = x.shape[:2]
     co = w2.shape[0]
@@ -335,14 +335,16 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     lib = _lib.load()
     dims = (ctypes.c_int * 6)()
     one = ctypes.c_void_p(1) if has_l1 else None   # layout query: only null / non-null of w1 matters
+    T = x.shape[-1]
+    sT = skip.shape[-1] if mode == 2 else 0
     rc = lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, one, None, None, None, None, None, None, 0, dims, b, ci, cm,
-                                    co, P, c1, c2, mode, None)
+                                    co, P, T, sT, c1, c2, mode, None)
     if rc != 0:
         return None
     COP, CB, CM1, CIP, per_row, _ = list(dims)
     dev = x.device
     xs, dz = x.detach().contiguous(), dout.detach().contiguous()
-    sk = skip.detach().contiguous() if mode == 1 else None
+    sk = skip.detach().contiguous() if mode else None
     mat = lambda w: w.detach().reshape(w.shape[0], -1)
     w1m = mat(w1).contiguous() if has_l1 else None
     w2t = mat(w2).t().contiguous()
@@ -350,13 +352,14 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     vec = lambda t: t.detach().contiguous() if t is not None else None
     b1v, b2v, bsv = vec(b1), vec(b2), vec(bs)
     dx = torch.empty_like(xs)
-    ds = torch.empty_like(sk) if mode == 1 else None
+    ds = torch.empty_like(sk) if mode == 1 else (torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=dev)
+                                                 if mode == 2 else None)
     max_waves = 2048
     partials = torch.empty(max_waves, per_row, dtype=torch.float32, device=dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise_bwd(ptr(xs), ptr(sk), ptr(dz), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t), ptr(b2v),
-                                        ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, c1, c2, mode,
+                                        ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1, c2, mode,
                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd")
     tot = partials[: dims[5]].sum(dim=0, dtype=torch.float64).float()
@@ -371,7 +374,12 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
         Bm = tot[COP * CB:].view(CM1, CIP)
         g_w1 = Bm[:cm, :ci].reshape(w1.shape)
         g_b1 = Bm[:cm, ci].contiguous() if b1 is not None else None
-    return (dx.view_as(x), ds.view_as(skip) if ds is not None else None, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
+    if mode == 2:   # the skip's last time slice was broadcast over t: its gradient is the t-sum of dL/dz2
+        g_skip = torch.zeros_like(skip)
+        g_skip[..., -1] = ds.sum(dim=-1)
+    else:
+        g_skip = ds.view_as(skip) if ds is not None else None
+    return (dx.view_as(x), g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
 
 
 class _PointwiseFn(torch.autograd.Function):
