@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-sfno", action="store_true", help="skip the secondary SFNO config-5 measurement")
     ap.add_argument("--fused-steps", action="store_true",
                     help="advance all K steps in ONE forward(steps=K) call (amortises the per-call prologue)")
     return ap.parse_args()
@@ -94,6 +95,46 @@ def cpu_baseline(n, real, dt, seconds):
         "sample": f"oracle/ns2d.py (torch-CPU restatement of the reference op sequence), {n}^2 {str(real)[6:]}, "
                   f"B={Bs}, {steps} steps in {el:.1f}s ({per_step_b2*1e3:.0f} ms/step), extrapolated linearly to B=64",
     }
+
+
+def sfno_config5(dev):
+    """Secondary measurement (BASELINE configs[4], SURVEY 8d "C5"): SFNO(24,24,5, width 10, 4 layers) forward +
+    SobolevLoss on x = randn(32,256,256,10) fp32, random-init weights (seed 0); plus one training step
+    (forward + loss + backward).  Algorithmic bytes: 21.5 A_H = 18.0 GB per forward+loss."""
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(32, 256, 256, 10, generator=g).to(dev)
+    y = torch.randn(32, 256, 256, 10, generator=g).to(dev)
+    loss_fn = fno.SobolevLoss(n_grid=256, norm_order=0, relative=True).to(dev)
+
+    def timeit(fn, n):
+        fn(); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    with torch.no_grad():
+        t_fwd = timeit(lambda: model(x), 10)
+        t_all = timeit(lambda: loss_fn(model(x), y), 10)
+    model.train()
+
+    def train_step():
+        model.zero_grad(set_to_none=True)
+        loss_fn(model(x), y).backward()
+
+    t_train = timeit(train_step, 3)
+    algo_gb = 21.5 * 32 * 10 * 256 * 256 * 10 * 4 / 1e9
+    return {"workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
+            "forward_ms": round(t_fwd, 3), "forward_plus_loss_ms": round(t_all, 3), "train_step_ms": round(t_train, 2),
+            "samples_per_s": round(32 / (t_all * 1e-3), 1), "algo_GB": round(algo_gb, 2),
+            "algo_GBps": round(algo_gb / (t_all * 1e-3), 1), "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4)}
 
 
 def main():
@@ -233,6 +274,13 @@ def main():
         "kernels": kern,
         "hbm_probe": probe,
     }
+    if rank == 0 and world == 1 and not args.no_sfno:
+        try:
+            del w
+            torch.cuda.empty_cache()
+            out["sfno_config5"] = sfno_config5(dev)
+        except Exception as e:  # secondary measurement: never takes the headline line down
+            out["sfno_config5"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(n, real, dt, args.cpu_seconds)
