@@ -809,8 +809,25 @@ struct ProfState {
     std::vector<ProfRec> recs;
 };
 
+// hipGraph of ONE interior RK step (nstages x {row pass, fused column pass}, state upad -> upad): for small grids a
+// step is 10 launches of 7-20 us each and launch gaps are a quarter of the time; a steps=k call replays the graph
+// for its k-2 interior steps on a plan-owned stream (capture is not allowed on the legacy default stream PyTorch
+// hands over), fenced by events against the caller's stream.
+struct GraphState {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    // key of the captured sequence
+    long batch = -1;
+    int nstages = 0;
+    void* ws = nullptr;
+    std::vector<double> coef;
+};
+
 struct tcfd_ns2d_plan {
     ProfState* prof;  // mutable side-car (tcfd_ns2d_profile_begin/end); null until first use
+    GraphState* gs;   // mutable side-car: captured interior step (null until first use)
     int n, m, dtype;
     int ldw;        // workspace row pitch in elements: m rounded up so that a row is a multiple of 128 bytes
     void* tw;       // cx<T>[n]
@@ -952,6 +969,14 @@ extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     if (p->prof) {
         for (auto& r : p->prof->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         delete p->prof;
+    }
+    if (p->gs) {
+        if (p->gs->exec) (void)hipGraphExecDestroy(p->gs->exec);
+        if (p->gs->graph) (void)hipGraphDestroy(p->gs->graph);
+        if (p->gs->ev_in) (void)hipEventDestroy(p->gs->ev_in);
+        if (p->gs->ev_out) (void)hipEventDestroy(p->gs->ev_out);
+        if (p->gs->stream) (void)hipStreamDestroy(p->gs->stream);
+        delete p->gs;
     }
     delete p;
 }
@@ -1263,10 +1288,12 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     // write of a call touch that layout, every stage in between uses the aligned copy `upad`
     const cx<T>* u_src = (const cx<T>*)w_in;
     int u_src_ld = p->m;
-    for (int s = 0; s < steps; ++s) {
+    // one RK step on stream `q`; `first`/`final` select the caller-layout source / destination
+    auto run_step = [&](hipStream_t q, bool final) -> int {
         for (int k = 0; k < nstages; ++k) {
-            if ((rc = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, st))) return rc;
-            const bool last = (s == steps - 1) && (k == nstages - 1);
+            int r;
+            if ((r = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, q))) return r;
+            const bool last = final && (k == nstages - 1);
             a.u_in = u_src;
             a.u_in_ld = u_src_ld;
             a.u_out = last ? (cx<T>*)w_out : W.upad;
@@ -1275,12 +1302,51 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.gdt = (T)gdt[k];
             a.mu = (T)mu[k];
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
-            rc = last ? launch_cols<T, N, MODE_C>(p, a, batch, st) : launch_cols<T, N, MODE_CA>(p, a, batch, st);
-            if (rc) return rc;
+            r = last ? launch_cols<T, N, MODE_C>(p, a, batch, q) : launch_cols<T, N, MODE_CA>(p, a, batch, q);
+            if (r) return r;
             u_src = a.u_out;
             u_src_ld = a.u_out_ld;
         }
+        return 0;
+    };
+    const long state_bytes = (long)batch * N * p->ldw * (long)sizeof(cx<T>);
+    const int graph_env = env_int("TCFD_GRAPH", -1);
+    const bool profiling = p->prof && p->prof->on;
+    const bool use_graph = steps >= 3 && !profiling &&
+                           (graph_env == 1 || (graph_env != 0 && state_bytes <= (long)16 << 20));  // launch-bound regime
+    int s0 = 0;
+    if (use_graph) {
+        tcfd_ns2d_plan* mp = const_cast<tcfd_ns2d_plan*>(p);
+        if (!mp->gs) mp->gs = new GraphState();
+        GraphState* g = mp->gs;
+        if (!g->stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming));
+        }
+        if ((rc = run_step(st, false))) return rc;   // step 1: caller layout -> upad (also sets every kernel attribute)
+        std::vector<double> coef;
+        for (int k = 0; k < nstages; ++k) { coef.push_back(beta[k]); coef.push_back(gdt[k]); coef.push_back(mu[k]); }
+        if (!g->exec || g->batch != batch || g->nstages != nstages || g->ws != ws || g->coef != coef) {
+            if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+            if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
+            HIP_TRY(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+            rc = run_step(g->stream, false);         // upad -> upad
+            hipError_t e = hipStreamEndCapture(g->stream, &g->graph);
+            if (rc) return rc;
+            if (e != hipSuccess) return fail(TCFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIP_TRY(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+            g->batch = batch; g->nstages = nstages; g->ws = ws; g->coef = coef;
+        }
+        HIP_TRY(hipEventRecord(g->ev_in, st));
+        HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_in, 0));
+        for (int s = 1; s < steps - 1; ++s) HIP_TRY(hipGraphLaunch(g->exec, g->stream));
+        HIP_TRY(hipEventRecord(g->ev_out, g->stream));
+        HIP_TRY(hipStreamWaitEvent(st, g->ev_out, 0));
+        s0 = steps - 1;
     }
+    for (int s = s0; s < steps; ++s)
+        if ((rc = run_step(st, s == steps - 1))) return rc;
     if (dwdt) {
         const size_t count = (size_t)batch * N * p->m;
         const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
