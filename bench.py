@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-sfno", action="store_true", help="skip the secondary SFNO config-5 measurement")
+    ap.add_argument("--no-probe", action="store_true", help="skip the STREAM-style HBM probe (keeps profiles clean)")
     ap.add_argument("--fused-steps", action="store_true",
                     help="advance all K steps in ONE forward(steps=K) call (amortises the per-call prologue)")
     return ap.parse_args()
@@ -207,6 +208,8 @@ def main():
     # STREAM-style probe of this box: what a plain 16-B/lane copy / read / fill reaches next to the 8 TB/s spec
     probe = {}
     try:
+        if args.no_probe:
+            raise RuntimeError("skipped (--no-probe)")
         nbytes = 1 << 30
         a_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         b_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -9,5 +9,5 @@ for line in sys.stdin:
         print('  ms/step=%.2f steps/s=%.1f | '%(d['ms_per_step'],d['value'])+' '.join('%s=%.3f'%(k.replace('k_',''),v['avg_ms']) for k,v in d['kernels'].items()))
 "; }
 for cfg in "$@"; do
-  echo "[$cfg]"; env $cfg python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-sfno ${BENCH_ARGS} 2>&1 | show
+  echo "[$cfg]"; env $cfg python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-sfno --no-probe ${BENCH_ARGS} 2>&1 | show
 done
