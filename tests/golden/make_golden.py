@@ -316,6 +316,22 @@ def gen_grads():
             out[f"{name}_sd_{k}"] = npy(v)
         for k, v in layer.named_parameters():
             out[f"{name}_g_{k}"] = npy(v.grad)
+    # SpectralConvT with the Helmholtz projection between contraction and inverse transform (out_dim = 2 OutConv core)
+    from fno.sfno import HelmholtzProjection
+    hp = SpectralConvT(2, 2, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True,
+                       postprocess=HelmholtzProjection(n_grid=16, diam=2 * math.pi))
+    with torch.no_grad():
+        for p_ in hp.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.2)
+    xh = torch.randn(2, 2, 16, 16, 6, generator=g).requires_grad_(True)
+    yh = hp(xh, out_steps=9)
+    th = torch.randn(yh.shape, generator=g)
+    ((yh * th).sum() + 0.5 * (yh ** 2).sum()).backward()
+    out["convT_helm_x"], out["convT_helm_t"], out["convT_helm_y"], out["convT_helm_gx"] = npy(xh), npy(th), npy(yh), npy(xh.grad)
+    for k, v in hp.state_dict().items():
+        out[f"convT_helm_sd_{k}"] = npy(v)
+    for k, v in hp.named_parameters():
+        out[f"convT_helm_g_{k}"] = npy(v.grad)
     torch.manual_seed(0)
     model = SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).train()
     with torch.no_grad():

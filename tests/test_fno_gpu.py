@@ -2,6 +2,8 @@
 reference-generated golden vectors and the CPU oracle.  Tolerance: rel-L2 <= 1e-5 (north_star: FNO
 forward within 1e-5), fp32."""
 import numpy as np
+import math
+
 import pytest
 import torch
 
@@ -147,9 +149,6 @@ def test_errors_are_loud(dev):
     with pytest.raises(_lib.TcfdError):
         m(torch.randn(1, 2, 16, 16, 10))  # CPU tensor
     assert m(torch.randn(1, 2, 16, 16, 10, device=dev)).grad_fn is not None  # autograd on: differentiable path
-    hp = fno.SpectralConvT(2, 2, 4, 4, 3, postprocess=fno.HelmholtzProjection(n_grid=16, diam=1.0)).to(dev)
-    with pytest.raises(_lib.TcfdError, match="forward-only"):
-        hp(torch.randn(1, 2, 16, 16, 10, device=dev), out_steps=10)  # spectrum post-processing has no backward yet
     with torch.no_grad():
         with pytest.raises(_lib.TcfdError, match="powers of two"):
             m(torch.randn(1, 2, 24, 16, 10, device=dev))
@@ -257,6 +256,8 @@ def _load_layer_sd(layer, g, name):
     ("convS", lambda f: f.SpectralConvS(3, 5, 4, 3, 3, bias=True, delta=0.3), {}),
     ("convT_pad", lambda f: f.SpectralConvT(4, 4, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True), {"out_steps": 9}),
     ("convT_plain", lambda f: f.SpectralConvT(2, 3, 3, 4, 4, delta=0.1, bias=False, temporal_padding=False), {"out_steps": 12}),
+    ("convT_helm", lambda f: f.SpectralConvT(2, 2, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True,
+                                             postprocess=f.HelmholtzProjection(n_grid=16, diam=2 * math.pi)), {"out_steps": 9}),
 ])
 def test_spectral_conv_backward_golden(name, ctor, kw, dev):
     """Hand-written backward of the HIP spectral convolution against the reference's autograd (torch.fft, CPU):

@@ -14,7 +14,7 @@ The spectral convolutions call ``tcfd_fno_spectral_conv`` (include/tcfd.h): five
 kernels that read and write the (b, C, X, Y, T) activations exactly once instead
 of the reference's full rfftn / zero-filled spectrum / irfftn.  fp32, HIP device
 tensors, X and Y powers of two; anything else raises (no fallback).  Under autograd the
-spectral convolutions run a hand-written backward on the same kernels (``_SpectralConvFn``);
+spectral convolutions run a hand-written backward on the same kernels (``hip_spectral_conv_autograd``);
 the pointwise blocks keep their HIP forward and recompute the block with torch einsums in the
 backward (``_PointwiseFn``).
 The pointwise layers around them (1x1x1 convolutions, GroupNorm, activations) are
@@ -112,8 +112,7 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     t_keep = t_out if t_keep is None else t_keep
     params = list(weights) + (list(bias) if bias is not None else [])
     if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params)):
-        return _SpectralConvFn.apply(v, (float(delta), tuple(modes), t_pad, t_out, t_keep, norm, bias is not None,
-                                         use_mfma), *params)
+        return hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma)
     v = v.detach().contiguous()
 
     def as_real(w, shape):
@@ -212,64 +211,95 @@ def _corner_slices(mx: int, my: int):
     return [(sx[k % 2], sy[k // 2]) for k in range(4)]
 
 
-class _SpectralConvFn(torch.autograd.Function):
-    """Spectral convolution with a hand-written backward on the same HIP kernels.
-
-    y = G(W . F(v)): F = truncated rfftn of the left-padded input (an R-linear map real -> complex), G = zero-padded
-    irfftn with c2r semantics.  With complex cotangents in torch's convention (dL/dRe + i dL/dIm):
-      G^T(dy)  = c_out * F'(dy)        F' = the forward transform of the plan with (T_in, t_pad) := (t_keep, t_out - t_keep)
-      grad W   = conj(v^) (x) G^T(dy)  summed over the batch,   grad bias = delta * sum_{b, o} G^T(dy)
-      grad v^  = conj(W)^T . G^T(dy)   (the MFMA contraction kernel with transposed, conjugated weights)
-      F^T(z)   = G'(z / c_in)          G' = the inverse transform of that plan, output length T_in + t_pad, kept tail T_in
-    c_out / c_in are the c2r multiplicities (1 for DC / Nyquist in t, else 2) of the two time lengths: the inverse
-    kernel doubles the interior modes, the adjoint of an r2c transform does not."""
+class _FwdTruncFn(torch.autograd.Function):
+    """F: truncated rfftn of the left-padded input on the HIP kernels.  For a complex cotangent z (torch's convention
+    dL/dRe + i dL/dIm),  F^T(z) = G'(z / c_in): the zero-padded inverse of the plan with output length T_in + t_pad
+    (kept tail T_in) applied to z with the interior time modes halved -- the c2r kernel doubles them, the adjoint of
+    an r2c transform does not (c = 1 for DC / Nyquist in t, else 2)."""
 
     @staticmethod
-    def forward(ctx, v, cfg, *params):
-        delta, modes, t_pad, t_out, t_keep, norm, has_bias, use_mfma = cfg
-        weights, bias = list(params[:4]), (list(params[4:8]) if has_bias else None)
-        with torch.no_grad():
-            vh, plan = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
-            oh = hip_contract(vh, [w.detach() for w in weights], [x.detach() for x in bias] if bias else None, delta, modes,
-                              use_mfma=use_mfma)
-            out = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
-        ctx.cfg, ctx.in_shape = cfg, tuple(v.shape)
-        ctx.save_for_backward(vh, *params)
-        return out
+    def forward(ctx, v, modes, t_pad, t_out, norm):
+        vh, _ = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
+        ctx.cfg = (tuple(v.shape), tuple(modes), t_pad, t_out, norm)
+        return vh
+
+    @staticmethod
+    def backward(ctx, z):
+        (b, c, X, Y, T), modes, t_pad, t_out, norm = ctx.cfg
+        Tp = T + t_pad
+        fs, _ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
+        plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device)       # its inverse reconstructs Tp steps
+        zh = (z / _c2r_weights(modes[2], Tp, z.device)).contiguous()
+        return hip_truncated_irfftn(zh, plan, T, scale=fs), None, None, None, None
+
+
+class _InvTruncFn(torch.autograd.Function):
+    """G: zero-padded irfftn (c2r semantics, last t_keep of t_out steps).  G^T(dy) = c_out * F'(dy) with F' the forward
+    transform of the plan whose input is t_keep steps left-padded to t_out."""
+
+    @staticmethod
+    def forward(ctx, oh, plan_key, t_keep, norm):
+        plan = _plan(plan_key, oh.device)
+        ctx.cfg = (plan_key, t_keep, norm)
+        return hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
 
     @staticmethod
     def backward(ctx, dy):
-        delta, modes, t_pad, t_out, t_keep, norm, has_bias, use_mfma = ctx.cfg
+        (X, Y, T, t_pad, t_out, mx, my, mt), t_keep, norm = ctx.cfg
+        _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+        gh, _ = hip_truncated_rfftn(dy.contiguous(), (mx, my, mt), t_pad=t_out - t_keep, t_out=t_out, scale=is_)
+        return gh * _c2r_weights(mt, t_out, dy.device), None, None, None
+
+
+class _ContractFn(torch.autograd.Function):
+    """The 4-corner mode contraction (+ delta * bias) on the MFMA kernel.  Backward: the same kernel with the
+    conjugate-transposed weight blocks for the spectrum, batch-summed outer products for the weights."""
+
+    @staticmethod
+    def forward(ctx, vh, delta, modes, use_mfma, has_bias, *params):
+        weights, bias = list(params[:4]), (list(params[4:8]) if has_bias else None)
+        ctx.cfg = (delta, tuple(modes), use_mfma, has_bias)
+        ctx.save_for_backward(vh, *params)
+        return hip_contract(vh, [w.detach() for w in weights], [x.detach() for x in bias] if bias else None, delta, modes,
+                            use_mfma=use_mfma)
+
+    @staticmethod
+    def backward(ctx, gh):
+        delta, modes, use_mfma, has_bias = ctx.cfg
         vh, *params = ctx.saved_tensors
         weights = params[:4]
-        b, ci, X, Y, T = ctx.in_shape
         mx, my, mt = modes
-        Tp = T + t_pad
-        fs, is_ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
-        dev = dy.device
-        with torch.no_grad():
-            gh, plan_b = hip_truncated_rfftn(dy.contiguous(), modes, t_pad=t_out - t_keep, t_out=Tp, scale=is_)
-            gh = gh * _c2r_weights(mt, t_out, dev)                                  # G^T(dy)
-            grads = [None] * len(params)
-            need_w = [ctx.needs_input_grad[2 + k] for k in range(len(params))]
-            for k, (sx, sy) in enumerate(_corner_slices(mx, my)):
-                if need_w[k]:
-                    gw = torch.einsum("bixyt,boxyt->ioxyt", vh[:, :, sx, sy].conj(), gh[:, :, sx, sy])
-                    grads[k] = gw if weights[k].is_complex() else torch.view_as_real(gw.contiguous())
-                if has_bias and need_w[4 + k]:
-                    gb = delta * gh[:, :, sx, sy].sum(dim=(0, 1))
-                    grads[4 + k] = gb if params[4 + k].is_complex() else torch.view_as_real(gb.contiguous())
-            gv = None
-            if ctx.needs_input_grad[0]:
-                wh = []
-                for w in weights:
-                    w = w.detach()
-                    w = w if w.is_complex() else torch.view_as_complex(w.contiguous())
-                    wh.append(w.conj().transpose(0, 1).resolve_conj().contiguous())   # (Co, Ci, mx, my, mt)
-                zh = hip_contract(gh, wh, None, 0.0, modes, use_mfma=use_mfma)
-                zh = zh / _c2r_weights(mt, Tp, dev)
-                gv = hip_truncated_irfftn(zh, plan_b, T, scale=fs)
-        return (gv, None, *grads)
+        gh = gh.contiguous()
+        grads = [None] * len(params)
+        for k, (sx, sy) in enumerate(_corner_slices(mx, my)):
+            if ctx.needs_input_grad[5 + k]:
+                gw = torch.einsum("bixyt,boxyt->ioxyt", vh[:, :, sx, sy].conj(), gh[:, :, sx, sy])
+                grads[k] = gw if weights[k].is_complex() else torch.view_as_real(gw.contiguous())
+            if has_bias and ctx.needs_input_grad[9 + k]:
+                gb = delta * gh[:, :, sx, sy].sum(dim=(0, 1))
+                grads[4 + k] = gb if params[4 + k].is_complex() else torch.view_as_real(gb.contiguous())
+        gv = None
+        if ctx.needs_input_grad[0]:
+            wh = []
+            for w in weights:
+                w = w.detach()
+                w = w if w.is_complex() else torch.view_as_complex(w.contiguous())
+                wh.append(w.conj().transpose(0, 1).resolve_conj().contiguous())   # (Co, Ci, mx, my, mt)
+            gv = hip_contract(gh, wh, None, 0.0, modes, use_mfma=use_mfma)
+        return (gv, None, None, None, None, *grads)
+
+
+def hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma=True, post=None):
+    """Differentiable spectral convolution  y = G(post(W . F(v)))  (SURVEY 8f rank 4): three autograd Functions on the
+    same HIP kernels as the forward-only path; ``post`` (e.g. the Helmholtz projection of SpectralConvT) acts on the
+    small truncated spectrum with ordinary differentiable torch ops."""
+    b, ci, X, Y, T = v.shape
+    params = list(weights) + (list(bias) if bias is not None else [])
+    vh = _FwdTruncFn.apply(v, tuple(modes), t_pad, t_out, norm)
+    oh = _ContractFn.apply(vh, float(delta), tuple(modes), use_mfma, bias is not None, *params)
+    if post is not None:
+        oh = post(oh)
+    return _InvTruncFn.apply(oh, (X, Y, T, t_pad, t_out) + tuple(modes), t_keep, norm)
 
 
 # ----------------------------------------------------------------------------- pointwise helpers
@@ -593,7 +623,10 @@ class SpectralConvT(SpectralConvS):
             if not v.is_cuda or v.dtype != torch.float32:
                 raise _lib.TcfdError("expected an fp32 HIP device tensor (torch-cfd_amd has no CPU fallback)")
             if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
-                raise _lib.TcfdError("SpectralConvT with a spectrum post-processor is forward-only: use torch.no_grad()")
+                post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
+                    self.postprocess, "forward_truncated") else self.postprocess
+                return hip_spectral_conv_autograd(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad,
+                                                  out_steps + t_pad, out_steps, self.norm, post=post)
             vh, plan = hip_truncated_rfftn(v, self.modes, t_pad=t_pad, t_out=out_steps + t_pad, norm=self.norm)
             oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
             oh = self.postprocess.forward_truncated(oh, self.modes, v.shape[-3]) if hasattr(
