@@ -82,6 +82,18 @@ int tcfd_ns2d_step(const tcfd_ns2d_plan* plan, const void* w_in, void* w_out, vo
                    int nstages, const double* beta, const double* gdt, const double* mu, int steps,
                    double inv_total_dt, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same fused step for the reference's other IMEX schedules (IMEXStepper._imex / _rk2_crank_nicolson,
+ * torch_cfd/equations.py:174-228).  Stage k:
+ *     h <- fa[k] F(u) + beta[k] h ;   u <- (base + gdt[k] h + mu_num[k] L base) / (1 - mu_den[k] L)
+ * with base = the current state, or, where base0[k] != 0, the state the STEP started from.
+ *   forward-backward Euler / IMEX-CN (order 1, 1.5):  1 stage,  fa 1, beta 0, gdt dt, mu_num (1-alpha) dt, mu_den alpha dt
+ *   RK2-CN (order 2): 2 stages, fa {1, alpha}, beta {0, 1-alpha}, gdt dt, mu_num = mu_den = beta_cn dt, base0 {0, 1}
+ * fa, mu_den, base0 may be NULL (1, mu_num, all 0: tcfd_ns2d_step).  Everything else as tcfd_ns2d_step. */
+int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* plan, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
+                        const double* fa, const double* beta, const double* gdt, const double* mu_num,
+                        const double* mu_den, const int* base0, int steps, double inv_total_dt, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* F(w): NavierStokes2DSpectral.explicit_terms (equations.py:413-441). */
 int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* plan, const void* w, void* out, long batch,
                              void* workspace, size_t workspace_bytes, void* stream);

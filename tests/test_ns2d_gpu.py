@@ -438,9 +438,10 @@ def test_config2_1000_steps_fp32(dev):
 
 
 @pytest.mark.parametrize("order,alpha,beta", [(1, 1.0, 1.0), (1.5, 0.5, 0.5), (2, 0.5, 0.5), (2, 2 / 3, 0.5)])
-def test_imex_steppers_golden(order, alpha, beta, dev):
-    """IMEXStepper orders 1 / 1.5 / 2 (equations.py:174-228) behind the same operator: the
-    explicit term runs on the HIP kernels, the few combinations around it are device tensor ops."""
+def test_imex_steppers_golden(order, alpha, beta, dev, monkeypatch):
+    """IMEXStepper orders 1 / 1.5 / 2 (equations.py:174-228) behind the same operator, every stage
+    fused in the HIP step kernels through the general schedule h <- fa F + beta h, u <- (base + gdt h + mu L base) /
+    (1 - mu_den L) with base = current or step-initial state."""
     import torch_cfd_amd as tc
 
     g = load_golden("ns2d_imex.npz")
@@ -449,9 +450,22 @@ def test_imex_steppers_golden(order, alpha, beta, dev):
     fn = tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4)
     op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, forcing_fn=fn,
                                    solver=tc.IMEXStepper(order=order, alpha=alpha, beta=beta)).to(dev)
-    w, d = op(torch.from_numpy(g["w0"]).to(dev), 1e-3, steps=3)
+    w0 = torch.from_numpy(g["w0"]).to(dev)
+    w, d = op(w0, 1e-3, steps=3)                       # fused schedule (tcfd_ns2d_step_imex), graph replay inside
     assert rel_l2(w, g[f"o{order}_a{alpha:.3f}_w"]) < 1e-10
     assert rel_l2(d, g[f"o{order}_a{alpha:.3f}_dwdt"]) < 1e-8
+    # the fused step against the generic form (explicit term on HIP + element-wise torch ops), one and many steps
+    one_fused = op.solver(w0, 1e-3, op)
+    one_generic = op.solver.stepper(w0, 1e-3, op)
+    assert rel_l2(one_fused, one_generic) < 1e-13
+    wg = w0
+    for _ in range(6):
+        wg = op.solver.stepper(wg, 1e-3, op)
+    monkeypatch.setenv("TCFD_GRAPH", "0")
+    w6_plain, _ = op(w0, 1e-3, steps=6)
+    monkeypatch.setenv("TCFD_GRAPH", "1")
+    w6_graph, _ = op(w0, 1e-3, steps=6)
+    assert torch.equal(w6_plain, w6_graph) and rel_l2(w6_plain, wg) < 1e-12
 
 
 @pytest.mark.parametrize("n,tag", [(16, "f64"), (64, "f32"), (256, "f64"), (512, "f32")])

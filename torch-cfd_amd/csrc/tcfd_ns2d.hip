@@ -117,6 +117,7 @@ struct ColArgs {
     const cx<T>* tw;      // [n]
     size_t plane_stride;  // elements between planes
     T beta, gdt, mu, scale;
+    T fa, mud;   // h <- fa F + beta h ;  u <- (base + gdt h + mu L base) / (1 - mud L)   (RK4-CN: fa = 1, mud = mu)
     int m;        // row pitch (elements) of caller-layout arrays: u_in, u_out, wt, out, psi
     int ldw;      // row pitch of workspace arrays (adv, h, planes): m rounded up to a 128-byte multiple
     int in_ld;    // MODE_FWD / MODE_INV: pitch of `in`
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     const int sl = j + t * G;
                     const int i = TCFD_IROW(sl);
                     const size_t gw = wbase + (wq + (size_t)sl) * a.ldw;  // h is stored parity-major when split
-                    cx<T> hn = x[t];
+                    cx<T> hn = cscale(x[t], a.fa);
                     // pruned entries: F = 0 at every stage, so h stays 0 and is not stored at all
                     const bool h_live = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[sl] != (T)0));
                     if (h_live) {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
                     // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                     cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
-                    const T den = fast_rcp((T)1 - a.mu * L);
+                    const T den = fast_rcp((T)1 - a.mud * L);
                     x[t] = cscale(rhs, den);
                     a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                 }
@@ -1021,7 +1022,7 @@ static size_t field_bytes(const tcfd_ns2d_plan* p, long batch) {
 
 extern "C" size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
     if (!p || batch <= 0) return 0;
-    return 7 * field_bytes(p, batch);  // h, adv, 4 planes, line-aligned copy of the state
+    return 8 * field_bytes(p, batch);  // h, adv, 4 planes, line-aligned state, second state (schedules that keep u0)
 }
 
 // ------------------------------------------------------------------ optional per-launch event timing
@@ -1254,6 +1255,7 @@ struct Ws {
     cx<T>* adv;
     cx<T>* planes;
     cx<T>* upad;          // state in the line-aligned internal pitch (stages 1.. of a call)
+    cx<T>* upad2;         // intermediate state of schedules whose later stages restart from the step's initial state
     size_t plane_stride;  // elements
 };
 template <typename T>
@@ -1265,6 +1267,7 @@ static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
     w.adv = (cx<T>*)(base + fb);
     w.planes = (cx<T>*)(base + 2 * fb);
     w.upad = (cx<T>*)(base + 6 * fb);
+    w.upad2 = (cx<T>*)(base + 7 * fb);
     w.plane_stride = fb / sizeof(cx<T>);
     return w;
 }
@@ -1272,8 +1275,8 @@ static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
 // ------------------------------------------------------------------ step driver
 template <typename T, int N>
 static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
-                     const double* beta, const double* gdt, const double* mu, int steps, double inv_total_dt, void* ws,
-                     hipStream_t st) {
+                     const double* beta, const double* gdt, const double* mu, const double* fa, const double* mud,
+                     const int* base0, int steps, double inv_total_dt, void* ws, hipStream_t st) {
     Ws<T> W = carve<T>(p, ws, batch);
     int rc;
     ColArgs<T> a{};
@@ -1289,18 +1292,30 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     const cx<T>* u_src = (const cx<T>*)w_in;
     int u_src_ld = p->m;
     // one RK step on stream `q`; `first`/`final` select the caller-layout source / destination
+    // General IMEX stage:  h <- fa_k F(u) + beta_k h ;  u <- (base + gdt_k h + mu_k L base) / (1 - mud_k L)  with
+    // base = the current state, or (base0[k]) the state the step started from (IMEX RK2-CN, equations.py:190-228).
+    // A stage whose successors still need the step's initial state writes to the second state buffer.
     auto run_step = [&](hipStream_t q, bool final) -> int {
+        const cx<T>* u0 = u_src;
+        const int u0_ld = u_src_ld;
         for (int k = 0; k < nstages; ++k) {
             int r;
             if ((r = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, q))) return r;
             const bool last = final && (k == nstages - 1);
-            a.u_in = u_src;
-            a.u_in_ld = u_src_ld;
-            a.u_out = last ? (cx<T>*)w_out : W.upad;
+            bool u0_needed_later = false;
+            for (int k2 = k + 1; k2 < nstages; ++k2) u0_needed_later |= (base0 && base0[k2]);
+            const bool from_u0 = base0 && base0[k];
+            a.u_in = from_u0 ? u0 : u_src;
+            a.u_in_ld = from_u0 ? u0_ld : u_src_ld;
+            cx<T>* dst = W.upad;
+            if (u0_needed_later && (const cx<T>*)dst == u0) dst = W.upad2;
+            a.u_out = last ? (cx<T>*)w_out : dst;
             a.u_out_ld = last ? p->m : p->ldw;
             a.beta = (T)beta[k];
             a.gdt = (T)gdt[k];
             a.mu = (T)mu[k];
+            a.fa = fa ? (T)fa[k] : (T)1;
+            a.mud = mud ? (T)mud[k] : (T)mu[k];
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
             r = last ? launch_cols<T, N, MODE_C>(p, a, batch, q) : launch_cols<T, N, MODE_CA>(p, a, batch, q);
             if (r) return r;
@@ -1326,7 +1341,10 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
         }
         if ((rc = run_step(st, false))) return rc;   // step 1: caller layout -> upad (also sets every kernel attribute)
         std::vector<double> coef;
-        for (int k = 0; k < nstages; ++k) { coef.push_back(beta[k]); coef.push_back(gdt[k]); coef.push_back(mu[k]); }
+        for (int k = 0; k < nstages; ++k) {
+            coef.push_back(beta[k]); coef.push_back(gdt[k]); coef.push_back(mu[k]);
+            coef.push_back(fa ? fa[k] : 1.0); coef.push_back(mud ? mud[k] : mu[k]); coef.push_back(base0 ? base0[k] : 0);
+        }
         if (!g->exec || g->batch != batch || g->nstages != nstages || g->ws != ws || g->coef != coef) {
             if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
             if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
@@ -1459,17 +1477,25 @@ static int check_ws(const tcfd_ns2d_plan* p, long batch, void* ws, size_t bytes,
     return 0;
 }
 
-extern "C" int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
-                              int nstages, const double* beta, const double* gdt, const double* mu, int steps,
-                              double inv_total_dt, void* ws, size_t ws_bytes, void* stream) {
-    if (!p || !w_in || !w_out || !beta || !gdt || !mu) return fail(TCFD_EINVAL, "step: null argument");
+extern "C" int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
+                                   int nstages, const double* fa, const double* beta, const double* gdt,
+                                   const double* mu_num, const double* mu_den, const int* base0, int steps,
+                                   double inv_total_dt, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !w_in || !w_out || !beta || !gdt || !mu_num) return fail(TCFD_EINVAL, "step: null argument");
     if (batch <= 0 || steps <= 0 || nstages <= 0) return fail(TCFD_EINVAL, "step: batch/steps/nstages must be > 0");
     if (dwdt && w_in == w_out) return fail(TCFD_EINVAL, "step: w_out may alias w_in only when dwdt is NULL");
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    TCFD_DISPATCH(p, (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu, steps, inv_total_dt, ws,
-                                         st)));
+    TCFD_DISPATCH(p, (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps,
+                                         inv_total_dt, ws, st)));
+}
+
+extern "C" int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
+                              int nstages, const double* beta, const double* gdt, const double* mu, int steps,
+                              double inv_total_dt, void* ws, size_t ws_bytes, void* stream) {
+    return tcfd_ns2d_step_imex(p, w_in, w_out, dwdt, batch, nstages, nullptr, beta, gdt, mu, nullptr, nullptr, steps,
+                               inv_total_dt, ws, ws_bytes, stream);
 }
 
 extern "C" int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* p, const void* w, void* out, long batch, void* ws,

@@ -114,17 +114,22 @@ class _HipPlan:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- operations
-    def step(self, w, beta, gdt, mu, steps: int, inv_total_dt: float, want_dwdt: bool = True):
+    def step(self, w, beta, gdt, mu, steps: int, inv_total_dt: float, want_dwdt: bool = True, fa=None, mu_den=None,
+             base0=None):
+        """``steps`` fused IMEX steps; stage k: h <- fa_k F(u) + beta_k h, u <- (base + gdt_k h + mu_k L base) / (1 - mu_den_k L)
+        (include/tcfd.h, tcfd_ns2d_step_imex).  fa / mu_den / base0 default to the RK4-CN form (1, mu, current state)."""
         w, batch = self._prep(w)
         out = torch.empty_like(w)
         dwdt = torch.empty_like(w) if want_dwdt else None
         ws = self.workspace(batch)
+        ints = (ctypes.c_int * len(beta))(*[int(v) for v in base0]) if base0 is not None else None
         with torch.cuda.device(self.device):
-            rc = self.lib.tcfd_ns2d_step(
+            rc = self.lib.tcfd_ns2d_step_imex(
                 self.handle, w.data_ptr(), out.data_ptr(), dwdt.data_ptr() if want_dwdt else None, batch,
-                len(beta), _lib.darray(beta), _lib.darray(gdt), _lib.darray(mu), steps, inv_total_dt,
+                len(beta), _lib.darray(fa) if fa is not None else None, _lib.darray(beta), _lib.darray(gdt),
+                _lib.darray(mu), _lib.darray(mu_den) if mu_den is not None else None, ints, steps, inv_total_dt,
                 ws.data_ptr(), ws.numel(), self._stream())
-        _lib.check(rc, "tcfd_ns2d_step")
+        _lib.check(rc, "tcfd_ns2d_step_imex")
         return out, dwdt
 
     def explicit_terms(self, w):
@@ -227,9 +232,9 @@ class ImplicitExplicitODE(nn.Module):
 
 class IMEXStepper(nn.Module):
     """IMEX steppers of order 1 / 1.5 (forward-backward Euler, IMEX-CN) and 2
-    (RK2 + CN).  The explicit term of a ``NavierStokes2DSpectral`` is evaluated
-    by the HIP kernels; the few element-wise combinations around it are device
-    tensor ops."""
+    (RK2 + CN).  On a ``NavierStokes2DSpectral`` the whole step runs in the fused
+    HIP kernels (``stage_schedule`` -> ``tcfd_ns2d_step_imex``); ``_imex`` /
+    ``_rk2_crank_nicolson`` are the generic forms for other equations."""
 
     def __init__(self, order: float = 2, alpha: float = 0.5, beta: Optional[float] = 0.5,
                  requires_grad: bool = False, *args, **kwargs):
@@ -264,7 +269,24 @@ class IMEXStepper(nn.Module):
         h = alpha * equation.explicit_terms(u) + (1 - alpha) * h
         return equation.implicit_solve(g + dt * h, beta * dt)
 
+    def stage_schedule(self, params: Params, dt: float) -> Dict[str, list]:
+        """The scheme as per-stage scalars of the fused HIP step (include/tcfd.h, tcfd_ns2d_step_imex), rounded the
+        way the reference's 0-dim tensor arithmetic rounds them (equations.py:174-228)."""
+        alpha = params["alpha"].detach().cpu()
+        if self.order in (1, 1.5):
+            return {"fa": [1.0], "beta": [0.0], "gdt": [float(dt)], "mu": [((1 - alpha) * dt).item()],
+                    "mu_den": [(alpha * dt).item()], "base0": [0]}
+        if self.order == 2:
+            bcn = (params["beta"].detach().cpu() * dt).item()
+            return {"fa": [1.0, alpha.item()], "beta": [0.0, (1 - alpha).item()], "gdt": [float(dt)] * 2,
+                    "mu": [bcn, bcn], "mu_den": [bcn, bcn], "base0": [0, 1]}
+        raise ValueError(f"no fused schedule for order {self.order}")
+
     def forward(self, u, dt, equation, params=None):
+        params = self.params if params is None else params
+        if isinstance(equation, NavierStokes2DSpectral) and u.is_cuda and type(self) is IMEXStepper:
+            out, _ = equation._fused_steps(u, dt, 1, params, want_dwdt=False, stepper=self)
+            return out
         return self.stepper(u, dt, equation, params)
 
 
@@ -407,15 +429,22 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
             self._plans = {key: plan}  # tables changed -> drop stale plans
         return plan
 
-    def _fused_steps(self, vort_hat, dt, steps, params=None, want_dwdt=True):
-        params = self.solver.params if params is None else params
+    def _fused_steps(self, vort_hat, dt, steps, params=None, want_dwdt=True, stepper=None):
+        stepper = self.solver if stepper is None else stepper
+        params = stepper.params if params is None else params
         # the coefficient tensors may live on the GPU: read them back once, not per step
-        ckey = (float(dt),) + tuple((params[k].data_ptr(), params[k]._version) for k in ("alphas", "betas", "gammas"))
+        ckey = (float(dt), id(stepper)) + tuple((k, v.data_ptr(), v._version) for k, v in params.items())
         if self._coef_cache is None or self._coef_cache[0] != ckey:
-            self._coef_cache = (ckey, RK4CrankNicolsonStepper.stage_scalars(params, dt))
-        beta, gdt, mu = self._coef_cache[1]
+            if isinstance(stepper, RK4CrankNicolsonStepper):
+                beta, gdt, mu = RK4CrankNicolsonStepper.stage_scalars(params, dt)
+                sched = {"beta": beta, "gdt": gdt, "mu": mu, "fa": None, "mu_den": None, "base0": None}
+            else:
+                sched = stepper.stage_schedule(params, dt)
+            self._coef_cache = (ckey, sched)
+        sc = self._coef_cache[1]
         plan = self._plan(vort_hat)
-        out, dwdt = plan.step(vort_hat, beta, gdt, mu, steps, 1 / (steps * dt), want_dwdt)
+        out, dwdt = plan.step(vort_hat, sc["beta"], sc["gdt"], sc["mu"], steps, 1 / (steps * dt), want_dwdt, fa=sc["fa"],
+                              mu_den=sc["mu_den"], base0=sc["base0"])
         return out.reshape(vort_hat.shape), (dwdt.reshape(vort_hat.shape) if want_dwdt else None)
 
     def residual(self, vhat: torch.Tensor, vt_hat: torch.Tensor):
@@ -445,8 +474,8 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
     def forward(self, vort_hat, dt, steps=1) -> Tuple[torch.Tensor, torch.Tensor]:
         """vort_hat: (B, n, m), (B, T, n, m) or (n, m) half spectrum; returns
         (vort_hat after ``steps`` steps, (new - old) / (steps * dt))."""
-        if isinstance(self.solver, RK4CrankNicolsonStepper):
-            return self._fused_steps(vort_hat, dt, steps)
+        if isinstance(self.solver, RK4CrankNicolsonStepper) or type(self.solver) is IMEXStepper:
+            return self._fused_steps(vort_hat, dt, steps)   # every stage fused in the HIP kernels
         if self.solver is None:
             raise TypeError("NavierStokes2DSpectral.forward needs a solver (e.g. RK4CrankNicolsonStepper())")
         vort_old = vort_hat
