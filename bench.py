@@ -32,9 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-KIND_NAMES = {0: "k_cols<MODE_A>", 1: "k_rows_advect", 2: "k_cols<MODE_CA>", 3: "k_cols<MODE_C>", 4: "k_dwdt", 5: "other"}
+KIND_NAMES = {0: "k_cols<MODE_A>", 1: "k_rows_advect", 2: "k_cols<MODE_CA>", 3: "k_cols<MODE_C>+dwdt", 4: "k_dwdt", 5: "other"}
 # algorithmic bytes per launch in units of S = B*n*m*sizeof(complex)  (SURVEY 8d pass model)
-KIND_ALGO_S = {0: 5.0, 1: 5.0, 2: 9.0, 3: 5.0, 4: 3.0}
+KIND_ALGO_S = {0: 5.0, 1: 5.0, 2: 9.0, 3: 7.0, 4: 3.0}   # MODE_C of a forward() call also reads w_old and writes dw/dt
 
 
 def parse():

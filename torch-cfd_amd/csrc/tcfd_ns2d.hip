@@ -97,6 +97,8 @@ struct ColArgs {
     cx<T>* planes;        // 4 output planes (MODE_A/CA)
     cx<T>* out;           // MODE_F / FWD / INV output ; MODE_RES residual
     cx<T>* psi;           // MODE_RES
+    const cx<T>* w0;      // MODE_C with dwdt: the call's input (caller layout), dwdt = (u_new - w0) * dwdt_scale
+    cx<T>* dwdt;          // or null
     const T* kx;          // [n]
     const T* ky;          // [m]
     const T* lin;         // [n*m]
@@ -117,6 +119,7 @@ struct ColArgs {
     const cx<T>* tw;      // [n]
     size_t plane_stride;  // elements between planes
     T beta, gdt, mu, scale;
+    T dwdt_scale;
     T fa, mud;   // h <- fa F + beta h ;  u <- (base + gdt h + mu L base) / (1 - mud L)   (RK4-CN: fa = 1, mud = mu)
     int m;        // row pitch (elements) of caller-layout arrays: u_in, u_out, wt, out, psi
     int ldw;      // row pitch of workspace arrays (adv, h, planes): m rounded up to a 128-byte multiple
@@ -359,6 +362,12 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     const T den = fast_rcp((T)1 - a.mud * L);
                     x[t] = cscale(rhs, den);
                     a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
+                    if constexpr (MODE == MODE_C) {
+                        if (a.dwdt) {   // (w_new - w_old) / (steps dt), equations.py:461-462, fused into the last stage
+                            const size_t gi = (size_t)b * N * a.m + jc + (size_t)i * a.m;
+                            a.dwdt[gi] = cscale(x[t] - a.w0[gi], a.dwdt_scale);
+                        }
+                    }
                 }
             }
             if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
@@ -1317,6 +1326,9 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.fa = fa ? (T)fa[k] : (T)1;
             a.mud = mud ? (T)mud[k] : (T)mu[k];
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
+            a.dwdt = last ? (cx<T>*)dwdt : nullptr;
+            a.w0 = (const cx<T>*)w_in;
+            a.dwdt_scale = (T)inv_total_dt;
             r = last ? launch_cols<T, N, MODE_C>(p, a, batch, q) : launch_cols<T, N, MODE_CA>(p, a, batch, q);
             if (r) return r;
             u_src = a.u_out;
@@ -1365,14 +1377,6 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     }
     for (int s = s0; s < steps; ++s)
         if ((rc = run_step(st, s == steps - 1))) return rc;
-    if (dwdt) {
-        const size_t count = (size_t)batch * N * p->m;
-        const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 2048);
-        ProfScope prof(p, 4, st);
-        hipLaunchKernelGGL(k_dwdt<T>, dim3(blocks), dim3(256), 0, st, (const cx<T>*)w_out, (const cx<T>*)w_in,
-                           (cx<T>*)dwdt, (T)inv_total_dt, count);
-        HIP_TRY(hipGetLastError());
-    }
     return 0;
 }
 
