@@ -552,3 +552,24 @@ def test_graph_replay_of_interior_steps_is_bit_identical(tag, dev, monkeypatch):
         outs[flag] = (a.clone(), da.clone(), b.clone(), c.clone())
     for x, y in zip(outs["0"], outs["1"]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("tag,B,steps", [("f64", 5, 3), ("f32", 2, 1), ("f64", 4, 2)])
+def test_half_batch_overlap_is_bit_identical(tag, B, steps, dev, monkeypatch):
+    """Large problems run the step on two half batches on two streams (row pass of one half beside the column pass of
+    the other, TCFD_OVERLAP); batch elements are independent, so the result is bit-identical to the single-stream
+    path, odd batch sizes and the dw/dt output included."""
+    n = 128
+    _, op = build_op(n, tag, "kolmogorov", dev)
+    from oracle import ns2d as O
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, REAL[tag])) for s in range(B)]).to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TCFD_OVERLAP", flag)
+        monkeypatch.setenv("TCFD_GRAPH", "0")
+        w, d = op(w0, 1e-3, steps=steps)
+        w2, d2 = op(w, 1e-3)
+        torch.cuda.synchronize()
+        res[flag] = (w.clone(), d.clone(), w2.clone(), d2.clone())
+    for x, y in zip(res["0"], res["1"]):
+        assert torch.equal(x, y)

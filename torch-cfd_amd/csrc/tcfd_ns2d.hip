@@ -826,6 +826,8 @@ struct ProfState {
 struct GraphState {
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t stream2 = nullptr;                 // batch-halves overlap (TCFD_OVERLAP): second lane
+    hipEvent_t ev_out2 = nullptr, ev_rows = nullptr;
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
     // key of the captured sequence
@@ -985,6 +987,9 @@ extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
         if (p->gs->graph) (void)hipGraphDestroy(p->gs->graph);
         if (p->gs->ev_in) (void)hipEventDestroy(p->gs->ev_in);
         if (p->gs->ev_out) (void)hipEventDestroy(p->gs->ev_out);
+        if (p->gs->ev_out2) (void)hipEventDestroy(p->gs->ev_out2);
+        if (p->gs->ev_rows) (void)hipEventDestroy(p->gs->ev_rows);
+        if (p->gs->stream2) (void)hipStreamDestroy(p->gs->stream2);
         if (p->gs->stream) (void)hipStreamDestroy(p->gs->stream);
         delete p->gs;
     }
@@ -1281,11 +1286,113 @@ static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
     return w;
 }
 
+// ------------------------------------------------------------------ two batch halves, software pipelined
+// The fused column pass saturates the HBM copy rate while the row pass is LDS / latency bound and leaves ~40 % of the
+// read bandwidth idle.  The batch elements are independent, so the step is run on two half batches on two streams,
+// half B one row pass behind half A: B's row pass then shares the chip with A's column pass and vice versa.
+// (Experiment, off by default -- see step_impl.)
+template <typename T, int N>
+static int step_overlap_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
+                             const double* beta, const double* gdt, const double* mu, const double* fa,
+                             const double* mud, const int* base0, int steps, double inv_total_dt, void* ws,
+                             hipStream_t st) {
+    tcfd_ns2d_plan* mp = const_cast<tcfd_ns2d_plan*>(p);
+    if (!mp->gs) mp->gs = new GraphState();
+    GraphState* g = mp->gs;
+    if (!g->stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming));
+    }
+    if (!g->stream2) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_out2, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_rows, hipEventDisableTiming));
+    }
+    Ws<T> W = carve<T>(p, ws, batch);
+    struct Half {
+        ColArgs<T> a;
+        const cx<T>* u_src; int u_src_ld;
+        const cx<T>* w_in; cx<T>* w_out; cx<T>* dwdt;
+        cx<T>* planes; cx<T>* adv; cx<T>* upad; cx<T>* upad2;
+        long batch; hipStream_t q;
+    } H[2];
+    const long bA = batch / 2;
+    for (int i = 0; i < 2; ++i) {
+        const long b0 = i ? bA : 0;
+        const size_t oc = (size_t)b0 * N * p->m, ow = (size_t)b0 * N * p->ldw;
+        Half& h = H[i];
+        h.batch = i ? batch - bA : bA;
+        h.q = i ? g->stream2 : g->stream;
+        h.w_in = (const cx<T>*)w_in + oc;
+        h.w_out = (cx<T>*)w_out + oc;
+        h.dwdt = dwdt ? (cx<T>*)dwdt + oc : nullptr;
+        h.planes = W.planes + ow; h.adv = W.adv + ow; h.upad = W.upad + ow; h.upad2 = W.upad2 + ow;
+        h.a = ColArgs<T>{};
+        h.a.planes = h.planes; h.a.plane_stride = W.plane_stride; h.a.h = W.h + ow; h.a.in = h.adv;
+        h.a.u_in = h.w_in; h.a.u_in_ld = p->m;
+        h.u_src = h.w_in; h.u_src_ld = p->m;
+    }
+    HIP_TRY(hipEventRecord(g->ev_in, st));
+    int rc;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamWaitEvent(H[i].q, g->ev_in, 0));
+        if ((rc = launch_cols<T, N, MODE_A>(p, H[i].a, H[i].batch, H[i].q))) return rc;
+    }
+    auto cols = [&](Half& h, int k, bool last, const cx<T>* u0, int u0_ld) -> int {
+        bool u0_needed_later = false;
+        for (int k2 = k + 1; k2 < nstages; ++k2) u0_needed_later |= (base0 && base0[k2]);
+        const bool from_u0 = base0 && base0[k];
+        h.a.u_in = from_u0 ? u0 : h.u_src;
+        h.a.u_in_ld = from_u0 ? u0_ld : h.u_src_ld;
+        cx<T>* dst = h.upad;
+        if (u0_needed_later && (const cx<T>*)dst == u0) dst = h.upad2;
+        h.a.u_out = last ? h.w_out : dst;
+        h.a.u_out_ld = last ? p->m : p->ldw;
+        h.a.beta = (T)beta[k]; h.a.gdt = (T)gdt[k]; h.a.mu = (T)mu[k];
+        h.a.fa = fa ? (T)fa[k] : (T)1;
+        h.a.mud = mud ? (T)mud[k] : (T)mu[k];
+        h.a.load_h = (k != 0);
+        h.a.dwdt = last ? h.dwdt : nullptr;
+        h.a.w0 = h.w_in;
+        h.a.dwdt_scale = (T)inv_total_dt;
+        int r = last ? launch_cols<T, N, MODE_C>(p, h.a, h.batch, h.q) : launch_cols<T, N, MODE_CA>(p, h.a, h.batch, h.q);
+        h.u_src = h.a.u_out;
+        h.u_src_ld = h.a.u_out_ld;
+        return r;
+    };
+    for (int s = 0; s < steps; ++s) {
+        const cx<T>* u0[2] = {H[0].u_src, H[1].u_src};
+        const int u0_ld[2] = {H[0].u_src_ld, H[1].u_src_ld};
+        for (int k = 0; k < nstages; ++k) {
+            const bool last = (s == steps - 1) && (k == nstages - 1);
+            if ((rc = launch_rows_advect<T, N>(p, H[0].planes, W.plane_stride, H[0].adv, H[0].batch, H[0].q))) return rc;
+            HIP_TRY(hipEventRecord(g->ev_rows, H[0].q));
+            HIP_TRY(hipStreamWaitEvent(H[1].q, g->ev_rows, 0));   // B stays one row pass behind A
+            if ((rc = launch_rows_advect<T, N>(p, H[1].planes, W.plane_stride, H[1].adv, H[1].batch, H[1].q))) return rc;
+            if ((rc = cols(H[0], k, last, u0[0], u0_ld[0]))) return rc;
+            if ((rc = cols(H[1], k, last, u0[1], u0_ld[1]))) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(g->ev_out, H[0].q));
+    HIP_TRY(hipEventRecord(g->ev_out2, H[1].q));
+    HIP_TRY(hipStreamWaitEvent(st, g->ev_out, 0));
+    HIP_TRY(hipStreamWaitEvent(st, g->ev_out2, 0));
+    return 0;
+}
+
 // ------------------------------------------------------------------ step driver
 template <typename T, int N>
 static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
                      const double* beta, const double* gdt, const double* mu, const double* fa, const double* mud,
                      const int* base0, int steps, double inv_total_dt, void* ws, hipStream_t st) {
+    {
+        // opt-in (TCFD_OVERLAP=1): measured +2.6 % at 1024^2 x 64 fp64 -- both kernels fill the VGPR file, so the CUs
+        // time-slice the two halves instead of co-running them; not worth two streams by default
+        if (batch >= 2 && env_int("TCFD_OVERLAP", 0) == 1)
+            return step_overlap_impl<T, N>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu, fa, mud, base0, steps,
+                                           inv_total_dt, ws, st);
+    }
     Ws<T> W = carve<T>(p, ws, batch);
     int rc;
     ColArgs<T> a{};
