@@ -1,6 +1,7 @@
 """Build profiles/traffic.json (HBM bytes per launch of the step kernels) from a tests/prof.sh output directory.
 HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 on gfx950 tallies the 128-byte requests of 16-byte/lane
-streams as 64 B (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact (calibrated here on k_dwdt: 3*S)."""
+streams as 64 B (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact (calibrated on the pure-streaming k_dwdt of
+the earlier builds: 3*S measured to 0.002 %, profiles/r01_final_*)."""
 import json
 import re
 import sys
@@ -16,7 +17,7 @@ for b in blocks:
     vals = {l.split()[0]: float(l.split()[1]) for l in lines[1:] if len(l.split()) >= 2}
     m = re.match(r"k_cols<\w+, (\d+), \d+, \d+, (\d)", name)
     if m and int(m.group(1)) == n:
-        key, alg = {0: ("k_cols<MODE_A>", 5), 1: ("k_cols<MODE_CA>", 9), 2: ("k_cols<MODE_C>", 5)}.get(int(m.group(2)), (None, 0))
+        key, alg = {0: ("k_cols<MODE_A>", 5), 1: ("k_cols<MODE_CA>", 9), 2: ("k_cols<MODE_C>+dwdt", 7)}.get(int(m.group(2)), (None, 0))
     elif name.startswith("k_rows_advect") and f", {n}," in name:
         key, alg = "k_rows_advect", 5
     elif name.startswith("k_dwdt"):
