@@ -166,8 +166,10 @@ int tcfd_fno_contract(const void* vin, const void* const* weights, const void* c
 int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w1, const void* b1, const void* w2t,
                        const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
                        int T, int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride,
-                       void* stream);
-/* w2_bstride / b2_bstride: element offsets of w2t / b2 per batch element (0 = shared weights); a per-sample
+                       const void* pe, void* stream);
+/* pe (ci, P) or NULL: when given, x is ONE channel (batch, 1, P) and the block input is x + pe[c] -- the lifting
+ * operator's "input + positional encoding" (fno/sfno.py:109-113) without materialising the (batch, ci, P) tensor.
+ * w2_bstride / b2_bstride: element offsets of w2t / b2 per batch element (0 = shared weights); a per-sample
  * affine map such as a folded LayerNormnd (fno/base.py:61-83) then rides in the single-layer form.
  * tcfd_row_moments: sum and sum of squares (double, stats[rows][2]) of every row of a (rows, L) fp32 matrix --
  * the statistics of LayerNormnd / GroupNorm(1 group) with the rows cut across many workgroups. */

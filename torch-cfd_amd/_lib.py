@@ -102,7 +102,7 @@ SIGNATURES = {
     "tcfd_fno_contract": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                _i, _i, _vp]),
     "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
-                                _l, _vp]),
+                                _l, _vp, _vp]),
     "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_fno_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),

@@ -842,6 +842,8 @@ extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, co
 // scalar unit (they are lane uniform): the (b, C, P) activations are read once and written once, where the
 // reference-style op stream makes ~6 passes and materialises the 4x wider hidden tensor.
 struct PwArgs {
+    const float* pe;    // (CI, P) or null.  Not null: x is ONE channel (b, 1, P) and the block input is x + pe[c]
+                        // (the lifting operator's v + positional encoding, fno/sfno.py:109-113, never materialised)
     const float* x;     // (b, CI, P)
     const float* s;     // skip input or null: mode 1 (b, CI, P); mode 2 (b, CO, P / T * sT), last time slice is added
     float* out;         // (b, CO, P)
@@ -884,9 +886,15 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     const int b = blockIdx.y;
     if (p >= a.P) return;
     vf x[CI], o[CO];
-    const float* xb = a.x + (size_t)b * CI * a.P + p;
+    if (a.pe) {
+        const vf v1 = *reinterpret_cast<const vf*>(a.x + (size_t)b * a.P + p);
 #pragma unroll
-    for (int i = 0; i < CI; ++i) x[i] = *reinterpret_cast<const vf*>(xb + (size_t)i * a.P);
+        for (int i = 0; i < CI; ++i) x[i] = v1 + *reinterpret_cast<const vf*>(a.pe + (size_t)i * a.P + p);
+    } else {
+        const float* xb = a.x + (size_t)b * CI * a.P + p;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) x[i] = *reinterpret_cast<const vf*>(xb + (size_t)i * a.P);
+    }
     const float* w2t_b = a.w2t + (size_t)b * a.w2_bstride;
     const float* b2_b = a.b2 ? a.b2 + (size_t)b * a.b2_bstride : nullptr;
 #pragma unroll
@@ -942,7 +950,7 @@ static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
     // broadcast skip, 8-byte aligned base pointers
     // (wide layers keep one point per lane: two would need > 128 VGPRs and lose more in occupancy than they gain)
     const bool pairs = (CI <= 16) && (a.P % 2 == 0) && (a.skip_mode != 2 || a.T % 2 == 0) &&
-                       (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)(a.skip_mode == 1 ? a.s : nullptr)) % 8 == 0);
+                       (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.pe | (uintptr_t)(a.skip_mode == 1 ? a.s : nullptr)) % 8 == 0);
     if (pairs) {
         dim3 grid((unsigned)((a.P / 2 + 255) / 256), (unsigned)batch);
         hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 2>), grid, dim3(256), 0, st, a);
@@ -959,14 +967,14 @@ static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
 extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w1, const void* b1,
                                   const void* w2t, const void* b2, const void* wst, const void* bs, int batch, int ci,
                                   int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
-                                  long w2_bstride, long b2_bstride, void* stream) {
+                                  long w2_bstride, long b2_bstride, const void* pe, void* stream) {
     if (!x || !out || !w2t || batch <= 0 || P <= 0) return FAIL(TCFD_EINVAL, "fno_pointwise: bad argument");
     if (skip_mode && !skip) return FAIL(TCFD_EINVAL, "fno_pointwise: skip input missing");
     if (skip_mode == 2 && (T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise: bad T");
     PwArgs a;
     a.x = (const float*)x; a.s = (const float*)skip; a.out = (float*)out;
     a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
-    a.wst = (const float*)wst; a.bs = (const float*)bs;
+    a.wst = (const float*)wst; a.bs = (const float*)bs; a.pe = (const float*)pe;
     a.P = P; a.T = T; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
     a.w2_bstride = w2_bstride; a.b2_bstride = b2_bstride;
     hipStream_t st = (hipStream_t)stream;

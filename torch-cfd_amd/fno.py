@@ -543,8 +543,70 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     lib = _lib.load()
     with torch.cuda.device(x.device):
         rc = lib.tcfd_fno_pointwise(x.data_ptr(), ptr(s_t), out.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst),
-                                    ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs,
+                                    ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs, None,
                                     ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+        return None
+    _lib.check(rc, "tcfd_fno_pointwise")
+    return out
+
+
+_LIFT_TABLE_CONSTS: Dict[tuple, tuple] = {}
+
+
+def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj) -> Optional[torch.Tensor]:
+    """``proj(norm(v1 + q))`` of the lifting operator (fno/sfno.py:252-254) without ever forming ``v1 + q``.
+
+    v1 (b, 1, X, Y, T) is the single input channel, q (1, C, X, Y, T) the positional-encoding table that the reference
+    adds to it by broadcasting.  The LayerNorm statistics of the (C, X, Y, T) block of a sample follow from three
+    reductions over the ONE-channel input and constants of the table,
+        sum = C sum(v) + sum(q),   sum of squares = C sum(v^2) + 2 sum_p v_p (sum_c q_cp) + sum(q^2),
+    and the projection kernel rebuilds v + q[c] in registers (``pe`` mode of ``tcfd_fno_pointwise``): 84 MB + a 26 MB
+    L2-resident table are read instead of writing and re-reading an 839 MB tensor twice (config 5).  Forward only;
+    returns None when the combination is not covered."""
+    if (not v1.is_cuda or v1.dtype != torch.float32 or v1.shape[1] != 1 or not _is_pointwise(proj) or norm.num_groups != 1
+            or torch.is_grad_enabled() and (v1.requires_grad or any(p.requires_grad for m in (norm, proj) for p in m.parameters()))):
+        return None
+    q = q.reshape(-1, *q.shape[-3:]) if q.dim() == 5 else q
+    C = q.shape[0]
+    if q.shape[1:] != v1.shape[2:] or norm.num_channels != C or proj.in_channels != C:
+        return None
+    b, co = v1.shape[0], proj.out_channels
+    P = v1[0, 0].numel()
+    dev = v1.device
+    qf = q.detach().to(device=dev, dtype=torch.float32).reshape(C, P).contiguous()
+    vf = v1.detach().reshape(b, P).contiguous()
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    stats = torch.empty(b, 2, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.tcfd_row_moments(vf.data_ptr(), stats.data_ptr(), b, P, stream), "tcfd_row_moments")
+    key = (qf.data_ptr(), qf._version, C, P, str(dev))
+    consts = _LIFT_TABLE_CONSTS.get(key)
+    if consts is None:   # constants of the table: channel sum per point, total sum, total sum of squares
+        qd = qf.double()
+        consts = (qd.sum(dim=0).float().contiguous(), qd.sum(), (qd * qd).sum())
+        _LIFT_TABLE_CONSTS.clear()
+        _LIFT_TABLE_CONSTS[key] = consts
+    qs, sq, sq2 = consts
+    cross = torch.mv(vf.double() if P < 4096 else vf, qs.double() if P < 4096 else qs).double()
+    L = C * P
+    s1 = C * stats[:, 0] + sq
+    s2 = C * stats[:, 1] + 2 * cross + sq2
+    mu = s1 / L
+    rstd = torch.rsqrt((s2 / L - mu * mu).clamp_min(0) + norm.eps)
+    gamma = norm.weight.detach().double() if norm.weight is not None else torch.ones(C, dtype=torch.float64, device=dev)
+    beta = norm.bias.detach().double() if norm.bias is not None else torch.zeros(C, dtype=torch.float64, device=dev)
+    W = proj.weight.detach().reshape(co, C).double()
+    w2t = (W.t()[None] * (gamma[None, :, None] * rstd[:, None, None])).float().contiguous()      # (b, C, co)
+    fb = (beta[None, :] - gamma[None, :] * (mu * rstd)[:, None]) @ W.t()
+    if proj.bias is not None:
+        fb = fb + proj.bias.detach().double()[None]
+    fb = fb.float().contiguous()
+    out = torch.empty(b, co, *v1.shape[2:], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tcfd_fno_pointwise(vf.data_ptr(), None, out.data_ptr(), None, None, w2t.data_ptr(), fb.data_ptr(), None, None,
+                                    b, C, C, co, P, v1.shape[-1], 0, 0, 0, 0, C * co, co, qf.data_ptr(), stream)
     if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
         return None
     _lib.check(rc, "tcfd_fno_pointwise")
@@ -696,12 +758,16 @@ class SpaceTimePositionalEncoding(nn.Module):
                 pe.append(col.reshape(1, 1, nt).repeat(nx, ny, 1))
         self.pe = torch.stack(pe).unsqueeze(0)
 
-    def forward(self, v):
+    def encoding(self, v):
+        """The (1, C, X, Y, T) table that ``forward`` adds to v."""
         if self.pe is None or self.pe.shape[-3:] != v.shape[-3:]:
             self._build(*v.shape[-3:])
         if self.pe.device != v.device or self.pe.dtype != v.dtype:
             self.pe = self.pe.to(device=v.device, dtype=v.dtype)  # keep the table resident on the device
-        return v + self.proj(self.pe)
+        return self.proj(self.pe)
+
+    def forward(self, v):
+        return v + self.encoding(v)
 
 
 class HelmholtzProjection(nn.Module):
@@ -786,10 +852,13 @@ class LiftingOperator(nn.Module):
 
     def forward(self, v):
         assert self.latent_steps <= v.size(-1)
-        vp = self.pe(v)
-        v = hip_pointwise(vp, None, None, self.proj, norm=self.norm)  # LayerNormnd folded into the projection
+        vin = v
+        v = hip_lift_project(vin, self.pe.encoding(vin), self.norm, self.proj) if vin.shape[1] == 1 else None
         if v is None:
-            v = self.proj(self.norm(vp))
+            vp = self.pe(vin)
+            v = hip_pointwise(vp, None, None, self.proj, norm=self.norm)  # LayerNormnd folded into the projection
+            if v is None:
+                v = self.proj(self.norm(vp))
         x1 = self.sconv(v)
         if isinstance(self.mlp, PointwiseFFN):
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=v,
