@@ -387,3 +387,28 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
     for k, v in ref.items():
         if v is not None:
             assert got[k] is not None and rel_l2(got[k], v) < 2e-5, k
+
+
+@pytest.mark.parametrize("random_feats", [False, True])
+def test_lifting_projection_without_materialising_the_encoded_input(random_feats, dev):
+    """hip_lift_project: proj(LayerNorm(v + positional encoding)) from the one-channel input, analytic statistics and
+    the pe mode of the projection kernel, against the torch modules on the materialised tensor."""
+    import torch.nn as nn
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(3)
+    C = 10
+    pe = fno.SpaceTimePositionalEncoding(2, 2, 2, num_channels=C, input_shape=(16, 8, 10),
+                                         spatial_random_feats=random_feats).to(dev)
+    norm = fno.LayerNormnd(C).to(dev)
+    proj = nn.Conv3d(C, C, 1).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C) + 0.5)
+        norm.bias.copy_(torch.randn(C) * 0.1)
+        v = torch.randn(3, 1, 16, 8, 10, device=dev) * 2 + 0.7
+        ref = proj(norm(pe(v)))
+        out = fno.hip_lift_project(v, pe.encoding(v), norm, proj, consts=pe.table_constants(v))
+        assert (pe.table_constants(v) is None) == random_feats
+        assert out is not None and rel_l2(out, ref) < 2e-6
+        out2 = fno.hip_lift_project(v * 3 - 1, pe.encoding(v), norm, proj, consts=pe.table_constants(v))
+        assert rel_l2(out2, proj(norm(pe(v * 3 - 1)))) < 2e-6

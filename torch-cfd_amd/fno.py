@@ -551,10 +551,12 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     return out
 
 
-_LIFT_TABLE_CONSTS: Dict[tuple, tuple] = {}
+def _lift_table_constants(qf: torch.Tensor):
+    qd = qf.reshape(qf.shape[0] if qf.dim() == 2 else qf.shape[-4], -1).double()
+    return qd.sum(dim=0).float().contiguous(), qd.sum(), (qd * qd).sum()
 
 
-def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj) -> Optional[torch.Tensor]:
+def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj, consts=None) -> Optional[torch.Tensor]:
     """``proj(norm(v1 + q))`` of the lifting operator (fno/sfno.py:252-254) without ever forming ``v1 + q``.
 
     v1 (b, 1, X, Y, T) is the single input channel, q (1, C, X, Y, T) the positional-encoding table that the reference
@@ -562,7 +564,8 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
     reductions over the ONE-channel input and constants of the table,
         sum = C sum(v) + sum(q),   sum of squares = C sum(v^2) + 2 sum_p v_p (sum_c q_cp) + sum(q^2),
     and the projection kernel rebuilds v + q[c] in registers (``pe`` mode of ``tcfd_fno_pointwise``): 84 MB + a 26 MB
-    L2-resident table are read instead of writing and re-reading an 839 MB tensor twice (config 5).  Forward only;
+    L2-resident table are read instead of writing and re-reading an 839 MB tensor twice (config 5).  ``consts`` are the
+    table's constants when the caller has them cached (``SpaceTimePositionalEncoding.table_constants``).  Forward only;
     returns None when the combination is not covered."""
     if (not v1.is_cuda or v1.dtype != torch.float32 or v1.shape[1] != 1 or not _is_pointwise(proj) or norm.num_groups != 1
             or torch.is_grad_enabled() and (v1.requires_grad or any(p.requires_grad for m in (norm, proj) for p in m.parameters()))):
@@ -581,13 +584,8 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
     stats = torch.empty(b, 2, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.tcfd_row_moments(vf.data_ptr(), stats.data_ptr(), b, P, stream), "tcfd_row_moments")
-    key = (qf.data_ptr(), qf._version, C, P, str(dev))
-    consts = _LIFT_TABLE_CONSTS.get(key)
     if consts is None:   # constants of the table: channel sum per point, total sum, total sum of squares
-        qd = qf.double()
-        consts = (qd.sum(dim=0).float().contiguous(), qd.sum(), (qd * qd).sum())
-        _LIFT_TABLE_CONSTS.clear()
-        _LIFT_TABLE_CONSTS[key] = consts
+        consts = _lift_table_constants(qf)
     qs, sq, sq2 = consts
     cross = torch.mv(vf.double() if P < 4096 else vf, qs.double() if P < 4096 else qs).double()
     L = C * P
@@ -762,9 +760,21 @@ class SpaceTimePositionalEncoding(nn.Module):
         """The (1, C, X, Y, T) table that ``forward`` adds to v."""
         if self.pe is None or self.pe.shape[-3:] != v.shape[-3:]:
             self._build(*v.shape[-3:])
+            self._consts = None
         if self.pe.device != v.device or self.pe.dtype != v.dtype:
             self.pe = self.pe.to(device=v.device, dtype=v.dtype)  # keep the table resident on the device
+            self._consts = None
         return self.proj(self.pe)
+
+    def table_constants(self, v):
+        """(channel sum per point, total sum, total sum of squares) of the table, cached with it; None when the table
+        goes through a learned projection (then it changes with the weights and is reduced per call)."""
+        if not isinstance(self.proj, nn.Identity):
+            return None
+        self.encoding(v)
+        if getattr(self, "_consts", None) is None:
+            self._consts = _lift_table_constants(self.pe.to(torch.float32))
+        return self._consts
 
     def forward(self, v):
         return v + self.encoding(v)
@@ -853,7 +863,8 @@ class LiftingOperator(nn.Module):
     def forward(self, v):
         assert self.latent_steps <= v.size(-1)
         vin = v
-        v = hip_lift_project(vin, self.pe.encoding(vin), self.norm, self.proj) if vin.shape[1] == 1 else None
+        v = hip_lift_project(vin, self.pe.encoding(vin), self.norm, self.proj,
+                             consts=self.pe.table_constants(vin)) if vin.shape[1] == 1 else None
         if v is None:
             vp = self.pe(vin)
             v = hip_pointwise(vp, None, None, self.proj, norm=self.norm)  # LayerNormnd folded into the projection
