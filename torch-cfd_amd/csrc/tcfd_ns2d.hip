@@ -1116,13 +1116,14 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
 #define TCFD_SPLIT_A_MINW4 1
 #endif
 // Split plans: the column transform is cut radix-2 across the row pass so that a column tile is half as big
-// and two workgroups share a CU.  Default: where the full tile would fill the CU's LDS (n = 1024 in fp64).
+// and two workgroups share a CU.  Default: n = 1024 (fp64: the full tile would fill the CU's LDS; fp32: the half
+// tiles are 16 columns = full 128-byte lines instead of 8).
 template <typename T, int N>
 static bool use_split() {
     static const int force = env_int("TCFD_SPLIT", -1);
     if (N < 16) return false;
     if (force >= 0) return force != 0;
-    return N == 1024 && sizeof(T) == 8;
+    return N == 1024;   // fp64: 7.99 vs 8.6 ms/step; fp32 (16-column, 128-byte tiles of 512 rows): 5.61 vs 6.05 ms/step
 }
 
 template <typename T, int N, int MODE>
