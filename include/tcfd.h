@@ -197,7 +197,10 @@ int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* k
 int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, void* dx, void* dskip, const void* w1,
                            const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
                            void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
-                           int skip_T, int act1, int act2, int skip_mode, void* stream);
+                           int skip_T, int act1, int act2, int skip_mode, int per_sample, void* stream);
+/* per_sample = 1: the rows written (dims[5], a multiple of batch) are per-SAMPLE partial sums, row r belongs to batch
+ * element r % batch -- what the backward of a LayerNorm folded into the convolution needs (its statistics differ per
+ * sample); dx may then be NULL (only the sums are wanted). */
 
 /* STREAM-style device probe (measurement aid, SURVEY 8d "verify with a device STREAM-style probe"): `iters`
  * launches of a 16-byte-per-lane grid-stride kernel over `bytes` (a multiple of 16) of caller-owned device memory,

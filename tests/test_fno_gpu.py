@@ -412,3 +412,33 @@ def test_lifting_projection_without_materialising_the_encoded_input(random_feats
         assert out is not None and rel_l2(out, ref) < 2e-6
         out2 = fno.hip_lift_project(v * 3 - 1, pe.encoding(v), norm, proj, consts=pe.table_constants(v))
         assert rel_l2(out2, proj(norm(pe(v * 3 - 1)))) < 2e-6
+
+
+@pytest.mark.parametrize("C,co", [(10, 10), (4, 4), (8, 8)])
+def test_layernorm_projection_backward_on_hip(C, co, dev):
+    """Backward of proj(LayerNormnd(x)) in two HIP passes (per-sample MFMA sums, per-sample convolution of dy + a
+    rank-one correction) against float64 autograd of GroupNorm + Conv3d: input, weight, bias, gamma and beta gradients."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(C)
+    norm = fno.LayerNormnd(C).to(dev)
+    proj = nn.Conv3d(C, co, 1).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C) + 0.5)
+        norm.bias.copy_(torch.randn(C) * 0.2)
+    x = (torch.randn(3, C, 9, 8, 10, device=dev) * 1.7 + 0.4).requires_grad_(True)
+    out = fno.hip_pointwise(x, None, None, proj, norm=norm)
+    assert out is not None and out.grad_fn is not None
+    t = torch.randn_like(out)
+    (out * t).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    gd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    wd, pd = proj.weight.detach().double().requires_grad_(True), proj.bias.detach().double().requires_grad_(True)
+    ref = F.conv3d(F.group_norm(xd, 1, gd, bd, norm.eps), wd, pd)
+    assert rel_l2(out, ref) < 1e-5
+    (ref * t.double()).sum().backward()
+    for name, got, want in (("x", x.grad, xd.grad), ("gamma", norm.weight.grad, gd.grad), ("beta", norm.bias.grad, bd.grad),
+                            ("W", proj.weight.grad, wd.grad), ("b", proj.bias.grad, pd.grad)):
+        assert got is not None and rel_l2(got, want) < 3e-5, name

@@ -1021,6 +1021,8 @@ struct PwBwdArgs {
     long chunks_per_batch, total_chunks;
     int act1, act2, skip_mode;
     int T, sT;           // skip_mode 2: s is (b, CO, P / T * sT), its last time slice is added; ds receives dL/dz2 (b, CO, P)
+    int per_sample;      // 1: wave w only visits batch element w % batch, so its partial sums belong to ONE sample
+    int batch;
 };
 
 __device__ __forceinline__ float pw_dact(float z, int act) {   // d act / dz
@@ -1096,8 +1098,13 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
     for (auto& v : accA) v = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (auto& v : accB) v = f4{0.f, 0.f, 0.f, 0.f};
-    const long wstride = (long)gridDim.x * Gm::WAVES;
-    for (long chunk = (long)blockIdx.x * Gm::WAVES + wave; chunk < a.total_chunks; chunk += wstride) {
+    const long gw = (long)blockIdx.x * Gm::WAVES + wave, nw = (long)gridDim.x * Gm::WAVES;
+    // default: waves stride over all (sample, 64-point chunk) pairs.  per_sample: wave gw owns sample gw % batch and
+    // strides over that sample's chunks with the nw / batch waves that share it (nw is a multiple of batch).
+    const long c_first = a.per_sample ? (gw % a.batch) * a.chunks_per_batch + gw / a.batch : gw;
+    const long c_stride = a.per_sample ? nw / a.batch : nw;
+    const long c_end = a.per_sample ? (gw % a.batch + 1) * a.chunks_per_batch : a.total_chunks;
+    for (long chunk = c_first; chunk < c_end; chunk += c_stride) {
         const long b = chunk / a.chunks_per_batch;
         const long p = (chunk - b * a.chunks_per_batch) * 64 + lane;
         const bool live = p < a.P;
@@ -1229,10 +1236,12 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
                 for (int c = 0; c < CO; ++c) dx[m] = fmaf(w2[c], g2[c], dx[m]);
             }
         }
-        if (live) {
+        if (live && a.dx) {
             float* dxb = a.dx + (size_t)b * CI * a.P + p;
 #pragma unroll
             for (int i = 0; i < CI; ++i) dxb[(size_t)i * a.P] = dx[i];
+        }
+        if (live) {
             if (a.skip_mode == 1 && a.ds) {
                 float* dsb = a.ds + (size_t)b * CI * a.P + p;
 #pragma unroll
@@ -1289,6 +1298,14 @@ static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipSt
     long resident = (long)std::max(per_cu, 1) * cus;
     int blocks = (int)std::min<long>({(a.total_chunks + Gm::WAVES - 1) / Gm::WAVES, (long)(max_waves / Gm::WAVES), resident});
     if (blocks < 1) blocks = 1;
+    a.batch = batch;
+    if (a.per_sample) {   // the wave count must be a multiple of the batch size
+        long waves = (long)blocks * Gm::WAVES / batch * batch;
+        if (waves < batch) waves = batch;
+        while (waves % Gm::WAVES) waves += batch;
+        if (waves > max_waves) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: %ld waves needed for per-sample partials, %d rows given", waves, max_waves);
+        blocks = (int)(waves / Gm::WAVES);
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * Gm::WAVES), lds, st, a);
     HIP_TRY(hipGetLastError());
     dims[5] = blocks * Gm::WAVES;
@@ -1304,9 +1321,9 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
                                       const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
                                       const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
                                       int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
-                                      void* stream) {
+                                      int per_sample, void* stream) {
     if (!dims) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: null dims");
-    if (x && (!dout || !dx || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
+    if (x && (!dout || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
         return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad argument");
     if (skip_mode < 0 || skip_mode > 2) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode %d not supported", skip_mode);
     if (x && skip_mode == 1 && (!skip || !wst)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip input missing");
@@ -1316,6 +1333,7 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
     a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
     a.wst = (const float*)wst; a.bs = (const float*)bs; a.partials = (float*)partials;
     a.P = P; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode; a.T = T; a.sT = skip_T;
+    a.per_sample = per_sample; a.batch = batch;
     a.chunks_per_batch = a.total_chunks = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool l1 = cm != ci || w1 != nullptr;

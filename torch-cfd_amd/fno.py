@@ -356,8 +356,10 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     block with torch einsums."""
     has_l1, act1, act2, mode, eps = spec
     c1, c2 = _act_code(act1), _act_code(act2)
-    if eps is not None or c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
+    if c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
         return None
+    if eps is not None:
+        return _hip_norm_proj_backward(eps, dout, x, w2, b2, gamma, beta) if (not has_l1 and mode == 0 and c2 == 0) else None
     b, ci = x.shape[:2]
     co = w2.shape[0]
     cm = w1.shape[0] if has_l1 else ci
@@ -368,7 +370,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     T = x.shape[-1]
     sT = skip.shape[-1] if mode == 2 else 0
     rc = lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, one, None, None, None, None, None, None, 0, dims, b, ci, cm,
-                                    co, P, T, sT, c1, c2, mode, None)
+                                    co, P, T, sT, c1, c2, mode, 0, None)
     if rc != 0:
         return None
     COP, CB, CM1, CIP, per_row, _ = list(dims)
@@ -389,7 +391,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     ptr = lambda t: t.data_ptr() if t is not None else None
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise_bwd(ptr(xs), ptr(sk), ptr(dz), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t), ptr(b2v),
-                                        ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1, c2, mode,
+                                        ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1, c2, mode, 0,
                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd")
     tot = partials[: dims[5]].sum(dim=0, dtype=torch.float64).float()
@@ -410,6 +412,73 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     else:
         g_skip = ds.view_as(skip) if ds is not None else None
     return (dx.view_as(x), g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
+
+
+def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta):
+    """Backward of ``proj(LayerNorm(x))`` (one group over (C, X, Y, T), per-channel affine) in two passes over the data.
+
+    Pass 1 (``tcfd_fno_pointwise_bwd`` with per-sample partial sums, no dx): M_b[o, c] = sum_p dy[o] x[c] and
+    M_b[o, C] = sum_p dy[o] on MFMA.  Everything the LayerNorm backward needs follows from these (b, Co, C+1) numbers and
+    the per-sample statistics: with x^ = (x - mu) r and g = W^T dy,
+        sum_p dy[o] x^[c] = r (M[o,c] - mu M[o,C]),   dW = sum_b gamma (.) + beta M[.,C],   dbias = sum_b M[.,C],
+        dgamma_c = sum_b sum_o W[o,c] sum_p dy[o] x^[c],   dbeta_c = sum_b sum_o W[o,c] M[o,C],
+        A_b = sum_{c,p} gamma_c g,   B_b = sum_{c,p} gamma_c g x^.
+    Pass 2: dx = r (gamma g - A/L - x^ B/L) = (per-sample 1x1x1 convolution of dy) + alpha_b + kappa_b x  -- the
+    convolution on ``tcfd_fno_pointwise`` with per-sample weights, the rank-one correction as one fused multiply-add."""
+    b, C = x.shape[:2]
+    co = w.shape[0]
+    P = x[0, 0].numel()
+    L = C * P
+    dev = x.device
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    dims = (ctypes.c_int * 6)()
+    if lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, None, None, None, None, None, None, None, 0, dims, b, C, C, co,
+                                  P, 0, 0, 0, 0, 0, 1, None) != 0:
+        return None
+    COP, CB, _, _, per_row, _ = list(dims)
+    xs, dz = x.detach().contiguous(), dout.detach().contiguous()
+    stats = torch.empty(b, 2, dtype=torch.float64, device=dev)
+    W = w.detach().reshape(co, C)
+    w2t = W.t().contiguous()
+    max_waves = 2048 + b
+    partials = torch.empty(max_waves, per_row, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.tcfd_row_moments(xs.data_ptr(), stats.data_ptr(), b, L, stream), "tcfd_row_moments")
+        rc = lib.tcfd_fno_pointwise_bwd(xs.data_ptr(), None, dz.data_ptr(), None, None, None, None, w2t.data_ptr(), None, None,
+                                        None, partials.data_ptr(), max_waves, dims, b, C, C, co, P, 0, 0, 0, 0, 0, 1, stream)
+    _lib.check(rc, "tcfd_fno_pointwise_bwd")
+    rows = dims[5]
+    M = partials[:rows].view(rows // b, b, per_row).sum(dim=0, dtype=torch.float64)[:, : COP * CB].view(b, COP, CB)
+    Mx, M1 = M[:, :co, :C], M[:, :co, C]                                   # (b, co, C), (b, co)
+    mu = stats[:, 0] / L
+    r = torch.rsqrt((stats[:, 1] / L - mu * mu).clamp_min(0) + eps)
+    Wd = W.double()
+    g_ = gamma.detach().double() if gamma is not None else torch.ones(C, dtype=torch.float64, device=dev)
+    b_ = beta.detach().double() if beta is not None else torch.zeros(C, dtype=torch.float64, device=dev)
+    Sx = r[:, None, None] * (Mx - mu[:, None, None] * M1[:, :, None])      # sum_p dy[o] x^[c]
+    g_w = (g_[None, None, :] * Sx + b_[None, None, :] * M1[:, :, None]).sum(0)
+    g_b = M1.sum(0)
+    G1 = torch.einsum("oc,bo->bc", Wd, M1)                                  # sum_p g[c]
+    Gx = torch.einsum("oc,boc->bc", Wd, Sx)                                 # sum_p g[c] x^[c]
+    g_beta, g_gamma = G1.sum(0), Gx.sum(0)
+    A = (g_[None] * G1).sum(1)
+    B = (g_[None] * Gx).sum(1)
+    # pass 2: dx = sum_o (r gamma_c W[o,c]) dy[o] + alpha_b + kappa_b x
+    wb = (r[:, None, None] * g_[None, None, :] * Wd[None]).float().contiguous()          # (b, co, C) = w2t per sample
+    kappa = -(r * r) * B / L
+    alpha = (-r * A / L - kappa * mu).float()
+    bias2 = alpha[:, None].expand(b, C).contiguous()
+    dx = torch.empty_like(xs)
+    with torch.cuda.device(dev):
+        rc = lib.tcfd_fno_pointwise(dz.data_ptr(), None, dx.data_ptr(), None, None, wb.data_ptr(), bias2.data_ptr(), None, None,
+                                    b, co, co, C, P, x.shape[-1], 0, 0, 0, 0, co * C, C, None, stream)
+    if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+        return None
+    _lib.check(rc, "tcfd_fno_pointwise")
+    dx.addcmul_(xs, kappa.float().view(b, *([1] * (x.dim() - 1))))
+    cast = lambda t, like: t.to(like.dtype).reshape(like.shape) if like is not None else None
+    return (dx.view_as(x), None, None, None, cast(g_w, w), cast(g_b, bias), None, None, cast(g_gamma, gamma), cast(g_beta, beta))
 
 
 class _PointwiseFn(torch.autograd.Function):
