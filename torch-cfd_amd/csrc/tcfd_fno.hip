@@ -1278,6 +1278,254 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
     }
 }
 
+// Two-layer form, FOUR waves on the same 64 points.  The one-wave kernel above runs at 1.5 waves per SIMD (21 KB of
+// staging per wave).  Here a 256-thread workgroup owns 64 points: every wave holds the points' inputs, takes a quarter of
+// the hidden units (z1, h, its share of z2, g1 and its share of dx -- the partial sums meet in LDS), one tile of each
+// weight-gradient product on MFMA, and a quarter of the output channels.  One staging region per workgroup instead of per
+// wave: ~4 waves per SIMD, a quarter of the weight reads per wave.  Same partial-sum layout (one row per WORKGROUP).
+template <int CI, int CM, int CO, bool WLDS>
+__global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
+    using Gm = PwBwdGeom<CI, CM, CO, true>;
+    using Wm = PwBwdW<CI, CM, CO, true>;
+    constexpr int PITCH = Gm::PITCH;
+    constexpr int TO = Gm::COP / 16, TB = Gm::CB / 16, TI = Gm::CIP / 16, TM = Gm::CM1 / 16;
+    constexpr int RI = Wm::RI, RO = Wm::RO;
+    constexpr int MQ = CM / 4;                       // hidden units per wave
+    constexpr int RED = CO > CI ? CO : CI;           // rows per wave of the cross-wave reduction scratch
+    static_assert(CM % 4 == 0 && TO == 1 && TB <= 4 && TM <= 4 && TI == 1, "k_pointwise_bwd4 geometry");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float* Wl = reinterpret_cast<float*>(smem_raw);
+    float* L0 = Wl + ((Wm::TOTAL + 3) & ~3);         // g2, later [x, 1]
+    float* L1 = L0 + Gm::R0 * PITCH;                 // [h, 1, s], later g1 over h
+    float* RD = L1 + Gm::CB * PITCH;                 // [4][RED][PITCH] partial sums of z2, later of dx
+    for (int i = threadIdx.x; i < Wm::TOTAL; i += blockDim.x) Wl[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CM * CI; i += blockDim.x) Wl[Wm::W1 + (i / CI) * RI + i % CI] = a.w1[i];
+    if (a.b1) for (int i = threadIdx.x; i < CM; i += blockDim.x) Wl[Wm::B1 + i] = a.b1[i];
+    for (int i = threadIdx.x; i < CM * CO; i += blockDim.x) Wl[Wm::W2 + (i / CO) * RO + i % CO] = a.w2t[i];
+    for (int i = threadIdx.x; i < CO; i += blockDim.x)
+        Wl[Wm::B2 + i] = (a.b2 ? a.b2[i] : 0.f) + ((a.skip_mode == 1 && a.bs) ? a.bs[i] : 0.f);
+    if (a.skip_mode == 1)
+        for (int i = threadIdx.x; i < CI * CO; i += blockDim.x) Wl[Wm::WS + (i / CO) * RO + i % CO] = a.wst[i];
+    __syncthreads();
+    // WLDS (default): weights from the LDS copy (uniform-address ds_reads).  !WLDS reads them from global memory; inside
+    // the persistent loop the compiler cannot prove them invariant against the kernel's own stores and emits VECTOR loads
+    // instead of s_loads: measured 50.9 vs 34.9 ms per training step -- kept only as a switch (TCFD_PW_BWD_WLDS=0).
+    auto W1row = [&](int m) -> const float* { return WLDS ? Wl + Wm::W1 + m * RI : a.w1 + m * CI; };
+    auto W2row = [&](int m) -> const float* { return WLDS ? Wl + Wm::W2 + m * RO : a.w2t + m * CO; };
+    auto WSrow = [&](int i) -> const float* { return WLDS ? Wl + Wm::WS + i * RO : a.wst + i * CO; };
+    auto B1at = [&](int m) -> float { return WLDS ? Wl[Wm::B1 + m] : (a.b1 ? a.b1[m] : 0.f); };
+    const int kq = lane >> 4, kc = lane & 15;
+    f4 accA = f4{0.f, 0.f, 0.f, 0.f}, accB = f4{0.f, 0.f, 0.f, 0.f};
+    const long c_first = a.per_sample ? ((long)blockIdx.x % a.batch) * a.chunks_per_batch + blockIdx.x / a.batch : blockIdx.x;
+    const long c_stride = a.per_sample ? gridDim.x / a.batch : gridDim.x;
+    const long c_end = a.per_sample ? ((long)blockIdx.x % a.batch + 1) * a.chunks_per_batch : a.total_chunks;
+    const bool from_h = a.act1 == 0 || a.act1 == 1 || a.act1 == 4;
+    for (long chunk = c_first; chunk < c_end; chunk += c_stride) {
+        const long b = chunk / a.chunks_per_batch;
+        const long p = (chunk - b * a.chunks_per_batch) * 64 + lane;
+        const bool live = p < a.P;
+        const long pc = live ? p : a.P - 1;
+        float x[CI], g2[CO], z2[CO];
+        const float* xb = a.x + (size_t)b * CI * a.P + pc;
+        const float* db = a.dout + (size_t)b * CO * a.P + pc;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) g2[c] = live ? db[(size_t)c * a.P] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) z2[c] = 0.f;
+        // this wave's hidden units
+#pragma unroll 2
+        for (int mm = 0; mm < MQ; ++mm) {
+            const int m = wave * MQ + mm;
+            float z = B1at(m);
+            const float* w1 = W1row(m);
+#pragma unroll
+            for (int i = 0; i < CI; ++i) z = fmaf(w1[i], x[i], z);
+            const float h = live ? pw_act(z, a.act1) : 0.f;
+            L1[m * PITCH + lane] = h;
+            const float* w2 = W2row(m);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) z2[c] = fmaf(w2[c], h, z2[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) RD[(wave * RED + c) * PITCH + lane] = z2[c];
+        // the constant-1 channel and the skip input rows of the second operand (wave 3 and wave 2: spread the stores)
+        if (wave == 3) L1[CM * PITCH + lane] = live ? 1.f : 0.f;
+        float sv[CI];
+        if (a.skip_mode == 1) {
+            const float* sb = a.s + (size_t)b * CI * a.P + pc;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) sv[i] = live ? sb[(size_t)i * a.P] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) sv[i] = 0.f;
+        }
+        if (wave == 2) {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) L1[(CM + 1 + i) * PITCH + lane] = sv[i];
+        }
+        __syncthreads();
+        // z2 = bias + skip part + the four partial sums; g2 (every wave, the same values)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            float v = Wl[Wm::B2 + c];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += RD[(w * RED + c) * PITCH + lane];
+            z2[c] = v;
+        }
+        if (a.skip_mode == 1) {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) {
+                const float* ws = WSrow(i);
+#pragma unroll
+                for (int c = 0; c < CO; ++c) z2[c] = fmaf(ws[c], sv[i], z2[c]);
+            }
+        } else if (a.skip_mode == 2) {
+            const long xy = pc / a.T;
+            const long sP = (a.P / a.T) * a.sT;
+            const float* sb = a.s + (size_t)b * CO * sP + xy * a.sT + (a.sT - 1);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) z2[c] += sb[(size_t)c * sP];
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) g2[c] *= pw_dact(z2[c], a.act2);
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) L0[c * PITCH + lane] = g2[c];
+        }
+        __syncthreads();
+        if (wave < TB) {   // [dW2 | db2 | dWs] tile `wave`
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const float av = L0[kc * PITCH + 4 * q + kq];
+                const float bv = L1[(16 * wave + kc) * PITCH + 4 * q + kq];
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accA, 0, 0, 0);
+            }
+        }
+        __syncthreads();   // the products have read h and g2: h rows become g1, the g2 rows become [x, 1]
+        float dx[CI];
+#pragma unroll
+        for (int i = 0; i < CI; ++i) dx[i] = 0.f;
+#pragma unroll 2
+        for (int mm = 0; mm < MQ; ++mm) {
+            const int m = wave * MQ + mm;
+            const float* w1 = W1row(m);
+            const float h = L1[m * PITCH + lane];
+            float d1;
+            if (from_h) {
+                d1 = a.act1 == 1 ? (h > 0.f ? 1.f : 0.f) : (a.act1 == 4 ? 1.f - h * h : 1.f);
+            } else {
+                float z = B1at(m);
+#pragma unroll
+                for (int i = 0; i < CI; ++i) z = fmaf(w1[i], x[i], z);
+                d1 = pw_dact(z, a.act1);
+            }
+            const float* w2 = W2row(m);
+            float dh = 0.f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) dh = fmaf(w2[c], g2[c], dh);
+            const float g1 = dh * d1;
+            L1[m * PITCH + lane] = g1;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) dx[i] = fmaf(w1[i], g1, dx[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < CI; ++i) RD[(wave * RED + i) * PITCH + lane] = dx[i];
+        if (wave == 1) {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) L0[i * PITCH + lane] = live ? x[i] : 0.f;
+            L0[CI * PITCH + lane] = live ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (wave < TM) {   // [dW1 | db1] tile `wave`
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const float bv = L0[kc * PITCH + 4 * q + kq];
+                const float av = L1[(16 * wave + kc) * PITCH + 4 * q + kq];
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accB, 0, 0, 0);
+            }
+        }
+        // outputs: channel i is summed and stored by wave i % 4
+        if (live) {
+            if (a.dx) {
+                float* dxb = a.dx + (size_t)b * CI * a.P + p;
+#pragma unroll
+                for (int i = 0; i < CI; ++i)
+                    if ((i & 3) == wave) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) v += RD[(w * RED + i) * PITCH + lane];
+                        dxb[(size_t)i * a.P] = v;
+                    }
+            }
+            if (a.skip_mode == 1 && a.ds) {
+                float* dsb = a.ds + (size_t)b * CI * a.P + p;
+#pragma unroll
+                for (int i = 0; i < CI; ++i)
+                    if ((i & 3) == wave) {
+                        const float* ws = WSrow(i);
+                        float v = 0.f;
+#pragma unroll
+                        for (int c = 0; c < CO; ++c) v = fmaf(ws[c], g2[c], v);
+                        dsb[(size_t)i * a.P] = v;
+                    }
+            } else if (a.skip_mode == 2 && a.ds) {
+                float* dsb = a.ds + (size_t)b * CO * a.P + p;
+#pragma unroll
+                for (int c = 0; c < CO; ++c)
+                    if ((c & 3) == wave) dsb[(size_t)c * a.P] = g2[c];
+            }
+        }
+        __syncthreads();   // the next chunk overwrites the staging rows and the reduction scratch
+    }
+    // partial sums of this workgroup: A (COP x CB) | B (CM1 x CIP), tile `wave` of each from wave `wave`
+    float* out = a.partials + (size_t)blockIdx.x * Gm::TOTAL;
+    if (wave < TB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(4 * kq + r) * Gm::CB + 16 * wave + kc] = accA[r];
+    }
+    if (wave < TM) {
+        float* o1 = out + Gm::N_A;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o1[(16 * wave + 4 * kq + r) * Gm::CIP + kc] = accB[r];
+    }
+}
+
+template <int CI, int CM, int CO>
+static int launch_pw_bwd4(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
+    using Gm = PwBwdGeom<CI, CM, CO, true>;
+    using Wm = PwBwdW<CI, CM, CO, true>;
+    dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
+    if (!a.x) return 0;
+    a.chunks_per_batch = (a.P + 63) / 64;
+    a.total_chunks = a.chunks_per_batch * batch;
+    a.batch = batch;
+    constexpr int RED = CO > CI ? CO : CI;
+    const size_t lds = ((size_t)((Wm::TOTAL + 3) & ~3) + (size_t)(Gm::ROWS + 4 * RED) * Gm::PITCH) * sizeof(float);
+    auto kern = env_int("TCFD_PW_BWD_WLDS", 1) ? k_pointwise_bwd4<CI, CM, CO, true> : k_pointwise_bwd4<CI, CM, CO, false>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    int per_cu = 0, dev = 0, cus = 256;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    long blocks = std::min<long>({a.total_chunks, (long)max_rows, (long)std::max(per_cu, 1) * cus});
+    if (blocks < 1) blocks = 1;
+    if (a.per_sample) {
+        blocks = blocks / batch * batch;
+        if (blocks < batch) blocks = batch;
+        if (blocks > max_rows) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: %ld rows needed for per-sample partials, %d given", blocks, max_rows);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    dims[5] = (int)blocks;
+    return 0;
+}
+
 template <int CI, int CM, int CO, bool HAS_L1>
 static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, HAS_L1>;
@@ -1339,6 +1587,11 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
     const bool l1 = cm != ci || w1 != nullptr;
 #define PWB_CASE(CI_, CM_, CO_, L1_) \
     if (ci == CI_ && cm == CM_ && co == CO_ && l1 == L1_) return launch_pw_bwd<CI_, CM_, CO_, L1_>(a, batch, max_waves, dims, st);
+    if (l1 && env_int("TCFD_PW_BWD", 4) == 4) {   // four waves per 64 points (default); 1 = one wave per 64 points
+        if (ci == 4 && cm == 16 && co == 4) return launch_pw_bwd4<4, 16, 4>(a, batch, max_waves, dims, st);
+        if (ci == 8 && cm == 32 && co == 8) return launch_pw_bwd4<8, 32, 8>(a, batch, max_waves, dims, st);
+        if (ci == 10 && cm == 40 && co == 10) return launch_pw_bwd4<10, 40, 10>(a, batch, max_waves, dims, st);
+    }
     PWB_CASE(4, 16, 4, true) PWB_CASE(8, 32, 8, true) PWB_CASE(10, 40, 10, true)
     PWB_CASE(4, 4, 4, false) PWB_CASE(4, 4, 1, false) PWB_CASE(8, 8, 8, false) PWB_CASE(8, 8, 1, false)
     PWB_CASE(10, 10, 10, false) PWB_CASE(10, 10, 1, false)
