@@ -138,6 +138,38 @@ def sfno_config5(dev):
             "algo_GBps": round(algo_gb / (t_all * 1e-3), 1), "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4)}
 
 
+def other_baseline_configs(dev):
+    """Secondary lines for the other single-GPU BASELINE configs on the same kernels: C2 = 256^2, B=16,
+    fp32, unforced McWilliams, dt=1e-3 (1000-step job, measured over 400 steps through forward(w, dt, steps=k)); C4 per-GPU
+    shard = 512^2, B=64, fp64, unforced, dt=1e-3.  value = batch steps/s."""
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    out = {}
+    for name, n, B, real, steps, fused in (("C2_256x16_f32", 256, 16, torch.float32, 400, True),
+                                           ("C4_shard_512x64_f64", 512, 64, torch.float64, 40, False)):
+        torch.set_default_dtype(real)
+        L = 2 * math.pi
+        grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+        op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.0, smooth=True, solver=tc.RK4CrankNicolsonStepper()).to(dev)
+        cdt = torch.complex64 if real == torch.float32 else torch.complex128
+        with torch.no_grad():
+            w = tc.fft_plan(n, cdt, dev).rfft2(torch.cat([vorticity_field(grid, 4, batch_seeds=list(range(i, min(i + 8, B))),
+                                                                          device=dev) for i in range(0, B, 8)]))
+            run = (lambda w: op(w, 1e-3, steps=steps)[0]) if fused else (lambda w: [w := op(w, 1e-3)[0] for _ in range(steps)][-1])
+            w = run(w)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            w = run(w)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+        S = B * n * (n // 2 + 1) * (8 if real == torch.float32 else 16)
+        out[name] = {"steps_per_s": round(steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+                     "step_algo_GBps": round(70.0 * S * steps / el / 1e9, 1),
+                     "api": "forward(w,dt,steps=k)" if fused else "k x forward(w,dt)"}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -281,6 +313,10 @@ def main():
         try:
             del w
             torch.cuda.empty_cache()
+            out["other_configs"] = other_baseline_configs(dev)
+        except Exception as e:
+            out["other_configs"] = {"error": repr(e)}
+        try:
             out["sfno_config5"] = sfno_config5(dev)
         except Exception as e:  # secondary measurement: never takes the headline line down
             out["sfno_config5"] = {"error": repr(e)}
