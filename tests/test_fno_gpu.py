@@ -149,6 +149,9 @@ def test_errors_are_loud(dev):
     with pytest.raises(_lib.TcfdError):
         m(torch.randn(1, 2, 16, 16, 10))  # CPU tensor
     assert m(torch.randn(1, 2, 16, 16, 10, device=dev)).grad_fn is not None  # autograd on: differentiable path
+    import torch.nn as nn
+    with torch.no_grad(), pytest.raises(TypeError, match="float64 parameter"):   # fp64 layer on fp32 data: loud, like torch
+        fno.hip_pointwise(torch.randn(1, 4, 8, 8, 10, device=dev), None, None, nn.Conv3d(4, 4, 1).double().to(dev))
     with torch.no_grad():
         with pytest.raises(_lib.TcfdError, match="powers of two"):
             m(torch.randn(1, 2, 24, 16, 10, device=dev))

@@ -537,6 +537,13 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     if (c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32 or not _is_pointwise(lin2)
             or (lin1 is not None and not _is_pointwise(lin1)) or (skip_conv is not None and not _is_pointwise(skip_conv))):
         return None
+    for mod in (lin1, lin2, skip_conv, norm):
+        for prm in (mod.parameters() if mod is not None else ()):
+            if prm.dtype != torch.float32 or prm.device != x.device:   # torch's own conv raises on this too
+                raise TypeError(f"fp32 input on {x.device} but a {prm.dtype} parameter on {prm.device}: build / move the "
+                                "layer in float32 on the input's device")
+    if skip is not None and (skip.dtype != torch.float32 or skip.device != x.device):
+        raise TypeError("the skip input must be float32 on the same device as x")
     if torch.is_grad_enabled():
         mods = [m for m in (lin1, lin2, skip_conv, norm) if m is not None]
         tensors = [x, skip] + [p for m in mods for p in m.parameters()]
@@ -639,6 +646,9 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
     if (not v1.is_cuda or v1.dtype != torch.float32 or v1.shape[1] != 1 or not _is_pointwise(proj) or norm.num_groups != 1
             or torch.is_grad_enabled() and (v1.requires_grad or any(p.requires_grad for m in (norm, proj) for p in m.parameters()))):
         return None
+    for prm in list(norm.parameters()) + list(proj.parameters()):
+        if prm.dtype != torch.float32 or prm.device != v1.device:
+            raise TypeError(f"fp32 input on {v1.device} but a {prm.dtype} parameter on {prm.device}")
     q = q.reshape(-1, *q.shape[-3:]) if q.dim() == 5 else q
     C = q.shape[0]
     if q.shape[1:] != v1.shape[2:] or norm.num_channels != C or proj.in_channels != C:
