@@ -445,3 +445,29 @@ def test_layernorm_projection_backward_on_hip(C, co, dev):
     for name, got, want in (("x", x.grad, xd.grad), ("gamma", norm.weight.grad, gd.grad), ("beta", norm.bias.grad, bd.grad),
                             ("W", proj.weight.grad, wd.grad), ("b", proj.bias.grad, pd.grad)):
         assert got is not None and rel_l2(got, want) < 3e-5, name
+
+
+def test_layers_built_under_a_float64_default_dtype(dev):
+    """A model constructed while the default dtype is float64 (the solver's setting) has float64 parameters: the spectral
+    layers cast them, the Helmholtz tables promote the spectrum to complex128 and are cast back, the pointwise layers
+    refuse loudly -- nothing silently reads 8-byte weights as 4-byte ones."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(1)
+    x = torch.randn(2, 2, 16, 16, 6, device=dev)
+    torch.set_default_dtype(torch.float64)
+    try:
+        hp64 = fno.SpectralConvT(2, 2, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True,
+                                 postprocess=fno.HelmholtzProjection(n_grid=16, diam=2 * math.pi, dtype=torch.float64)).to(dev)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    hp32 = fno.SpectralConvT(2, 2, 4, 4, 3, delta=0.1, bias=True, temporal_padding=True,
+                             postprocess=fno.HelmholtzProjection(n_grid=16, diam=2 * math.pi)).to(dev)
+    hp32.load_state_dict({k: v.float() for k, v in hp64.state_dict().items()})
+    with torch.no_grad():
+        y64, y32 = hp64(x, out_steps=9), hp32(x, out_steps=9)
+    assert y64.dtype == torch.float32 and rel_l2(y64, y32) < 1e-6
+    # and under autograd
+    xg = x.clone().requires_grad_(True)
+    hp64(xg, out_steps=9).square().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()

@@ -164,7 +164,9 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
     """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep)."""
     X, Y, T, t_pad, t_out, mx, my, mt = plan.key
     b, c = vh.shape[:2]
-    vh = vh.contiguous()
+    if tuple(vh.shape[2:]) != (2 * mx, 2 * my, mt) or not vh.is_complex():
+        raise ValueError(f"expected a complex (b, C, {2 * mx}, {2 * my}, {mt}) truncated spectrum, got {tuple(vh.shape)} {vh.dtype}")
+    vh = vh.detach().to(torch.complex64).contiguous()   # e.g. a float64 post-processing table promotes to complex128
     out = torch.empty(b, c, X, Y, t_keep, dtype=torch.float32, device=vh.device)
     ws = plan.workspace(b, c, c)
     _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
@@ -181,11 +183,10 @@ def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -
     b, ci = vh.shape[:2]
     mx, my, mt = modes
     co = weights[0].shape[1]
-    vh = vh.contiguous()
-    ws_ = [torch.view_as_real(w).contiguous() if w.is_complex() else w.contiguous() for w in weights]
-    bs_ = None
-    if bias is not None:
-        bs_ = [torch.view_as_real(x).contiguous() if x.is_complex() else x.contiguous() for x in bias]
+    vh = vh.detach().to(torch.complex64).contiguous()
+    f32 = lambda t: (torch.view_as_real(t) if t.is_complex() else t).detach().to(device=vh.device, dtype=torch.float32).contiguous()
+    ws_ = [f32(w) for w in weights]
+    bs_ = [f32(x) for x in bias] if bias is not None else None
     out = torch.empty(b, co, 2 * mx, 2 * my, mt, dtype=torch.complex64, device=vh.device)
     lib = _lib.load()
     with torch.cuda.device(vh.device):
@@ -298,7 +299,7 @@ def hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_k
     vh = _FwdTruncFn.apply(v, tuple(modes), t_pad, t_out, norm)
     oh = _ContractFn.apply(vh, float(delta), tuple(modes), use_mfma, bias is not None, *params)
     if post is not None:
-        oh = post(oh)
+        oh = post(oh).to(torch.complex64)
     return _InvTruncFn.apply(oh, (X, Y, T, t_pad, t_out) + tuple(modes), t_keep, norm)
 
 
