@@ -180,7 +180,7 @@ int tcfd_row_moments(const void* x, void* stats, int rows, long L, void* stream)
  * bracketed by a pair of HIP events recorded on the launch stream (up to
  * max_records launches).  profile_end synchronises on them and returns, per
  * launch, the kernel kind (0 column pass A, 1 row pass, 2 column pass C+A,
- * 3 column pass C, 4 dw/dt, 5 other) and its duration in milliseconds.
+ * 3 column pass C incl. dw/dt, 5 other; 4 is unused) and its duration in milliseconds.
  * Mutates the plan: not to be used concurrently with other calls on it. */
 int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* plan, int max_records);
 int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* kinds, float* ms);

@@ -783,15 +783,6 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_c2r(cons
 
 // ------------------------------------------------------------------ small elementwise kernels
 template <typename T>
-__global__ void k_dwdt(const cx<T>* __restrict__ w_new, const cx<T>* __restrict__ w_old, cx<T>* __restrict__ out,
-                       T s, size_t count) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        const cx<T> a = w_new[i], b = w_old[i];
-        out[i] = mk<T>((a.x - b.x) * s, (a.y - b.y) * s);
-    }
-}
-
-template <typename T>
 __global__ void k_velocity(const cx<T>* __restrict__ w, cx<T>* __restrict__ uh, cx<T>* __restrict__ vh,
                            cx<T>* __restrict__ psi, const T* __restrict__ kxs, const T* __restrict__ kys, int n,
                            int m, size_t count) {
@@ -1040,7 +1031,7 @@ extern "C" size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch)
 }
 
 // ------------------------------------------------------------------ optional per-launch event timing
-// kinds: 0 cols MODE_A, 1 rows_advect, 2 cols MODE_CA, 3 cols MODE_C, 4 dwdt, 5 other
+// kinds: 0 cols MODE_A, 1 rows_advect, 2 cols MODE_CA, 3 cols MODE_C (+ dw/dt), 5 other   (4 was the separate dw/dt pass)
 struct ProfScope {
     ProfState* ps;
     hipStream_t st;
