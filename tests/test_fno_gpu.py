@@ -471,3 +471,55 @@ def test_layers_built_under_a_float64_default_dtype(dev):
     xg = x.clone().requires_grad_(True)
     hp64(xg, out_steps=9).square().sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+# ----------------------------------------------------------------------------- the reference's own shape suite
+# (fno/sfno_pytest.py:36-51, 140-296: PE, LiftingOperator, OutConv, SpectralConvS/T, SFNO at three resolutions,
+# output_steps) -- same constructor calls, same assertions, on the HIP layers.
+@pytest.mark.parametrize("n,T", [(64, 10), (128, 20), (256, 40)])
+def test_reference_shape_suite_sfno_resolutions(n, T, dev):
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(0)
+    model = fno.SFNO(8, 8, 5, width=10, num_spectral_layers=2).to(dev).eval()
+    with torch.no_grad():
+        assert model(torch.randn(2, n, n, T, device=dev)).shape == (2, n, n, T)
+        for out_steps in (10, 20, 40):
+            assert model(torch.randn(2, n, n, 10, device=dev), out_steps=out_steps).shape == (2, n, n, out_steps)
+
+
+def test_reference_shape_suite_layers(dev):
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(0)
+    with torch.no_grad():
+        pe = fno.SpaceTimePositionalEncoding(8, 8, 4, num_channels=20, input_shape=(64, 64, 10)).to(dev)
+        assert pe(torch.randn(2, 1, 64, 64, 10, device=dev)).shape == (2, 20, 64, 64, 10)
+        assert pe(torch.randn(2, 1, 32, 32, 6, device=dev)).shape == (2, 20, 32, 32, 6)        # table rebuilt for a new mesh
+        lift = fno.LiftingOperator(10, 8, 8, 5, latent_steps=10).to(dev)
+        assert lift(torch.randn(2, 1, 64, 64, 10, device=dev)).shape == (2, 10, 64, 64, 10)
+        outc = fno.OutConv(8, 8, 5, n_grid=64).to(dev)
+        v, v_res = torch.randn(2, 1, 64, 64, 10, device=dev), torch.randn(2, 64, 64, 10, device=dev)
+        for out_steps in (10, 20, 40):
+            assert outc(v, v_res, out_steps=out_steps).shape == (2, 64, 64, out_steps)
+        convs = fno.SpectralConvS(10, 10, 8, 8, 5).to(dev)
+        assert convs(torch.randn(2, 10, 64, 64, 10, device=dev)).shape == (2, 10, 64, 64, 10)
+        convt = fno.SpectralConvT(10, 10, 8, 8, 5, temporal_padding=True).to(dev)
+        for out_steps in (10, 20, 40):
+            assert convt(torch.randn(2, 10, 64, 64, 10, device=dev), out_steps=out_steps).shape == (2, 10, 64, 64, out_steps)
+
+
+@pytest.mark.parametrize("ns", ["1", "2", "5"])
+def test_results_do_not_depend_on_the_workgroup_geometry(ns, dev, monkeypatch):
+    """LDS-race hunt: the t/y transform kernels give bit-identical results whatever number of slabs
+    a workgroup owns, on an odd slab count that leaves the last workgroup partly empty."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(2)
+    layer = fno.SpectralConvT(3, 3, 6, 5, 4, temporal_padding=True, bias=True).to(dev)
+    x = torch.randn(3, 3, 32, 64, 7, device=dev)     # 3*3*32 = 288 slabs
+    with torch.no_grad():
+        monkeypatch.delenv("TCFD_FNO_NS", raising=False)
+        ref = layer(x, out_steps=9)
+        monkeypatch.setenv("TCFD_FNO_NS", ns)
+        assert torch.equal(layer(x, out_steps=9), ref)
