@@ -13,7 +13,7 @@ plan (include/tcfd.h: ``forcing_hat``).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.nn as nn

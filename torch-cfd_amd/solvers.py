@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import math
 from datetime import datetime
-from typing import Dict, Tuple
+from typing import Dict
 
 import torch
 

@@ -11,7 +11,6 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib
 from .grids import Grid
 
 
