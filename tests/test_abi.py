@@ -56,3 +56,17 @@ def test_plan_create_rejects_bad_sizes_without_touching_the_gpu():
     assert rc == -1 and b"power of two" in lib.tcfd_last_error()
     rc = lib.tcfd_ns2d_plan_create(ctypes.byref(h), 16, 7, one, one, one, one, None)
     assert rc == -1
+
+
+def test_header_is_plain_c():
+    """include/tcfd.h is the drop-in boundary: it must compile as C99 on its own (no C++ or torch types)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tcfd.h")
+    r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", hdr],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
