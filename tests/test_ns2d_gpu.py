@@ -7,6 +7,7 @@ reference's own fp32 results <= 2e-6 @1 step, <= 1e-5 @10 steps, <= 5e-4 @1000
 (SURVEY note N5).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -573,3 +574,27 @@ def test_half_batch_overlap_is_bit_identical(tag, B, steps, dev, monkeypatch):
         res[flag] = (w.clone(), d.clone(), w2.clone(), d2.clone())
     for x, y in zip(res["0"], res["1"]):
         assert torch.equal(x, y)
+
+
+def test_c_abi_without_python(dev, tmp_path):
+    """examples/c_abi_taylor_green.c: plain C99 + HIP runtime against include/tcfd.h, no Python or PyTorch in the
+    process.  Known answer: the Taylor-Green vortex decays like exp(-2 nu k^2 t); the program checks 1e-8 itself."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / ROCm headers")
+    import torch_cfd_amd as tc
+    tc._lib.load()                                   # makes sure the library is built
+    csrc = os.path.join(ROOT, "torch-cfd_amd", "csrc")
+    exe = str(tmp_path / "c_abi_taylor_green")
+    cmd = [gcc, "-std=c99", "-O2", os.path.join(ROOT, "examples", "c_abi_taylor_green.c"), "-I" + os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-L" + csrc, "-L/opt/rocm/lib", "-ltcfd_hip", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "PASS" in out, out
