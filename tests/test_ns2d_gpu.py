@@ -598,3 +598,17 @@ def test_c_abi_without_python(dev, tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = r.stdout.decode()
     assert r.returncode == 0 and "PASS" in out, out
+
+
+def test_empty_batch_returns_empty_tensors(dev):
+    """Edge case: a (0, n, m) batch goes through like the reference's tensor ops do -- empty results, no launch."""
+    _, op = build_op(32, "f64", "kolmogorov", dev)
+    w = torch.empty(0, 32, 17, dtype=torch.complex128, device=dev)
+    out, dwdt = op(w, 1e-3, steps=3)
+    assert out.shape == (0, 32, 17) and dwdt.shape == (0, 32, 17)
+    assert op.explicit_terms(w).shape == (0, 32, 17) and op.residual(w, w).shape == (0, 32, 17)
+    from torch_cfd_amd import fno
+    torch.set_default_dtype(torch.float32)
+    with torch.no_grad():
+        y = fno.SpectralConvS(2, 3, 4, 4, 3).to(dev)(torch.empty(0, 2, 16, 16, 10, device=dev))
+    assert y.shape == (0, 3, 16, 16, 10)

@@ -121,6 +121,8 @@ class _HipPlan:
         w, batch = self._prep(w)
         out = torch.empty_like(w)
         dwdt = torch.empty_like(w) if want_dwdt else None
+        if batch == 0:   # empty batch: the reference's tensor ops return empty tensors
+            return out, dwdt
         ws = self.workspace(batch)
         ints = (ctypes.c_int * len(beta))(*[int(v) for v in base0]) if base0 is not None else None
         with torch.cuda.device(self.device):
@@ -135,6 +137,8 @@ class _HipPlan:
     def explicit_terms(self, w):
         w, batch = self._prep(w)
         out = torch.empty_like(w)
+        if batch == 0:
+            return out
         ws = self.workspace(batch)
         with torch.cuda.device(self.device):
             rc = self.lib.tcfd_ns2d_explicit_terms(self.handle, w.data_ptr(), out.data_ptr(), batch,
@@ -147,6 +151,8 @@ class _HipPlan:
         wt_, _ = self._prep(wt)
         psi = torch.empty_like(w) if want_psi else None
         res = torch.empty_like(w) if want_res else None
+        if batch == 0:
+            return psi, res
         ws = self.workspace(batch)
         with torch.cuda.device(self.device):
             rc = self.lib.tcfd_ns2d_stream_residual(
@@ -158,6 +164,8 @@ class _HipPlan:
     def velocity(self, w):
         w, batch = self._prep(w)
         uh, vh, psi = torch.empty_like(w), torch.empty_like(w), torch.empty_like(w)
+        if batch == 0:
+            return (uh, vh), psi
         with torch.cuda.device(self.device):
             rc = self.lib.tcfd_ns2d_velocity(self.handle, w.data_ptr(), uh.data_ptr(), vh.data_ptr(),
                                              psi.data_ptr(), batch, self._stream())
@@ -170,6 +178,8 @@ class _HipPlan:
         x = x.detach().to(self.rdtype).contiguous()
         batch = x.numel() // (self.n * self.n)
         out = torch.empty(*x.shape[:-1], self.m, dtype=self.cdtype, device=x.device)
+        if batch == 0:
+            return out
         with torch.cuda.device(self.device):
             rc = self.lib.tcfd_rfft2(self.handle, x.data_ptr(), out.data_ptr(), batch, self._stream())
         _lib.check(rc, "tcfd_rfft2")
@@ -178,6 +188,8 @@ class _HipPlan:
     def irfft2(self, xh):
         xh, batch = self._prep(xh)
         out = torch.empty(*xh.shape[:-1], self.n, dtype=self.rdtype, device=xh.device)
+        if batch == 0:
+            return out
         ws = self.workspace(batch)
         with torch.cuda.device(self.device):
             rc = self.lib.tcfd_irfft2(self.handle, xh.data_ptr(), out.data_ptr(), batch, ws.data_ptr(),

@@ -114,6 +114,8 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params)):
         return hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma)
     v = v.detach().contiguous()
+    if b == 0:   # empty batch, like the reference's tensor ops
+        return torch.empty(0, co, X, Y, t_keep, dtype=torch.float32, device=v.device)
 
     def as_real(w, shape):
         w = w.detach()
