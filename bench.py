@@ -172,16 +172,26 @@ def other_baseline_configs(dev):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on stdout (flushed at exit,
+    # i.e. AFTER anything Python prints): keep a private handle on the real stdout for the JSON line and point fd 1 at
+    # stderr for everything else (libraries, warnings, the banner).
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the env switch exercises the RCCL path on 1 GPU
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     import torch_cfd_amd as tc
@@ -218,7 +228,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -255,7 +265,7 @@ def main():
     except Exception as e:
         probe = {"error": repr(e)}
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -328,8 +338,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
