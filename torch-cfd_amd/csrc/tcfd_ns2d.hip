@@ -70,7 +70,6 @@ TCFD_CFG(float, 512, 8, 16, 8, 256)
 TCFD_CFG(float, 1024, 16, 8, 16, 256)
 TCFD_CFG(float, 2048, 16, 8, 16, 256)
 
-// run-time variant override for tuning sweeps (TCFD_VARIANT_COLS / TCFD_VARIANT_ROWS, n=1024 fp64 only)
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -444,41 +443,6 @@ struct RowGeom {
     static constexpr int LDS_PER_GROUP = lds_elems<N, EPT, 1, true>();
     static constexpr size_t LDS_BYTES = (size_t)GROUPS * LDS_PER_GROUP * sizeof(cx<T>);
 };
-
-template <typename T, int N, int EPT, int THR>
-__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect(
-    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
-    long npairs, int m) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using Gm = RowGeom<T, N, EPT, THR>;
-    constexpr int G = Gm::G;
-    constexpr bool WG = (G > 64);
-    const int grp = threadIdx.x / G;
-    const int j = threadIdx.x % G;
-    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
-    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
-    const bool valid = pair < npairs;
-    if (!valid) pair = npairs - 1;  // keep the barriers uniform; results discarded
-    const size_t row0 = (size_t)pair * 2;
-
-    cx<T> p[EPT];  // advection of (row0, row0+1) packed as re / im
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const size_t off = (row0 + r) * (size_t)m;
-        cx<T> z1[EPT], z2[EPT];
-        load_herm_pair<T, N, EPT>(z1, planes + off, planes + plane_stride + off, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(z1, lds, tw, j, 0);  // vx + i vy
-        load_herm_pair<T, N, EPT>(z2, planes + 2 * plane_stride + off, planes + 3 * plane_stride + off, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(z2, lds, tw, j, 0);  // dx w + i dy w
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) {
-            const T adv_t = -(z2[t].x * z1[t].x + z2[t].y * z1[t].y);
-            if (r == 0) p[t].x = adv_t; else p[t].y = adv_t;
-        }
-    }
-    tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
-    unpack_store_pair<T, N, EPT>(p, lds, adv + row0 * (size_t)m, adv + (row0 + 1) * (size_t)m, j, valid);
-}
 
 // ---- row pass, software-pipelined ("v3") -------------------------------------------------
 // The un-mirrored half rows of two planes as they come from HBM: k = j + G*t, t < EPT/2, plus the
@@ -1147,36 +1111,7 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
         static const int two = env_int("TCFD_TWO_WG", 1);
         if (two) return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);
     }
-    if constexpr (N == 1024 && sizeof(T) == 8 && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
-        static const int variant = env_int("TCFD_VARIANT_COLS", 0);
-        switch (variant) {
-            case 1: return launch_cols_v<T, N, MODE, 8, 8>(p, a, batch, st);    // 1024 threads, <=128 VGPR
-            case 2: return launch_cols_v<T, N, MODE, 16, 4>(p, a, batch, st);   // 256 threads, 64 KB LDS
-            case 3: return launch_cols_v<T, N, MODE, 8, 4>(p, a, batch, st);    // 512 threads, 64 KB LDS
-            default: break;
-        }
-    }
     return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
-}
-
-template <typename T, int N, int EPT, int THR>
-static int launch_rows_advect_v(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
-                                long batch, hipStream_t st) {
-    using Gm = RowGeom<T, N, EPT, THR>;
-    auto kern = k_rows_advect<T, N, EPT, THR>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = set_lds(kern, Gm::LDS_BYTES);
-        if (rc) return rc;
-        attr_done = true;
-    }
-    const long npairs = batch * (N / 2);
-    const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
-    ProfScope prof(p, 1, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
-                       (const cx<T>*)p->tw, npairs, p->ldw);
-    HIP_TRY(hipGetLastError());
-    return 0;
 }
 
 template <typename T, int N, int EPT, int THR>
@@ -1234,24 +1169,6 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         if (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256))
             return launch_rows_advect3<T, N, 8, 64>(p, planes, plane_stride, adv, batch, st);
     }
-    if constexpr (N == 1024 && sizeof(T) == 8) {
-        static const int variant = env_int("TCFD_VARIANT_ROWS", 0);
-        switch (variant) {
-            case 5: return launch_rows_advect3<T, N, 8, 128>(p, planes, plane_stride, adv, batch, st);
-            case 6: return launch_rows_advect3<T, N, 8, 256>(p, planes, plane_stride, adv, batch, st);
-            case 7: return launch_rows_advect3<T, N, 4, 256>(p, planes, plane_stride, adv, batch, st);
-            case 8: return launch_rows_advect3<T, N, 16, 64>(p, planes, plane_stride, adv, batch, st);
-            case 1: return launch_rows_advect_v<T, N, 16, 256>(p, planes, plane_stride, adv, batch, st);  // 1 wave / pair
-            case 2: return launch_rows_advect_v<T, N, 16, 64>(p, planes, plane_stride, adv, batch, st);
-            case 3: return launch_rows_advect_v<T, N, 8, 256>(p, planes, plane_stride, adv, batch, st);   // 2 pairs / WG
-            case 4: return launch_rows_advect_v<T, N, 4, 256>(p, planes, plane_stride, adv, batch, st);   // 4 waves / pair
-            default: break;
-        }
-    }
-    static const int legacy = env_int("TCFD_ROWS_LEGACY", 0);
-    if (legacy)
-        return launch_rows_advect_v<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv,
-                                                                                       batch, st);
     return launch_rows_advect3<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch, st);
 }
 
