@@ -7,12 +7,13 @@
 // output spectrum although only 2mx x 2my x mt modes are ever read or written.  Here the transforms
 // are pruned: five kernels, the big activation tensors are read / written exactly once,
 //
-//   k_fwd_ty   per (b,c,x) slab [Y][T]: real DFT in t (mt outputs) + Y-point FFT per kept kt,
-//              store only the 2my kept ky                         -> W1 (b,C,X,Q)   Q = 2my*mt
+//   k_fwd_ty2  per (b,c,x) slab [Y][T]: Y-point FFTs on pairs of time samples, then the short real DFT in t on
+//              the 2my kept ky only                                -> W1 (b,C,X,Q)   Q = 2my*mt
 //   k_fwd_x    X-point FFT down the columns of W1, store only the 2mx kept kx -> V (b,C,2mx,Q)
 //   k_contract per-mode (b x Ci)(Ci x Co) complex products on MFMA (f32 16x16x4), + delta*bias
 //   k_inv_x    zero-padded X-point inverse FFT                     -> W2 (b,C,X,Q)
-//   k_inv_ty   zero-padded Y-point inverse FFT per kt + inverse real DFT in t -> (b,C,X,Y,T_keep)
+//   k_inv_ty2  c2r step in t on the kept ky, then zero-padded Y-point inverse FFTs (two output steps per transform)
+//                                                                  -> (b,C,X,Y,T_keep)
 //
 // fp32 only (SpectralConv3d is cfloat-only in the reference).
 #include <hip/hip_runtime.h>
@@ -130,118 +131,6 @@ extern "C" size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* p, int batch, in
     const size_t v = al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf));    // truncated input spectrum
     const size_t o = al256((size_t)batch * cout * 2 * p->mx * Q * sizeof(cf));   // truncated output spectrum
     return w + v + o;
-}
-
-// ------------------------------------------------------------------ forward: t DFT + y FFT, pruned
-// block = one (b, c, x) slab; thread = (kt, j): kt-th time mode, lane j of the G-lane Y-point transform.
-template <int Y, int EPT>
-__global__ __launch_bounds__(1024) void k_fwd_ty(const float* __restrict__ v, cf* __restrict__ w1,
-                                                 const cf* __restrict__ tw_y, const cf* __restrict__ tw_tf, int T_in,
-                                                 int t_pad, int mt, int my, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int G = Y / EPT;
-    constexpr bool WG = (G > 64);
-    const int Tp = T_in + t_pad;
-    float* slab = reinterpret_cast<float*>(smem_raw);                            // [Y][T_in]
-    const size_t head = (size_t)Y * T_in * 4 > (size_t)2 * my * mt * sizeof(cf) ? (size_t)Y * T_in * 4
-                                                                                 : (size_t)2 * my * mt * sizeof(cf);
-    cf* ex = reinterpret_cast<cf*>(smem_raw + al16c(head));                       // exchange: mt * lds_elems
-    const int kt = threadIdx.x / G, j = threadIdx.x % G;
-    const size_t slab_elems = (size_t)Y * T_in;
-    const float* src = v + (size_t)blockIdx.x * slab_elems;
-    // the slab is one contiguous, 16-byte aligned run (Y is a multiple of 8): 16-byte loads
-    {
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        float4* d4 = reinterpret_cast<float4*>(slab);
-        for (int i = threadIdx.x; i < (int)(slab_elems / 4); i += blockDim.x) d4[i] = s4[i];
-    }
-    __syncthreads();
-    // real DFT in t for this lane's EPT rows.  With 64 lanes per transform the time mode is wave uniform, so the
-    // twiddles come through the scalar unit straight from the table (no LDS traffic for them).
-    const int kt_u = (G >= 64) ? __builtin_amdgcn_readfirstlane(kt) : kt;
-    const cf* w = tw_tf + (size_t)kt_u * Tp + t_pad;  // the first t_pad samples are the zero padding
-    cf x[EPT];
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) x[t] = mk<float>(0.f, 0.f);
-    for (int s = 0; s < T_in; ++s) {
-        const cf ws = w[s];
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) {
-            const float r = slab[(size_t)(j + t * G) * T_in + s];
-            x[t].x += r * ws.x;
-            x[t].y += r * ws.y;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) x[t] = cscale(x[t], scale);
-    cf* lds = ex + (size_t)kt * lds_elems<Y, EPT, 1, true>();
-    tile_fft<float, Y, EPT, -1, 1, true, WG>(x, lds, tw_y, j, 0);
-    // kept ky of all time modes -> one contiguous (2my, mt) block: stage in LDS, store coalesced
-    __syncthreads();
-    cf* stage = reinterpret_cast<cf*>(slab);  // the slab is dead
-    const int Q = 2 * my * mt;
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) {
-        const int ky = j + t * G;
-        int kyi = -1;
-        if (ky < my) kyi = ky;
-        else if (ky >= Y - my) kyi = ky - (Y - 2 * my);
-        if (kyi >= 0) stage[kyi * mt + kt] = x[t];
-    }
-    __syncthreads();
-    cf* dst = w1 + (size_t)blockIdx.x * Q;
-    for (int i = threadIdx.x; i < Q; i += blockDim.x) dst[i] = stage[i];
-}
-
-// ------------------------------------------------------------------ inverse: y IFFT + t inverse real DFT
-template <int Y, int EPT>
-__global__ __launch_bounds__(1024) void k_inv_ty(const cf* __restrict__ w2, float* __restrict__ out,
-                                                 const cf* __restrict__ tw_y, const cf* __restrict__ tw_ti, int T_out,
-                                                 int t_keep, int mt, int my, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int G = Y / EPT;
-    constexpr bool WG = (G > 64);
-    cf* spec = reinterpret_cast<cf*>(smem_raw);                  // [Y][mt] physical-y, spectral-t
-    cf* twt = spec + (size_t)Y * mt;                             // [T_out][mt]
-    cf* ex = twt + (size_t)T_out * mt;                           // exchange
-    const int kt = threadIdx.x / G, j = threadIdx.x % G;
-    const int Q = 2 * my * mt;
-    const cf* src = w2 + (size_t)blockIdx.x * Q;
-    for (int i = threadIdx.x; i < T_out * mt; i += blockDim.x) twt[i] = tw_ti[i];
-    cf x[EPT];
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) {
-        const int ky = j + t * G;
-        int kyi = -1;
-        if (ky < my) kyi = ky;
-        else if (ky >= Y - my) kyi = ky - (Y - 2 * my);
-        x[t] = kyi >= 0 ? src[kyi * mt + kt] : mk<float>(0.f, 0.f);
-    }
-    cf* lds = ex + (size_t)kt * lds_elems<Y, EPT, 1, true>();
-    tile_fft<float, Y, EPT, +1, 1, true, WG>(x, lds, tw_y, j, 0);
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) spec[(size_t)(j + t * G) * mt + kt] = x[t];
-    __syncthreads();
-    // out[y][t] = scale * sum_k Re( spec[y][k] * twi[t][k] ),   t in the kept tail of [0, T_out)
-    const int t0 = T_out - t_keep;
-    const int total = Y * t_keep;
-    float* oslab = reinterpret_cast<float*>(ex);  // the exchange buffers are free again: reuse as [Y][t_keep]
-    float* dst = out + (size_t)blockIdx.x * total;
-    const bool stage = (size_t)total * 4 <= (size_t)mt * lds_elems<Y, EPT, 1, true>() * sizeof(cf) && (total & 3) == 0;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int y = i / t_keep, tt = i % t_keep;
-        const cf* s = spec + (size_t)y * mt;
-        const cf* w = twt + (size_t)(t0 + tt) * mt;
-        float acc = 0.f;
-        for (int k = 0; k < mt; ++k) acc += s[k].x * w[k].x - s[k].y * w[k].y;
-        if (stage) oslab[i] = acc * scale; else dst[i] = acc * scale;
-    }
-    if (stage) {
-        __syncthreads();
-        const float4* s4 = reinterpret_cast<const float4*>(oslab);
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int i = threadIdx.x; i < total / 4; i += blockDim.x) d4[i] = s4[i];
-    }
 }
 
 // ------------------------------------------------------------------ t/y transforms, packed form
@@ -598,44 +487,6 @@ static int set_lds_attr(K kernel, size_t bytes) {
     return 0;
 }
 
-template <int Y>
-struct TyCfg {
-    static constexpr int EPT = Y >= 256 ? Y / 64 : (Y >= 32 ? 4 : 2);  // 64 lanes per transform when possible
-    static constexpr int G = Y / EPT;
-};
-
-template <int Y>
-static int launch_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float scale, hipStream_t st) {
-    constexpr int EPT = TyCfg<Y>::EPT, G = TyCfg<Y>::G;
-    const size_t lds = al16c(std::max((size_t)Y * p->T_in * 4, (size_t)2 * p->my * p->mt * sizeof(cf))) +
-                       (size_t)p->mt * lds_elems<Y, EPT, 1, true>() * sizeof(cf);
-    if (p->mt * G > 1024) return FAIL(TCFD_EINVAL, "fno: modes_t * %d lanes exceed a workgroup", G);
-    if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T=%d)", Y, p->T_in);
-    auto kern = k_fwd_ty<Y, EPT>;
-    int rc = set_lds_attr(kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)slabs), dim3(p->mt * G), lds, st, v, w1, (const cf*)p->tw_y,
-                       (const cf*)p->tw_tf, p->T_in, p->t_pad, p->mt, p->my, scale);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int Y>
-static int launch_inv_ty(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float scale,
-                         hipStream_t st) {
-    constexpr int EPT = TyCfg<Y>::EPT, G = TyCfg<Y>::G;
-    const size_t lds = ((size_t)Y * p->mt + (size_t)p->T_out * p->mt + (size_t)p->mt * lds_elems<Y, EPT, 1, true>()) * sizeof(cf);
-    if (p->mt * G > 1024) return FAIL(TCFD_EINVAL, "fno: modes_t * %d lanes exceed a workgroup", G);
-    if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T_out=%d)", Y, p->T_out);
-    auto kern = k_inv_ty<Y, EPT>;
-    int rc = set_lds_attr(kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)slabs), dim3(p->mt * G), lds, st, w2, out, (const cf*)p->tw_y,
-                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 template <int X, bool FWD>
 static int launch_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
     constexpr int EPT = X >= 512 ? 16 : (X >= 64 ? 8 : 4);
@@ -725,12 +576,10 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cf* w2, float* out, long
     }
 
 static int do_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float s, hipStream_t st) {
-    if (env_int("TCFD_FNO_TY", 2) == 2) { DISPATCH_POW2(p->Y, (launch_fwd_ty2<N_>(p, v, w1, slabs, s, st))); }
-    DISPATCH_POW2(p->Y, (launch_fwd_ty<N_>(p, v, w1, slabs, s, st)));
+    DISPATCH_POW2(p->Y, (launch_fwd_ty2<N_>(p, v, w1, slabs, s, st)));
 }
 static int do_inv_ty(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float s, hipStream_t st) {
-    if (env_int("TCFD_FNO_TY", 2) == 2) { DISPATCH_POW2(p->Y, (launch_inv_ty2<N_>(p, w2, out, slabs, t_keep, s, st))); }
-    DISPATCH_POW2(p->Y, (launch_inv_ty<N_>(p, w2, out, slabs, t_keep, s, st)));
+    DISPATCH_POW2(p->Y, (launch_inv_ty2<N_>(p, w2, out, slabs, t_keep, s, st)));
 }
 static int do_fwd_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
     DISPATCH_POW2(p->X, (launch_x<N_, true>(p, in, out, bc, st)));
@@ -1283,7 +1132,7 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
 // the hidden units (z1, h, its share of z2, g1 and its share of dx -- the partial sums meet in LDS), one tile of each
 // weight-gradient product on MFMA, and a quarter of the output channels.  One staging region per workgroup instead of per
 // wave: ~4 waves per SIMD, a quarter of the weight reads per wave.  Same partial-sum layout (one row per WORKGROUP).
-template <int CI, int CM, int CO, bool WLDS>
+template <int CI, int CM, int CO>
 __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     using Wm = PwBwdW<CI, CM, CO, true>;
@@ -1310,13 +1159,13 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
     if (a.skip_mode == 1)
         for (int i = threadIdx.x; i < CI * CO; i += blockDim.x) Wl[Wm::WS + (i / CO) * RO + i % CO] = a.wst[i];
     __syncthreads();
-    // WLDS (default): weights from the LDS copy (uniform-address ds_reads).  !WLDS reads them from global memory; inside
-    // the persistent loop the compiler cannot prove them invariant against the kernel's own stores and emits VECTOR loads
-    // instead of s_loads: measured 50.9 vs 34.9 ms per training step -- kept only as a switch (TCFD_PW_BWD_WLDS=0).
-    auto W1row = [&](int m) -> const float* { return WLDS ? Wl + Wm::W1 + m * RI : a.w1 + m * CI; };
-    auto W2row = [&](int m) -> const float* { return WLDS ? Wl + Wm::W2 + m * RO : a.w2t + m * CO; };
-    auto WSrow = [&](int i) -> const float* { return WLDS ? Wl + Wm::WS + i * RO : a.wst + i * CO; };
-    auto B1at = [&](int m) -> float { return WLDS ? Wl[Wm::B1 + m] : (a.b1 ? a.b1[m] : 0.f); };
+    // weights come from the LDS copy (uniform-address ds_reads): read from global memory inside the persistent loop the
+    // compiler cannot prove them invariant against the kernel's own stores and emits VECTOR loads (50.9 vs 34.9 ms per
+    // training step)
+    auto W1row = [&](int m) -> const float* { return Wl + Wm::W1 + m * RI; };
+    auto W2row = [&](int m) -> const float* { return Wl + Wm::W2 + m * RO; };
+    auto WSrow = [&](int i) -> const float* { return Wl + Wm::WS + i * RO; };
+    auto B1at = [&](int m) -> float { return Wl[Wm::B1 + m]; };
     const int kq = lane >> 4, kc = lane & 15;
     f4 accA = f4{0.f, 0.f, 0.f, 0.f}, accB = f4{0.f, 0.f, 0.f, 0.f};
     const long c_first = a.per_sample ? ((long)blockIdx.x % a.batch) * a.chunks_per_batch + blockIdx.x / a.batch : blockIdx.x;
@@ -1506,7 +1355,7 @@ static int launch_pw_bwd4(PwBwdArgs a, int batch, int max_rows, int* dims, hipSt
     a.batch = batch;
     constexpr int RED = CO > CI ? CO : CI;
     const size_t lds = ((size_t)((Wm::TOTAL + 3) & ~3) + (size_t)(Gm::ROWS + 4 * RED) * Gm::PITCH) * sizeof(float);
-    auto kern = env_int("TCFD_PW_BWD_WLDS", 1) ? k_pointwise_bwd4<CI, CM, CO, true> : k_pointwise_bwd4<CI, CM, CO, false>;
+    auto kern = k_pointwise_bwd4<CI, CM, CO>;
     int rc = set_lds_attr(kern, lds);
     if (rc) return rc;
     int per_cu = 0, dev = 0, cus = 256;
