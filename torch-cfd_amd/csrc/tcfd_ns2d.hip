@@ -129,6 +129,7 @@ struct ColArgs {
     int ntiles;
     int batch;
     int load_h;
+    int store_h;   // 0 at the last stage of a step: the accumulator is dead (the next step starts from h = 0)
     int ablate;    // timing ablations (TCFD_ABLATE bit mask; results are WRONG when non-zero): 1 skip the
                    // transforms, 2 skip the plane stores, 4 skip the table reads, 8 skip the h traffic
     int pair_xcd;  // block->tile map: 0 = batch fastest; 1 = adjacent half-line tiles paired on one XCD
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     const bool h_live = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[sl] != (T)0));
                     if (h_live) {
                         if (a.load_h) hn = hn + cscale(a.h[gw], a.beta);
-                        a.h[gw] = hn;
+                        if (a.store_h) a.h[gw] = hn;
                     }
                     const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[sl] + lc : a.lin[(size_t)i * a.m + jc]);
                     const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
@@ -1262,6 +1263,7 @@ static int step_overlap_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_
         h.a.fa = fa ? (T)fa[k] : (T)1;
         h.a.mud = mud ? (T)mud[k] : (T)mu[k];
         h.a.load_h = (k != 0);
+        h.a.store_h = (k != nstages - 1);
         h.a.dwdt = last ? h.dwdt : nullptr;
         h.a.w0 = h.w_in;
         h.a.dwdt_scale = (T)inv_total_dt;
@@ -1342,6 +1344,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.fa = fa ? (T)fa[k] : (T)1;
             a.mud = mud ? (T)mud[k] : (T)mu[k];
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
+            a.store_h = (k != nstages - 1);
             a.dwdt = last ? (cx<T>*)dwdt : nullptr;
             a.w0 = (const cx<T>*)w_in;
             a.dwdt_scale = (T)inv_total_dt;
