@@ -48,10 +48,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     deps.append(os.path.join(INCLUDE, "tcfd.h"))
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(d) for d in deps)
-        if os.path.getmtime(LIB_PATH) >= newest:
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+
+    if not force and fresh():
+        return LIB_PATH
+    # several ranks of one node may get here at once (torch.distributed.run): one builds, the others wait for it
+    import fcntl
+
+    lock = open(os.path.join(CSRC, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and fresh():
             return LIB_PATH
+        return _build_locked(srcs, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(srcs, verbose):
     objs = []
     procs = []
     for s in srcs:
@@ -65,11 +81,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise TcfdError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH,
-            "-Wl,-rpath,/opt/rocm/lib"]
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp, "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise TcfdError("link failed: %s\n%s" % (" ".join(link), r.stdout.decode(errors="replace")))
+    os.replace(tmp, LIB_PATH)   # atomic: a process that already mapped the old file keeps a consistent image
     return LIB_PATH
 
 
