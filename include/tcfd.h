@@ -15,8 +15,17 @@
  *     allocator in practice); the library owns only what a plan holds
  *     (twiddle tables, wavenumbers, linear/mask/forcing tables).
  *   - every call is asynchronous on the given stream; no internal sync.
- *   - a plan is immutable after creation and may be shared by streams; calls
- *     that share a workspace must be stream-ordered by the caller.
+ *   - a plan's TABLES are immutable after creation.  A plan may be used from several
+ *     streams and host threads as long as every concurrent call has its own
+ *     workspace (calls that share a workspace must be stream-ordered by the
+ *     caller): the only mutable plan state -- the captured hipGraph of the
+ *     multi-step calls on small grids, its plan-owned stream / fence events, and
+ *     the two-stream TCFD_OVERLAP experiment -- is guarded by a mutex inside the
+ *     plan, so such calls are ENQUEUED one after the other (they still run
+ *     asynchronously).  tcfd_ns2d_profile_begin/end is a single-threaded debugging
+ *     aid and is not covered.  Distinct plans are fully independent.
+ *   - tuning switches (TCFD_* environment variables) are read once,
+ *     at plan creation, and frozen in the plan.
  *   - complex data are interleaved (re, im) pairs of the plan's real type,
  *     half spectra are (batch, n, m) row-major with m = n/2 + 1, n = 2^k,
  *     8 <= n <= 2048.
@@ -64,6 +73,10 @@ void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* plan);
  * instead of (n, m) tables), sparse forcing (CSC list), and keep_cols > 0 when F and the RK
  * accumulator are identically zero outside the 2/3-rule mask so those entries are never stored. */
 int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* plan, int* separable, int* sparse_forcing, int* keep_cols);
+
+/* Which kernel variants the plan launches: split = 1 when the column transform is cut radix-2 across the
+ * row pass; rows_kernel = 6 (LDS-DMA staged row pass), 5 (register staged) or 4 (round-1 kernel). */
+int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* plan, int* split, int* rows_kernel);
 
 /* Bytes of caller-owned scratch needed by the calls below for `batch` fields. */
 size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* plan, long batch);

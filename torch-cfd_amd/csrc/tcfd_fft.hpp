@@ -103,18 +103,30 @@ struct Dft<1, DIR, T> {
 };
 
 // ---- synchronisation flavour of one transform group -------------------------
-// WGSYNC: lanes of a group span several waves -> workgroup barrier.
-// otherwise the group lives inside one wave: LDS is in-order per wave, so only
-// the compiler has to be kept from reordering the exchange.
-template <bool WGSYNC>
+// SYNC = 1: lanes of a group span several waves -> workgroup barrier (__syncthreads).
+// SYNC = 0: the group lives inside one wave: LDS is in-order per wave, so only
+//           the compiler has to be kept from reordering the exchange.
+// SYNC = 2: workgroup barrier WITHOUT the release/acquire fence of __syncthreads: only the LDS
+//           queue is drained (lgkmcnt).  hipcc puts `s_waitcnt vmcnt(0)` in front of a fenced
+//           barrier, which would drain LDS-DMA loads (global_load_lds) that are meant to stay in
+//           flight across the exchanges of a transform (row kernel v6).
+template <int SYNC>
 __device__ __forceinline__ void group_sync() {
-    if constexpr (WGSYNC) {
+    if constexpr (SYNC == 1) {
         __syncthreads();
+    } else if constexpr (SYNC == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// called once by tile_fft after the FIRST exchange barrier of a transform (every lane of the group has then
+// consumed whatever the input registers were built from); default: nothing
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
 
 template <int EPT, int C, bool PAD>
 __device__ __forceinline__ int lds_addr(int e, int c) {
@@ -138,51 +150,142 @@ __device__ __forceinline__ cx<T> ldtw(const cx<T>* __restrict__ tw, int idx) {
     return w;
 }
 
-template <typename T, int N, int EPT, int DIR, int C, bool PAD, bool WGSYNC, int Ns>
+// TWSQ = 1: ONE twiddle load per pass and lane; the powers W^(2 base), W^(4 base) ... come from squaring it and the
+// sub-butterflies s > 0 of a short last pass from a constant rotation of the s = 0 twiddle (a few ulp of extra
+// round-off in the twiddles for 7 -> 3 table reads per 1024-point transform; the loads are what a compiler hoists
+// out of a loop over transforms and then has to keep in registers: 36 -> 12 VGPRs in fp64).
+// `jt` is the lane index used for the twiddle INDEX only (callers may pass an asm-opaque copy of it as `j` so that
+// the address arithmetic is redone per transform while the twiddle loads stay loop-invariant).
+template <typename T>
+__device__ __forceinline__ cx<T> csquare(cx<T> w) { return mk<T>((w.x - w.y) * (w.x + w.y), (T)2 * w.x * w.y); }
+
+// TWSQ = 2: as 1, but the per-pass twiddles are not loaded at all: the caller read them once (load_pass_tw, forward
+// sign) into `trg[P]`, P = index of the pass among those with a twiddle.  This is what keeps them in registers
+// across a loop whose body contains `asm volatile(... : "memory")` statements (loads cannot be hoisted over those).
+template <typename T, int N, int EPT, int Ns = 1, int P = 0>
+__device__ __forceinline__ void load_pass_tw(cx<T>* trg, const cx<T>* __restrict__ tw, int jt) {
+    constexpr int REM = N / Ns;
+    constexpr int R = REM >= EPT ? EPT : REM;
+    if constexpr (Ns > 1) trg[P] = tw[(jt & (Ns - 1)) * (N / (Ns * R))];
+    if constexpr (Ns * R < N) load_pass_tw<T, N, EPT, Ns * R, (Ns > 1 ? P + 1 : P)>(trg, tw, jt);
+}
+template <int N, int EPT, int Ns = 1>
+constexpr int pass_tw_count() {
+    constexpr int REM = N / Ns;
+    constexpr int R = REM >= EPT ? EPT : REM;
+    if constexpr (Ns * R < N) return (Ns > 1 ? 1 : 0) + pass_tw_count<N, EPT, Ns * R>();
+    else return (Ns > 1 ? 1 : 0);
+}
+// every pass with a twiddle needs only its s = 0 entry (Q == 1 or the constant-rotation chain applies)
+template <int N, int EPT, int Ns = 1>
+constexpr bool pass_tw_single() {
+    constexpr int REM = N / Ns;
+    constexpr int R = REM >= EPT ? EPT : REM;
+    constexpr int Q = EPT / R;
+    constexpr int G = N / EPT;
+    constexpr bool ok = (Ns == 1) || (Q == 1) ||
+                        ((Q * G <= Ns) && ((16 * G) % (Ns * R) == 0) && ((Q - 1) * ((16 * G) / (Ns * R)) < 8));
+    if constexpr (Ns * R < N) return ok && pass_tw_single<N, EPT, Ns * R>();
+    else return ok;
+}
+
+template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC, int Ns, typename Hook = NoHook, int TWSQ = 0,
+          int P = 0>
 struct Passes {
     static constexpr int REM = N / Ns;
     static constexpr int R = REM >= EPT ? EPT : REM;
     static constexpr int Q = EPT / R;
     static constexpr int G = N / EPT;
     static constexpr bool LAST = (Ns * R == N);
+    // sub-butterfly s of a pass with Q > 1: k_s = k_0 + s G when nothing wraps, i.e. the twiddle is the s = 0 one
+    // turned by s * G * N / (Ns R) table steps; usable when that is a whole number of sixteenths of a turn
+    static constexpr bool CHAIN = TWSQ && Q > 1 && (Q * G <= Ns) && ((16 * G) % (Ns * R) == 0) &&
+                                  ((Q - 1) * ((16 * G) / (Ns * R)) < 8);
+    static constexpr int STEP16 = CHAIN ? (16 * G) / (Ns * R) : 0;
+
+    template <int S>
+    static __device__ __forceinline__ cx<T> chain_tw(cx<T> w0) {
+        return rot<16, (S * STEP16) % 8, DIR, T>(w0);
+    }
 
     static __device__ __forceinline__ void run(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw,
-                                               int j, int c) {
+                                               int j, int c, Hook& hook, int jt, const cx<T>* trg = nullptr) {
+        if constexpr (Ns == 1 && LAST) hook();   // single-pass transform: no exchange at all
+        cx<T> w_first = mk<T>((T)1, (T)0);
+        if constexpr (TWSQ == 2 && Ns > 1) {
+            w_first = trg[P];
+            if constexpr (DIR > 0) w_first.y = -w_first.y;
+        }
+        run_s<0>(x, lds, tw, j, c, jt, w_first);
+        if constexpr (!LAST) {
+            group_sync<WGSYNC>();
+            if constexpr (Ns == 1) hook();
+            if constexpr (PAD && C == 1 && G % (EPT * EPT) == 0) {
+                // the swizzle term ((e / EPT) % EPT) is the same for e = j + t G: one address, constant offsets
+                const cx<T>* src = lds + lds_addr<EPT, 1, true>(j, 0);
 #pragma unroll
-        for (int s = 0; s < Q; ++s) {
-            const int jb = j + s * G;
+                for (int t = 0; t < EPT; ++t) x[t] = src[t * G];
+            } else {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) x[t] = lds[lds_addr<EPT, C, PAD>(j + t * G, c)];
+            }
+            group_sync<WGSYNC>();
+            Passes<T, N, EPT, DIR, C, PAD, WGSYNC, Ns * R, Hook, TWSQ, (Ns > 1 ? P + 1 : P)>::run(x, lds, tw, j, c, hook, jt,
+                                                                                                  trg);
+        }
+    }
+
+    template <int S>
+    static __device__ __forceinline__ void run_s(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw, int j,
+                                                 int c, int jt, cx<T>& w_first) {
+        if constexpr (S < Q) {
+            const int jb = j + S * G;
             const int k = jb & (Ns - 1);
             cx<T> v[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = x[s + Q * r];
+            for (int r = 0; r < R; ++r) v[r] = x[S + Q * r];
             if constexpr (Ns > 1) {
-                // v[r] *= W^(r*base): only the log2(R) powers W^(base*2^b) are loaded; every v[r]
+                // v[r] *= W^(r*base): only the log2(R) powers W^(base*2^b) are needed; every v[r]
                 // is multiplied by the ones whose bit is set in r (keeps 1 twiddle live instead of R)
-                const int base = k * (N / (Ns * R));
+                const int base = ((jt + S * G) & (Ns - 1)) * (N / (Ns * R));
+                if constexpr (TWSQ) {
+                    cx<T> w;
+                    if constexpr (CHAIN && S > 0) {
+                        w = chain_tw<S>(w_first);
+                    } else if constexpr (TWSQ == 2) {
+                        static_assert(S == 0, "register twiddles: every pass must need its s = 0 entry only");
+                        w = w_first;
+                    } else {
+                        w = ldtw<DIR, T>(tw, base);
+                        if constexpr (S == 0) w_first = w;
+                    }
 #pragma unroll
-                for (int bit = 1; bit < R; bit <<= 1) {
-                    const cx<T> w = ldtw<DIR, T>(tw, base * bit);
+                    for (int bit = 1; bit < R; bit <<= 1) {
 #pragma unroll
-                    for (int r = 1; r < R; ++r)
-                        if (r & bit) v[r] = cmul(v[r], w);
+                        for (int r = 1; r < R; ++r)
+                            if (r & bit) v[r] = cmul(v[r], w);
+                        if (2 * bit < R) w = csquare(w);
+                    }
+                } else {
+#pragma unroll
+                    for (int bit = 1; bit < R; bit <<= 1) {
+                        const cx<T> w = ldtw<DIR, T>(tw, base * bit);
+#pragma unroll
+                        for (int r = 1; r < R; ++r)
+                            if (r & bit) v[r] = cmul(v[r], w);
+                    }
                 }
             }
             Dft<R, DIR, T>::run(v);
             if constexpr (LAST) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) x[s + Q * r] = v[r];
+                for (int r = 0; r < R; ++r) x[S + Q * r] = v[r];
             } else {
                 const int o = (jb - k) * R + k;
 #pragma unroll
                 for (int r = 0; r < R; ++r) lds[lds_addr<EPT, C, PAD>(o + r * Ns, c)] = v[r];
             }
-        }
-        if constexpr (!LAST) {
-            group_sync<WGSYNC>();
-#pragma unroll
-            for (int t = 0; t < EPT; ++t) x[t] = lds[lds_addr<EPT, C, PAD>(j + t * G, c)];
-            group_sync<WGSYNC>();
-            Passes<T, N, EPT, DIR, C, PAD, WGSYNC, Ns * R>::run(x, lds, tw, j, c);
+            run_s<S + 1>(x, lds, tw, j, c, jt, w_first);
         }
     }
 };
@@ -191,9 +294,46 @@ struct Passes {
 // x[t] in lane j of the group; result in the same distribution.  `lds` is the
 // group's exchange buffer (lds_elems<N,EPT,C,PAD>() elements, shared by the C
 // transforms of a tile).  The buffer is free again when the call returns.
-template <typename T, int N, int EPT, int DIR, int C, bool PAD, bool WGSYNC>
+template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC>
 __device__ __forceinline__ void tile_fft(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw, int j, int c) {
-    Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1>::run(x, lds, tw, j, c);
+    NoHook hook;
+    Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, NoHook, 0>::run(x, lds, tw, j, c, hook, j);
+}
+template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC, typename Hook>
+__device__ __forceinline__ void tile_fft(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw, int j, int c,
+                                         Hook& hook) {
+    Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, Hook, 0>::run(x, lds, tw, j, c, hook, j);
+}
+// squared-twiddle form with the per-pass twiddles handed over in registers (see Passes, TWSQ = 2)
+template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC, typename Hook>
+__device__ __forceinline__ void tile_fft_rt(cx<T> (&x)[EPT], cx<T>* lds, int j, int c, Hook& hook, const cx<T>* trg) {
+    static_assert(pass_tw_single<N, EPT>(), "register twiddles need one table entry per pass");
+    Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, Hook, 2>::run(x, lds, nullptr, j, c, hook, j, trg);
+}
+// squared-twiddle form with a separate lane index for the twiddle table (see Passes)
+template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC, typename Hook>
+__device__ __forceinline__ void tile_fft_sq(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw, int j, int c,
+                                            Hook& hook, int jt) {
+    Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, Hook, 1>::run(x, lds, tw, j, c, hook, jt);
+}
+
+// ---- LDS-DMA (global -> LDS without a register round trip) ---------------------------------
+// One wave-instruction moves 64 x 16 bytes: lane l's 16 bytes at `gsrc` (per-lane address) land at LDS byte
+// address lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  The load is invisible to hipcc's s_waitcnt
+// bookkeeping: the consumer waits with wait_vmem_all() itself.  M0 is compiler-reserved: saved and restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);   // provably uniform for the "s" constraint
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS byte address of a pointer into shared memory, as a wave-uniform scalar
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
+    const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)a);
 }
 
 }  // namespace tcfd

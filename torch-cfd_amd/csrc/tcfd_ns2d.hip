@@ -11,12 +11,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 #include "../../include/tcfd.h"
@@ -689,6 +691,300 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
     }
 }
 
+// ---- row pass, one plane per transform ("v5") --------------------------------------------------
+// The kernels above ride two PLANES of one row through a complex transform, so the transformed velocity rows
+// of BOTH rows of a pair stay live while the gradient planes are transformed (z1r, z1s, x, p + two half quads:
+// 256 VGPR + 84 AGPR, one wave per SIMD at 1024^2 fp64).  Here the two ROWS of a pair ride through one transform
+// of ONE plane:  Z = P(row a) + i P(row b)  ->  real part = field on row a, imaginary part = field on row b, and
+//     p.x = -(vx_a dxw_a + vy_a dyw_a),  p.y = -(vx_b dxw_b + vy_b dyw_b)
+// accumulates plane by plane (order u^, dx w^, v^, dy w^): one kept transform + the working one + the product +
+// the next plane's half rows in flight -- half the live state, same loads / stores / transform count.
+// SP = 0: rows (2p, 2p+1).  SP = 1 (split column plans): rows (r, r + N/2), built from the E / O half-length column
+// transforms as  a = E + w O,  b = E - w O,  w = exp(+2 pi i r / N), and stored folded (S, D) as in k_rows_advect4.
+template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int OPQ = 0, int TWQ = 0>
+__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_rows_advect5(
+    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
+    long npairs, int ld, int kc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT, THR>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    constexpr int N2 = N / 2;
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    const long stride = (long)gridDim.x * Gm::GROUPS;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const long iters = (npairs + stride - 1) / stride;
+    // first row of pair p; the second row sits `second` elements further
+    auto row_a = [&](long p) -> size_t {
+        return SP ? (size_t)((p / N2) * N + (p % N2)) * (size_t)ld : (size_t)p * 2 * (size_t)ld;
+    };
+    const size_t second = SP ? (size_t)N2 * ld : (size_t)ld;
+
+    // PF = 1: half rows (a, b) -- or (E, O) -- of the plane whose turn is NEXT, in flight during the current transform;
+    // PF = 0: loaded right before use (fewer live registers: occupancy hides the latency instead)
+    RawPair<T, EPT> H;
+    if constexpr (PF) {
+        const size_t off = row_a(pair < npairs ? pair : npairs - 1);
+        load_raw<T, N, EPT>(H, planes + off, planes + off + second, j);
+    }
+    for (long it = 0; it < iters; ++it, pair += stride) {
+        const bool valid = pair < npairs;
+        const long cur = valid ? pair : npairs - 1;
+        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
+        const size_t off = row_a(cur), offn = row_a(nxt);
+        cx<T> wf = mk<T>((T)1, (T)0), wi = wf;
+        if constexpr (SP) {
+            wf = tw[(int)(cur % N2)];   // exp(-2 pi i r / N)
+            wi = cconj(wf);
+        }
+        cx<T> za[EPT], x[EPT], p[EPT];
+        // H -> Hermitian-packed sequence -> transform; the next plane's loads are issued in between
+        auto field = [&](cx<T>(&out)[EPT], const cx<T>* thisA, const cx<T>* nextA) {
+            if constexpr (!PF) load_raw<T, N, EPT>(H, thisA, thisA + second, j);
+            if constexpr (SP) {
+#pragma unroll
+                for (int t = 0; t < EPT / 2; ++t) {
+                    const cx<T> o = cmul(H.b[t], wi);
+                    H.b[t] = H.a[t] - o;
+                    H.a[t] = H.a[t] + o;
+                }
+                const cx<T> o = cmul(H.bn, wi);
+                H.bn = H.an - o;
+                H.an = H.an + o;
+            }
+            int jo = j;
+            if constexpr (OPQ) asm volatile("" : "+v"(jo));   // address arithmetic per transform, not ~40 loop-invariant registers
+            pack_herm<T, N, EPT, WG>(out, H, lds, jo);
+            if constexpr (PF) load_raw<T, N, EPT>(H, nextA, nextA + second, j);
+            if constexpr (TWQ) {
+                NoHook nohook;
+                tile_fft_sq<T, N, EPT, +1, 1, true, WG>(out, lds, tw, jo, 0, nohook, j);
+            } else {
+                tile_fft<T, N, EPT, +1, 1, true, WG>(out, lds, tw, jo, 0);
+            }
+        };
+        const cx<T>* P0 = planes + off;
+        const cx<T>* P1 = planes + plane_stride + off;
+        const cx<T>* P2 = planes + 2 * plane_stride + off;
+        const cx<T>* P3 = planes + 3 * plane_stride + off;
+        field(za, P0, P2);   // vx   (next: dx w)
+        field(x, P2, P1);    // dx w (next: v^)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(za[t].x * x[t].x, za[t].y * x[t].y);
+        field(za, P1, P3);               // vy   (next: dy w)
+        field(x, P3, planes + offn);     // dy w (next: u^ of the next pair)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(-(p[t].x + za[t].x * x[t].x), -(p[t].y + za[t].y * x[t].y));
+
+        int jf = j;
+        if constexpr (OPQ) asm volatile("" : "+v"(jf));
+        if constexpr (TWQ) {
+            NoHook nohook;
+            tile_fft_sq<T, N, EPT, -1, 1, true, WG>(p, lds, tw, jf, 0, nohook, j);
+        } else {
+            tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, jf, 0);
+        }
+        if constexpr (SP) {
+            // unpack the two real-row spectra and fold them for the parity workgroups of the column pass
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(jf + t * G, 0)] = p[t];
+            group_sync<WG>();
+            const T half = (T)0.5;
+            cx<T>* outS = adv + off;
+            cx<T>* outD = adv + off + second;
+#pragma unroll
+            for (int t = 0; t < EPT / 2; ++t) {
+                const int k = jf + t * G;
+                const cx<T> A = p[t];
+                const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
+                const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of row r
+                const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of row r + N/2
+                if (valid && k < kc) {
+                    outS[k] = X0 + X1;
+                    outD[k] = cmul(X0 - X1, wf);
+                }
+            }
+            if (jf == 0 && valid && N / 2 < kc) {
+                const cx<T> A = p[EPT / 2];
+                const cx<T> X0 = mk<T>(A.x, (T)0), X1 = mk<T>(A.y, (T)0);
+                outS[N / 2] = X0 + X1;
+                outD[N / 2] = cmul(X0 - X1, wf);
+            }
+            group_sync<WG>();
+        } else {
+            unpack_store_pair<T, N, EPT>(p, lds, adv + off, adv + off + second, jf, valid, kc);
+        }
+    }
+}
+
+// ---- row pass, LDS-DMA staged ("v6") -------------------------------------------------------------
+// v5 with the HBM side taken off the register file: the two half rows of the NEXT plane are copied HBM -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no VGPRs, 1 KB per wave-instruction) while the current plane is transformed,
+// and stay in flight across the exchange barriers of the transform (raw barriers, see group_sync<2>).  The packed
+// Hermitian sequence is then read straight from the staged rows -- the mirrored half from the mirrored LDS
+// address -- so the mirror exchange of pack_herm (one half-row of LDS stores per transform) is gone as well.
+// Per group: the transform's exchange buffer (N elements) + one staging buffer (2 x (N/2 + 2) elements).
+// Needs whole-wave groups whose half rows are a whole number of 1 KB pieces per wave.
+template <typename T, int N, int EPT, int THR>
+struct RowGeom6 {
+    static constexpr int G = N / EPT;
+    static constexpr int THREADS = G >= THR ? G : THR;
+    static constexpr int GROUPS = THREADS / G;
+    static constexpr int WAVES = G / 64;                          // waves per group
+    static constexpr int ROWB = (N / 2) * (int)sizeof(cx<T>);     // bytes of a half row without its Nyquist element
+    static constexpr int PIECES = ROWB / 1024;                    // LDS-DMA pieces per half row
+    static constexpr int SROW = N / 2 + 2;                        // staging pitch in elements (row + Nyquist + pad)
+    // exchange buffer (N elements + one: element N holds a copy of element 0 for the mirrored reads of the unpack)
+    static constexpr int XBUF = N + 2;
+    static constexpr size_t GROUP_BYTES = (size_t)(XBUF + 2 * SROW) * sizeof(cx<T>);
+    static constexpr size_t LDS_BYTES = GROUP_BYTES * GROUPS;
+    static constexpr bool OK = (G % 64 == 0) && (ROWB % (1024 * (WAVES > 0 ? WAVES : 1)) == 0) && pass_tw_single<N, EPT>();
+};
+
+template <typename T, int N, int EPT, int THR, int SP, int MINW>
+__global__ __launch_bounds__((RowGeom6<T, N, EPT, THR>::THREADS), MINW) void k_rows_advect6(
+    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
+    long npairs, int ld, int kc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom6<T, N, EPT, THR>;
+    static_assert(Gm::OK, "v6 needs whole-wave groups and half rows that split into 1 KB pieces per wave");
+    constexpr int G = Gm::G;
+    constexpr int SYNC = Gm::WAVES > 1 ? 2 : 0;
+    constexpr int N2 = N / 2;
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    const int wv = j / 64, lane = j % 64;
+    // Twiddles: a global load INSIDE the pair loop would make hipcc wait for vmcnt(0) at its use -- and with it for
+    // the staged rows that are meant to stay in flight.  The squared-twiddle transform needs ONE table entry per
+    // pass and lane: they are read here, once, and live in registers (3 entries = 12 VGPRs at 1024 points fp64);
+    // the address arithmetic of the transforms uses an asm-opaque copy of j (below) and is redone per transform.
+    unsigned char* gbase = smem_raw + (size_t)grp * Gm::GROUP_BYTES;
+    constexpr int NTW = pass_tw_count<N, EPT>() > 0 ? pass_tw_count<N, EPT>() : 1;
+    cx<T> trg[NTW];
+    load_pass_tw<T, N, EPT>(trg, tw, j);
+    cx<T>* lds = reinterpret_cast<cx<T>*>(gbase);          // exchange buffer of the transforms
+    cx<T>* SA = lds + Gm::XBUF;                            // staged half row a (or E)
+    cx<T>* SB = SA + Gm::SROW;                             // staged half row b (or O)
+    const unsigned sa_addr = lds_byte_address(SA), sb_addr = lds_byte_address(SB);
+    const long stride = (long)gridDim.x * Gm::GROUPS;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const long iters = (npairs + stride - 1) / stride;
+    auto row_a = [&](long p) -> size_t {
+        return SP ? (size_t)((p / N2) * N + (p % N2)) * (size_t)ld : (size_t)p * 2 * (size_t)ld;
+    };
+    const size_t second = SP ? (size_t)N2 * ld : (size_t)ld;
+
+    auto stage = [&](const cx<T>* rowA) {
+        const unsigned char* ga = reinterpret_cast<const unsigned char*>(rowA) + lane * 16;
+        const unsigned char* gb = reinterpret_cast<const unsigned char*>(rowA + second) + lane * 16;
+#pragma unroll
+        for (int c = 0; c < Gm::PIECES / Gm::WAVES; ++c) {
+            const int piece = c * Gm::WAVES + wv;
+            glds16(ga + piece * 1024, sa_addr + piece * 1024);
+            glds16(gb + piece * 1024, sb_addr + piece * 1024);
+        }
+        if (j == 0) {   // the Nyquist elements: one 16-byte piece each (fp32: element N/2 and one element of row padding)
+            glds16(rowA + N2, sa_addr + N2 * (unsigned)sizeof(cx<T>));
+            glds16(rowA + second + N2, sb_addr + N2 * (unsigned)sizeof(cx<T>));
+        }
+    };
+    stage(planes + row_a(pair < npairs ? pair : npairs - 1));
+
+    for (long it = 0; it < iters; ++it, pair += stride) {
+        const bool valid = pair < npairs;
+        const long cur = valid ? pair : npairs - 1;
+        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
+        const size_t off = row_a(cur), offn = row_a(nxt);
+        cx<T> wf = mk<T>((T)1, (T)0), wi = wf;
+        if constexpr (SP) {
+            wf = tw[(int)(cur % N2)];   // exp(-2 pi i r / N)
+            wi = cconj(wf);
+        }
+        cx<T> za[EPT], x[EPT], p[EPT];
+        // staged rows -> Hermitian-packed sequence Z = A~ + i B~ -> transform; the next plane is staged as soon as
+        // every lane of the group is past its reads (first exchange barrier of the transform)
+        auto field = [&](cx<T>(&out)[EPT], const cx<T>* nextA) {
+            wait_vmem_all();                               // this wave's pieces have landed
+            group_sync<SYNC>();                            // ... and the other waves' pieces
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) {
+                const int e = j + t * G;
+                const bool lower = t < EPT / 2;            // e < N/2: own element, else the mirror image of N - e
+                const int k = lower ? e : N - e;
+                cx<T> a = SA[k], b = SB[k];
+                if constexpr (SP) {
+                    const cx<T> o = cmul(b, wi);
+                    b = a - o;
+                    a = a + o;
+                }
+                if (k == 0 || k == N2) { a.y = 0; b.y = 0; }   // c2r drops Im of DC / Nyquist
+                out[t] = lower ? mk<T>(a.x - b.y, a.y + b.x) : mk<T>(a.x + b.y, b.x - a.y);
+            }
+            auto hook = [&]() { stage(nextA); };
+            int jo = j;
+            asm volatile("" : "+v"(jo));   // per-transform address arithmetic instead of ~40 loop-invariant address registers
+            tile_fft_rt<T, N, EPT, +1, 1, true, SYNC>(out, lds, jo, 0, hook, trg);
+        };
+        field(za, planes + 2 * plane_stride + off);   // vx   (next: dx w)
+        field(x, planes + plane_stride + off);        // dx w (next: v^)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(za[t].x * x[t].x, za[t].y * x[t].y);
+        field(za, planes + 3 * plane_stride + off);   // vy   (next: dy w)
+        field(x, planes + offn);                      // dy w (next: u^ of the next pair)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(-(p[t].x + za[t].x * x[t].x), -(p[t].y + za[t].y * x[t].y));
+
+        int jf = j;
+        asm volatile("" : "+v"(jf));   // as in field(): keep the address arithmetic inside the iteration
+        NoHook nohook;
+        tile_fft_rt<T, N, EPT, -1, 1, true, SYNC>(p, lds, jf, 0, nohook, trg);
+        // unpack the two real-row spectra (mirror through the exchange buffer; element N = element 0, so that the
+        // mirrored index N - k needs no wrap-around and, the swizzle term being the same for every t, ONE address)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(jf + t * G, 0)] = p[t];
+        if (jf == 0) lds[N] = p[0];
+        group_sync<SYNC>();
+        const T half = (T)0.5;
+        cx<T>* out0 = adv + off;
+        cx<T>* out1 = adv + off + second;
+        const cx<T>* mir = lds + lds_addr<EPT, 1, true>(N - jf, 0);
+#pragma unroll
+        for (int t = 0; t < EPT / 2; ++t) {
+            const int k = jf + t * G;
+            const cx<T> A = p[t];
+            cx<T> Bm;
+            if constexpr (G % (EPT * EPT) == 0) Bm = mir[-t * G];
+            else Bm = lds[lds_addr<EPT, 1, true>(N - k, 0)];
+            const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of the first row
+            const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of the second row
+            if (valid && k < kc) {
+                if constexpr (SP) {   // folded for the parity workgroups of the column pass
+                    out0[k] = X0 + X1;
+                    out1[k] = cmul(X0 - X1, wf);
+                } else {
+                    out0[k] = X0;
+                    out1[k] = X1;
+                }
+            }
+        }
+        if (jf == 0 && valid && N2 < kc) {
+            const cx<T> A = p[EPT / 2];
+            const cx<T> X0 = mk<T>(A.x, (T)0), X1 = mk<T>(A.y, (T)0);
+            if constexpr (SP) {
+                out0[N2] = X0 + X1;
+                out1[N2] = cmul(X0 - X1, wf);
+            } else {
+                out0[N2] = X0;
+                out1[N2] = X1;
+            }
+        }
+        group_sync<SYNC>();
+    }
+    wait_vmem_all();   // the last iteration staged one more plane: nothing may be in flight into LDS at wave end
+}
+
 // real (rows, N) -> half spectrum (rows, m): first half of rfft2
 template <typename T, int N, int EPT>
 __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_r2c(const T* __restrict__ in,
@@ -793,7 +1089,23 @@ struct GraphState {
     std::vector<double> coef;
 };
 
+// Tuning switches (environment, read ONCE at plan creation and frozen in the plan: two plans of one process may
+// differ, a plan never changes its kernels behind the caller's back).  -1 = automatic.
+struct Tuning {
+    int split;               // TCFD_SPLIT: radix-2 split of the column transform across the row pass
+    int small_tiles;         // TCFD_SMALL_TILES: 4-column tiles / 64-lane row groups for small problems
+    int two_wg;              // TCFD_TWO_WG: 128-VGPR cap (two workgroups per CU) for the 512-point fp64 column tiles
+    int rows_blocks_per_cu;  // TCFD_ROWS_BLOCKS_PER_CU: persistent row-pass grid
+    int pair_xcd;            // TCFD_PAIR_XCD: pair the two half-line tiles of a 128-byte line on one XCD
+    int ablate;              // TCFD_ABLATE: timing ablations (results are WRONG when non-zero)
+    int rows_v;              // TCFD_ROWS_V: 0 = per size; 6 = LDS-DMA staged rows, 5 = register-staged rows (one plane per
+                             // transform), 4 = two planes per transform (round 1)
+    int rows_minw;           // TCFD_ROWS_MINW: waves/SIMD the row kernel is compiled for (register cap), 0 = per size
+};
+
 struct tcfd_ns2d_plan {
+    Tuning tune;
+    std::mutex mu;    // guards the mutable side-cars below (the tables are immutable after creation)
     ProfState* prof;  // mutable side-car (tcfd_ns2d_profile_begin/end); null until first use
     GraphState* gs;   // mutable side-car: captured interior step (null until first use)
     int n, m, dtype;
@@ -957,11 +1269,18 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
     if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048]", n);
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "plan_create: bad dtype %d", dtype);
-    tcfd_ns2d_plan* p = new tcfd_ns2d_plan();
-    memset(p, 0, sizeof(*p));
+    tcfd_ns2d_plan* p = new tcfd_ns2d_plan();   // value-initialised: every pointer / flag starts at zero
     p->n = n;
     p->m = n / 2 + 1;
     p->dtype = dtype;
+    p->tune.split = env_int("TCFD_SPLIT", -1);
+    p->tune.small_tiles = env_int("TCFD_SMALL_TILES", -1);
+    p->tune.two_wg = env_int("TCFD_TWO_WG", 1);
+    p->tune.rows_blocks_per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 0);
+    p->tune.pair_xcd = env_int("TCFD_PAIR_XCD", 1);
+    p->tune.ablate = env_int("TCFD_ABLATE", 0);
+    p->tune.rows_v = env_int("TCFD_ROWS_V", 0);
+    p->tune.rows_minw = env_int("TCFD_ROWS_MINW", 0);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
         p->ldw = (p->m + per_line - 1) / per_line * per_line;
@@ -1016,11 +1335,20 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------ launch helpers
+// Dynamic LDS above 64 KB needs a function attribute, and the attribute belongs to the function instance of ONE device:
+// it is set once per (kernel, device), tracked by a bit mask at the launch site (one process may drive several GPUs
+// from several host threads).
+struct DevOnce { std::atomic<unsigned long long> mask{0}; };
 template <typename K>
-static int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes));
+static int set_lds(DevOnce& once, K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (once.mask.load(std::memory_order_acquire) & bit) return 0;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes));
+    once.mask.fetch_or(bit, std::memory_order_release);
     return 0;
 }
 
@@ -1051,16 +1379,11 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.keep_cols = p->keep_cols;
     a.tw = (const cx<T>*)(SP ? p->tw2 : p->tw);
     auto kern = k_cols<T, N, EPT, C, MODE, MINW, SP>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = set_lds(kern, lds);
-        if (rc) return rc;
-        attr_done = true;
-    }
+    static DevOnce lds_once;
+    if (int rc_ = set_lds(lds_once, kern, lds)) return rc_;
     long blocks = batch * a.ntiles;
-    a.pair_xcd = (C * sizeof(cx<T>) < 128) ? env_int("TCFD_PAIR_XCD", 1) : 0;
-    static const int ablate = env_int("TCFD_ABLATE", 0);
-    a.ablate = ablate;
+    a.pair_xcd = (C * sizeof(cx<T>) < 128) ? p->tune.pair_xcd : 0;
+    a.ablate = p->tune.ablate;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
     ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SP ? 2u : 1u), dim3(C * G), lds, st, a);
@@ -1075,8 +1398,8 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
 // and two workgroups share a CU.  Default: n = 1024 (fp64: the full tile would fill the CU's LDS; fp32: the half
 // tiles are 16 columns = full 128-byte lines instead of 8).
 template <typename T, int N>
-static bool use_split() {
-    static const int force = env_int("TCFD_SPLIT", -1);
+static bool use_split(const tcfd_ns2d_plan* p) {
+    const int force = p->tune.split;
     if (N < 16) return false;
     if (force >= 0) return force != 0;
     return N == 1024;   // fp64: 7.99 vs 8.6 ms/step; fp32 (16-column, 128-byte tiles of 512 rows): 5.61 vs 6.05 ms/step
@@ -1097,22 +1420,27 @@ static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, 
 template <typename T, int N, int MODE>
 static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
     if constexpr (MODE != MODE_FWD && MODE != MODE_INV) {
-        if (use_split<T, N>()) return launch_cols_split<T, N, MODE>(p, a, batch, st);
+        if (use_split<T, N>(p)) return launch_cols_split<T, N, MODE>(p, a, batch, st);
     }
     // small problems (few column tiles for 256 CUs, working set cache resident): narrow 4-column tiles and
     // 4 elements per lane give ~4x more, shorter workgroups (measured at 256^2 x 16 fp32: CA 29 -> 21 us)
     if constexpr ((N == 128 || N == 256) && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
-        static const int force = env_int("TCFD_SMALL_TILES", -1);
+        const int force = p->tune.small_tiles;
         const long tiles = batch * ((p->m + Cfg<T, N>::COLS - 1) / Cfg<T, N>::COLS);
         if (force == 1 || (force != 0 && tiles < 2 * 256)) return launch_cols_v<T, N, MODE, 4, 4>(p, a, batch, st);
     }
     // 512-point fp64 tiles are 64 KB: capping the update kernels at 128 VGPRs lets TWO workgroups share a CU,
     // so one tile's memory phases overlap the other's transforms (measured at 512^2 x 256: CA 1.05 -> 0.87 ms)
     if constexpr (N == 512 && sizeof(T) == 8 && (MODE == MODE_CA || MODE == MODE_C)) {
-        static const int two = env_int("TCFD_TWO_WG", 1);
-        if (two) return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);
+        if (p->tune.two_wg) return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);
     }
     return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
+}
+
+// persistent row-pass grid: `per_cu` workgroups per CU, grid-stride over the row pairs
+static long rows_grid(const tcfd_ns2d_plan* p, long want, int dflt_per_cu) {
+    const int per_cu = p->tune.rows_blocks_per_cu > 0 ? p->tune.rows_blocks_per_cu : dflt_per_cu;
+    return std::min<long>(want, 256L * per_cu);
 }
 
 template <typename T, int N, int EPT, int THR>
@@ -1120,16 +1448,10 @@ static int launch_rows_advect3(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
                                long batch, hipStream_t st) {
     using Gm = RowGeom<T, N, EPT, THR>;
     auto kern = k_rows_advect3<T, N, EPT, THR>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = set_lds(kern, Gm::LDS_BYTES);
-        if (rc) return rc;
-        attr_done = true;
-    }
+    static DevOnce lds_once;
+    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
     const long npairs = batch * (N / 2);
-    const long want = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
-    static const int per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 8);
-    const long blocks = std::min<long>(want, 256L * per_cu);  // persistent groups, grid-stride over row pairs
+    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, 8);
     ProfScope prof(p, 1, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
                        (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
@@ -1142,16 +1464,10 @@ static int launch_rows_advect4(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
                                long batch, hipStream_t st) {
     using Gm = RowGeom<T, N, EPT, THR>;
     auto kern = k_rows_advect4<T, N, EPT, THR>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = set_lds(kern, Gm::LDS_BYTES);
-        if (rc) return rc;
-        attr_done = true;
-    }
+    static DevOnce lds_once;
+    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
     const long npairs = batch * (N / 2);
-    const long want = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
-    static const int per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 8);
-    const long blocks = std::min<long>(want, 256L * per_cu);
+    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, 8);
     ProfScope prof(p, 1, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
                        (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
@@ -1159,18 +1475,93 @@ static int launch_rows_advect4(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
+template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int OPQ = 0, int TWQ = 0>
+static int launch_rows_advect5(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
+                               long batch, hipStream_t st) {
+    using Gm = RowGeom<T, N, EPT, THR>;
+    auto kern = k_rows_advect5<T, N, EPT, THR, SP, MINW, PF, OPQ, TWQ>;
+    static DevOnce lds_once;
+    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
+    const long npairs = batch * (N / 2);
+    // resident workgroups per CU: MINW waves per SIMD x 4 SIMDs / waves per workgroup (LDS allows it for every size)
+    constexpr int WAVES = (Gm::THREADS + 63) / 64;
+    constexpr int PER_CU = (4 * MINW / WAVES) > 0 ? (4 * MINW / WAVES) : 1;
+    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, PER_CU);
+    ProfScope prof(p, 1, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
+                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int N, int EPT, int THR, int SP, int MINW>
+static int launch_rows_advect6(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
+                               long batch, hipStream_t st) {
+    using Gm = RowGeom6<T, N, EPT, THR>;
+    auto kern = k_rows_advect6<T, N, EPT, THR, SP, MINW>;
+    static DevOnce lds_once;
+    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
+    const long npairs = batch * (N / 2);
+    constexpr int WG_WAVES = Gm::THREADS / 64;
+    constexpr int BY_REGS = (4 * MINW / WG_WAVES) > 0 ? (4 * MINW / WG_WAVES) : 1;
+    constexpr int BY_LDS = (int)((160 * 1024) / Gm::LDS_BYTES) > 0 ? (int)((160 * 1024) / Gm::LDS_BYTES) : 1;
+    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, BY_REGS < BY_LDS ? BY_REGS : BY_LDS);
+    ProfScope prof(p, 1, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
+                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Row-pass kernel of a size.  5 = register-staged rows (default everywhere); 6 = LDS-DMA staged rows, opt-in
+// (TCFD_ROWS_V=6): measured 0.644 ms against 0.603 ms per launch at 1024^2 x 64 fp64 and no gain at 512^2 -- the
+// per-transform address arithmetic it needs to stay under 256 VGPRs costs more than the staging saves.
+template <typename T, int N>
+static constexpr int rows_default_version() {
+    return 5;
+}
+
 template <typename T, int N>
 static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
                               hipStream_t st) {
-    if (use_split<T, N>())
-        return launch_rows_advect4<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch,
-                                                                                     st);
-    if constexpr (N == 128 || N == 256) {
-        static const int force = env_int("TCFD_SMALL_TILES", -1);
-        if (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256))
-            return launch_rows_advect3<T, N, 8, 64>(p, planes, plane_stride, adv, batch, st);
+    constexpr int EPT = Cfg<T, N>::ROW_EPT, THR = Cfg<T, N>::ROW_THREADS;
+    const bool split = use_split<T, N>(p);
+    if (p->tune.rows_v == 4) {   // round-1 kernels (two planes per transform), kept for A/B measurements
+        if (split) return launch_rows_advect4<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
+        return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
     }
-    return launch_rows_advect3<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>(p, planes, plane_stride, adv, batch, st);
+    if constexpr (N == 128 || N == 256) {
+        const int force = p->tune.small_tiles;
+        if (!split && (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256)))
+            return launch_rows_advect5<T, N, 8, 64, 0, 1>(p, planes, plane_stride, adv, batch, st);
+    }
+    if constexpr (RowGeom6<T, N, EPT, THR>::OK) {
+        if (p->tune.rows_v == 6 || (p->tune.rows_v != 5 && p->tune.rows_minw == 0 && rows_default_version<T, N>() == 6)) {
+            if constexpr (N >= 16) {
+                if (split) return launch_rows_advect6<T, N, EPT, THR, 1, 2>(p, planes, plane_stride, adv, batch, st);
+            }
+            return launch_rows_advect6<T, N, EPT, THR, 0, 2>(p, planes, plane_stride, adv, batch, st);
+        }
+    }
+    if constexpr (N == 1024 && sizeof(T) == 8) {
+        if (split) {
+            switch (p->tune.rows_minw) {
+                case 1: return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st);
+                case 2: return launch_rows_advect5<T, N, EPT, THR, 1, 2>(p, planes, plane_stride, adv, batch, st);
+                case 221: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 1, 1, 1>(p, planes, plane_stride, adv, batch, st);
+                case 220: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0, 1, 1>(p, planes, plane_stride, adv, batch, st);
+                case 321: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 1, 0, 1>(p, planes, plane_stride, adv, batch, st);
+                case 320: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0, 0, 1>(p, planes, plane_stride, adv, batch, st);
+                case 311: return launch_rows_advect5<T, N, EPT, THR, 1, 1, 1, 0, 1>(p, planes, plane_stride, adv, batch, st);
+                case 20: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
+                default: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
+            }
+        }
+    }
+    if constexpr (N >= 16) {
+        if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st);
+    }
+    return launch_rows_advect5<T, N, EPT, THR, 0, 1>(p, planes, plane_stride, adv, batch, st);
 }
 
 template <typename T>
@@ -1207,6 +1598,7 @@ static int step_overlap_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_
                              const double* mud, const int* base0, int steps, double inv_total_dt, void* ws,
                              hipStream_t st) {
     tcfd_ns2d_plan* mp = const_cast<tcfd_ns2d_plan*>(p);
+    std::lock_guard<std::mutex> lock(mp->mu);   // the plan-owned streams / events serve one call at a time
     if (!mp->gs) mp->gs = new GraphState();
     GraphState* g = mp->gs;
     if (!g->stream) {
@@ -1363,6 +1755,9 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     int s0 = 0;
     if (use_graph) {
         tcfd_ns2d_plan* mp = const_cast<tcfd_ns2d_plan*>(p);
+        // the captured graph, its stream and its fence events are plan-owned and mutable: host threads that share a
+        // plan take turns here (the replays of one call are enqueued before the next call may re-capture)
+        std::lock_guard<std::mutex> lock(mp->mu);
         if (!mp->gs) mp->gs = new GraphState();
         GraphState* g = mp->gs;
         if (!g->stream) {
@@ -1425,12 +1820,8 @@ template <typename T, int N>
 static int rfft2_impl(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, hipStream_t st) {
     using Gm = RowGeom<T, N, Cfg<T, N>::ROW_EPT>;
     auto kern = k_rows_r2c<T, N, Cfg<T, N>::ROW_EPT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = set_lds(kern, Gm::LDS_BYTES);
-        if (rc) return rc;
-        attr_done = true;
-    }
+    static DevOnce lds_once;
+    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
     const long npairs = batch * (N / 2);
     const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, (const T*)x, (cx<T>*)out,
@@ -1456,11 +1847,10 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
     if ((rc = launch_cols<T, N, MODE_INV>(p, a, batch, st))) return rc;
     using Gm = RowGeom<T, N, Cfg<T, N>::ROW_EPT>;
     auto kern = k_rows_c2r<T, N, Cfg<T, N>::ROW_EPT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        rc = set_lds(kern, Gm::LDS_BYTES);
+    static DevOnce lds_once;
+    {
+        rc = set_lds(lds_once, kern, Gm::LDS_BYTES);
         if (rc) return rc;
-        attr_done = true;
     }
     const long npairs = batch * (N / 2);
     const long blocks = (npairs + Gm::GROUPS - 1) / Gm::GROUPS;
@@ -1571,6 +1961,24 @@ extern "C" int tcfd_irfft2(const tcfd_ns2d_plan* p, const void* xh, void* out, l
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     TCFD_DISPATCH(p, (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)));
+}
+
+template <typename T, int N>
+static int variant_impl(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
+    const bool sp = use_split<T, N>(p);
+    if (split) *split = sp ? 1 : 0;
+    if (rows_kernel) {
+        int v = p->tune.rows_v;
+        if (v != 4 && v != 5 && v != 6) v = rows_default_version<T, N>();
+        if (v == 6 && !RowGeom6<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>::OK) v = 5;
+        *rows_kernel = v;
+    }
+    return 0;
+}
+
+extern "C" int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
+    if (!p) return fail(TCFD_EINVAL, "plan_variant: null plan");
+    TCFD_DISPATCH(p, (variant_impl<T_, N_>(p, split, rows_kernel)));
 }
 
 // ------------------------------------------------------------------ profiling side-car

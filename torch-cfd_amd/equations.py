@@ -86,7 +86,10 @@ class _HipPlan:
         a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(self.lib.tcfd_ns2d_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
                    "tcfd_ns2d_plan_info")
-        return {"separable": a.value, "sparse_forcing": b.value, "keep_cols": c.value}
+        d, e = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self.lib.tcfd_ns2d_plan_variant(self.handle, ctypes.byref(d), ctypes.byref(e)), "tcfd_ns2d_plan_variant")
+        return {"separable": a.value, "sparse_forcing": b.value, "keep_cols": c.value, "split": d.value,
+                "rows_kernel": e.value}
 
     # -- helpers
     def workspace(self, batch: int) -> torch.Tensor:
