@@ -23,15 +23,16 @@ def _fake_records(start, stop, T=3, n=8):
             (("vorticity", 1.0), ("stream", 0.5), ("vort_t", 2.0), ("residual", -1.0))}
 
 
-def _worker(rank, world, port, total, q):
+def _worker(rank, world, port, total, q, dst=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from torch_cfd_amd.distributed import gather_trajectory, shard_batch
 
         a, b = shard_batch(total, rank, world)
-        full = gather_trajectory(_fake_records(a, b), total, dst=0)
-        if rank == 0:
+        local = _fake_records(a, b) if b > a else {}   # an empty shard holds no tensors at all
+        full = gather_trajectory(local, total, dst=dst)
+        if rank == dst:
             ref = _fake_records(0, total)
             ok = all(torch.equal(full[k], ref[k]) for k in ref) and sorted(full) == sorted(ref)
             q.put(("ok" if ok else "mismatch", {k: tuple(v.shape) for k, v in full.items()}))
@@ -41,12 +42,12 @@ def _worker(rank, world, port, total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [6, 7])  # even and ragged split
-def test_gather_trajectory_world2(total):
+@pytest.mark.parametrize("total,dst", [(6, 0), (7, 0), (7, 1), (1, 0), (1, 1)])  # even, ragged, empty shard (either end)
+def test_gather_trajectory_world2(total, dst):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q, dst)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

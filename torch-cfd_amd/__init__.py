@@ -2,20 +2,22 @@
 
 Operator API (same names/signatures as the reference) over hand-written HIP
 kernels reached through the C ABI in ``include/tcfd.h``.  No CPU fallback.
-The directory name carries a hyphen; import it as ``torch_cfd_amd`` (the shim
-package next to it points here).
+The directory name carries a hyphen (the repository layout asks for it); the
+importable name ``torch_cfd_amd`` is a symbolic link to this very directory, so
+there is ONE package with one module identity.
 """
 from . import _lib  # noqa: F401
 from .grids import Grid  # noqa: F401
 from .equations import (  # noqa: F401
     IMEXStepper,
+    run_stage_schedule,
     ImplicitExplicitODE,
     NavierStokes2DSpectral,
     RK4CrankNicolsonStepper,
     fft_plan,
     stable_time_step,
 )
-from .forcings import ForcingFn, KolmogorovForcing, SimpleSolenoidalForcing, SinCosForcing  # noqa: F401
+from .forcings import FieldArray, ForcingFn, KolmogorovForcing, SinCosForcing  # noqa: F401
 from .solvers import get_trajectory_imex  # noqa: F401
 from .spectral import brick_wall_filter_2d, vorticity_to_velocity  # noqa: F401
 

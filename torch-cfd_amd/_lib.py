@@ -19,7 +19,7 @@ from typing import Optional
 
 import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
+_HERE = os.path.dirname(os.path.realpath(__file__))   # realpath: the package may be imported through its symlink
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_NAME = "libtcfd_hip.so"

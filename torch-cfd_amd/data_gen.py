@@ -18,11 +18,14 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from .distributed import gather_trajectory, shard_batch
+from .distributed import TRAJECTORY_FIELDS, gather_trajectory, shard_batch
 from .equations import NavierStokes2DSpectral, RK4CrankNicolsonStepper, fft_plan
 from .grids import Grid
 from .initial_conditions import vorticity_field
 from .solvers import get_trajectory_imex
+
+
+DATASET_FIELDS = TRAJECTORY_FIELDS + ("random_states",)
 
 
 def spectral_to_physical(value_hat: torch.Tensor, out_size: Optional[int] = None,
@@ -71,8 +74,8 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
         result = {k: spectral_to_physical(v, ns, dtype) for k, v in result.items()}
         result["random_states"] = torch.tensor(seeds, dtype=torch.int32, device=device)
         chunks.append(result)
-    local = {k: torch.cat([c[k] for c in chunks]) for k in chunks[0]} if chunks else {}
-    full = gather_trajectory(local, total_samples, dst=dst) if world > 1 else local
+    local = {k: torch.cat([c[k] for c in chunks]) for k in chunks[0]} if chunks else {}   # empty shard: no tensors
+    full = gather_trajectory(local, total_samples, dst=dst, keys=DATASET_FIELDS) if world > 1 else local
     if full is None:
         return None
     full = {k: v.cpu() for k, v in full.items()}

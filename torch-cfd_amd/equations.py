@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from . import _lib
 from .grids import Grid
-from .spectral import brick_wall_filter_2d, spectral_curl_2d
+from .spectral import brick_wall_filter_2d
 
 Params = Union[nn.ParameterDict, Dict]
 
@@ -79,7 +79,7 @@ class _HipPlan:
                 _lib.dptr_of_tensor(msk), fptr)
         _lib.check(rc, "tcfd_ns2d_plan_create")
         self.handle = handle
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
         self._finalizer = weakref.finalize(self, self.lib.tcfd_ns2d_plan_destroy, handle)
 
     def info(self) -> Dict[str, int]:
@@ -93,12 +93,13 @@ class _HipPlan:
 
     # -- helpers
     def workspace(self, batch: int) -> torch.Tensor:
-        ws = self._ws.get(batch)
-        if ws is None:
-            nbytes = self.lib.tcfd_ns2d_workspace_bytes(self.handle, batch)
-            self._ws = {batch: torch.empty(nbytes, dtype=torch.uint8, device=self.device)}  # keep one
-            ws = self._ws[batch]
-        return ws
+        """Scratch for ``batch`` fields.  One buffer, grown to the largest batch seen: the library carves it by
+        ``batch`` alone, so a larger buffer serves smaller batches (alternating batch sizes do not reallocate)."""
+        need = self.lib.tcfd_ns2d_workspace_bytes(self.handle, batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None   # release before allocating the larger one
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
 
     def _prep(self, w: torch.Tensor) -> Tuple[torch.Tensor, int]:
         if not w.is_cuda:
@@ -229,271 +230,267 @@ def fft_plan(n: int, cdtype: torch.dtype, device, diam: float = 2 * torch.pi) ->
 
 # ----------------------------------------------------------------------------- ODE interface + steppers
 class ImplicitExplicitODE(nn.Module):
-    r"""du/dt = explicit_terms(u) + implicit_terms(u); the implicit part is
-    linear and solved exactly (``implicit_solve``)."""
+    r"""du/dt = explicit_terms(u) + implicit_terms(u) with a linear implicit part that ``implicit_solve`` inverts:
+    ``implicit_solve(u, s)`` returns ``(1 - s L)^{-1} u``.  (Interface of torch_cfd/equations.py:67-107.)"""
 
-    def explicit_terms(self, *, u):
+    def explicit_terms(self, u):
         raise NotImplementedError
 
-    def implicit_terms(self, *, u):
+    def implicit_terms(self, u):
         raise NotImplementedError
 
-    def implicit_solve(self, *, u: torch.Tensor, step_size: float):
+    def implicit_solve(self, u: torch.Tensor, step_size: float):
         raise NotImplementedError
 
     def residual(self, u: torch.Tensor, u_t: torch.Tensor):
         raise NotImplementedError
 
 
+def run_stage_schedule(u: torch.Tensor, equation: ImplicitExplicitODE, sched: Dict[str, list]) -> torch.Tensor:
+    """One IMEX step of ANY ``ImplicitExplicitODE`` from the per-stage scalars the fused HIP step consumes
+    (include/tcfd.h, ``tcfd_ns2d_step_imex``).  Stage k:
+
+        h <- fa_k F(u) + beta_k h
+        u <- (1 - mu_den_k L)^{-1} (b + gdt_k h + mu_k L b),    b = u, or the step's initial state when base0_k
+
+    Every scheme of this module (forward/backward Euler, IMEX-CN, RK2-CN, low-storage RK-CN) is an instance, so this
+    one loop is the generic (non-fused) form of all of them; on a ``NavierStokes2DSpectral`` the same scalars go to
+    the kernels instead and this function is only the cross-check (``tests/test_ns2d_gpu.py``)."""
+    n = len(sched["beta"])
+    fa = sched.get("fa") or [1.0] * n
+    mu_den = sched.get("mu_den") or sched["mu"]
+    base0 = sched.get("base0") or [0] * n
+    start, h = u, None
+    for k in range(n):
+        f = equation.explicit_terms(u)
+        h = fa[k] * f if h is None else fa[k] * f + sched["beta"][k] * h
+        b = start if base0[k] else u
+        u = equation.implicit_solve(b + sched["gdt"][k] * h + sched["mu"][k] * equation.implicit_terms(b), mu_den[k])
+    return u
+
+
 class IMEXStepper(nn.Module):
-    """IMEX steppers of order 1 / 1.5 (forward-backward Euler, IMEX-CN) and 2
-    (RK2 + CN).  On a ``NavierStokes2DSpectral`` the whole step runs in the fused
-    HIP kernels (``stage_schedule`` -> ``tcfd_ns2d_step_imex``); ``_imex`` /
-    ``_rk2_crank_nicolson`` are the generic forms for other equations."""
+    """One-step IMEX schemes: ``order`` 1 / 1.5 (explicit Euler + theta-weighted implicit part, theta = ``alpha``) and
+    2 (two-stage RK + Crank-Nicolson).  A scheme is DATA here -- ``stage_schedule`` turns the parameters and ``dt`` into
+    per-stage scalars -- executed either by the fused HIP kernels (equation = ``NavierStokes2DSpectral``) or by
+    ``run_stage_schedule`` (any other equation).  Constructor / ``params`` names follow torch_cfd/equations.py:110-246."""
 
     def __init__(self, order: float = 2, alpha: float = 0.5, beta: Optional[float] = 0.5,
                  requires_grad: bool = False, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        if order not in (1, 1.5, 2, 4):
+            raise ValueError(f"IMEXStepper: unsupported order {order}")
         self.order = order
-        params = {"alpha": torch.tensor(alpha), "beta": torch.tensor(beta)}
-        if order == 1 or order == 1.5:
-            self.stepper = self._imex
-        elif order == 2:
-            self.stepper = self._rk2_crank_nicolson
-        self._set_params(params, requires_grad=requires_grad)
+        self._set_params({"alpha": torch.tensor(alpha), "beta": torch.tensor(beta)}, requires_grad=requires_grad)
 
     def _set_params(self, params: Params, requires_grad: bool = False):
-        self.params = nn.ParameterDict(params)
-        if not requires_grad:
-            for _, v in self.params.items():
-                v.requires_grad = False
+        self.params = nn.ParameterDict({k: nn.Parameter(v, requires_grad=requires_grad) for k, v in params.items()})
         self.requires_grad = requires_grad
 
-    def _imex(self, u, dt, equation, params=None):
-        params = self.params if params is None else params
-        alpha = params["alpha"]
-        g = u + dt * equation.explicit_terms(u) + (1 - alpha) * dt * equation.implicit_terms(u)
-        return equation.implicit_solve(g, alpha * dt)
-
-    def _rk2_crank_nicolson(self, u, dt, equation, params=None):
-        params = self.params if params is None else params
-        alpha, beta = params["alpha"], params["beta"]
-        g = u + beta * dt * equation.implicit_terms(u)
-        h = equation.explicit_terms(u)
-        u = equation.implicit_solve(g + dt * h, beta * dt)
-        h = alpha * equation.explicit_terms(u) + (1 - alpha) * h
-        return equation.implicit_solve(g + dt * h, beta * dt)
-
     def stage_schedule(self, params: Params, dt: float) -> Dict[str, list]:
-        """The scheme as per-stage scalars of the fused HIP step (include/tcfd.h, tcfd_ns2d_step_imex), rounded the
-        way the reference's 0-dim tensor arithmetic rounds them (equations.py:174-228)."""
+        """Per-stage scalars, each rounded the way the reference's 0-dim tensor arithmetic rounds it
+        (``(1 - alpha) * dt`` is a default-dtype tensor product there, equations.py:174-228)."""
         alpha = params["alpha"].detach().cpu()
         if self.order in (1, 1.5):
             return {"fa": [1.0], "beta": [0.0], "gdt": [float(dt)], "mu": [((1 - alpha) * dt).item()],
                     "mu_den": [(alpha * dt).item()], "base0": [0]}
-        if self.order == 2:
-            bcn = (params["beta"].detach().cpu() * dt).item()
-            return {"fa": [1.0, alpha.item()], "beta": [0.0, (1 - alpha).item()], "gdt": [float(dt)] * 2,
-                    "mu": [bcn, bcn], "mu_den": [bcn, bcn], "base0": [0, 1]}
-        raise ValueError(f"no fused schedule for order {self.order}")
+        half = (params["beta"].detach().cpu() * dt).item()   # Crank-Nicolson weight of both stages
+        return {"fa": [1.0, alpha.item()], "beta": [0.0, (1 - alpha).item()], "gdt": [float(dt)] * 2,
+                "mu": [half, half], "mu_den": [half, half], "base0": [0, 1]}
+
+    def stepper(self, u, dt, equation, params=None):
+        """The step in its generic form (explicit terms of ``equation`` + element-wise tensor ops)."""
+        return run_stage_schedule(u, equation, self.stage_schedule(self.params if params is None else params, dt))
 
     def forward(self, u, dt, equation, params=None):
         params = self.params if params is None else params
-        if isinstance(equation, NavierStokes2DSpectral) and u.is_cuda and type(self) is IMEXStepper:
+        if isinstance(equation, NavierStokes2DSpectral):
             out, _ = equation._fused_steps(u, dt, 1, params, want_dwdt=False, stepper=self)
             return out
         return self.stepper(u, dt, equation, params)
 
 
+_CARPENTER_KENNEDY = {   # 5-stage low-storage RK4 (2N storage), the reference's default weights (equations.py:294-317)
+    "alphas": [0, 0.1496590219993, 0.3704009573644, 0.6222557631345, 0.9582821306748, 1],
+    "betas": [0, -0.4178904745, -1.192151694643, -1.697784692471, -1.514183444257],
+    "gammas": [0.1496590219993, 0.3792103129999, 0.8229550293869, 0.6994504559488, 0.1530572479681],
+}
+_CLASSIC_RK4 = {"alphas": [0.0, 0.5, 0.5, 1.0, 1.0], "betas": [0.0, 0.0, 0.0, 0.0], "gammas": [1 / 6, 1 / 3, 1 / 3, 1 / 6]}
+
+
 class RK4CrankNicolsonStepper(IMEXStepper):
-    """Low-storage Carpenter-Kennedy RK (explicit part) + Crank-Nicolson
-    (implicit part).  With ``low_storage=False`` the classic RK4 weights are
-    used -- stored as floating point here (the reference builds integer
-    ``betas`` for that case and cannot construct the module, SURVEY bug 2)."""
+    """Low-storage Runge-Kutta for the explicit part, Crank-Nicolson over each stage interval for the implicit one:
+    ``mu_k = dt/2 (alpha_{k+1} - alpha_k)``.  ``params`` holds ``alphas / betas / gammas`` in the default dtype at
+    construction, as in the reference (a float32 run steps with float32-rounded coefficients).  ``weights`` replaces
+    the tables; ``low_storage=False`` selects classic RK4 weights (stored as floats: the reference builds an integer
+    tensor for that case and cannot construct the module)."""
 
     def __init__(self, order: float = 4, requires_grad: bool = False, weights: Optional[Params] = None,
                  low_storage: bool = True, *args, **kwargs):
         super().__init__(order, *args, **kwargs)
-        if low_storage:
-            weights = {
-                "alphas": [0, 0.1496590219993, 0.3704009573644, 0.6222557631345, 0.9582821306748, 1],
-                "betas": [0, -0.4178904745, -1.192151694643, -1.697784692471, -1.514183444257],
-                "gammas": [0.1496590219993, 0.3792103129999, 0.8229550293869, 0.6994504559488, 0.1530572479681],
-            }
-        else:
-            weights = {
-                "alphas": [0.0, 0.5, 0.5, 1.0, 1.0],
-                "betas": [0.0, 0.0, 0.0, 0.0],
-                "gammas": [1 / 6, 1 / 3, 1 / 3, 1 / 6],
-            }
-        params = {k: torch.tensor(v, dtype=torch.get_default_dtype()) for k, v in weights.items()}
-        self._set_params(params, requires_grad=requires_grad)
+        table = weights if weights is not None else (_CARPENTER_KENNEDY if low_storage else _CLASSIC_RK4)
+        dtype = torch.get_default_dtype()
+        self._set_params({k: torch.as_tensor(v, dtype=dtype).clone() for k, v in table.items()}, requires_grad=requires_grad)
 
     @staticmethod
     def stage_scalars(params: Params, dt: float):
-        """(beta_k, gamma_k*dt, mu_k = dt/2 (alpha_{k+1}-alpha_k)) as Python floats,
-        rounded the way the reference's 0-dim tensor arithmetic rounds them."""
-        al = params["alphas"].detach().cpu()
-        be = params["betas"].detach().cpu()
-        ga = params["gammas"].detach().cpu()
-        if len(al) - 1 != len(be) != len(ga):
+        """(beta_k, gamma_k dt, mu_k) as Python floats, rounded like the reference's 0-dim tensor products."""
+        al, be, ga = (params[k].detach().cpu() for k in ("alphas", "betas", "gammas"))
+        if len(al) - 1 != len(be) != len(ga):   # the reference's own (chained) comparison, equations.py:350
             raise ValueError("number of RK coefficients does not match")
-        n = len(be)
-        beta = [be[k].item() for k in range(n)]
-        gdt = [(ga[k] * dt).item() for k in range(n)]
-        mu = [(0.5 * dt * (al[k + 1] - al[k])).item() for k in range(n)]
-        return beta, gdt, mu
+        stages = range(len(be))
+        return ([be[k].item() for k in stages], [(ga[k] * dt).item() for k in stages],
+                [(0.5 * dt * (al[k + 1] - al[k])).item() for k in stages])
 
-    def forward(self, u, dt, equation, params=None):
-        params = self.params if params is None else params
-        if isinstance(equation, NavierStokes2DSpectral):
-            out, _ = equation._fused_steps(u, dt, 1, params, want_dwdt=False)
-            return out
-        alphas, betas, gammas = params["alphas"], params["betas"], params["gammas"]
-        if len(alphas) - 1 != len(betas) != len(gammas):
-            raise ValueError("number of RK coefficients does not match")
-        h = 0
-        for k in range(len(betas)):
-            h = equation.explicit_terms(u) + betas[k] * h
-            mu = 0.5 * dt * (alphas[k + 1] - alphas[k])
-            u = equation.implicit_solve(u + gammas[k] * dt * h + mu * equation.implicit_terms(u), mu)
-        return u
+    def stage_schedule(self, params: Params, dt: float) -> Dict[str, list]:
+        beta, gdt, mu = self.stage_scalars(params, dt)
+        return {"beta": beta, "gdt": gdt, "mu": mu, "fa": None, "mu_den": None, "base0": None}
 
 
 # ----------------------------------------------------------------------------- the operator
 class NavierStokes2DSpectral(ImplicitExplicitODE):
-    """2-D vorticity equation on a periodic box, pseudo-spectral.
+    """2-D vorticity equation on a periodic box, pseudo-spectral:
 
-    dw/dt = -(u . grad) w [+ f]  (explicit, 2/3-rule de-aliased)
-            + (nu lap - drag) w  (implicit)
+        dw/dt = -(u . grad) w [+ f]      explicit, 2/3-rule de-aliased       (``explicit_terms``)
+              + (nu lap - drag) w        implicit                            (``implicit_terms / implicit_solve``)
 
-    Attributes / buffers as in the reference: ``kx, ky, laplace, linear_term,
-    filter``; ``solver`` holds the RK coefficients (``solver.params.*``).
-    """
+    Constructor, buffers (``kx ky laplace linear_term filter`` -- the ``state_dict`` contract) and methods as in
+    torch_cfd/equations.py:361-463; every method that touches the state runs the HIP kernels."""
+
+    #: Entries of the forcing spectrum below ``forcing_noise_floor * eps * max|f^|`` are set to exact zeros: they are
+    #: the round-off of transforming an analytically band-limited forcing (sin(k y) leaves ~2e-14 relative noise at
+    #: n = 1024 in fp64), carry no information, and exact zeros let the plan use its sparse / pruned forms.
+    #: ``None`` -> n (the grid size); 0 keeps every entry.  A caller-visible difference from the reference, see
+    #: INTEGRATION.md.
+    forcing_noise_floor: Optional[float] = None
 
     def __init__(self, viscosity: float, grid: Grid, drag: float = 0.0, smooth: bool = True,
                  forcing_fn: Optional[Callable] = None, solver: IMEXStepper = None, **kwargs):
         super().__init__()
-        self.viscosity = viscosity
-        self.grid = grid
-        self.drag = drag
-        self.smooth = smooth
+        self.viscosity, self.grid, self.drag, self.smooth = viscosity, grid, drag, smooth
         self.forcing_fn = forcing_fn
         self.solver = solver
         self._plans: Dict[tuple, _HipPlan] = {}
         self._coef_cache = None
         self._initialize()
 
-    def __getstate__(self):  # device plans are rebuilt lazily after copy / unpickle
-        state = self.__dict__.copy()
-        state["_plans"] = {}
-        state["_coef_cache"] = None
-        return state
-
     def _initialize(self):
         kx, ky = self.grid.rfft_mesh()
-        self.register_buffer("kx", kx)
-        self.register_buffer("ky", ky)
-        laplace = -4 * (torch.pi) ** 2 * (abs(self.kx) ** 2 + abs(self.ky) ** 2)
-        self.register_buffer("laplace", laplace)
-        filter_ = brick_wall_filter_2d(self.grid)
-        linear_term = self.viscosity * self.laplace - self.drag
-        self.register_buffer("linear_term", linear_term)
-        self.register_buffer("filter", filter_)
+        laplace = -4 * torch.pi**2 * (abs(kx) ** 2 + abs(ky) ** 2)
+        for name, table in (("kx", kx), ("ky", ky), ("laplace", laplace),
+                            ("linear_term", self.viscosity * laplace - self.drag),
+                            ("filter", brick_wall_filter_2d(self.grid))):
+            self.register_buffer(name, table)
 
-    # -- forcing table: evaluated once (the reference re-evaluates it every stage)
-    #: Entries of the forcing spectrum below ``forcing_noise_floor * eps * max|f^|`` are set to exact zeros.
-    #: They are the round-off of transforming an analytically band-limited forcing in this precision
-    #: (sin(k y) leaves ~2e-14 relative noise at n=1024 in fp64, amplified by the curl's 2 pi i k factor):
-    #: they carry no information, and exact zeros let the kernels use the sparse / pruned forms.
-    #: ``None`` -> n (the grid size); 0 keeps every entry.
-    forcing_noise_floor: Optional[float] = None
+    def __getstate__(self):  # device plans are rebuilt lazily after copy / unpickle
+        state = self.__dict__.copy()
+        state["_plans"], state["_coef_cache"] = {}, None
+        return state
 
+    # -- forcing table: sampled once per plan
     def forcing_hat(self) -> Optional[torch.Tensor]:
+        """(n, m) spectrum of the force on the vorticity equation: rfft2 of the sampled forcing (its curl for a
+        momentum forcing), small entries flushed to zero (``forcing_noise_floor``).  Evaluated on the CPU in the
+        precision of the operator's tables, once per plan."""
         if self.forcing_fn is None:
             return None
         real = self.kx.dtype
-        kx, ky = self.kx.detach().cpu(), self.ky.detach().cpu()
-        if not self.forcing_fn.vorticity:
-            fx, fy = self.forcing_fn(self.grid, None)
-            fxh = torch.fft.rfft2(fx.data.detach().cpu().to(real))
-            fyh = torch.fft.rfft2(fy.data.detach().cpu().to(real))
-            fh = spectral_curl_2d((fxh, fyh), (kx, ky))
+        try:
+            sampled = self.forcing_fn(self.grid, None)
+        except Exception as e:  # a forcing that needs the state cannot be a plan table
+            raise _lib.TcfdError(
+                "forcing_fn(grid, None) failed: the HIP spectral path supports state-independent forcings only "
+                f"(sampled once per plan) -- {type(e).__name__}: {e}") from e
+
+        def spectrum(field):
+            return torch.fft.rfft2(field.data.detach().to("cpu", real))
+
+        if getattr(self.forcing_fn, "vorticity", False):
+            fh = spectrum(sampled)
         else:
-            f = self.forcing_fn(self.grid, None)
-            fh = torch.fft.rfft2(f.data.detach().cpu().to(real))
-        nf = float(self.kx.shape[-2]) if self.forcing_noise_floor is None else float(self.forcing_noise_floor)
-        if nf > 0:
+            fxh, fyh = (spectrum(c) for c in sampled)
+            kx, ky = self.kx.detach().cpu(), self.ky.detach().cpu()
+            fh = 2j * torch.pi * (fyh * kx - fxh * ky)   # curl in k-space
+        scale = self.kx.shape[-2] if self.forcing_noise_floor is None else self.forcing_noise_floor
+        if scale > 0:
             mag = fh.abs()
-            floor = nf * torch.finfo(real).eps * mag.max()
-            fh = torch.where(mag > floor, fh, torch.zeros_like(fh))
+            fh = torch.where(mag > scale * torch.finfo(real).eps * mag.max(), fh, torch.zeros_like(fh))
         return fh
+
+    def _forcing_key(self):
+        fn = self.forcing_fn
+        if fn is None:
+            return None
+        return fn.fingerprint() if hasattr(fn, "fingerprint") else ("id", id(fn))
+
+    def invalidate_plan(self):
+        """Drop the device plans (tables, forcing spectrum): the next call rebuilds them.  Needed only after
+        mutating a user-defined forcing that has no ``fingerprint()``; buffer and built-in forcing changes are
+        detected."""
+        self._plans, self._coef_cache = {}, None
 
     def _plan(self, like: torch.Tensor) -> _HipPlan:
         cdtype = torch.promote_types(like.dtype, _COMPLEX_OF.get(self.linear_term.dtype, torch.complex64))
         tables = (self.kx, self.ky, self.linear_term, self.filter)
-        key = (cdtype, like.device, self.smooth, id(self.forcing_fn)) + tuple((t.data_ptr(), t._version) for t in tables)
+        key = (cdtype, like.device, self.smooth, self._forcing_key(), self.forcing_noise_floor) + tuple(
+            (t.data_ptr(), t._version) for t in tables)
         plan = self._plans.get(key)
         if plan is None:
             n, m = self.kx.shape[-2:]
             if self.grid.shape[0] != self.grid.shape[1] or n != self.grid.shape[0]:
                 raise ValueError("the HIP spectral path needs a square n x n grid")
             mask = self.filter if self.smooth else torch.ones_like(self.filter)
-            plan = _HipPlan(n, cdtype, like.device, self.kx[:, 0], self.ky[0, :], self.linear_term, mask,
-                            self.forcing_hat())
+            plan = _HipPlan(n, cdtype, like.device, self.kx[:, 0], self.ky[0, :], self.linear_term, mask, self.forcing_hat())
             self._plans = {key: plan}  # tables changed -> drop stale plans
         return plan
 
     def _fused_steps(self, vort_hat, dt, steps, params=None, want_dwdt=True, stepper=None):
         stepper = self.solver if stepper is None else stepper
+        if stepper is None:
+            raise TypeError("NavierStokes2DSpectral needs a solver (e.g. RK4CrankNicolsonStepper()) to step")
         params = stepper.params if params is None else params
         # the coefficient tensors may live on the GPU: read them back once, not per step
         ckey = (float(dt), id(stepper)) + tuple((k, v.data_ptr(), v._version) for k, v in params.items())
         if self._coef_cache is None or self._coef_cache[0] != ckey:
-            if isinstance(stepper, RK4CrankNicolsonStepper):
-                beta, gdt, mu = RK4CrankNicolsonStepper.stage_scalars(params, dt)
-                sched = {"beta": beta, "gdt": gdt, "mu": mu, "fa": None, "mu_den": None, "base0": None}
-            else:
-                sched = stepper.stage_schedule(params, dt)
-            self._coef_cache = (ckey, sched)
+            self._coef_cache = (ckey, stepper.stage_schedule(params, dt))
         sc = self._coef_cache[1]
-        plan = self._plan(vort_hat)
-        out, dwdt = plan.step(vort_hat, sc["beta"], sc["gdt"], sc["mu"], steps, 1 / (steps * dt), want_dwdt, fa=sc["fa"],
-                              mu_den=sc["mu_den"], base0=sc["base0"])
+        out, dwdt = self._plan(vort_hat).step(vort_hat, sc["beta"], sc["gdt"], sc["mu"], steps, 1 / (steps * dt), want_dwdt,
+                                              fa=sc["fa"], mu_den=sc["mu_den"], base0=sc["base0"])
         return out.reshape(vort_hat.shape), (dwdt.reshape(vort_hat.shape) if want_dwdt else None)
+
+    # -- ImplicitExplicitODE interface
+    def explicit_terms(self, vort_hat):
+        return self._plan(vort_hat).explicit_terms(vort_hat).reshape(vort_hat.shape)
+
+    _explicit_terms = explicit_terms
+
+    def implicit_terms(self, vort_hat):
+        return self.linear_term * vort_hat
+
+    def implicit_solve(self, vort_hat, dt):
+        return vort_hat / (1 - dt * self.linear_term)
 
     def residual(self, vhat: torch.Tensor, vt_hat: torch.Tensor):
         _, res = self._plan(vhat).stream_residual(vhat, vt_hat, want_psi=False)
         return res.reshape(vhat.shape)
 
     def stream_and_residual(self, vhat: torch.Tensor, vt_hat: torch.Tensor):
-        """(psi_hat, residual) in one fused sweep -- what the trajectory recorder needs."""
+        """(psi_hat, residual) in one fused sweep -- what the trajectory recorder needs per record."""
         psi, res = self._plan(vhat).stream_residual(vhat, vt_hat)
         return psi.reshape(vhat.shape), res.reshape(vhat.shape)
 
-    def _explicit_terms(self, vort_hat):
-        return self._plan(vort_hat).explicit_terms(vort_hat).reshape(vort_hat.shape)
-
-    def explicit_terms(self, vort_hat):
-        return self._explicit_terms(vort_hat)
-
-    def implicit_terms(self, vort_hat):
-        return self.linear_term * vort_hat
-
-    def implicit_solve(self, vort_hat, dt):
-        return 1 / (1 - dt * self.linear_term) * vort_hat
-
-    def step(self, *args, **kwargs):
-        return self.forward(*args, **kwargs)
-
+    # -- time stepping
     def forward(self, vort_hat, dt, steps=1) -> Tuple[torch.Tensor, torch.Tensor]:
-        """vort_hat: (B, n, m), (B, T, n, m) or (n, m) half spectrum; returns
-        (vort_hat after ``steps`` steps, (new - old) / (steps * dt))."""
-        if isinstance(self.solver, RK4CrankNicolsonStepper) or type(self.solver) is IMEXStepper:
-            return self._fused_steps(vort_hat, dt, steps)   # every stage fused in the HIP kernels
+        """``vort_hat``: (B, n, m), (B, T, n, m) or (n, m) half spectrum.  Returns the state after ``steps`` steps and
+        ``(new - old) / (steps * dt)``.  With a stepper of this module all stages of all steps run fused in the HIP
+        kernels; a foreign ``solver(u, dt, equation)`` callable is looped over (its explicit terms still run on HIP)."""
+        if isinstance(self.solver, IMEXStepper):
+            return self._fused_steps(vort_hat, dt, steps)
         if self.solver is None:
             raise TypeError("NavierStokes2DSpectral.forward needs a solver (e.g. RK4CrankNicolsonStepper())")
-        vort_old = vort_hat
+        new = vort_hat
         for _ in range(steps):
-            vort_hat = self.solver(vort_hat, dt, self)
-        return vort_hat, 1 / (steps * dt) * (vort_hat - vort_old)
+            new = self.solver(new, dt, self)
+        return new, (new - vort_hat) / (steps * dt)
+
+    step = forward

@@ -25,7 +25,6 @@ from __future__ import annotations
 import ctypes
 import math
 import weakref
-from copy import deepcopy
 from typing import Dict, List, Optional, Tuple, Union
 
 import torch
@@ -816,27 +815,33 @@ class SpaceTimePositionalEncoding(nn.Module):
         else:
             self.proj = nn.Identity()
 
+    @staticmethod
+    def _wave(order: torch.Tensor, coord: torch.Tensor, sine_when_even: torch.Tensor) -> torch.Tensor:
+        """Rows sin(pi order_r coord) / cos(pi order_r coord), sine where ``sine_when_even`` holds: (R, len(coord))."""
+        phase = (torch.pi * order)[:, None] * coord[None, :]
+        return torch.where(sine_when_even[:, None], torch.sin(phase), torch.cos(phase))
+
     def _build(self, nx, ny, nt):
-        gx = torch.linspace(0, 1, nx)
-        gy = torch.linspace(0, 1, ny)
-        gt = torch.linspace(0, 1, self.max_time_steps + 1)[1: nt + 1]
-        X, Y, Tt = torch.meshgrid(gx, gy, gt, indexing="ij")
-        pe = [X, Y, Tt]
+        """The (1, C, nx, ny, nt) table: coordinates x, y in [0, 1], t = (1..nt) / max_time_steps, then either
+        C - 3 purely temporal channels e^{beta t} {sin, cos}(pi (k+1) t), k = 0..C-4 (sine for even k), broadcast
+        over space, or -- random-feature variant -- the mx my mt separable products
+        e^{beta t} b_i(x) b_j(y) b_k(t) / (i j k), b_r = sine for even r, cosine for odd r, frequency pi r."""
+        x = torch.linspace(0, 1, nx)
+        y = torch.linspace(0, 1, ny)
+        t = torch.linspace(0, 1, self.max_time_steps + 1)[1: nt + 1]
+        growth = torch.exp(self.time_exponential_scale * t)
+        coords = torch.stack(torch.meshgrid(x, y, t, indexing="ij"))
         if self.spatial_random_feats:
-            for i in range(1, self.modes_x + 1):
-                bx = torch.sin if i % 2 == 0 else torch.cos
-                for j in range(1, self.modes_y + 1):
-                    by = torch.sin if j % 2 == 0 else torch.cos
-                    for k in range(1, self.modes_t + 1):
-                        bt = torch.sin if k % 2 == 0 else torch.cos
-                        pe.append(1 / (i * j * k) * torch.exp(self.time_exponential_scale * Tt)
-                                  * bx(torch.pi * i * X) * by(torch.pi * j * Y) * bt(torch.pi * k * Tt))
+            def basis(count, coord):
+                r = torch.arange(1, count + 1)
+                return self._wave(r.to(coord.dtype), coord, r % 2 == 0) / r[:, None]
+
+            bx, by, bt = basis(self.modes_x, x), basis(self.modes_y, y), basis(self.modes_t, t) * growth
+            feats = torch.einsum("ix,jy,kt->ijkxyt", bx, by, bt).reshape(-1, nx, ny, nt)
         else:
-            for k in range(self.num_channels - 3):
-                basis = torch.sin if k % 2 == 0 else torch.cos
-                col = torch.exp(self.time_exponential_scale * gt) * basis(torch.pi * (k + 1) * gt)
-                pe.append(col.reshape(1, 1, nt).repeat(nx, ny, 1))
-        self.pe = torch.stack(pe).unsqueeze(0)
+            k = torch.arange(self.num_channels - 3)
+            feats = (self._wave((k + 1).to(t.dtype), t, k % 2 == 0) * growth)[:, None, None, :].expand(-1, nx, ny, -1)
+        self.pe = torch.cat([coords, feats]).unsqueeze(0).contiguous()
 
     def encoding(self, v):
         """The (1, C, X, Y, T) table that ``forward`` adds to v."""
@@ -1002,19 +1007,6 @@ class FNOBase(nn.Module):
         self.debug = debug
         self.num_spectral_layers = num_spectral_layers
 
-    @staticmethod
-    def _set_modulelist(module, num_layers, *args):
-        return nn.ModuleList([deepcopy(module(*args)) for _ in range(num_layers)])
-
-    def _set_spectral_layers(self, num_layers, modes, width, activation, spectral_conv, mlp, linear,
-                             channel_expansion: int = 4):
-        act = getattr(nn, activation)
-        for attr, module, args in zip(
-            ["spectral_conv", "mlp", "w", "activations"], [spectral_conv, mlp, linear, act],
-            [(width, width, *modes), (width, width, channel_expansion * width, activation), (width, width, 1), ()],
-        ):
-            setattr(self, attr, self._set_modulelist(module, num_layers, *args))
-
 
 class SFNO(FNOBase):
     """Spectral-refiner FNO for (2+1)-D fields: (b, x, y, t_in) -> (b, x, y, out_steps)."""
@@ -1029,11 +1021,15 @@ class SFNO(FNOBase):
                          spatial_random_feats=spatial_random_feats, lift_activation=lift_activation, debug=debug,
                          **kwargs)
         self.modes_x, self.modes_y, self.modes_t, self.width = modes_x, modes_y, modes_t, width
-        assert num_spectral_layers > 1
-        num_spectral_layers -= 1  # the lifting operator holds the first spectral convolution
-        self._set_spectral_layers(num_spectral_layers, [modes_x, modes_y, modes_t], width, spectral_conv=SpectralConvS,
-                                  mlp=PointwiseFFN, linear=nn.Conv3d, activation=activation,
-                                  channel_expansion=channel_expansion)
+        if num_spectral_layers < 2:
+            raise ValueError("SFNO needs at least two spectral layers (the lifting operator holds the first)")
+        # hidden layers: x1 = K(v) ; v <- act(mlp(x1) + w(v)).  The four ModuleList names are the checkpoint
+        # contract of the reference (fno/sfno.py:539-556: spectral_conv / mlp / w / activations).
+        hidden = range(num_spectral_layers - 1)
+        self.spectral_conv = nn.ModuleList(SpectralConvS(width, width, modes_x, modes_y, modes_t) for _ in hidden)
+        self.mlp = nn.ModuleList(PointwiseFFN(width, width, channel_expansion * width, activation) for _ in hidden)
+        self.w = nn.ModuleList(nn.Conv3d(width, width, 1) for _ in hidden)
+        self.activations = nn.ModuleList(getattr(nn, activation)() for _ in hidden)
         self.lifting_operator = LiftingOperator(width, modes_x, modes_y, modes_t, latent_steps=latent_steps,
                                                 norm=fft_norm, beta=beta, activation=activation,
                                                 spatial_random_feats=spatial_random_feats,

@@ -1,32 +1,36 @@
-"""State-independent body forces of the spectral solver.
+"""Body forces of the spectral solver.
 
-Same constructor arguments and call protocol as the reference forcings
-(torch_cfd/forcings.py:61-349): ``fn(grid, field)`` returns physical-space
-arrays exposing ``.data``; ``fn.vorticity`` says whether it is a force on the
-vorticity (one array) or on the velocity (an (fx, fy) pair whose curl is taken,
-torch_cfd/equations.py:429-437).
+A forcing of this path is *state independent*: the operator samples it ONCE when it builds its device plan,
+transforms it, and hands the (n, m) spectrum to the kernels as a table (include/tcfd.h ``forcing_hat``) -- the
+reference re-evaluates mesh + sin + two rfft2 inside every RK stage (torch_cfd/equations.py:429-437).
 
-The reference re-evaluates the forcing (meshgrid + sin + 2 rfft2) inside every
-RK stage although none of its forcings depends on the state; here the operator
-evaluates it ONCE, transforms it, and hands the (n, m) complex table to the HIP
-plan (include/tcfd.h: ``forcing_hat``).
+Call protocol (what ``NavierStokes2DSpectral.forcing_hat`` consumes, and what a user-defined forcing has to offer):
+``fn(grid, field)`` returns sampled physical-space data -- objects with a ``.data`` tensor -- either ONE array when
+``fn.vorticity`` is true (a force on the vorticity equation) or an ``(fx, fy)`` pair (a force on the momentum
+equation; the operator takes its curl).  Constructor keywords follow the reference classes
+(torch_cfd/forcings.py:118-210 Kolmogorov, :305-349 sin/cos) so that scripts carry over.
 """
 from __future__ import annotations
 
-from typing import Optional
+import math
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 
 from .grids import Grid
 
+_CORNERS = ((0, 0), (0, 0))   # both components sampled at the cell corners x_i = lo + i h (the reference's default)
+
 
 class FieldArray:
-    """Minimal stand-in for the reference's GridArray: data + offset + grid."""
+    """Sampled field: ``data`` plus where it was sampled (``offset`` in cells, ``grid``)."""
 
-    def __init__(self, data: torch.Tensor, offset, grid: Grid):
+    __slots__ = ("data", "offset", "grid")
+
+    def __init__(self, data: torch.Tensor, offset: Optional[Sequence[float]] = None, grid: Optional[Grid] = None):
         self.data = data
-        self.offset = tuple(offset)
+        self.offset = None if offset is None else tuple(offset)
         self.grid = grid
 
     @property
@@ -35,8 +39,14 @@ class FieldArray:
 
 
 class ForcingFn(nn.Module):
-    def __init__(self, grid: Grid, scale: float = 1, wave_number: int = 1, diam: float = 1.0,
-                 swap_xy: bool = False, vorticity: bool = False, offsets=None, device=None, **kwargs):
+    """Base of the built-in forcings: a plane wave family with angular wavenumber ``wave_number * 2 pi / diam``.
+
+    Subclasses implement ``momentum(x, y)`` -> (fx, fy) and / or ``curl(x, y)`` -> the same force acting on the
+    vorticity equation, both on coordinate arrays.  ``fingerprint()`` identifies the sampled table (the operator
+    keys its device plan on it, so changing e.g. ``scale`` after construction rebuilds the plan)."""
+
+    def __init__(self, grid: Grid, scale: float = 1.0, wave_number: float = 1, diam: float = 1.0, swap_xy: bool = False,
+                 vorticity: bool = False, offsets=None, device=None):
         super().__init__()
         self.grid = grid
         self.scale = scale
@@ -44,96 +54,72 @@ class ForcingFn(nn.Module):
         self.diam = diam
         self.swap_xy = swap_xy
         self.vorticity = vorticity
-        self.offsets = grid.cell_faces if offsets is None else offsets
+        self.offsets = _CORNERS if offsets is None else tuple(tuple(o) for o in offsets)
         self.device = grid.device if device is None else device
 
-    def velocity_eval(self, grid, velocity=None):
-        raise NotImplementedError
+    @property
+    def angular_wavenumber(self) -> float:
+        return self.wave_number * (2 * math.pi / self.diam)
 
-    def vorticity_eval(self, grid, vorticity=None):
-        raise NotImplementedError
+    def fingerprint(self) -> tuple:
+        return (type(self).__qualname__, float(self.scale), float(self.wave_number), float(self.diam), bool(self.swap_xy),
+                bool(self.vorticity), self.offsets)
 
-    def forward(self, grid: Optional[Grid] = None, velocity=None, vorticity=None):
-        if not self.vorticity:
-            return self.velocity_eval(grid, velocity)
-        return self.vorticity_eval(grid, vorticity)
+    def momentum(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        raise NotImplementedError(f"{type(self).__name__} has no momentum-equation form")
+
+    def curl(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(f"{type(self).__name__} has no vorticity-equation form")
+
+    def forward(self, grid: Optional[Grid] = None, field=None):
+        grid = self.grid if grid is None else grid
+        off_x, off_y = self.offsets
+        if self.vorticity:
+            x, y = grid.mesh(off_x)
+            return FieldArray(self.curl(x, y), off_x, grid)
+        (x, _), (_, y) = grid.mesh(off_x), grid.mesh(off_y)
+        fx, fy = self.momentum(x, y)
+        return FieldArray(fx, off_x, grid), FieldArray(fy, off_y, grid)
 
 
 class KolmogorovForcing(ForcingFn):
-    """fx = scale * sin(k * y) (or fy = scale * sin(k * x) with swap_xy), k = wave_number * 2 pi / diam;
-    vorticity form: -scale * k * cos(k * y).  (torch_cfd/forcings.py:118-210)"""
+    """Shear forcing ``f = scale * sin(k y) e_x`` (``swap_xy``: ``scale * sin(k x) e_y``); on the vorticity equation the
+    reference applies ``-scale * k * cos(k s)`` along the sheared coordinate s in both cases."""
 
-    def __init__(self, diam=2 * torch.pi, offsets=((0, 0), (0, 0)), vorticity=False, *args, **kwargs):
-        super().__init__(*args, diam=diam, offsets=offsets, vorticity=vorticity, **kwargs)
+    def __init__(self, grid: Grid, scale: float = 1.0, wave_number: float = 1, diam: float = 2 * math.pi,
+                 swap_xy: bool = False, vorticity: bool = False, offsets=None, device=None, **unused):
+        super().__init__(grid, scale=scale, wave_number=wave_number, diam=diam, swap_xy=swap_xy, vorticity=vorticity,
+                         offsets=offsets, device=device)
 
-    def velocity_eval(self, grid, velocity=None):
-        grid = self.grid if grid is None else grid
-        k = self.wave_number * (2 * torch.pi / self.diam)
+    def momentum(self, x, y):
+        k = self.angular_wavenumber
         if self.swap_xy:
-            x = grid.mesh(self.offsets[1])[0]
-            v = FieldArray(self.scale * torch.sin(k * x), self.offsets[1], grid)
-            u = FieldArray(torch.zeros_like(v.data), (1, 1 / 2), grid)
-        else:
-            y = grid.mesh(self.offsets[0])[1]
-            u = FieldArray(self.scale * torch.sin(k * y), self.offsets[0], grid)
-            v = FieldArray(torch.zeros_like(u.data), (1 / 2, 1), grid)
-        return u, v
+            wave = self.scale * torch.sin(k * x)
+            return torch.zeros_like(wave), wave
+        wave = self.scale * torch.sin(k * y)
+        return wave, torch.zeros_like(wave)
 
-    def vorticity_eval(self, grid, vorticity=None):
-        grid = self.grid if grid is None else grid
-        k = self.wave_number * (2 * torch.pi / self.diam)
-        if self.swap_xy:
-            s, off = grid.mesh(self.offsets[1])[0], self.offsets[1]
-        else:
-            s, off = grid.mesh(self.offsets[0])[1], self.offsets[0]
-        return FieldArray(-self.scale * k * torch.cos(k * s), off, grid)
+    def curl(self, x, y):
+        k = self.angular_wavenumber
+        s = x if self.swap_xy else y
+        return -self.scale * k * torch.cos(k * s)
 
 
-class SimpleSolenoidalForcing(ForcingFn):
-    """Divergence-free forcing F = (psi, -psi) given by a scalar potential
-    (torch_cfd/forcings.py:220-302); subclasses provide the potentials."""
+class SinCosForcing(ForcingFn):
+    """The FNO-paper forcing ``scale * (sin(k (x + y)) + cos(k (x + y)))`` on the vorticity equation (the default
+    here as in the reference, ``vorticity=True``).  Its momentum form is the solenoidal pair ``(g, -g)`` with
+    ``g = a (sin(k (x + y)) - cos(k (x + y)))``, ``a = scale / (4 pi wave_number)``; ``swap_xy`` flips its sign."""
 
-    def __init__(self, scale=1, diam=1.0, k=1.0, offsets=((0, 0), (0, 0)), vorticity=True, *args, **kwargs):
-        super().__init__(*args, scale=scale, diam=diam, wave_number=k, offsets=offsets,
-                         vorticity=vorticity, **kwargs)
+    def __init__(self, grid: Grid, scale: float = 0.1, diam: float = 1.0, k: float = 1.0, swap_xy: bool = False,
+                 vorticity: bool = True, offsets=None, device=None, **unused):
+        super().__init__(grid, scale=scale, wave_number=k, diam=diam, swap_xy=swap_xy, vorticity=vorticity,
+                         offsets=offsets, device=device)
 
-    def potential(self, x, y, s, k):
-        raise NotImplementedError
+    def momentum(self, x, y):
+        phase = self.angular_wavenumber * (x + y)
+        g = self.scale / (4 * math.pi * self.wave_number) * (torch.sin(phase) - torch.cos(phase))
+        return (-g, g) if self.swap_xy else (g, -g)
 
-    def vort_potential(self, x, y, s, k):
-        raise NotImplementedError
-
-    def velocity_eval(self, grid, velocity=None):
-        grid = self.grid if grid is None else grid
-        k = self.wave_number * (2 * torch.pi / self.diam)
-        s = 0.5 * self.scale / (2 * torch.pi) / self.wave_number
-        if self.swap_xy:
-            x, y = grid.mesh(self.offsets[1])[0], grid.mesh(self.offsets[0])[1]
-            rot = self.potential(x, y, s, k)
-            return FieldArray(-rot, (1, 1 / 2), grid), FieldArray(rot, self.offsets[1], grid)
-        x, y = grid.mesh(self.offsets[0])[0], grid.mesh(self.offsets[1])[1]
-        rot = self.potential(x, y, s, k)
-        return FieldArray(rot, self.offsets[0], grid), FieldArray(-rot, (1 / 2, 1), grid)
-
-    def vorticity_eval(self, grid, vorticity=None):
-        grid = self.grid if grid is None else grid
-        k = self.wave_number * (2 * torch.pi / self.diam)
-        if self.swap_xy:
-            x, y = grid.mesh(self.offsets[1])[0], grid.mesh(self.offsets[0])[1]
-        else:
-            x, y = grid.mesh(self.offsets[0])[0], grid.mesh(self.offsets[1])[1]
-        return self.vort_potential(x, y, self.scale, k)
-
-
-class SinCosForcing(SimpleSolenoidalForcing):
-    """The FNO-paper forcing a*(sin(k(x+y)) + cos(k(x+y))) on the vorticity
-    (torch_cfd/forcings.py:305-349)."""
-
-    def __init__(self, scale=0.1, diam=1.0, k=1.0, offsets=((0, 0), (0, 0)), *args, **kwargs):
-        super().__init__(*args, scale=scale, diam=diam, k=k, offsets=offsets, **kwargs)
-
-    def potential(self, x, y, s, k):
-        return s * (torch.sin(k * (x + y)) - torch.cos(k * (x + y)))
-
-    def vort_potential(self, x, y, s, k):
-        return s * (torch.cos(k * (x + y)) + torch.sin(k * (x + y)))
+    def curl(self, x, y):
+        phase = self.angular_wavenumber * (x + y)
+        return self.scale * (torch.cos(phase) + torch.sin(phase))

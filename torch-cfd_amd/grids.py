@@ -1,102 +1,90 @@
-"""Periodic-box grid descriptor: the constructor argument of the spectral operator.
+"""Periodic box descriptor handed to the spectral operator.
 
-Mirrors the part of the reference ``Grid`` the spectral path touches
-(torch_cfd/grids.py:37-218: shape/step/domain, ``axes``, ``mesh``, ``fft_axes``,
-``fft_mesh``, ``rfft_mesh``).  The staggered-grid data model of the reference
-(GridArray/GridVariable, grids.py:221-1095) belongs to its finite-volume solver
-and is out of scope.
+The spectral path needs three things from a grid: the sample counts, the box
+(for the wavenumbers ``k = index / length``) and sample positions (for forcings
+and initial conditions).  ``Grid`` keeps the constructor keywords and the
+attribute / method names the reference's callers use (``Grid(shape=, domain=,
+step=, device=)``, ``.shape .domain .step .ndim .mesh() .fft_axes() .fft_mesh()
+.rfft_mesh()``, torch_cfd/grids.py:37-201) so that scripts written against the
+reference construct the operator unchanged; the staggered-grid data model behind
+the reference class (offsets per variable, GridArray / GridVariable) belongs to
+its finite-volume solver and is not part of this path.
 """
 from __future__ import annotations
-
-import math
-import numbers
-import operator
-from typing import Optional, Sequence, Tuple, Union
 
 import torch
 
 
+def _as_box(counts, step, domain):
+    """((lo, hi), ...) per axis from either a cell size or an extent."""
+    d = len(counts)
+    if step is not None and domain is not None:
+        raise TypeError("Grid: give the cell size (`step`) or the box (`domain`), not both")
+    if domain is None:
+        h = torch.as_tensor(1.0 if step is None else step, dtype=torch.float64).flatten()
+        if h.numel() not in (1, d):
+            raise ValueError(f"Grid: `step` has {h.numel()} entries for a {d}-D grid")
+        h = h.expand(d)
+        return tuple((0.0, float(h[a]) * counts[a]) for a in range(d))
+    box = torch.as_tensor(domain, dtype=torch.float64)
+    if box.ndim == 0:  # a single length: the box [0, L]^d
+        return tuple((0.0, float(box)) for _ in range(d))
+    if tuple(box.shape) != (d, 2):
+        raise ValueError(f"Grid: `domain` must be one length or {d} (lo, hi) pairs, got shape {tuple(box.shape)}")
+    return tuple((float(lo), float(hi)) for lo, hi in box.tolist())
+
+
 class Grid:
-    def __init__(
-        self,
-        shape: Sequence[int],
-        step: Optional[Union[float, Sequence[float]]] = None,
-        domain: Optional[Union[float, Sequence[Tuple[float, float]]]] = None,
-        device: Optional[Union[str, torch.device]] = "cpu",
-    ):
-        shape = tuple(operator.index(s) for s in shape)
-        ndim = len(shape)
-        if step is not None and domain is not None:
-            raise TypeError("cannot provide both step and domain")
-        if domain is not None:
-            if isinstance(domain, (int, float)):
-                domain = ((0, domain),) * ndim
-            elif len(domain) != ndim:
-                raise ValueError(f"length of domain does not match ndim: {len(domain)} != {ndim}")
-            for bounds in domain:
-                if len(bounds) != 2:
-                    raise ValueError(f"domain is not sequence of pairs of numbers: {domain}")
-            domain = tuple((float(lo), float(hi)) for lo, hi in domain)
-        else:
-            if step is None:
-                step = 1
-            if isinstance(step, numbers.Number):
-                step = (step,) * ndim
-            elif len(step) != ndim:
-                raise ValueError(f"length of step does not match ndim: {len(step)} != {ndim}")
-            domain = tuple((0.0, float(s * n)) for s, n in zip(step, shape))
-        self.shape = shape
-        self.domain = domain
-        self.step = tuple((hi - lo) / n for (lo, hi), n in zip(domain, shape))
+    """``shape`` samples on the periodic box ``domain``; sample i of axis a sits at
+    ``lo_a + (i + offset_a) * step_a`` (offset 1/2 = cell centres, 0 = cell corners)."""
+
+    __slots__ = ("shape", "domain", "step", "device")
+
+    def __init__(self, shape, step=None, domain=None, device="cpu"):
+        self.shape = tuple(int(n) for n in shape)
+        if any(n <= 0 for n in self.shape):
+            raise ValueError(f"Grid: sample counts must be positive, got {self.shape}")
+        self.domain = _as_box(self.shape, step, domain)
+        # the same expression the wavenumber spacing is built from: (hi - lo) / n
+        self.step = tuple((hi - lo) / n for (lo, hi), n in zip(self.domain, self.shape))
         self.device = device
 
+    # -- geometry
     @property
-    def ndim(self) -> int:
+    def ndim(self):
         return len(self.shape)
 
-    @property
-    def cell_center(self) -> Tuple[float, ...]:
-        return self.ndim * (0.5,)
-
-    @property
-    def cell_faces(self):
-        d = self.ndim
-        return tuple(tuple(1.0 if i == j else 0.5 for j in range(d)) for i in range(d))
-
-    def axes(self, offset: Optional[Sequence[float]] = None):
-        """Grid points along each axis, shifted by ``offset * step`` (default: cell centres)."""
-        if offset is None:
-            offset = self.cell_center
+    def mesh(self, offset=None):
+        """Coordinate arrays (``indexing='ij'``) of the samples shifted by ``offset`` cells (default 1/2)."""
+        offset = (0.5,) * self.ndim if offset is None else tuple(offset)
         if len(offset) != self.ndim:
-            raise ValueError(f"unexpected offset length: {len(offset)} vs {self.ndim}")
-        return tuple(
-            lo + (torch.arange(n) + off) * h
-            for (lo, _), off, n, h in zip(self.domain, offset, self.shape, self.step)
-        )
+            raise ValueError(f"Grid.mesh: offset {offset} for a {self.ndim}-D grid")
+        lines = [lo + (torch.arange(n) + o) * h for (lo, _), n, o, h in zip(self.domain, self.shape, offset, self.step)]
+        return tuple(c.to(self.device) for c in torch.meshgrid(*lines, indexing="ij"))
 
-    def mesh(self, offset: Optional[Sequence[float]] = None):
-        x, y = torch.meshgrid(*self.axes(offset), indexing="ij")
-        return x.to(self.device), y.to(self.device)
-
+    # -- wavenumbers (ordinal: cycles per unit length; the kernels multiply by 2 pi)
     def fft_axes(self):
-        """Ordinal frequencies per axis (multiply by 2*pi for angular ones)."""
-        return tuple(torch.fft.fftfreq(n, d=h) for n, h in zip(self.shape, self.step))
+        return tuple(torch.fft.fftfreq(count, d=width) for count, width in zip(self.shape, self.step))
 
     def fft_mesh(self):
-        kx, ky = torch.meshgrid(*self.fft_axes(), indexing="ij")
-        return kx.to(self.device), ky.to(self.device)
+        return tuple(k.to(self.device) for k in torch.meshgrid(*self.fft_axes(), indexing="ij"))
 
     def rfft_mesh(self):
-        """Half-spectrum wavenumbers: last axis cut to n//2+1 entries, so the
-        Nyquist column carries the negative frequency (grids.py:197-201)."""
-        k_max = math.floor(self.shape[-1] / 2.0)
-        return tuple(k[..., : k_max + 1] for k in self.fft_mesh())
+        """Wavenumbers of the half spectrum (last axis: entries 0 .. n//2).  The last kept column is the
+        Nyquist one and carries the NEGATIVE frequency -n/2/L, because it is cut out of the full
+        ``fftfreq`` ordering -- the c2r semantics of the kernels rely on exactly this table."""
+        keep = self.shape[-1] // 2 + 1
+        return tuple(k[..., :keep] for k in self.fft_mesh())
 
-    def __repr__(self):
+    # -- value semantics
+    def _key(self):
+        return (self.shape, self.domain)
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, Grid) and self._key() == other._key()
+
+    def __hash__(self) -> int:
+        return hash(self._key())
+
+    def __repr__(self) -> str:
         return f"Grid(shape={self.shape}, domain={self.domain})"
-
-    def __eq__(self, other):
-        return isinstance(other, Grid) and self.shape == other.shape and self.domain == other.domain
-
-    def __hash__(self):
-        return hash((self.shape, self.domain))
