@@ -62,6 +62,29 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu():
+    """(model string, physical cores, logical cpus) of this host from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "model name":
+                model = val
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                core = val
+            elif not key and phys is not None:   # blank line closes one logical cpu
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) if cores else logical), logical
+
+
 def cpu_baseline(n, real, dt, seconds):
     """CPU oracle on the host cores: same workload at B=2, linearly extrapolated to B=64."""
     from oracle import ns2d as O
@@ -96,10 +119,14 @@ def cpu_baseline(n, real, dt, seconds):
             if el > seconds or steps >= 200:
                 break
     per_step_b2 = el / steps
+    model, physical, logical = host_cpu()
     return {
         "value": 1.0 / (per_step_b2 * 64 / Bs),
         "unit": "steps/s (batch 64)",
-        "cores": torch.get_num_threads(),
+        "cores": physical,                      # physical cores of the host
+        "threads": torch.get_num_threads(),     # threads the run used: the fastest of a small sweep (more is slower here)
+        "logical_cpus": logical,
+        "cpu_model": model,
         "kind": "port",
         "sample": f"oracle/ns2d.py (torch-CPU restatement of the reference op sequence), {n}^2 {str(real)[6:]}, "
                   f"B={Bs}, {steps} steps in {el:.1f}s ({per_step_b2*1e3:.0f} ms/step), extrapolated linearly to B=64",
@@ -288,17 +315,30 @@ def main():
         if k in KIND_ALGO_S:
             ent["algo_GBps"] = round(KIND_ALGO_S[k] * S / (avg * 1e-3) / 1e9, 1)
         kern[KIND_NAMES[k]] = ent
-    dom = max((k for k in per_kind if k in KIND_ALGO_S), key=lambda k: sum(per_kind[k]))
-    dom_avg_ms = sum(per_kind[dom]) / len(per_kind[dom])
-    achieved = KIND_ALGO_S[dom] * S / (dom_avg_ms * 1e-3) / 1e9
-    traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(f"{KIND_NAMES[dom]}|n{n}|B{B}|{args.dtype}")
-        except Exception:
-            traffic = None
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        tj = {}
+
+    def roofline_of(k):
+        avg_ms = sum(per_kind[k]) / len(per_kind[k])
+        ach = KIND_ALGO_S[k] * S / (avg_ms * 1e-3) / 1e9
+        traffic = tj.get(f"{KIND_NAMES[k]}|n{n}|B{B}|{args.dtype}")
+        return {"kernel": KIND_NAMES[k], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                # HBM bytes per launch from rocprofv3 PMC passes of this same command (tests/prof_traffic.py); the
+                # file ships with the repo and is NOT re-measured by this run
+                "traffic_source": ("profiles/traffic.json: " + str(tj.get("_build", "round-2 build"))) if traffic else None,
+                "algo_bytes_per_launch": KIND_ALGO_S[k] * S, "avg_launch_ms": round(avg_ms, 4),
+                "share_of_step": round(sum(per_kind[k]) / sum(sum(v) for v in per_kind.values()), 3)}
+
+    timed = [k for k in per_kind if k in KIND_ALGO_S]
+    dom = max(timed, key=lambda k: sum(per_kind[k]))
+    # the kernel furthest below its roofline among those that matter (>= 5 % of the step)
+    total_ms = sum(sum(v) for v in per_kind.values())
+    worst = min((k for k in timed if sum(per_kind[k]) >= 0.05 * total_ms),
+                key=lambda k: KIND_ALGO_S[k] / (sum(per_kind[k]) / len(per_kind[k])))
 
     steps_per_s = world * args.steps / elapsed
     out = {
@@ -321,9 +361,8 @@ def main():
         "sample_steps_per_s": round(steps_per_s * B, 1),
         "step_algo_GBps": round(70.0 * S * args.steps / elapsed / 1e9, 1),
         "step_algo_frac_of_peak": round(70.0 * S * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": {"kernel": KIND_NAMES[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algo_bytes_per_launch": KIND_ALGO_S[dom] * S, "avg_launch_ms": round(dom_avg_ms, 4)},
+        "roofline": roofline_of(dom),
+        "roofline_worst": roofline_of(worst),
         "kernels": kern,
         "hbm_probe": probe,
     }

@@ -38,7 +38,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run, also with one rank
+    if launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -54,7 +55,7 @@ def main():
                                        dtype=torch.float32, cdtype=torch.complex64, device=dev, path=args.out)
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         tmax = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = tmax.item()
@@ -63,10 +64,10 @@ def main():
         shapes = {k: list(v.shape) for k, v in data.items()}
         finite = all(bool(torch.isfinite(v).all()) for k, v in data.items() if v.is_floating_point())
         print(json.dumps({"config": f"C4: {args.n}^2, {args.per_gpu} samples/GPU x {world} GPU, fp64, {args.warmup_steps}+{args.steps} steps, "
-                                    f"record every {args.record_every}", "n_gpus": world, "seconds": round(el, 3),
+                                    f"record every {args.record_every}", "n_gpus": world, "process_group": bool(launched), "seconds": round(el, 3),
                           "sample_steps_per_s": round(total * nsteps / el, 1), "batch_steps_per_s_per_gpu": round(nsteps / el, 1),
                           "shapes": shapes, "finite": finite}), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

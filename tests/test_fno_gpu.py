@@ -178,6 +178,42 @@ def test_sfno_tiny_end_to_end_golden(dev):
     assert rel_l2(y20, g["y20"]) < 1e-5
 
 
+def test_config5_full_size_against_oracle(dev):
+    """BASELINE configs[4] exactly as ``bench.py`` times it: SFNO(24, 24, 5, width 10, 4 spectral layers), random-init
+    weights (seed 0), x = randn(32, 256, 256, 10) fp32, SobolevLoss(n_grid 256, order 0, relative).  Samples do not
+    interact (LayerNormnd normalises per sample), so a two-sample slice of the full-batch output is compared with
+    the CPU oracle (oracle/sfno.py, pinned against the reference on the tiny model) run on those two samples, and
+    the loss of the slice with oracle/fno.py's; the same slice run alone must reproduce the full-batch rows."""
+    from oracle import fno as OF
+    from oracle import sfno as OS
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(32, 256, 256, 10, generator=g)
+    y = torch.randn(32, 256, 256, 10, generator=g)
+    loss_fn = fno.SobolevLoss(n_grid=256, norm_order=0, relative=True).to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev))
+        loss_slice = loss_fn(out[3:5], y[3:5].to(dev))
+        loss_full = loss_fn(out, y.to(dev))
+        alone = model(x[3:5].to(dev))
+    assert out.shape == (32, 256, 256, 10) and torch.isfinite(out).all()
+    assert rel_l2(alone, out[3:5]) < 1e-6
+    ref = OS.sfno_forward(sd, x[3:5], (24, 24, 5), width=10, num_hidden=3, out_steps=10)
+    assert rel_l2(out[3:5], ref) < 1e-5          # north_star: FNO forward within 1e-5
+    ref_loss = OF.sobolev_loss(ref, y[3:5], 256, norm_order=0, relative=True)
+    assert float(loss_slice) == pytest.approx(float(ref_loss), rel=2e-5)
+    # the batch mean of the full loss is the mean of per-sample losses: the slice's share is consistent with it
+    per = torch.stack([loss_fn(out[i:i + 1], y[i:i + 1].to(dev)) for i in (3, 4)])
+    assert float(per.mean()) == pytest.approx(float(loss_slice), rel=1e-5)
+    assert math.isfinite(float(loss_full))
+
+
 @pytest.mark.parametrize("order", [0, -1, 1])
 @pytest.mark.parametrize("rel", [0, 1])
 def test_sobolev_loss_golden(order, rel, dev):

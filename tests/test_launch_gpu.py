@@ -1,0 +1,102 @@
+"""GPU box, ONE GPU: what can be proven about the multi-GPU and multi-thread paths without a second device.
+
+  * ``bench.py`` and the BASELINE config-4 example under ``torch.distributed.run --nproc-per-node 1`` -- RCCL
+    initialisation, the barrier / max-reduce timing path and the hand-over collective all run (world size 1);
+  * two host threads stepping through ONE plan concurrently (own streams, own workspaces), including the
+    graph-replay path that mutates plan-owned state -- the contract stated in include/tcfd.h.
+"""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(script_args, extra_env=None, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_torchrun_with_rccl():
+    out = _torchrun(["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-sfno", "--no-cpu-baseline",
+                     "--no-probe"], {"BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 10 and out["scaling"] == "weak"
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline_worst"]["kernel"] in out["kernels"]
+
+
+def test_config4_example_under_torchrun_with_rccl():
+    out = _torchrun(["examples/c4_mcwilliams_ensemble.py", "--per-gpu", "8", "--warmup-steps", "5", "--steps", "55",
+                     "--record-every", "55"])
+    assert out["process_group"] is True and out["finite"] is True
+    assert out["shapes"]["vorticity"] == [8, 1, 256, 256] and out["shapes"]["random_states"] == [8]
+
+
+@pytest.mark.parametrize("n,steps", [(64, 6), (256, 2)])   # 64^2: graph replay of the interior steps (mutable plan state)
+def test_two_threads_share_one_plan(n, steps):
+    import torch_cfd_amd as tc
+    from oracle import ns2d as O
+
+    dev = torch.device("cuda:0")
+    torch.set_default_dtype(torch.float64)
+    L = 2 * torch.pi
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, forcing_fn=tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4),
+                                   solver=tc.RK4CrankNicolsonStepper()).to(dev)
+    B = 3
+    fields = [torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 10 * t + s, torch.float64)) for s in range(B)]).to(dev)
+              for t in range(2)]
+    plan = op._plan(fields[0])
+    lib = tc._lib.load()
+    beta, gdt, mu = tc.RK4CrankNicolsonStepper.stage_scalars(op.solver.params, 1e-3)
+    serial = [op(f, 1e-3, steps=steps)[0].clone() for f in fields]
+    torch.cuda.synchronize()
+    nbytes = lib.tcfd_ns2d_workspace_bytes(plan.handle, B)
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            out = torch.empty_like(fields[i])
+            with torch.cuda.device(dev):
+                for _ in range(20):
+                    rc = lib.tcfd_ns2d_step(plan.handle, fields[i].data_ptr(), out.data_ptr(), None, B, len(beta),
+                                            tc._lib.darray(beta), tc._lib.darray(gdt), tc._lib.darray(mu), steps,
+                                            1 / (steps * 1e-3), ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream.cuda_stream))
+                    if rc != 0:
+                        raise RuntimeError(lib.tcfd_last_error().decode())
+                stream.synchronize()
+            results[i] = out
+        except Exception as e:  # surfaced in the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for i in range(2):
+        assert torch.equal(results[i], serial[i])

@@ -34,6 +34,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+def scaled_err(a, b, scale_of):
+    """||a - b|| / ||scale_of||: the error of a quantity that is a DIFFERENCE of larger terms, measured against the
+    terms that cancel.  dw/dt = (w_new - w_old) / (k dt) inherits the round-off of w amplified by |w| / |w_new - w_old|
+    (~1e2..1e3 at dt = 1e-3), and the PDE residual w_t - F - L w is a truncation-size remainder of terms of size
+    |w_t|: a plain relative L2 of those in fp32 only measures that amplification (round 1 had to allow 5e-3 .. 0.5).
+    Scaled by what cancels, fp32 dw/dt and residual must meet the SAME bound as w itself."""
+    a, b, s = (torch.as_tensor(x).to("cpu", torch.complex128) for x in (a, b, scale_of))
+    return (torch.linalg.norm((a - b).reshape(-1)) / torch.linalg.norm(s.reshape(-1))).item()
+
+
 def build_op(n, tag, forcing, dev, drag=None, smooth=True, nu=1e-3):
     import torch_cfd_amd as tc
 
@@ -84,11 +94,19 @@ def test_golden_steps(n, forcing, B, tag, dev):
     w1, d1 = op(w0, 1e-3)
     assert w1.dtype == CPLX[tag] and w1.is_cuda
     assert rel_l2(w1, g[key + "_w1"]) < t1
-    assert rel_l2(d1, g[key + "_dwdt1"]) < (1e-8 if tag == "f64" else 5e-3)
+    w1_ref = torch.from_numpy(g[key + "_w1"])
+    if tag == "f64":
+        assert rel_l2(d1, g[key + "_dwdt1"]) < 1e-8
+    assert scaled_err(d1, g[key + "_dwdt1"], w1_ref / 1e-3) < t1          # same bound as w1 itself
     w10, d10 = op(w0, 1e-3, steps=10)
     assert rel_l2(w10, g[key + "_w10"]) < t10
-    assert rel_l2(d10, g[key + "_dwdt10"]) < (1e-8 if tag == "f64" else 5e-3)
-    assert rel_l2(op.residual(w1, d1), g[key + "_res1"]) < (1e-6 if tag == "f64" else 5e-2)
+    if tag == "f64":
+        assert rel_l2(d10, g[key + "_dwdt10"]) < 1e-8
+    assert scaled_err(d10, g[key + "_dwdt10"], w1_ref / 1e-2) < t10
+    res1 = op.residual(w1, d1)
+    if tag == "f64":
+        assert rel_l2(res1, g[key + "_res1"]) < 1e-6
+    assert scaled_err(res1, g[key + "_res1"], g[key + "_dwdt1"]) < (1e-10 if tag == "f64" else 3e-4)
     (uh, vh), psi = tc.vorticity_to_velocity(grid, w0, (op.kx, op.ky))
     assert rel_l2(psi, g[key + "_psi"]) < (1e-13 if tag == "f64" else 1e-6)
     if n == 16:
@@ -203,11 +221,17 @@ def test_trajectory_matches_reference(tag, dev):
     out = tc.get_trajectory_imex(op, torch.from_numpy(g[f"{tag}_w0"]).to(dev), 1e-3, num_steps=7,
                                  record_every_steps=3, dtype=CPLX[tag])
     tol = {"vorticity": 1e-10, "stream": 1e-10, "vort_t": 1e-8, "residual": 1e-6} if tag == "f64" else \
-          {"vorticity": 5e-6, "stream": 5e-6, "vort_t": 2e-2, "residual": 0.5}
+          {"vorticity": 5e-6, "stream": 5e-6}
     for k in ("vorticity", "stream", "vort_t", "residual"):
         ref = g[f"{tag}_{k}"]
         assert tuple(out[k].shape) == ref.shape and out[k].dtype == CPLX[tag] and out[k].device.type == "cpu"
-        assert rel_l2(out[k], ref) < tol[k], k
+        if k in tol:
+            assert rel_l2(out[k], ref) < tol[k], k
+    # fp32 differences-of-large-terms against what cancels (see scaled_err): same 5e-6 as the vorticity itself for
+    # dw/dt; the residual adds the round-off of F (2e-6 |F|, |F| ~ 1e2 |w_t| here)
+    w_ref = torch.from_numpy(g[f"{tag}_vorticity"])
+    assert scaled_err(out["vort_t"], g[f"{tag}_vort_t"], w_ref / 1e-3) < (1e-10 if tag == "f64" else 5e-6)
+    assert scaled_err(out["residual"], g[f"{tag}_residual"], g[f"{tag}_vort_t"]) < (1e-9 if tag == "f64" else 5e-4)
 
 
 def test_fft_semantics_golden(dev):
@@ -234,7 +258,9 @@ def test_against_oracle(n, B, tag, dev):
     ref, ref_dt = O.advance(w0, 1e-3, t, steps=steps)
     out, out_dt = op(w0.to(dev), 1e-3, steps=steps)
     assert rel_l2(out, ref) < (1e-10 if tag == "f64" else 4e-6)
-    assert rel_l2(out_dt, ref_dt) < (1e-8 if tag == "f64" else 1e-2)
+    if tag == "f64":
+        assert rel_l2(out_dt, ref_dt) < 1e-8
+    assert scaled_err(out_dt, ref_dt, ref / (steps * 1e-3)) < (1e-10 if tag == "f64" else 4e-6)   # bound of `out` itself
     # fp32: the reference's forcing table carries ~1e-6 |F| of transform round-off in every bin, which the
     # operator zeroes (NavierStokes2DSpectral.forcing_noise_floor)
     assert rel_l2(op.explicit_terms(w0.to(dev)), O.explicit_terms(w0, t)) < (1e-10 if tag == "f64" else 2e-5)
@@ -313,6 +339,65 @@ def test_config3_full_size_batch_consistency(dev):
     # F is exactly band-limited: masking it again changes nothing
     F = op.explicit_terms(w0[:4]) - op.forcing_hat().to(dev)
     assert torch.equal(F * op.filter, F)
+
+
+def test_config4_shard_full_size(dev):
+    """BASELINE configs[3], one GPU's shard: McWilliams decaying turbulence, 512^2, 64 fields, fp64, unforced, dt = 1e-3,
+    ICs generated on the device (seeds 0..63).  12 steps through the trajectory API (fused steps between records):
+    the first two fields against the oracle, every record field present, each field evolves as it does alone."""
+    from oracle import ns2d as O
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    n, B, dt = 512, 64, 1e-3
+    grid, op = build_op(n, "f64", None, dev, drag=0.0)
+    plan = tc.fft_plan(n, torch.complex128, dev)
+    w0 = torch.cat([plan.rfft2(vorticity_field(grid, 4, batch_seeds=list(range(i, i + 16)), device=dev))
+                    for i in range(0, B, 16)])
+    ic_ref = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64)) for s in range(2)])
+    assert rel_l2(w0[:2], ic_ref) < 1e-11
+    traj = tc.get_trajectory_imex(op, w0, dt, num_steps=12, record_every_steps=5, dtype=torch.complex128, to_cpu=False)
+    assert {k: tuple(v.shape) for k, v in traj.items()} == {k: (B, 3, n, n // 2 + 1) for k in
+                                                           ("vorticity", "stream", "vort_t", "residual")}
+    t = oracle_tables(n, "f64", None, drag=0.0)
+    ref = O.trajectory(ic_ref, dt, t, num_steps=12, record_every_steps=5, dtype=torch.complex128)
+    for k, tol in (("vorticity", 1e-10), ("stream", 1e-10), ("vort_t", 1e-8), ("residual", 1e-6)):
+        assert rel_l2(traj[k][:2], ref[k]) < tol, k
+    w12, _ = op(w0, dt, steps=11)   # records are taken after steps 1, 6, 11
+    assert rel_l2(w12, traj["vorticity"][:, 2]) < 1e-13
+    for idx in (0, 41, 63):
+        alone, _ = op(w0[idx:idx + 1].clone(), dt, steps=11)
+        assert torch.equal(alone[0], w12[idx])
+
+
+def test_config4_dataset_generation_512(dev, tmp_path):
+    """The data-generation loop of BASELINE configs[3] at its real grid size with a short schedule: 512^2, 8 samples
+    in batches of 4, 3 warm-up + 11 recorded steps (records every 5), 4x subsample, float32 / complex64 storage --
+    against the oracle running the same loop on the CPU for the first batch."""
+    from oracle import ns2d as O
+    from torch_cfd_amd.data_gen import generate_mcwilliams_dataset
+
+    torch.set_default_dtype(torch.float64)
+    n, dt = 512, 1e-3
+    path = str(tmp_path / "c4.pt")
+    data = generate_mcwilliams_dataset(n, total_samples=8, batch_size=4, dt=dt, warmup_steps=3, total_steps=11,
+                                       record_every_steps=5, subsample=4, device=dev, path=path)
+    assert sorted(data) == ["random_states", "residual", "stream", "vort_t", "vorticity"]
+    assert data["vorticity"].shape == (8, 3, 128, 128) and data["vorticity"].dtype == torch.float32
+    assert data["random_states"].tolist() == list(range(8))
+    saved = torch.load(path)
+    assert all(torch.equal(saved[k], data[k]) for k in data)
+    t = O.make_tables(n, L, 1e-3, 0.0, True, None, torch.float64)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64)) for s in range(4)])
+    w0, _ = O.advance(w0, dt, t, steps=3)
+    ref = O.trajectory(w0, dt, t, num_steps=11, record_every_steps=5, dtype=torch.complex64)
+    phys = {k: torch.nn.functional.interpolate(torch.fft.irfft2(v).float(), size=(128, 128), mode="bilinear")
+            for k, v in ref.items()}
+    for k in ("vorticity", "stream"):
+        assert rel_l2(data[k][:4], phys[k]) < 1e-6, k
+    # stored through complex64 records: dw/dt carries the storage round-off of w amplified by 1 / dt
+    assert scaled_err(data["vort_t"][:4], phys["vort_t"], phys["vorticity"] / dt) < 1e-6
+    assert scaled_err(data["residual"][:4], phys["residual"], phys["vort_t"]) < 1e-3
 
 
 def test_linearity_of_transforms_and_roundtrip(dev):

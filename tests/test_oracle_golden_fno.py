@@ -89,3 +89,15 @@ def test_gradients_of_the_oracle_match_the_reference(name, modes, delta, kw):
         assert rel_l2(wr[k].grad, g[f"{name}_g_weight.{k}"]) < 1e-6
         if br:
             assert rel_l2(br[k].grad, g[f"{name}_g_bias.{k}"]) < 1e-6
+
+
+@pytest.mark.parametrize("steps", [10, 20])
+def test_oracle_sfno_matches_reference_golden(steps):
+    """oracle/sfno.py (the functional whole-model restatement used as the checker of the full config-5 model on the
+    GPU) against the reference's own SFNO output on the tiny model of make_golden.gen_sfno."""
+    from oracle import sfno as OS
+
+    g = load_golden("fno_sfno_tiny.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    y = OS.sfno_forward(sd, torch.from_numpy(g["x"]), (4, 4, 3), width=4, num_hidden=2, out_steps=steps)
+    assert rel_l2(y, g[f"y{steps}"]) < 2e-6

@@ -54,8 +54,9 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     import torch.distributed as dist
 
     device = torch.device(device)
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if distributed else 1
+    rank = dist.get_rank() if distributed else 0
     lo, hi = shard_batch(total_samples, rank, world)
     grid = Grid(shape=(n, n), domain=((0, diam), (0, diam)), device=device)
     op = NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=0, smooth=True, forcing_fn=None,
@@ -75,7 +76,8 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
         result["random_states"] = torch.tensor(seeds, dtype=torch.int32, device=device)
         chunks.append(result)
     local = {k: torch.cat([c[k] for c in chunks]) for k in chunks[0]} if chunks else {}   # empty shard: no tensors
-    full = gather_trajectory(local, total_samples, dst=dst, keys=DATASET_FIELDS) if world > 1 else local
+    # with a process group (even of one rank: torchrun --nproc-per-node 1) the hand-over goes through the collective path
+    full = gather_trajectory(local, total_samples, dst=dst, keys=DATASET_FIELDS) if distributed else local
     if full is None:
         return None
     full = {k: v.cpu() for k, v in full.items()}
