@@ -45,3 +45,11 @@ def rel_l2(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _default_dtype_is_float32():
+    """Several tests switch the torch default dtype (the reference's drivers do): none may leak into the next."""
+    torch.set_default_dtype(torch.float32)
+    yield
+    torch.set_default_dtype(torch.float32)
