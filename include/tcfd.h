@@ -78,6 +78,12 @@ int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* plan, int* separable, int* sparse_
  * row pass; rows_kernel = 6 (LDS-DMA staged row pass), 5 (register staged) or 4 (round-1 kernel). */
 int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* plan, int* split, int* rows_kernel);
 
+/* Test hook: the cross-lane 1024-point transform of the row pass on its own (complex128, `count` sequences of
+ * 1024 elements, one 128-lane group each).  dir = +1: natural-order input -> output in the kernel's internal
+ * permutation (register t of lane j at out[1024 s + 128 t + j]); dir = -1: the reverse.  Needs a 1024^2
+ * complex128 plan (for its twiddle table). */
+int tcfd_debug_xl_fft1024(const tcfd_ns2d_plan* plan, const void* in, void* out, int count, int dir, void* stream);
+
 /* Bytes of caller-owned scratch needed by the calls below for `batch` fields. */
 size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* plan, long batch);
 

@@ -576,6 +576,28 @@ def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
         assert rel_l2(a, b) < tol
 
 
+@pytest.mark.parametrize("n,tag,B", [(64, "f64", 7), (256, "f32", 10), (1024, "f64", 9)])
+def test_batch_chunking_is_bit_identical(n, tag, B, dev, monkeypatch):
+    """Batched calls run chunk by chunk (cache-sized chunks by default, TCFD_CHUNK forces a size, 0 disables): the
+    fields are independent and every chunk runs the same kernels, so results must not change by a single bit --
+    steps (one call, several steps, dw/dt), explicit terms and the residual sweep; ragged last chunk included."""
+    from oracle import ns2d as O
+
+    real = REAL[tag]
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 50 + s, real)) for s in range(B)]).to(dev)
+    res = {}
+    for chunk in ("0", "4", "-1"):
+        monkeypatch.setenv("TCFD_CHUNK", chunk)
+        _, op = build_op(n, tag, "kolmogorov", dev)
+        out, dwdt = op(w0, 1e-3, steps=3)
+        psi, r = op.stream_and_residual(out, dwdt)
+        res[chunk] = (out, dwdt, op.explicit_terms(w0), psi, r)
+    monkeypatch.delenv("TCFD_CHUNK")
+    for chunk in ("4", "-1"):
+        for a, b in zip(res["0"], res[chunk]):
+            assert torch.equal(a, b), chunk
+
+
 @pytest.mark.parametrize("n,tag", [(64, "f64"), (512, "f64"), (1024, "f64"), (512, "f32"), (1024, "f32"), (256, "f32")])
 def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
     """Row pass: LDS-DMA staged rows (6), register staged rows (5) and the round-1 two-planes-per-transform kernel
@@ -587,7 +609,7 @@ def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
     B = 2
     w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, real)) for s in range(B)]).to(dev)
     res, kern = {}, {}
-    for v in ("4", "5", "6"):
+    for v in ("4", "5", "6", "7"):
         monkeypatch.setenv("TCFD_ROWS_V", v)
         _, op = build_op(n, tag, "kolmogorov", dev)
         out, _ = op(w0, 1e-3, steps=2)
@@ -595,12 +617,13 @@ def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
         res[v] = (out, op.explicit_terms(w0))
     monkeypatch.delenv("TCFD_ROWS_V")
     assert kern["4"] == 4 and kern["5"] == 5 and kern["6"] in (5, 6)
+    assert kern["7"] == (7 if (n, tag) == (1024, "f64") else 5)   # cross-lane transforms: 1024 points fp64 only
     if (n, tag) in ((512, "f64"), (1024, "f64"), (512, "f32"), (1024, "f32")):
         assert kern["6"] == 6
     tols = (1e-13, 1e-12) if tag == "f64" else (5e-7, 2e-6)
-    for v in ("4", "5"):
+    for v in ("4", "5", "7"):
         for a, b, tol in zip(res[v], res["6"], tols):
-            assert rel_l2(a, b) < tol
+            assert rel_l2(a, b) < tol, v
 
 
 def test_dataset_generation_loop_matches_reference_driver_shape(dev, tmp_path):

@@ -101,6 +101,7 @@ SIGNATURES = {
     "tcfd_ns2d_plan_destroy": (None, [_vp]),
     "tcfd_ns2d_plan_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "tcfd_ns2d_plan_variant": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "tcfd_debug_xl_fft1024": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tcfd_ns2d_workspace_bytes": (_sz, [_vp, _l]),
     "tcfd_ns2d_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _dp, _dp, _dp, _i, _d, _vp, _sz, _vp]),
     "tcfd_ns2d_step_imex": (_i, [_vp, _vp, _vp, _vp, _l, _i, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(_i), _i, _d, _vp, _sz,

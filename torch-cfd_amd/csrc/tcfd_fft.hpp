@@ -280,6 +280,28 @@ struct Passes {
             if constexpr (LAST) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) x[S + Q * r] = v[r];
+            } else if constexpr (PAD && C == 1 && Q == 1 && (Ns == 1 || Ns == EPT || Ns % (EPT * EPT) == 0)) {
+                // The swizzled slot of element e_r = o + r Ns, o = (jb - k) R + k, in closed form (R = EPT here):
+                //   Ns = 1      : (e/EPT) % EPT = jb % EPT            -> jb R + (r ^ (jb % EPT))
+                //   Ns = EPT    : (e/EPT) % EPT = r                   -> (jb - k) R + r EPT + (k ^ r)
+                //   EPT^2 | Ns  : (e/EPT) % EPT = (k/EPT) % EPT       -> (o ^ that) + r Ns      (one address + offsets)
+                // i.e. one XOR + one add per store instead of the generic divide / modulo / XOR chain per element
+                // (this arithmetic is redone per transform in the kernels that cannot afford ~40 address registers).
+                if constexpr (Ns == 1) {
+                    const int cj = jb & (EPT - 1);
+                    cx<T>* dst = lds + jb * R;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[r ^ cj] = v[r];
+                } else if constexpr (Ns == EPT) {
+                    cx<T>* dst = lds + (jb - k) * R;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[r * EPT + (k ^ r)] = v[r];
+                } else {
+                    const int o = (jb - k) * R + k;
+                    cx<T>* dst = lds + (o ^ ((k / EPT) & (EPT - 1)));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[r * Ns] = v[r];
+                }
             } else {
                 const int o = (jb - k) * R + k;
 #pragma unroll
@@ -334,6 +356,189 @@ __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(
 __device__ __forceinline__ unsigned lds_byte_address(const void* p) {
     const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
     return (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+}
+
+}  // namespace tcfd
+
+namespace tcfd {
+
+// =====================================================================================================
+// 1024-point transform on a 128-lane group (two waves), 8 elements per lane, with ONE LDS exchange.
+//
+// The Stockham passes above move all 1024 elements through LDS between every two radix passes (three exchanges,
+// six workgroup barriers).  Here only the exchange that crosses the wave boundary goes through LDS; the other two
+// are transpositions of REGISTER-index bits with LANE-index bits inside a wave:
+//     lane bits 5, 4  <->  v_permlane32_swap / v_permlane16_swap   (one instruction per dword and register pair)
+//     lane bits 3, 2  <->  v_mov_dpp row_ror:8 / row_shl:4 + row_shr:4 with a bank mask (two per dword and pair;
+//                          a DPP "bank" is four ADJACENT lanes, so the mask selects on lane bits 3 and 2 -- lane
+//                          bits 1, 0 would need an extra select and are left alone: they carry output digits)
+// which works because nothing has to be SORTED: the inverse transforms of the row pass feed a point-wise product,
+// so their output may sit in any fixed permutation `pi` of the physical row as long as the forward transform of the
+// product starts from the same permutation.  Decimation in frequency, in place (index bits n9..n0 of the input,
+// registers t = (t2 t1 t0), lanes l5..l0, wave w; digits of the output index k appear where the input digits were):
+//
+//   natural layout           t = n[9:7]            (w, l) = n[6:0]              (element j + 128 t in lane j)
+//   radix 8 over t           t = k[2:0]            twiddle W_1024^(t j)
+//   LDS exchange             t = n[6:4]            w l1 l0 = k[2:0],  l5 l4 l3 l2 = n[3:0] =: m
+//   radix 8 over t           t = k[5:3]            twiddle W_128^(t m)
+//   t2 <-> l5, t1 <-> l4     t2 t1 = n[3:2]        l5 l4 = k[5:4]
+//   radix 4 over (t2 t1)     t2 t1 = k[7:6]        twiddle W_16^((t2 t1) (l3 l2))
+//   t2 <-> l3, t1 <-> l2     t2 t1 = n[1:0]        l3 l2 = k[7:6]
+//   radix 4 over (t2 t1)     t2 t1 = k[9:8]
+//
+//   pi:  k = (w l1 l0) + 8 (l5 l4 t0) + 64 (l3 l2) + 256 (t2 t1)
+//
+// DIR = +1 runs this (natural -> pi); DIR = -1 runs the transposed flow graph (pi -> natural): the DFT matrix is
+// symmetric, so the same stages in reverse order with conjugated roots are the forward transform.
+// (tests/micro/xlane_fft_model.py is the numpy model of this data flow.)
+// =====================================================================================================
+template <int LANEBIT>
+__device__ __forceinline__ void xswap_word(unsigned& a, unsigned& b) {
+    if constexpr (LANEBIT == 5) {
+        const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    } else if constexpr (LANEBIT == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    } else if constexpr (LANEBIT == 3) {
+        // partner lane ^ 8 = row_ror:8 (0x128); receivers: banks {2,3} (lanes 8..15 of a row) resp. {0,1}
+        const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x128, 0xF, 0xC, false);
+        const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x128, 0xF, 0x3, false);
+        a = na;
+        b = nb;
+    } else {
+        static_assert(LANEBIT == 2, "lane bits 5, 4, 3, 2 only");
+        // a (register bit 0) receives in the lanes with l2 = 1 (banks 1, 3) from lane - 4: row_shr:4 (0x114);
+        // b (register bit 1) receives in the lanes with l2 = 0 (banks 0, 2) from lane + 4: row_shl:4 (0x104)
+        const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x114, 0xF, 0xA, false);
+        const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x104, 0xF, 0x5, false);
+        a = na;
+        b = nb;
+    }
+}
+// a: register whose index bit is 0, b: register whose index bit is 1.  Afterwards the register bit and the lane bit
+// have traded places: a holds, in the lanes whose LANEBIT is set, what b held in the partner lanes, and vice versa.
+template <int LANEBIT>
+__device__ __forceinline__ void xswap(cx<double>& a, cx<double>& b) {
+    unsigned long long ax = __builtin_bit_cast(unsigned long long, a.x), ay = __builtin_bit_cast(unsigned long long, a.y);
+    unsigned long long bx = __builtin_bit_cast(unsigned long long, b.x), by = __builtin_bit_cast(unsigned long long, b.y);
+    unsigned w[8] = {(unsigned)ax, (unsigned)(ax >> 32), (unsigned)ay, (unsigned)(ay >> 32),
+                     (unsigned)bx, (unsigned)(bx >> 32), (unsigned)by, (unsigned)(by >> 32)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xswap_word<LANEBIT>(w[i], w[4 + i]);
+    a.x = __builtin_bit_cast(double, (unsigned long long)w[0] | ((unsigned long long)w[1] << 32));
+    a.y = __builtin_bit_cast(double, (unsigned long long)w[2] | ((unsigned long long)w[3] << 32));
+    b.x = __builtin_bit_cast(double, (unsigned long long)w[4] | ((unsigned long long)w[5] << 32));
+    b.y = __builtin_bit_cast(double, (unsigned long long)w[6] | ((unsigned long long)w[7] << 32));
+}
+template <int LANEBIT>
+__device__ __forceinline__ void xswap(cx<float>& a, cx<float>& b) {
+    unsigned w[4] = {__builtin_bit_cast(unsigned, a.x), __builtin_bit_cast(unsigned, a.y),
+                     __builtin_bit_cast(unsigned, b.x), __builtin_bit_cast(unsigned, b.y)};
+    xswap_word<LANEBIT>(w[0], w[2]);
+    xswap_word<LANEBIT>(w[1], w[3]);
+    a.x = __builtin_bit_cast(float, w[0]);
+    a.y = __builtin_bit_cast(float, w[1]);
+    b.x = __builtin_bit_cast(float, w[2]);
+    b.y = __builtin_bit_cast(float, w[3]);
+}
+// trade register-index bit REGBIT (of 3) with lane bit LANEBIT for all 8 registers
+template <int REGBIT, int LANEBIT, typename T>
+__device__ __forceinline__ void xtranspose(cx<T> (&x)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (!(t & (1 << REGBIT))) xswap<LANEBIT>(x[t], x[t | (1 << REGBIT)]);
+}
+
+// per-lane twiddles of the three twiddled stages, forward sign (exp(-2 pi i e / 1024)); loaded once per kernel
+template <typename T>
+struct XlTw {
+    cx<T> w1;   // W^j        j = lane index in the group (0..127)
+    cx<T> w2;   // W^(8 m)    m = (l5 l4 l3 l2)
+    cx<T> w3;   // W^(64 c)   c = (l3 l2)
+};
+template <typename T>
+__device__ __forceinline__ XlTw<T> xl_load_tw(const cx<T>* __restrict__ tw, int j) {
+    const int m = (j & 63) >> 2;
+    XlTw<T> r;
+    r.w1 = tw[j];
+    r.w2 = tw[8 * m];
+    r.w3 = tw[64 * (m & 3)];
+    return r;
+}
+// x[t] *= w^(digit of t over the register bits listed in MASK), powers of w by squaring
+template <int DIR, int NBITS, int SHIFT, typename T>
+__device__ __forceinline__ void xl_twiddle(cx<T> (&x)[8], cx<T> w) {
+    if constexpr (DIR > 0) w.y = -w.y;
+#pragma unroll
+    for (int b = 0; b < NBITS; ++b) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if ((t >> SHIFT) & (1 << b)) x[t] = cmul(x[t], w);
+        if (b + 1 < NBITS) w = csquare(w);
+    }
+}
+template <int DIR, typename T>
+__device__ __forceinline__ void xl_radix4_pairs(cx<T> (&x)[8]) {   // radix 4 over (t2 t1), for t0 = 0 and 1
+#pragma unroll
+    for (int t0 = 0; t0 < 2; ++t0) {
+        cx<T> v[4] = {x[t0], x[2 + t0], x[4 + t0], x[6 + t0]};
+        Dft<4, DIR, T>::run(v);
+        x[t0] = v[0]; x[2 + t0] = v[1]; x[4 + t0] = v[2]; x[6 + t0] = v[3];
+    }
+}
+// LDS slot of element (q, jj) of the exchange, q = k[2:0] digit, jj = n[6:0]: rows of 128; bits 3:2 of the column are
+// XORed with (q1 q0) so that the 16 lanes a 16-byte read serves together (4 values of m x 4 values of (q1 q0), the
+// same 16 a) fall on 16 different 16-byte bank groups
+__device__ __forceinline__ int xl_slot(int q, int jj) { return q * 128 + (jj ^ ((q & 3) << 2)); }
+
+template <typename T, int DIR, int SYNC, typename Hook>
+__device__ __forceinline__ void xl_fft1024(cx<T> (&x)[8], cx<T>* lds, const XlTw<T>& tw, int j, Hook& hook) {
+    const int q_lane = ((j >> 6) << 2) | (j & 3);   // (w l1 l0)
+    const int m_lane = (j & 63) >> 2;               // (l5 l4 l3 l2)
+    // lane-side view of the exchange buffer: element (q_lane, 16 a + m_lane) for a = 0..7: one address + 16 a
+    cx<T>* lane_side = lds + q_lane * 128 + (m_lane ^ ((q_lane & 3) << 2));
+    if constexpr (DIR > 0) {
+        Dft<8, DIR, T>::run(x);
+        xl_twiddle<DIR, 3, 0>(x, tw.w1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lds[xl_slot(q, j)] = x[q];
+        group_sync<SYNC>();
+        hook();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) x[a] = lane_side[16 * a];
+        group_sync<SYNC>();
+        Dft<8, DIR, T>::run(x);
+        xl_twiddle<DIR, 3, 0>(x, tw.w2);
+        xtranspose<2, 5>(x);
+        xtranspose<1, 4>(x);
+        xl_radix4_pairs<DIR>(x);
+        xl_twiddle<DIR, 2, 1>(x, tw.w3);
+        xtranspose<2, 3>(x);
+        xtranspose<1, 2>(x);
+        xl_radix4_pairs<DIR>(x);
+    } else {
+        xl_radix4_pairs<DIR>(x);
+        xtranspose<1, 2>(x);
+        xtranspose<2, 3>(x);
+        xl_twiddle<DIR, 2, 1>(x, tw.w3);
+        xl_radix4_pairs<DIR>(x);
+        xtranspose<1, 4>(x);
+        xtranspose<2, 5>(x);
+        xl_twiddle<DIR, 3, 0>(x, tw.w2);
+        Dft<8, DIR, T>::run(x);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) lane_side[16 * a] = x[a];
+        group_sync<SYNC>();
+        hook();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = lds[xl_slot(q, j)];
+        group_sync<SYNC>();
+        xl_twiddle<DIR, 3, 0>(x, tw.w1);
+        Dft<8, DIR, T>::run(x);
+    }
 }
 
 }  // namespace tcfd

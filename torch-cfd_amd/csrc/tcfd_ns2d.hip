@@ -477,18 +477,30 @@ __device__ __forceinline__ void load_raw(RawPair<T, EPT>& r, const cx<T>* __rest
 template <typename T, int N, int EPT, bool WG>
 __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>& r, cx<T>* lds, int j) {
     constexpr int G = N / EPT;
+    // G % EPT^2 == 0: the swizzle term of lds_addr is the same for every t, so the mirrored slots N - j - t G and
+    // the read slots j + t G are ONE address each plus compile-time offsets
+    constexpr bool AFFINE = (G % (EPT * EPT) == 0);
+    cx<T>* mir = lds + lds_addr<EPT, 1, true>(N - j, 0);   // j = 0: slot N is never touched (k >= 1 below)
 #pragma unroll
     for (int t = 0; t < EPT / 2; ++t) {
         const int k = j + t * G;
         cx<T> pa = r.a[t], pb = r.b[t];
         if (k == 0) { pa.y = 0; pb.y = 0; }
         x[t] = mk<T>(pa.x - pb.y, pa.y + pb.x);
-        if (k >= 1) lds[lds_addr<EPT, 1, true>(N - k, 0)] = mk<T>(pa.x + pb.y, pb.x - pa.y);
+        if (k >= 1) {
+            const cx<T> m = mk<T>(pa.x + pb.y, pb.x - pa.y);
+            if constexpr (AFFINE) mir[-t * G] = m;
+            else lds[lds_addr<EPT, 1, true>(N - k, 0)] = m;
+        }
     }
     if (j == 0) lds[lds_addr<EPT, 1, true>(N / 2, 0)] = mk<T>(r.an.x, r.bn.x);
     group_sync<WG>();
+    const cx<T>* src = lds + lds_addr<EPT, 1, true>(j, 0);
 #pragma unroll
-    for (int t = EPT / 2; t < EPT; ++t) x[t] = lds[lds_addr<EPT, 1, true>(j + t * G, 0)];
+    for (int t = EPT / 2; t < EPT; ++t) {
+        if constexpr (AFFINE) x[t] = src[t * G];
+        else x[t] = lds[lds_addr<EPT, 1, true>(j + t * G, 0)];
+    }
     group_sync<WG>();
 }
 
@@ -819,6 +831,118 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
     }
 }
 
+// ---- row pass, cross-lane transforms ("v7", 1024 points on two-wave groups) ------------------------------------
+// v5 with the three-exchange Stockham transform replaced by xl_fft1024 (tcfd_fft.hpp): one LDS exchange per
+// transform, the other two are register <-> lane bit transpositions inside a wave (v_permlane32/16_swap, DPP).
+// The four inverse transforms leave the physical rows in the fixed permutation `pi`; the point-wise product does
+// not care, and the forward transform of the product starts from `pi` and ends in natural order.
+// LDS stores per row pair: 18 -> 8 exchange-equivalents of 16 KB; workgroup barriers per pair: ~40 -> ~20.
+template <typename T, int THR, int SP, int MINW, int PF>
+__global__ __launch_bounds__(128, MINW) void k_rows_advect7(
+    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
+    long npairs, int ld, int kc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = 1024, EPT = 8, G = 128, N2 = N / 2;
+    constexpr bool WG = true;
+    const int j = threadIdx.x;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+    const long stride = (long)gridDim.x;
+    long pair = (long)blockIdx.x;
+    const long iters = (npairs + stride - 1) / stride;
+    auto row_a = [&](long p) -> size_t {
+        return SP ? (size_t)((p / N2) * N + (p % N2)) * (size_t)ld : (size_t)p * 2 * (size_t)ld;
+    };
+    const size_t second = SP ? (size_t)N2 * ld : (size_t)ld;
+    const XlTw<T> xtw = xl_load_tw<T>(tw, j);
+    NoHook nohook;
+
+    RawPair<T, EPT> H;
+    if constexpr (PF) {
+        const size_t off = row_a(pair < npairs ? pair : npairs - 1);
+        load_raw<T, N, EPT>(H, planes + off, planes + off + second, j);
+    }
+    for (long it = 0; it < iters; ++it, pair += stride) {
+        const bool valid = pair < npairs;
+        const long cur = valid ? pair : npairs - 1;
+        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
+        const size_t off = row_a(cur), offn = row_a(nxt);
+        cx<T> wf = mk<T>((T)1, (T)0), wi = wf;
+        if constexpr (SP) {
+            wf = tw[(int)(cur % N2)];   // exp(-2 pi i r / N)
+            wi = cconj(wf);
+        }
+        cx<T> za[EPT], x[EPT], p[EPT];
+        auto field = [&](cx<T>(&out)[EPT], const cx<T>* thisA, const cx<T>* nextA) {
+            if constexpr (!PF) load_raw<T, N, EPT>(H, thisA, thisA + second, j);
+            if constexpr (SP) {
+#pragma unroll
+                for (int t = 0; t < EPT / 2; ++t) {
+                    const cx<T> o = cmul(H.b[t], wi);
+                    H.b[t] = H.a[t] - o;
+                    H.a[t] = H.a[t] + o;
+                }
+                const cx<T> o = cmul(H.bn, wi);
+                H.bn = H.an - o;
+                H.an = H.an + o;
+            }
+            pack_herm<T, N, EPT, WG>(out, H, lds, j);
+            if constexpr (PF) load_raw<T, N, EPT>(H, nextA, nextA + second, j);
+            xl_fft1024<T, +1, 1>(out, lds, xtw, j, nohook);
+        };
+        const cx<T>* P0 = planes + off;
+        const cx<T>* P1 = planes + plane_stride + off;
+        const cx<T>* P2 = planes + 2 * plane_stride + off;
+        const cx<T>* P3 = planes + 3 * plane_stride + off;
+        field(za, P0, P2);   // vx   (next: dx w)
+        field(x, P2, P1);    // dx w (next: v^)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(za[t].x * x[t].x, za[t].y * x[t].y);
+        field(za, P1, P3);               // vy   (next: dy w)
+        field(x, P3, planes + offn);     // dy w (next: u^ of the next pair)
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(-(p[t].x + za[t].x * x[t].x), -(p[t].y + za[t].y * x[t].y));
+
+        xl_fft1024<T, -1, 1>(p, lds, xtw, j, nohook);   // pi -> natural order
+        // unpack the two real-row spectra (mirror through the exchange buffer)
+        const cx<T>* mir = lds + lds_addr<EPT, 1, true>(N - j, 0);
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(j + t * G, 0)] = p[t];
+        group_sync<WG>();
+        const T half = (T)0.5;
+        cx<T>* out0 = adv + off;
+        cx<T>* out1 = adv + off + second;
+#pragma unroll
+        for (int t = 0; t < EPT / 2; ++t) {
+            const int k = j + t * G;
+            const cx<T> A = p[t];
+            const cx<T> Bm = (j == 0 && t == 0) ? p[0] : mir[-t * G];   // element N - k; k = 0 mirrors itself
+            const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of the first row
+            const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of the second row
+            if (valid && k < kc) {
+                if constexpr (SP) {   // folded for the parity workgroups of the column pass
+                    out0[k] = X0 + X1;
+                    out1[k] = cmul(X0 - X1, wf);
+                } else {
+                    out0[k] = X0;
+                    out1[k] = X1;
+                }
+            }
+        }
+        if (j == 0 && valid && N2 < kc) {
+            const cx<T> A = p[EPT / 2];
+            const cx<T> X0 = mk<T>(A.x, (T)0), X1 = mk<T>(A.y, (T)0);
+            if constexpr (SP) {
+                out0[N2] = X0 + X1;
+                out1[N2] = cmul(X0 - X1, wf);
+            } else {
+                out0[N2] = X0;
+                out1[N2] = X1;
+            }
+        }
+        group_sync<WG>();
+    }
+}
+
 // ---- row pass, LDS-DMA staged ("v6") -------------------------------------------------------------
 // v5 with the HBM side taken off the register file: the two half rows of the NEXT plane are copied HBM -> LDS by
 // LDS-DMA (global_load_lds_dwordx4: no VGPRs, 1 KB per wave-instruction) while the current plane is transformed,
@@ -1100,6 +1224,7 @@ struct Tuning {
     int ablate;              // TCFD_ABLATE: timing ablations (results are WRONG when non-zero)
     int rows_v;              // TCFD_ROWS_V: 0 = per size; 6 = LDS-DMA staged rows, 5 = register-staged rows (one plane per
                              // transform), 4 = two planes per transform (round 1)
+    int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
     int rows_minw;           // TCFD_ROWS_MINW: waves/SIMD the row kernel is compiled for (register cap), 0 = per size
 };
 
@@ -1281,6 +1406,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->tune.ablate = env_int("TCFD_ABLATE", 0);
     p->tune.rows_v = env_int("TCFD_ROWS_V", 0);
     p->tune.rows_minw = env_int("TCFD_ROWS_MINW", 0);
+    p->tune.chunk = env_int("TCFD_CHUNK", -1);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
         p->ldw = (p->m + per_line - 1) / per_line * per_line;
@@ -1494,6 +1620,20 @@ static int launch_rows_advect5(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
+template <typename T, int SP, int MINW, int PF>
+static int launch_rows_advect7(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
+                               long batch, hipStream_t st) {
+    auto kern = k_rows_advect7<T, 128, SP, MINW, PF>;
+    constexpr size_t lds = (size_t)(1024 + 1) * sizeof(cx<T>);   // + 1: the unpack reads slot N for lane 0 (value unused)
+    const long npairs = batch * 512;
+    const long blocks = rows_grid(p, npairs, 2 * MINW);   // two-wave workgroups: 2 per SIMD pair and wave slot
+    ProfScope prof(p, 1, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(128), lds, st, planes, plane_stride, adv,
+                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : 1024);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <typename T, int N, int EPT, int THR, int SP, int MINW>
 static int launch_rows_advect6(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
                                long batch, hipStream_t st) {
@@ -1518,7 +1658,10 @@ static int launch_rows_advect6(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
 // per-transform address arithmetic it needs to stay under 256 VGPRs costs more than the staging saves.
 template <typename T, int N>
 static constexpr int rows_default_version() {
-    return 5;
+    // 7 = cross-lane transforms (1024 points fp64): equal to 5 while the row pass streams from HBM (0.616 vs 0.607 ms
+    // per launch on the whole batch) and ahead of it once the planes come from the Infinity Cache (chunked calls:
+    // 7.54 vs 7.82 ms per step)
+    return (N == 1024 && sizeof(T) == 8) ? 7 : 5;
 }
 
 template <typename T, int N>
@@ -1544,6 +1687,16 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         }
     }
     if constexpr (N == 1024 && sizeof(T) == 8) {
+        if (p->tune.rows_v == 7 || (p->tune.rows_v == 0 && p->tune.rows_minw == 0)) {
+            if (split) {
+                switch (p->tune.rows_minw) {
+                    case 1: return launch_rows_advect7<T, 1, 1, 1>(p, planes, plane_stride, adv, batch, st);
+                    case 20: return launch_rows_advect7<T, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
+                    default: return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st);
+                }
+            }
+            return launch_rows_advect7<T, 0, 2, 1>(p, planes, plane_stride, adv, batch, st);
+        }
         if (split) {
             switch (p->tune.rows_minw) {
                 case 1: return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st);
@@ -1890,6 +2043,31 @@ static int check_ws(const tcfd_ns2d_plan* p, long batch, void* ws, size_t bytes,
     return 0;
 }
 
+// Fields per chunk of a batched call.  TCFD_CHUNK > 0 forces it, 0 disables chunking, -1 (default) sizes the chunk so
+// that its working set -- 4 planes + advection + RK accumulator + padded state, 7 workspace fields per batch element --
+// fits the 256 MB Infinity Cache (measured on MI355X, steps/s per call: 1024^2 x 64 fp64 122.7 -> 129.3 at 4 fields
+// per chunk, 114.5 at 5; 512^2 x 64 fp64 408 -> 501 at 16).  Chunks are balanced, and a chunk of fewer than 3 fields
+// (2048^2: a single field already exceeds the cache) is not worth the extra launches.
+static long chunk_fields(const tcfd_ns2d_plan* p, long batch) {
+    long c = p->tune.chunk;
+    if (c == 0) return batch;
+    if (c < 0) {
+        const size_t per_field = 7 * (size_t)p->n * p->ldw * (p->dtype == TCFD_C128 ? 16 : 8);
+        c = (long)(((size_t)244 << 20) / per_field);
+        if (c < 3) return batch;
+    }
+    if (c >= batch) return batch;
+    const long nchunks = (batch + c - 1) / c;
+    return (batch + nchunks - 1) / nchunks;
+}
+
+static int chunk_dispatch(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
+                          const double* beta, const double* gdt, const double* mu_num, const double* fa,
+                          const double* mu_den, const int* base0, int steps, double inv_total_dt, void* ws, hipStream_t st) {
+    TCFD_DISPATCH(p, (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps,
+                                         inv_total_dt, ws, st)));
+}
+
 extern "C" int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
                                    int nstages, const double* fa, const double* beta, const double* gdt,
                                    const double* mu_num, const double* mu_den, const int* base0, int steps,
@@ -1900,8 +2078,25 @@ extern "C" int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* p, const void* w_in, vo
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    TCFD_DISPATCH(p, (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps,
-                                         inv_total_dt, ws, st)));
+    // Batch chunking (TCFD_CHUNK = fields per chunk): the batch elements are independent, so the call may run chunk by
+    // chunk -- every stage of every step of one chunk back to back, all chunks through the SAME (chunk-sized) part of
+    // the workspace.  With a chunk whose working set (4 planes + adv + h + state) fits the 256 MB Infinity Cache the
+    // planes written by a column pass are still on die when the row pass reads them.
+    const long chunk = chunk_fields(p, batch);
+    if (chunk < batch) {
+        const size_t esz = (p->dtype == TCFD_C128 ? 16 : 8) * (size_t)p->n * p->m;
+        for (long b0 = 0; b0 < batch; b0 += chunk) {
+            const long nb = std::min(chunk, batch - b0);
+            const unsigned char* in = (const unsigned char*)w_in + b0 * esz;
+            unsigned char* out = (unsigned char*)w_out + b0 * esz;
+            unsigned char* dw = dwdt ? (unsigned char*)dwdt + b0 * esz : nullptr;
+            rc = chunk_dispatch(p, in, out, dw, nb, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps, inv_total_dt, ws, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    return chunk_dispatch(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps, inv_total_dt, ws,
+                          st);
 }
 
 extern "C" int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
@@ -1911,13 +2106,34 @@ extern "C" int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w
                                inv_total_dt, ws, ws_bytes, stream);
 }
 
+static int explicit_dispatch(const tcfd_ns2d_plan* p, const void* w, void* out, const void* wt, void* psi, bool residual,
+                             long batch, void* ws, hipStream_t st) {
+    TCFD_DISPATCH(p, (explicit_impl<T_, N_>(p, w, out, wt, psi, residual, batch, ws, st)));
+}
+// F(w) / residual sweeps chunk by chunk like the steps (the planes of a chunk stay on die between the two passes)
+static int explicit_chunked(const tcfd_ns2d_plan* p, const void* w, void* out, const void* wt, void* psi, bool residual,
+                            long batch, void* ws, hipStream_t st) {
+    const long chunk = chunk_fields(p, batch);
+    if (chunk >= batch) return explicit_dispatch(p, w, out, wt, psi, residual, batch, ws, st);
+    const size_t esz = (p->dtype == TCFD_C128 ? 16 : 8) * (size_t)p->n * p->m;
+    auto at = [&](const void* base, long b0) -> unsigned char* {
+        return base ? (unsigned char*)base + (size_t)b0 * esz : nullptr;
+    };
+    for (long b0 = 0; b0 < batch; b0 += chunk) {
+        const long nb = std::min(chunk, batch - b0);
+        int rc = explicit_dispatch(p, at(w, b0), at(out, b0), at(wt, b0), at(psi, b0), residual, nb, ws, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* p, const void* w, void* out, long batch, void* ws,
                                         size_t ws_bytes, void* stream) {
     if (!p || !w || !out || batch <= 0) return fail(TCFD_EINVAL, "explicit_terms: bad argument");
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    TCFD_DISPATCH(p, (explicit_impl<T_, N_>(p, w, out, nullptr, nullptr, false, batch, ws, st)));
+    return explicit_chunked(p, w, out, nullptr, nullptr, false, batch, ws, st);
 }
 
 extern "C" int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* p, const void* w, const void* wt, void* psi,
@@ -1926,7 +2142,7 @@ extern "C" int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* p, const void* w,
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    TCFD_DISPATCH(p, (explicit_impl<T_, N_>(p, w, residual, wt, psi, true, batch, ws, st)));
+    return explicit_chunked(p, w, residual, wt, psi, true, batch, ws, st);
 }
 
 template <typename T>
@@ -1969,7 +2185,8 @@ static int variant_impl(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
     if (split) *split = sp ? 1 : 0;
     if (rows_kernel) {
         int v = p->tune.rows_v;
-        if (v != 4 && v != 5 && v != 6) v = rows_default_version<T, N>();
+        if (v != 4 && v != 5 && v != 6 && v != 7) v = rows_default_version<T, N>();
+        if (v == 7 && !(N == 1024 && sizeof(T) == 8)) v = 5;
         if (v == 6 && !RowGeom6<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>::OK) v = 5;
         *rows_kernel = v;
     }
@@ -1979,6 +2196,39 @@ static int variant_impl(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
 extern "C" int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
     if (!p) return fail(TCFD_EINVAL, "plan_variant: null plan");
     TCFD_DISPATCH(p, (variant_impl<T_, N_>(p, split, rows_kernel)));
+}
+
+// ------------------------------------------------------------------ test hook: the cross-lane transform alone
+// One 128-lane group transforms `count` independent 1024-point sequences (complex128).  dir = +1: natural-order
+// input, output in the permutation pi of xl_fft1024 (element t of lane j at out[seq][128 t + j]); dir = -1: input in
+// that layout, natural-order output.  tests/test_ns2d_gpu.py checks both against numpy through the map of pi.
+template <int DIR>
+__global__ __launch_bounds__(128) void k_debug_xl(const cx<double>* __restrict__ in, cx<double>* __restrict__ out,
+                                                  const cx<double>* __restrict__ tw) {
+    __shared__ __attribute__((aligned(16))) cx<double> lds[1024];
+    const int j = threadIdx.x;
+    const XlTw<double> xtw = xl_load_tw<double>(tw, j);
+    cx<double> x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = in[(size_t)blockIdx.x * 1024 + 128 * t + j];
+    NoHook nohook;
+    xl_fft1024<double, DIR, 1>(x, lds, xtw, j, nohook);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) out[(size_t)blockIdx.x * 1024 + 128 * t + j] = x[t];
+}
+
+extern "C" int tcfd_debug_xl_fft1024(const tcfd_ns2d_plan* p, const void* in, void* out, int count, int dir, void* stream) {
+    if (!p || !in || !out || count <= 0 || (dir != 1 && dir != -1)) return fail(TCFD_EINVAL, "debug_xl_fft1024: bad argument");
+    if (p->n != 1024 || p->dtype != TCFD_C128) return fail(TCFD_EINVAL, "debug_xl_fft1024: needs a 1024^2 complex128 plan");
+    hipStream_t st = (hipStream_t)stream;
+    if (dir > 0)
+        hipLaunchKernelGGL(k_debug_xl<+1>, dim3(count), dim3(128), 0, st, (const cx<double>*)in, (cx<double>*)out,
+                           (const cx<double>*)p->tw);
+    else
+        hipLaunchKernelGGL(k_debug_xl<-1>, dim3(count), dim3(128), 0, st, (const cx<double>*)in, (cx<double>*)out,
+                           (const cx<double>*)p->tw);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------ profiling side-car
