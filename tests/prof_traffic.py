@@ -7,6 +7,7 @@ import re
 import sys
 
 src, n, B, dtype = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+nchunks = int(sys.argv[5]) if len(sys.argv) > 5 else 1   # launches per full-batch pass (cache-sized chunks, bench.py prints it)
 txt = open(f"{src}/summary.txt").read()
 blocks = re.split(r"\n(?=k_)", txt.split("== PMC (mean per dispatch)\n")[1])
 S = B * n * (n // 2 + 1) * (16 if dtype == "f64" else 8)
@@ -26,9 +27,11 @@ for b in blocks:
         key = None
     if not key or "FETCH_SIZE" not in vals:
         continue
-    traffic = (2 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0)) * 1024
+    traffic = (2 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0)) * 1024 * nchunks   # per PASS over the whole batch
     out[f"{key}|n{n}|B{B}|{dtype}"] = round(traffic)
     print(f"{key:18s} algorithmic {alg*S/1e9:6.2f} GB   measured {traffic/1e9:6.2f} GB   (TCC_MISS*128 = {vals.get('TCC_MISS_sum',0)*128/1e9:.2f} GB)")
-out["_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
-                "(tests/prof.sh -> profiles/*_rocprofv3_summary.txt)")
+out["_note"] = ("bytes between L2 and the memory side per full-batch PASS of a kernel (= launches_per_pass chunk launches) = "
+                "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch x launches per pass, from separate rocprofv3 --pmc passes "
+                "(tests/prof.sh -> profiles/*_rocprofv3_summary.txt); Infinity-Cache hits are included in these counters")
+out["_build"] = sys.argv[6] if len(sys.argv) > 6 else "unlabelled"
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)

@@ -576,6 +576,29 @@ def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
         assert rel_l2(a, b) < tol
 
 
+@pytest.mark.parametrize("n", [512, 1024])
+def test_cross_lane_column_transforms_agree_with_stockham(n, dev, monkeypatch):
+    """512-point column tiles (512^2 and the split 1024^2 plans, fp64) run their transforms with one LDS exchange +
+    register<->lane transpositions (xl_col_fft512); TCFD_COLS_XL=0 selects the three-pass Stockham form.  Same
+    arithmetic in a different order: steps, explicit terms, residual / stream function agree to round-off."""
+    from oracle import ns2d as O
+
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 7 + s, torch.float64)) for s in range(2)]).to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TCFD_COLS_XL", flag)
+        _, op = build_op(n, "f64", "kolmogorov", dev)
+        out, dwdt = op(w0, 1e-3, steps=2)
+        psi, r = op.stream_and_residual(out, dwdt)
+        res[flag] = (out, op.explicit_terms(w0), psi, dwdt, r)
+    monkeypatch.delenv("TCFD_COLS_XL")
+    t = oracle_tables(n, "f64", "kolmogorov")
+    ref, _ = O.advance(w0.cpu(), 1e-3, t, steps=2)
+    assert rel_l2(res["1"][0], ref) < 1e-10
+    for a, b, tol in zip(res["0"], res["1"], (1e-13, 1e-12, 1e-13, 1e-10, 1e-7)):
+        assert rel_l2(a, b) < tol
+
+
 @pytest.mark.parametrize("n,tag,B", [(64, "f64", 7), (256, "f32", 10), (1024, "f64", 9)])
 def test_batch_chunking_is_bit_identical(n, tag, B, dev, monkeypatch):
     """Batched calls run chunk by chunk (cache-sized chunks by default, TCFD_CHUNK forces a size, 0 disables): the

@@ -542,3 +542,75 @@ __device__ __forceinline__ void xl_fft1024(cx<T> (&x)[8], cx<T>* lds, const XlTw
 }
 
 }  // namespace tcfd
+
+namespace tcfd {
+
+// =====================================================================================================
+// 512-point transforms of a column tile (8 columns side by side, 8 elements per lane, 512 threads = 8 waves) with
+// ONE LDS exchange.  Thread tid = 8 j + c (c = column, j = 0..63): lane bits (l5 l4 l3) = j & 7, wave = j >> 3.
+// Index bits n8..n0 of the input, registers t, decimation in frequency:
+//
+//   natural layout           t = n[8:6]      wave = n[5:3]     (l5 l4 l3) = n[2:0]      (element j + 64 t)
+//   radix 8 over t           t = k[2:0]      twiddle W_512^(t j)
+//   LDS exchange             t <-> wave      (lanes stay: every wave moves whole 64-lane rows, conflict free)
+//   radix 8 over t           t = k[5:3]      twiddle W_64^(t m), m = (l5 l4 l3)
+//   t <-> (l5 l4 l3)         v_permlane32_swap, v_permlane16_swap, DPP row_ror:8 (lane bits 5, 4, 3)
+//   radix 8 over t           t = k[8:6]
+//
+// so register t of thread j ends up holding output element  swap3(j) + 64 t,  swap3(j) = ((j & 7) << 3) | (j >> 3):
+// the caller simply stores (DIR = +1) or loads (DIR = -1, the transposed flow graph) its rows at that index -- both
+// sides of the transform stay in natural order in memory.  tests/micro/xcol_fft_model.py is the numpy model.
+// =====================================================================================================
+template <typename T>
+struct XlColTw {
+    cx<T> w1;   // W_512^j
+    cx<T> w2;   // W_512^(8 (j & 7))
+};
+template <typename T>
+__device__ __forceinline__ XlColTw<T> xl_col_load_tw(const cx<T>* __restrict__ tw512, int j) {
+    XlColTw<T> r;
+    r.w1 = tw512[j];
+    r.w2 = tw512[8 * (j & 7)];
+    return r;
+}
+__device__ __forceinline__ int xl_col_row(int j) { return ((j & 7) << 3) | (j >> 3); }
+
+template <typename T, int DIR>
+__device__ __forceinline__ void xl_col_fft512(cx<T> (&x)[8], cx<T>* lds, const XlColTw<T>& tw, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    cx<T>* by_reg_wave = lds + wave * 64 + lane;          // slot (q = register, a = wave): + 512 q
+    cx<T>* by_wave_reg = lds + wave * 512 + lane;         // slot (q = wave, a = register): + 64 a
+    if constexpr (DIR > 0) {
+        Dft<8, DIR, T>::run(x);
+        xl_twiddle<DIR, 3, 0>(x, tw.w1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) by_reg_wave[512 * q] = x[q];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) x[a] = by_wave_reg[64 * a];
+        __syncthreads();
+        Dft<8, DIR, T>::run(x);
+        xl_twiddle<DIR, 3, 0>(x, tw.w2);
+        xtranspose<2, 5>(x);
+        xtranspose<1, 4>(x);
+        xtranspose<0, 3>(x);
+        Dft<8, DIR, T>::run(x);
+    } else {
+        Dft<8, DIR, T>::run(x);
+        xtranspose<0, 3>(x);
+        xtranspose<1, 4>(x);
+        xtranspose<2, 5>(x);
+        xl_twiddle<DIR, 3, 0>(x, tw.w2);
+        Dft<8, DIR, T>::run(x);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) by_wave_reg[64 * a] = x[a];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = by_reg_wave[512 * q];
+        __syncthreads();
+        xl_twiddle<DIR, 3, 0>(x, tw.w1);
+        Dft<8, DIR, T>::run(x);
+    }
+}
+
+}  // namespace tcfd

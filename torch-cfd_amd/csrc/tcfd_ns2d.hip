@@ -141,7 +141,9 @@ struct ColArgs {
 // transforms on them; the radix-2 butterfly that joins the two parities rides in the row kernel, which works
 // on row pairs (r, r + N/2) anyway.  Workspace rows [0, N/2) then hold the even-part transforms E (resp. the
 // folded sums S of the advection), rows [N/2, N) the odd parts O (resp. the twiddled differences D).
-template <typename T, int N, int EPT, int C, int SP>
+// XL = 1 (512-point tiles of 8 columns): the transforms are xl_col_fft512 (one LDS exchange + lane transpositions);
+// register t of thread j then holds physical row xl_col_row(j) + t G instead of j + t G.
+template <typename T, int N, int EPT, int C, int SP, int XL>
 __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, const T* rt_kx,
                                             size_t wbase, int j, int c, int jc, bool valid, int q) {
     constexpr int NT = N >> SP;
@@ -171,11 +173,20 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             if (f == 1) v = mk<T>(-v.x, -v.y);
             x[t] = valid ? v : mk<T>((T)0, (T)0);
         }
-        if (!(a.ablate & 1)) tile_fft<T, NT, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
+        int jrow = j;   // physical row (mod G) of this thread's outputs
+        if constexpr (XL) {
+            if (!(a.ablate & 1)) {
+                const XlColTw<T> xtw = xl_col_load_tw<T>(a.tw, j);
+                xl_col_fft512<T, +1>(x, lds, xtw, (int)threadIdx.x);
+            }
+            jrow = xl_col_row(j);
+        } else {
+            if (!(a.ablate & 1)) tile_fft<T, NT, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
+        }
         if (valid && !(a.ablate & 2)) {
             cx<T>* dst = a.planes + (size_t)f * a.plane_stride + wbase + (size_t)(SP ? q * NT : 0) * a.ldw;
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) dst[(size_t)(j + t * G) * a.ldw] = x[t];
+            for (int t = 0; t < EPT; ++t) dst[(size_t)(jrow + t * G) * a.ldw] = x[t];
         }
     }
 }
@@ -219,7 +230,7 @@ __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&
 #undef TCFD_IROW
 }
 
-template <typename T, int N, int EPT, int C, int MODE, int MINW, int SP = 0>
+template <typename T, int N, int EPT, int C, int MODE, int MINW, int SP = 0, int XL = 0>
 __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                 x[t] = valid ? a.u_in[ub + (size_t)TCFD_IROW(j + t * G) * a.u_in_ld] : mk<T>((T)0, (T)0);
         }
         __syncthreads();  // row tables visible
-        emit_planes<T, N, EPT, C, SP>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
+        emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
         return;
     } else {
         constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
@@ -293,11 +304,20 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
         // pruned plans never write the advection for columns >= keep_cols: they are exact zeros
         const bool col_live = valid && (GENERIC || a.keep_cols == 0 || jc < a.keep_cols);
         const bool tile_live = GENERIC || a.keep_cols == 0 || tile * C < a.keep_cols;  // block-uniform
+        constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
+        constexpr bool XLF = XL && !GENERIC;   // forward transform of the advection: physical rows come in at xl_col_row
+        const int jin = XLF ? xl_col_row(j) : j;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            x[t] = col_live ? a.in[inbase + (wq + (size_t)(j + t * G)) * in_ld] : mk<T>((T)0, (T)0);
-        constexpr int DIR = (MODE == MODE_INV) ? +1 : -1;
-        if (!(a.ablate & 1) && tile_live) tile_fft<T, NT, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+            x[t] = col_live ? a.in[inbase + (wq + (size_t)(jin + t * G)) * in_ld] : mk<T>((T)0, (T)0);
+        if constexpr (XLF) {
+            if (!(a.ablate & 1) && tile_live) {
+                const XlColTw<T> xtw = xl_col_load_tw<T>(a.tw, j);
+                xl_col_fft512<T, DIR>(x, lds, xtw, (int)threadIdx.x);
+            }
+        } else {
+            if (!(a.ablate & 1) && tile_live) tile_fft<T, NT, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
+        }
         if constexpr (NEEDS_TABLES) __syncthreads();  // row tables visible (a one-pass transform has no barrier)
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     }
                 }
             }
-            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
+            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
         }
     }
 #undef TCFD_IROW
@@ -1224,6 +1244,7 @@ struct Tuning {
     int ablate;              // TCFD_ABLATE: timing ablations (results are WRONG when non-zero)
     int rows_v;              // TCFD_ROWS_V: 0 = per size; 6 = LDS-DMA staged rows, 5 = register-staged rows (one plane per
                              // transform), 4 = two planes per transform (round 1)
+    int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
     int rows_minw;           // TCFD_ROWS_MINW: waves/SIMD the row kernel is compiled for (register cap), 0 = per size
 };
@@ -1407,6 +1428,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->tune.rows_v = env_int("TCFD_ROWS_V", 0);
     p->tune.rows_minw = env_int("TCFD_ROWS_MINW", 0);
     p->tune.chunk = env_int("TCFD_CHUNK", -1);
+    p->tune.cols_xl = env_int("TCFD_COLS_XL", 1);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
         p->ldw = (p->m + per_line - 1) / per_line * per_line;
@@ -1504,6 +1526,23 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.sep = p->sep;
     a.keep_cols = p->keep_cols;
     a.tw = (const cx<T>*)(SP ? p->tw2 : p->tw);
+    // 512-point tiles of 8 columns (1024^2 split plans and 512^2, fp64): cross-lane transforms unless TCFD_COLS_XL=0
+    constexpr bool XL_OK = (NT == 512 && EPT == 8 && C == 8 && MODE != MODE_FWD && MODE != MODE_INV);
+    if constexpr (XL_OK) {
+        if (p->tune.cols_xl) {
+            auto kx = k_cols<T, N, EPT, C, MODE, MINW, SP, 1>;
+            static DevOnce lds_once_x;
+            if (int rc_ = set_lds(lds_once_x, kx, lds)) return rc_;
+            long blocks_x = batch * a.ntiles;
+            a.pair_xcd = (C * sizeof(cx<T>) < 128) ? p->tune.pair_xcd : 0;
+            a.ablate = p->tune.ablate;
+            if (a.pair_xcd) blocks_x = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
+            ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
+            hipLaunchKernelGGL(kx, dim3((unsigned)blocks_x, SP ? 2u : 1u), dim3(C * G), lds, st, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     auto kern = k_cols<T, N, EPT, C, MODE, MINW, SP>;
     static DevOnce lds_once;
     if (int rc_ = set_lds(lds_once, kern, lds)) return rc_;
