@@ -19,7 +19,7 @@ for b in blocks:
     m = re.match(r"k_cols<\w+, (\d+), \d+, \d+, (\d)", name)
     if m and int(m.group(1)) == n:
         key, alg = {0: ("k_cols<MODE_A>", 5), 1: ("k_cols<MODE_CA>", 9), 2: ("k_cols<MODE_C>+dwdt", 7)}.get(int(m.group(2)), (None, 0))
-    elif name.startswith("k_rows_advect") and f", {n}," in name:
+    elif name.startswith("k_rows_advect") and (f", {n}," in name or (name.startswith("k_rows_advect7") and n == 1024)):
         key, alg = "k_rows_advect", 5
     elif name.startswith("k_dwdt"):
         key, alg = "k_dwdt", 3
