@@ -772,3 +772,79 @@ def test_empty_batch_returns_empty_tensors(dev):
     with torch.no_grad():
         y = fno.SpectralConvS(2, 3, 4, 4, 3).to(dev)(torch.empty(0, 2, 16, 16, 10, device=dev))
     assert y.shape == (0, 3, 16, 16, 10)
+
+
+# ----------------------------------------------------------------------------- gradients (differentiable step)
+def test_differentiable_step_matches_fused_step_and_cpu_autograd(dev):
+    """A state that requires grad steps through torch-cfd_amd/autograd.py (HIP transforms with hand-written adjoints):
+    same values as the fused kernels, and the gradient of a scalar loss equals torch's CPU autograd through the oracle's
+    torch.fft op sequence (reference: equations.py:139, 285 -- the reference path is differentiable)."""
+    from oracle import ns2d as O
+
+    n, B, dt = 32, 2, 1e-3
+    _, op = build_op(n, "f64", "kolmogorov", dev)
+    t = oracle_tables(n, "f64", "kolmogorov")
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64)) for s in range(B)])
+    tgt = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 9 + s, torch.float64)) for s in range(B)])
+
+    def loss_of(out, dwdt):
+        return (out - tgt.to(out.device)).abs().pow(2).sum() + 1e-6 * dwdt.abs().pow(2).sum()
+
+    fused, fused_dt = op(w0.to(dev), dt, steps=2)                       # no grad: the fused kernels
+    wg = w0.to(dev).requires_grad_(True)
+    out, dwdt = op(wg, dt, steps=2)                                     # grad: the differentiable path
+    assert out.requires_grad and rel_l2(out.detach(), fused) < 1e-12 and rel_l2(dwdt.detach(), fused_dt) < 1e-9
+    loss_of(out, dwdt).backward()
+    wc = w0.clone().requires_grad_(True)
+    ref, ref_dt = O.advance(wc, dt, t, steps=2)
+    loss_of(ref, ref_dt).backward()
+    assert rel_l2(wg.grad, wc.grad) < 1e-9
+    # explicit terms and residual alone
+    wg2 = w0.to(dev).requires_grad_(True)
+    op.explicit_terms(wg2).abs().pow(2).sum().backward()
+    wc2 = w0.clone().requires_grad_(True)
+    O.explicit_terms(wc2, t).abs().pow(2).sum().backward()
+    assert rel_l2(wg2.grad, wc2.grad) < 1e-10
+
+
+def test_trainable_rk_coefficients_receive_gradients(dev):
+    """RK4CrankNicolsonStepper(requires_grad=True): d loss / d gammas from the differentiable path against central
+    differences of the FUSED forward step (two different code paths must agree)."""
+    import torch_cfd_amd as tc
+    from oracle import ns2d as O
+
+    torch.set_default_dtype(torch.float64)
+    n, dt = 32, 2e-3
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, solver=tc.RK4CrankNicolsonStepper(requires_grad=True)).to(dev)
+    w0 = torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 1, torch.float64))[None].to(dev)
+    out, _ = op(w0, dt, steps=1)
+    assert out.requires_grad
+    out.abs().pow(2).sum().backward()
+    g = op.solver.params["gammas"].grad.clone()
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    fd = torch.zeros_like(g)
+    eps = 1e-4
+    with torch.no_grad():
+        for k in range(len(g)):
+            vals = []
+            for sgn in (+1, -1):
+                op.solver.params["gammas"][k] += sgn * eps
+                op._coef_cache = None
+                vals.append(op(w0, dt, steps=1)[0].abs().pow(2).sum().item())   # no grad: fused kernels
+                op.solver.params["gammas"][k] -= sgn * eps
+            fd[k] = (vals[0] - vals[1]) / (2 * eps)
+    assert rel_l2(g, fd) < 1e-6
+
+
+def test_trajectory_with_require_grad(dev):
+    """get_trajectory_imex(require_grad=True) (fno/data_gen/solvers.py:199): same records as without."""
+    import torch_cfd_amd as tc
+
+    g = load_golden("ns2d_trajectory.npz")
+    _, op = build_op(32, "f64", "kolmogorov", dev)
+    w0 = torch.from_numpy(g["f64_w0"]).to(dev)
+    a = tc.get_trajectory_imex(op, w0, 1e-3, num_steps=4, record_every_steps=3, dtype=torch.complex128)
+    b = tc.get_trajectory_imex(op, w0, 1e-3, num_steps=4, record_every_steps=3, dtype=torch.complex128, require_grad=True)
+    for k in a:
+        assert not b[k].requires_grad and rel_l2(b[k], a[k]) < 1e-11, k

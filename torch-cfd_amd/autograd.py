@@ -1,0 +1,106 @@
+"""Differentiable form of the spectral step: the HIP transforms as ``autograd.Function``s + the stage loop in tensor ops.
+
+The fused step kernels are forward-only.  When gradients are asked for -- the state requires grad, or the stepper's
+coefficients are trainable (the reference allows both: torch_cfd/equations.py:139, 285;
+fno/data_gen/solvers.py:199) -- ``NavierStokes2DSpectral`` steps through this module instead: the same arithmetic as
+the kernels, written as device tensor operations around the two hand-written transforms, whose adjoints are again the
+hand-written transforms:
+
+    y = irfft2(X)     (c2r drops Im of the DC / Nyquist columns)     grad X = (c / n^2) rfft2(grad y)
+    X = rfft2(y)                                                     grad y = n^2 irfft2(grad X / c)
+
+with c = 1 on the DC and Nyquist columns of the half spectrum and 2 elsewhere (the c2r transform counts the interior
+columns twice, the r2c transform once).  Nothing here touches torch.fft or the CPU; it is the slow path (a stage is
+~25 launches instead of 2) and exists for gradients only.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def _column_weights(plan, like: torch.Tensor) -> torch.Tensor:
+    c = torch.full((plan.m,), 2.0, dtype=plan.rdtype, device=like.device)
+    c[0] = c[-1] = 1.0
+    return c
+
+
+class Rfft2(torch.autograd.Function):
+    """(*, n, n) real -> (*, n, m) half spectrum on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, y, plan):
+        ctx.plan = plan
+        return plan.rfft2(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        scale = float(plan.n * plan.n) / _column_weights(plan, g)
+        return Irfft2.apply(g * scale, plan), None
+
+
+class Irfft2(torch.autograd.Function):
+    """(*, n, m) half spectrum -> (*, n, n) real on the HIP kernels (unnormalised inverse / n^2, as torch's)."""
+
+    @staticmethod
+    def forward(ctx, xh, plan):
+        ctx.plan = plan
+        return plan.irfft2(xh)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        scale = _column_weights(plan, g) / float(plan.n * plan.n)
+        return Rfft2.apply(g, plan) * scale, None
+
+
+def explicit_terms(op, plan, w_hat: torch.Tensor, forcing_hat) -> torch.Tensor:
+    """F(w) = mask * rfft2(-(dx w * u + dy w * v)) + f^  with  psi = -w / lap,  (u, v) = (dy psi, -dx psi)."""
+    kx, ky = op.kx.to(w_hat.device), op.ky.to(w_hat.device)
+    two_pi_i = 2j * torch.pi
+    lap = -4 * torch.pi**2 * (kx**2 + ky**2)
+    lap = lap.clone()
+    lap[..., 0, 0] = 1
+    psi = -w_hat / lap
+    fields = (two_pi_i * ky * psi, -two_pi_i * kx * psi, two_pi_i * kx * w_hat, two_pi_i * ky * w_hat)
+    u, v, wx, wy = (Irfft2.apply(f.to(plan.cdtype), plan) for f in fields)
+    out = Rfft2.apply(-(wx * u + wy * v), plan)
+    if op.smooth:
+        out = out * op.filter.to(w_hat.device)
+    if forcing_hat is not None:
+        out = out + forcing_hat
+    return out
+
+
+def rk_crank_nicolson_steps(op, plan, w_hat, dt, steps, params, forcing_hat):
+    """``steps`` low-storage RK + Crank-Nicolson steps with the coefficient TENSORS of ``params`` (alphas / betas /
+    gammas), so that trainable coefficients receive gradients."""
+    lin = op.linear_term.to(w_hat.device)
+    al, be, ga = (params[k].to(w_hat.device) for k in ("alphas", "betas", "gammas"))
+    u = w_hat
+    for _ in range(steps):
+        h = None
+        for k in range(len(be)):
+            f = explicit_terms(op, plan, u, forcing_hat)
+            h = f if h is None else f + be[k] * h
+            mu = 0.5 * dt * (al[k + 1] - al[k])
+            u = (u + ga[k] * dt * h + mu * lin * u) / (1 - mu * lin)
+    return u
+
+
+def scheduled_steps(op, plan, w_hat, steps, sched, forcing_hat):
+    """The generic stage schedule (``IMEXStepper.stage_schedule``) with detached scalars -- gradients w.r.t. the state."""
+    lin = op.linear_term.to(w_hat.device)
+    n = len(sched["beta"])
+    fa = sched.get("fa") or [1.0] * n
+    mu_den = sched.get("mu_den") or sched["mu"]
+    base0 = sched.get("base0") or [0] * n
+    u = w_hat
+    for _ in range(steps):
+        start, h = u, None
+        for k in range(n):
+            f = explicit_terms(op, plan, u, forcing_hat)
+            h = fa[k] * f if h is None else fa[k] * f + sched["beta"][k] * h
+            b = start if base0[k] else u
+            u = (b + sched["gdt"][k] * h + sched["mu"][k] * lin * b) / (1 - mu_den[k] * lin)
+    return u

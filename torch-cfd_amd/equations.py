@@ -12,9 +12,11 @@ error behaviour as the reference:
 but ``NavierStokes2DSpectral.forward`` / ``explicit_terms`` / ``residual`` run the
 hand-written gfx950 kernels of ``csrc/tcfd_ns2d.hip`` through the C ABI in
 ``include/tcfd.h`` (three launches per RK stage instead of ~40 ATen launches).
-There is no CPU or eager fallback: tensors must live on a HIP device, the grid
-must be square with n = 2^k (8..2048), and the path is forward-only (no
-autograd) -- anything else raises.
+There is no CPU or eager fallback: tensors must live on a HIP device and the grid
+must be square with n = 2^k (8..2048) -- anything else raises.  The fused kernels are
+forward-only; when gradients are asked for (a state that requires grad, trainable
+stepper coefficients) the operator steps through ``autograd.py``: the same arithmetic
+as device tensor ops around the HIP transforms and their hand-written adjoints.
 """
 from __future__ import annotations
 
@@ -106,8 +108,7 @@ class _HipPlan:
             raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
         if w.device != self.device:
             raise _lib.TcfdError(f"tensor on {w.device}, operator tables on {self.device}")
-        if w.requires_grad and torch.is_grad_enabled():
-            raise _lib.TcfdError("the HIP spectral path is forward-only; detach() the input or use torch.no_grad()")
+        # gradients never reach this point: NavierStokes2DSpectral routes them through torch-cfd_amd/autograd.py
         if not w.is_complex() or w.shape[-2:] != (self.n, self.m):
             raise ValueError(f"expected complex (*, {self.n}, {self.m}) half spectrum, got {tuple(w.shape)} {w.dtype}")
         w = w.detach().to(self.cdtype).contiguous()
@@ -444,11 +445,37 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
             self._plans = {key: plan}  # tables changed -> drop stale plans
         return plan
 
+    # -- gradients: the differentiable form of the same arithmetic (autograd.py), only when somebody asks
+    @staticmethod
+    def _wants_grad(*tensors) -> bool:
+        return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+    def _forcing_on(self, like: torch.Tensor):
+        fh = self.forcing_hat()
+        return None if fh is None else fh.to(device=like.device, dtype=self._plan(like).cdtype)
+
+    def _autograd_steps(self, vort_hat, dt, steps, params, stepper, want_dwdt):
+        from . import autograd as ad
+
+        plan = self._plan(vort_hat)
+        w = vort_hat.to(plan.cdtype)
+        lead = w.shape
+        w = w.reshape(-1, plan.n, plan.m)
+        forcing = self._forcing_on(w)
+        if isinstance(stepper, RK4CrankNicolsonStepper):
+            out = ad.rk_crank_nicolson_steps(self, plan, w, dt, steps, params, forcing)
+        else:
+            out = ad.scheduled_steps(self, plan, w, steps, stepper.stage_schedule(params, dt), forcing)
+        out = out.reshape(lead)
+        return out, ((out - vort_hat) / (steps * dt) if want_dwdt else None)
+
     def _fused_steps(self, vort_hat, dt, steps, params=None, want_dwdt=True, stepper=None):
         stepper = self.solver if stepper is None else stepper
         if stepper is None:
             raise TypeError("NavierStokes2DSpectral needs a solver (e.g. RK4CrankNicolsonStepper()) to step")
         params = stepper.params if params is None else params
+        if self._wants_grad(vort_hat, *params.values()):
+            return self._autograd_steps(vort_hat, dt, steps, params, stepper, want_dwdt)
         # the coefficient tensors may live on the GPU: read them back once, not per step
         ckey = (float(dt), id(stepper)) + tuple((k, v.data_ptr(), v._version) for k, v in params.items())
         if self._coef_cache is None or self._coef_cache[0] != ckey:
@@ -460,6 +487,12 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
 
     # -- ImplicitExplicitODE interface
     def explicit_terms(self, vort_hat):
+        if self._wants_grad(vort_hat):
+            from . import autograd as ad
+
+            plan = self._plan(vort_hat)
+            w = vort_hat.to(plan.cdtype).reshape(-1, plan.n, plan.m)
+            return ad.explicit_terms(self, plan, w, self._forcing_on(w)).reshape(vort_hat.shape)
         return self._plan(vort_hat).explicit_terms(vort_hat).reshape(vort_hat.shape)
 
     _explicit_terms = explicit_terms
@@ -471,6 +504,8 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
         return vort_hat / (1 - dt * self.linear_term)
 
     def residual(self, vhat: torch.Tensor, vt_hat: torch.Tensor):
+        if self._wants_grad(vhat, vt_hat):
+            return vt_hat - self.explicit_terms(vhat) - self.implicit_terms(vhat)
         _, res = self._plan(vhat).stream_residual(vhat, vt_hat, want_psi=False)
         return res.reshape(vhat.shape)
 

@@ -1055,23 +1055,7 @@ class SFNO(FNOBase):
 
 
 # ----------------------------------------------------------------------------- loss (config 5 "forward + loss")
-class _Rfft2Fn(torch.autograd.Function):
-    """rfft2 on the HIP kernels with its adjoint: for a cotangent g (dL/dRe + i dL/dIm of the half spectrum)
-    grad z = Re sum_{kx, ky <= n/2} g e^{+i(kx x + ky y)} = n^2 irfft2(g / c), c = 2 on the interior columns
-    (the c2r transform counts them twice, the adjoint of an r2c transform does not)."""
-
-    @staticmethod
-    def forward(ctx, z, plan):
-        ctx.plan = plan
-        return plan.rfft2(z)
-
-    @staticmethod
-    def backward(ctx, g):
-        plan = ctx.plan
-        n = plan.n
-        c = torch.full((n // 2 + 1,), 0.5 * n * n, dtype=plan.rdtype, device=g.device)
-        c[0] = c[-1] = float(n * n)
-        return plan.irfft2(g * c), None
+from .autograd import Rfft2 as _Rfft2Fn  # noqa: E402  (rfft2 on the HIP kernels with its hand-written adjoint)
 
 
 class SobolevLoss(nn.Module):

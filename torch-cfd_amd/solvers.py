@@ -39,8 +39,10 @@ def get_trajectory_imex(
     each (*, n_t, n, m) complex ``dtype`` with one snapshot after every step whose
     0-based index is a multiple of ``record_every_steps``.  ``to_cpu=False`` keeps
     the stacks on the device (used by the multi-GPU gather)."""
+    # require_grad: the reference marks w / dw/dt of every step as requiring grad and records DETACHED copies
+    # (solvers.py:224-250); here the steps then run through the differentiable path (torch-cfd_amd/autograd.py)
     if require_grad:
-        raise NotImplementedError("the HIP spectral path is forward-only (require_grad=True unsupported)")
+        w0 = w0.detach().requires_grad_(True)
     n_rec = len(range(0, num_steps, record_every_steps))
     lead, (n, m) = tuple(w0.shape[:-2]), w0.shape[-2:]
     names = ("vorticity", "stream", "vort_t", "residual")
@@ -54,7 +56,7 @@ def get_trajectory_imex(
         bar = tqdm(total=num_steps)
     w = w0
     rec = 0
-    fused = bar is None and isinstance(getattr(equation, "solver", None), RK4CrankNicolsonStepper)
+    fused = bar is None and not require_grad and isinstance(getattr(equation, "solver", None), RK4CrankNicolsonStepper)
     t_step = 0
     while t_step < num_steps:
         if fused and t_step % record_every_steps != 0:
@@ -63,15 +65,16 @@ def get_trajectory_imex(
             w, _ = equation._fused_steps(w, dt, nxt - t_step, want_dwdt=False)
             t_step = nxt
             continue
-        w, dwdt = equation.forward(w, dt=dt)
+        with torch.set_grad_enabled(bool(require_grad)):
+            w, dwdt = equation.forward(w, dt=dt)
         if bar is not None and t_step % update_every == 0:
             res = equation.residual(w, dwdt)
             res_norm = torch.linalg.norm(res.reshape(-1, n * m), dim=-1).mean().item() / n
             bar.set_description(f"{datetime.now():%d-%b-%Y %H:%M:%S} - {pbar_desc} - ||L(w) - f||: {res_norm:.4e}")
             bar.update(update_every)
         if t_step % record_every_steps == 0:
-            psi, res = equation.stream_and_residual(w, dwdt)
-            for key, val in zip(names, (w, psi, dwdt, res)):
+            psi, res = equation.stream_and_residual(w.detach(), dwdt.detach())
+            for key, val in zip(names, (w.detach(), psi, dwdt.detach(), res)):
                 out[key][..., rec, :, :].copy_(val)  # casts to `dtype` on the device
             rec += 1
         t_step += 1
