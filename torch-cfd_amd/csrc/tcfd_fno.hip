@@ -706,6 +706,7 @@ struct PwArgs {
     long w2_bstride, b2_bstride;  // per-batch-element offsets of w2t / b2 (0: shared) -- lets a per-sample
                                   // affine map (e.g. a folded LayerNorm) ride in the single-layer form
     int T, sT, act1, act2, skip_mode;
+    int cm;             // hidden width when the kernel is instantiated with CM = 0 (any channel expansion)
 };
 
 __device__ __forceinline__ float pw_act(float v, int act) {
@@ -749,8 +750,9 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
 #pragma unroll
     for (int c = 0; c < CO; ++c) o[c] = (vf)(b2_b ? b2_b[c] : 0.f);
     if constexpr (HAS_L1) {
+        const int cm = CM > 0 ? CM : a.cm;   // CM = 0: hidden width at run time (it is only a trip count)
 #pragma unroll 4
-        for (int m = 0; m < CM; ++m) {
+        for (int m = 0; m < cm; ++m) {
             vf h = (vf)(a.b1 ? a.b1[m] : 0.f);
             const float* w1 = a.w1 + m * CI;
 #pragma unroll
@@ -826,19 +828,30 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
     a.wst = (const float*)wst; a.bs = (const float*)bs; a.pe = (const float*)pe;
     a.P = P; a.T = T; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
     a.w2_bstride = w2_bstride; a.b2_bstride = b2_bstride;
+    a.cm = cm;
     hipStream_t st = (hipStream_t)stream;
     const bool l1 = w1 != nullptr;
 #define PW_CASE(CI_, CM_, CO_)                                                             \
     if (ci == CI_ && cm == CM_ && co == CO_)                                                \
         return l1 ? launch_pw<CI_, CM_, CO_, true>(a, batch, st) : launch_pw<CI_, CM_, CO_, false>(a, batch, st);
+    // the reference's default expansion (4 x width) with a compile-time trip count, then ANY hidden width for every even
+    // width up to 32 (SpaceTimePositionalEncoding needs an even width > 3; fno/sfno.py:607-614 accepts any):
+    // the channel counts index register arrays and stay template parameters, the hidden width is a loop bound
+#define PW_ANY(W_)                                                                         \
+    if (ci == W_ && co == W_ && l1) return launch_pw<W_, 0, W_, true>(a, batch, st);
     if (l1) {
         PW_CASE(4, 16, 4) PW_CASE(8, 32, 8) PW_CASE(10, 40, 10) PW_CASE(16, 64, 16) PW_CASE(20, 80, 20) PW_CASE(32, 128, 32)
+        PW_ANY(4) PW_ANY(6) PW_ANY(8) PW_ANY(10) PW_ANY(12) PW_ANY(14) PW_ANY(16) PW_ANY(18) PW_ANY(20) PW_ANY(24) PW_ANY(28)
+        PW_ANY(32)
     } else {
         if (cm != ci) return FAIL(TCFD_EINVAL, "fno_pointwise: single layer needs cm == ci");
         PW_CASE(4, 4, 4) PW_CASE(4, 4, 1) PW_CASE(8, 8, 8) PW_CASE(8, 8, 1) PW_CASE(10, 10, 10) PW_CASE(10, 10, 1)
         PW_CASE(16, 16, 16) PW_CASE(16, 16, 1) PW_CASE(20, 20, 20) PW_CASE(20, 20, 1) PW_CASE(32, 32, 32) PW_CASE(32, 32, 1)
+        PW_CASE(6, 6, 6) PW_CASE(6, 6, 1) PW_CASE(12, 12, 12) PW_CASE(12, 12, 1) PW_CASE(14, 14, 14) PW_CASE(14, 14, 1)
+        PW_CASE(18, 18, 18) PW_CASE(18, 18, 1) PW_CASE(24, 24, 24) PW_CASE(24, 24, 1) PW_CASE(28, 28, 28) PW_CASE(28, 28, 1)
     }
 #undef PW_CASE
+#undef PW_ANY
     return FAIL(TCFD_EINVAL, "fno_pointwise: channels (%d -> %d -> %d) not instantiated", ci, cm, co);
 }
 

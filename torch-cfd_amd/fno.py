@@ -65,6 +65,20 @@ class _FnoPlan:
 _PLANS: Dict[tuple, _FnoPlan] = {}
 
 
+_WARNED = set()
+
+
+def _note_torch_modules(what: str):
+    """The fused pointwise kernels cover even widths <= 32 (any expansion); other channel counts run the layer's own
+    torch modules ON THE DEVICE (never the oracle / CPU) -- said once, not silently."""
+    if what not in _WARNED:
+        _WARNED.add(what)
+        import warnings
+
+        warnings.warn(f"torch-cfd_amd: {what} is not instantiated in the fused HIP pointwise kernels; "
+                      "this layer uses its torch modules on the device (slower, same result)", stacklevel=3)
+
+
 def _plan(key, device) -> _FnoPlan:
     full = key + (torch.device(device),)
     p = _PLANS.get(full)
@@ -624,6 +638,7 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
                                     ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs, None,
                                     ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+        _note_torch_modules(f"pointwise block {ci} -> {cm} -> {co}")
         return None
     _lib.check(rc, "tcfd_fno_pointwise")
     return out
@@ -1059,7 +1074,9 @@ from .autograd import Rfft2 as _Rfft2Fn  # noqa: E402  (rfft2 on the HIP kernels
 
 
 class SobolevLoss(nn.Module):
-    """Fourier-domain weighted norm of (x - y), fno/losses.py:199-315 (freq_cutoff=None).
+    """Fourier-domain weighted norm of (x - y), fno/losses.py:199-315, including ``freq_cutoff`` (wavenumbers above it
+    are replaced by inf for negative orders and by 0 otherwise, exactly as the reference's mesh does) and every
+    ``fft_norm``.
 
     Copies the code's behaviour, not its comment: for ``norm_order == 0`` the multiplier is
     sqrt(alpha + 4 pi^2 |k|^2) itself, not 1.  The 2-D transforms over dims (1, 2) of the
@@ -1070,8 +1087,11 @@ class SobolevLoss(nn.Module):
                  relative: bool = False, inp_time_last: bool = True, freq_cutoff: int = None, norm_order: float = -1,
                  alpha: float = 0.1, fft_norm: str = "backward", diam: float = 1, debug: bool = False):
         super().__init__()
-        if fft_norm not in (None, "backward"):
-            raise NotImplementedError("SobolevLoss on the HIP path supports fft_norm='backward'")
+        if fft_norm not in (None, "backward", "ortho", "forward"):
+            raise ValueError(f"unknown fft norm {fft_norm!r}")
+        # |fftn(z, norm)|^2 = |fftn(z)|^2 / n^2 ("ortho") or / n^4 ("forward"): a scalar on the squared norms
+        self.fft_norm = fft_norm
+        self._sq_scale = {None: 1.0, "backward": 1.0, "ortho": 1.0 / n_grid**2, "forward": 1.0 / n_grid**4}[fft_norm]
         self.relative, self.time_average, self.reduction = relative, time_average, reduction
         self.mesh_weighted, self.norm_order, self.alpha = mesh_weighted, norm_order, alpha
         self.inp_time_last, self.n_grid, self.diam = inp_time_last, n_grid, diam
@@ -1094,7 +1114,7 @@ class SobolevLoss(nn.Module):
         herm = torch.full((n // 2 + 1,), 2.0, dtype=dtype, device=device)  # |X[k]|^2 counted twice except DC/Nyquist
         herm[0] = 1.0
         herm[-1] = 1.0
-        return w**2 * herm
+        return w**2 * herm * self._sq_scale
 
     def forward(self, x, y=None):
         from .equations import fft_plan
