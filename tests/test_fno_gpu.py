@@ -600,3 +600,22 @@ def test_results_do_not_depend_on_the_workgroup_geometry(ns, dev, monkeypatch):
         ref = layer(x, out_steps=9)
         monkeypatch.setenv("TCFD_FNO_NS", ns)
         assert torch.equal(layer(x, out_steps=9), ref)
+
+
+@pytest.mark.parametrize("n_grid,dtype,tol", [(64, torch.float32, 1e-5), (256, torch.float32, 1e-5),
+                                              (64, torch.float64, 1e-12), (512, torch.float64, 1e-12)])
+def test_helmholtz_projection_is_divergence_free(n_grid, dtype, tol, dev):
+    """The reference's own property tests of HelmholtzProjection (fno/sfno_pytest.py:72-129), fp32 and fp64, on the
+    device: the projected spectrum of a random vector field has zero divergence."""
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(n_grid)
+    hz = fno.HelmholtzProjection(n_grid=n_grid, diam=2 * math.pi, dtype=dtype).to(dev)
+    lap = hz.lap
+    fields = torch.randn(6, 2, 2, n_grid, n_grid, generator=g, dtype=dtype).to(dev)          # (T, component, b, x, y)
+    vhat = (torch.fft.fft2(fields) / (0.5 + lap)).permute(2, 1, 3, 4, 0).contiguous()        # (b, 2, x, y, T)
+    w_hat = hz(vhat)
+    div = hz.div(w_hat, (hz.kx, hz.ky))
+    div_phys = torch.fft.irfft2(div, s=(n_grid, n_grid), dim=(1, 2))
+    assert torch.linalg.norm(div_phys).item() < tol
