@@ -155,6 +155,12 @@ int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, l
  *   use_mfma 1: per-mode products on v_mfma_f32_16x16x4_f32; 0: plain VALU kernel */
 typedef struct tcfd_fno_plan tcfd_fno_plan;
 int tcfd_fno_plan_create(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt);
+/* Plan of an INVERSE transform onto a grid (X, Y) of a truncated spectrum taken from a grid (Xs, Ys): what
+ * SpectralConv.forward(v, out_mesh_size) does through irfftn(s = out_mesh_size) (fno/base.py:229-237) -- torch pads or
+ * trims the spectrum array at its end, so the high-frequency block keeps its array indices [Xs - mx, Xs) x [Ys - my, Ys).
+ * Only tcfd_fno_inverse_trunc may be called with such a plan. */
+int tcfd_fno_plan_create_resample(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt,
+                                  int Xs, int Ys);
 void tcfd_fno_plan_destroy(tcfd_fno_plan* plan);
 size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* plan, int batch, int cin, int cout);
 int tcfd_fno_spectral_conv(const tcfd_fno_plan* plan, const void* v, const void* const* weights,

@@ -112,6 +112,7 @@ SIGNATURES = {
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),
     "tcfd_irfft2": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
     "tcfd_fno_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i]),
+    "tcfd_fno_plan_create_resample": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tcfd_fno_plan_destroy": (None, [_vp]),
     "tcfd_fno_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "tcfd_fno_spectral_conv": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i, _i,

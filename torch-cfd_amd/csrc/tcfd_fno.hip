@@ -45,6 +45,9 @@ int tcfd_set_error(int code, const char* fmt, ...);  // defined in tcfd_ns2d.hip
 // ------------------------------------------------------------------ plan
 struct tcfd_fno_plan {
     int X, Y, T_in, t_pad, T_out, mx, my, mt;
+    int Xs, Ys;    // grid the truncated spectrum was TAKEN from (inverse transforms only; = X, Y unless the layer resamples):
+                   // torch's irfftn(s = other size) pads / trims the spectrum ARRAY at its end, so the high block keeps
+                   // its array indices [Xs - mx, Xs) / [Ys - my, Ys) in a transform of length X / Y (fno/base.py:229-237)
     int Tp;        // padded input length  T_in + t_pad (the rfft length in t)
     cf* tw_x;      // [X]   exp(-2 pi i k / X)
     cf* tw_y;      // [Y]
@@ -81,18 +84,26 @@ extern "C" void tcfd_fno_plan_destroy(tcfd_fno_plan* p) {
 
 extern "C" int tcfd_fno_plan_create(tcfd_fno_plan** out, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my,
                                     int mt) {
+    return tcfd_fno_plan_create_resample(out, X, Y, T_in, t_pad, T_out, mx, my, mt, X, Y);
+}
+
+extern "C" int tcfd_fno_plan_create_resample(tcfd_fno_plan** out, int X, int Y, int T_in, int t_pad, int T_out, int mx,
+                                             int my, int mt, int Xs, int Ys) {
     if (!out) return FAIL(TCFD_EINVAL, "fno_plan_create: null argument");
     if (!pow2(X) || !pow2(Y)) return FAIL(TCFD_EINVAL, "fno_plan_create: X=%d, Y=%d must be powers of two in [8, 1024]", X, Y);
     if (T_in < 1 || t_pad < 0 || T_out < 1 || mx < 1 || my < 1 || mt < 1)
         return FAIL(TCFD_EINVAL, "fno_plan_create: bad sizes");
     const int Tp = T_in + t_pad;
-    if (2 * mx > X || 2 * my > Y) return FAIL(TCFD_EINVAL, "fno_plan_create: 2*modes exceed the grid (%d,%d vs %d,%d)", mx, my, X, Y);
+    const bool resample = (Xs != X || Ys != Y);
+    if (2 * mx > Xs || 2 * my > Ys) return FAIL(TCFD_EINVAL, "fno_plan_create: 2*modes exceed the grid (%d,%d vs %d,%d)", mx, my, Xs, Ys);
+    if (resample && (Xs < 1 || Ys < 1)) return FAIL(TCFD_EINVAL, "fno_plan_create: bad source grid");
     if (mt > Tp / 2 + 1 || mt > T_out / 2 + 1 || mt > 16)
         return FAIL(TCFD_EINVAL, "fno_plan_create: modes_t=%d exceeds the half spectrum of T=%d / T_out=%d (or 16)", mt, Tp, T_out);
     tcfd_fno_plan* p = new tcfd_fno_plan();
     memset(p, 0, sizeof(*p));
     p->X = X; p->Y = Y; p->T_in = T_in; p->t_pad = t_pad; p->T_out = T_out;
     p->mx = mx; p->my = my; p->mt = mt; p->Tp = Tp;
+    p->Xs = Xs; p->Ys = Ys;
     std::vector<cf> tf((size_t)mt * Tp), ti((size_t)T_out * mt);
     const long double PI2 = 2.0L * 3.141592653589793238462643383279502884L;
     for (int k = 0; k < mt; ++k)
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, c
 template <int Y, int EPT>
 __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, float* __restrict__ out,
                                                   const cf* __restrict__ tw_y, const cf* __restrict__ tw_ti, int T_out,
-                                                  int t_keep, int mt, int my, float scale, int P, int NS, long slabs) {
+                                                  int t_keep, int mt, int my, float scale, int P, int NS, long slabs, int Ys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
     const int Q = 2 * my * mt, t0 = T_out - t_keep;
@@ -264,16 +275,24 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, flo
         const cf* e0 = twt + (size_t)(2 * p) * mt;
         const cf* e1 = twt + (size_t)(pair ? 2 * p + 1 : 2 * p) * mt;
         const cf* wq = win + (size_t)s * Q;
-        for (int ky = j; ky <= my; ky += G) {
+        // kept array indices of the length-Y spectrum: [0, my) and [Ys - my, Ys) (Ys = Y unless the layer resamples, see
+        // tcfd_fno_plan); slot() = row of the truncated spectrum, or -1.  Without resampling only ky in [0, my] and
+        // their mirrors carry data; with it any pair (ky, Y - ky) may.
+        auto slot = [&](int k) { return k < my ? k : ((k >= Ys - my && k < Ys) ? k - (Ys - 2 * my) : -1); };
+        const int kmax = (Ys == Y) ? my : Y / 2;
+        for (int ky = j; ky <= kmax; ky += G) {
             const int kyn = (Y - ky) & (Y - 1);
-            const bool ha = ky < my || ky >= Y - my;      // W[ky] kept (ky == my only when 2my == Y)
-            const cf* wa = wq + (size_t)(ky < my ? ky : (ha ? ky - (Y - 2 * my) : 0)) * mt;
-            const cf* wb = wq + (size_t)(kyn < my ? kyn : kyn - (Y - 2 * my)) * mt;   // -ky of [0, my] is always kept
+            const int sa = slot(ky), sb = slot(kyn);
+            const bool ha = sa >= 0, hb = sb >= 0;
+            if (!ha && !hb) continue;      // the buffer is pre-zeroed
+            const cf* wa = wq + (size_t)(ha ? sa : 0) * mt;
+            const cf* wb = wq + (size_t)(hb ? sb : 0) * mt;
             float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f;
             for (int k = 0; k < mt; ++k) {
                 cf a = wa[k];
                 if (!ha) a = mk<float>(0.f, 0.f);
-                const cf b = wb[k];
+                cf b = wb[k];
+                if (!hb) b = mk<float>(0.f, 0.f);
                 const float ux = a.x + b.x, uy = a.y + b.y, dx = a.x - b.x, dy = a.y - b.y;
                 const cf E0 = e0[k], E1 = e1[k];
                 g0x += E0.x * ux - E0.y * uy;  g0y += E0.y * dx + E0.x * dy;
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, flo
 // FWD: in (b*c, X, Q) -> out (b*c, 2mx, Q) kept rows;  INV: in (b*c, 2mx, Q) -> out (b*c, X, Q)
 template <int X, int EPT, int C, bool FWD>
 __global__ __launch_bounds__(C*(X / EPT)) void k_x(const cf* __restrict__ in, cf* __restrict__ out,
-                                                   const cf* __restrict__ tw_x, int Q, int mx, int ntiles) {
+                                                   const cf* __restrict__ tw_x, int Q, int mx, int ntiles, int Xs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);
     constexpr int G = X / EPT;
@@ -335,9 +354,9 @@ __global__ __launch_bounds__(C*(X / EPT)) void k_x(const cf* __restrict__ in, cf
         if constexpr (FWD) {
             x[t] = valid ? in[(bc * X + kx) * Q + q] : mk<float>(0.f, 0.f);
         } else {
-            int kxi = -1;
+            int kxi = -1;   // array index kx of a length-X spectrum cut out of / padded from one of length Xs
             if (kx < mx) kxi = kx;
-            else if (kx >= X - mx) kxi = kx - (X - 2 * mx);
+            else if (kx >= Xs - mx && kx < Xs) kxi = kx - (Xs - 2 * mx);
             x[t] = (valid && kxi >= 0) ? in[(bc * 2 * mx + kxi) * Q + q] : mk<float>(0.f, 0.f);
         }
     }
@@ -498,7 +517,7 @@ static int launch_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipS
     int rc = set_lds_attr(kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(bc * ntiles)), dim3(C * (X / EPT)), lds, st, in, out, (const cf*)p->tw_x, Q,
-                       p->mx, ntiles);
+                       p->mx, ntiles, FWD ? X : p->Xs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -557,7 +576,7 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cf* w2, float* out, long
     auto kern = k_inv_ty2<Y, EPT>;
     if ((rc = set_lds_attr(kern, lds))) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const cf*)p->tw_y,
-                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs);
+                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys);
     HIP_TRY(hipGetLastError());
     return 0;
 }

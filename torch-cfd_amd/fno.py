@@ -40,13 +40,19 @@ ActivationType = Union[str]
 # ----------------------------------------------------------------------------- HIP plan cache
 class _FnoPlan:
     def __init__(self, key, device):
-        X, Y, T_in, t_pad, T_out, mx, my, mt = key
+        """key = (X, Y, T_in, t_pad, T_out, mx, my, mt[, Xs, Ys]); the two extra entries make it the inverse plan of a
+        RESAMPLING layer (spectrum taken on an Xs x Ys grid, transformed onto X x Y; ``tcfd_fno_plan_create_resample``)."""
+        X, Y, T_in, t_pad, T_out, mx, my, mt = key[:8]
         self.lib = _lib.load()
-        self.key = key
+        self.key = tuple(key[:8])
         self.device = torch.device(device)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = self.lib.tcfd_fno_plan_create(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt)
+            if len(key) == 10:
+                rc = self.lib.tcfd_fno_plan_create_resample(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt,
+                                                            key[8], key[9])
+            else:
+                rc = self.lib.tcfd_fno_plan_create(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt)
         _lib.check(rc, "tcfd_fno_plan_create")
         self.handle = handle
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -753,11 +759,26 @@ class SpectralConvS(SpectralConv):
     def forward(self, v, out_mesh_size=None, **kwargs):
         t_out = None
         if out_mesh_size is not None:
-            if tuple(out_mesh_size[:2]) != tuple(v.shape[-3:-1]):
-                raise NotImplementedError("spatial resampling in SpectralConv.forward is not supported on the HIP path")
             t_out = out_mesh_size[-1]
+            if tuple(out_mesh_size[:2]) != tuple(v.shape[-3:-1]):
+                return self._resampled(v, tuple(int(n) for n in out_mesh_size))
         return hip_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_out=t_out,
                                  norm=self.norm)
+
+    def _resampled(self, v, out_size):
+        """``irfftn(spectrum, s=out_size)`` with a spatial size other than the input's (fno/base.py:229-237): torch pads /
+        trims the spectrum array at its END, so the high-frequency block stays at the array indices it had on the input
+        grid; the inverse plan reproduces exactly that placement (``tcfd_fno_plan_create_resample``).  Forward only."""
+        if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("spatial resampling of SpectralConv is forward-only on the HIP path")
+        b, c, X, Y, T = v.shape
+        Xo, Yo, To = out_size
+        mx, my, mt = self.modes
+        vh, _ = hip_truncated_rfftn(v, self.modes, norm=self.norm)
+        oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
+        inv = _plan((Xo, Yo, T, 0, To, mx, my, mt, X, Y), v.device)
+        _, scale = _norm_scales(self.norm, X * Y * T, Xo * Yo * To)
+        return hip_truncated_irfftn(oh, inv, To, scale=scale)
 
 
 class SpectralConvT(SpectralConvS):
