@@ -426,9 +426,10 @@ def test_errors_are_loud(dev):
     _, op = build_op(16, "f64", None, dev)
     with pytest.raises(ValueError):
         op(torch.zeros(2, 16, 8, dtype=torch.complex128, device=dev), 1e-3)  # wrong m
-    with pytest.raises(tc._lib.TcfdError):
-        w = torch.zeros(1, 16, 9, dtype=torch.complex128, device=dev, requires_grad=True)
-        op(w, 1e-3)
+    with pytest.raises(tc._lib.TcfdError):          # no CPU fallback
+        op(torch.zeros(1, 16, 9, dtype=torch.complex128), 1e-3)
+    w = torch.zeros(1, 16, 9, dtype=torch.complex128, device=dev, requires_grad=True)
+    assert op(w, 1e-3)[0].requires_grad            # round 1 raised here; gradients now go through autograd.py
     torch.set_default_dtype(torch.float64)
     grid = tc.Grid(shape=(24, 24), domain=((0, L), (0, L)))
     bad = tc.NavierStokes2DSpectral(1e-3, grid, solver=tc.RK4CrankNicolsonStepper()).to(dev)
