@@ -332,13 +332,6 @@ __device__ __forceinline__ void tile_fft_rt(cx<T> (&x)[EPT], cx<T>* lds, int j, 
     static_assert(pass_tw_single<N, EPT>(), "register twiddles need one table entry per pass");
     Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, Hook, 2>::run(x, lds, nullptr, j, c, hook, j, trg);
 }
-// squared-twiddle form with a separate lane index for the twiddle table (see Passes)
-template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC, typename Hook>
-__device__ __forceinline__ void tile_fft_sq(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw, int j, int c,
-                                            Hook& hook, int jt) {
-    Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, Hook, 1>::run(x, lds, tw, j, c, hook, jt);
-}
-
 // ---- LDS-DMA (global -> LDS without a register round trip) ---------------------------------
 // One wave-instruction moves 64 x 16 bytes: lane l's 16 bytes at `gsrc` (per-lane address) land at LDS byte
 // address lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  The load is invisible to hipcc's s_waitcnt

@@ -733,7 +733,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
 // the next plane's half rows in flight -- half the live state, same loads / stores / transform count.
 // SP = 0: rows (2p, 2p+1).  SP = 1 (split column plans): rows (r, r + N/2), built from the E / O half-length column
 // transforms as  a = E + w O,  b = E - w O,  w = exp(+2 pi i r / N), and stored folded (S, D) as in k_rows_advect4.
-template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int OPQ = 0, int TWQ = 0>
+template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1>
 __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_rows_advect5(
     const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
     long npairs, int ld, int kc) {
@@ -786,16 +786,9 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
                 H.bn = H.an - o;
                 H.an = H.an + o;
             }
-            int jo = j;
-            if constexpr (OPQ) asm volatile("" : "+v"(jo));   // address arithmetic per transform, not ~40 loop-invariant registers
-            pack_herm<T, N, EPT, WG>(out, H, lds, jo);
+            pack_herm<T, N, EPT, WG>(out, H, lds, j);
             if constexpr (PF) load_raw<T, N, EPT>(H, nextA, nextA + second, j);
-            if constexpr (TWQ) {
-                NoHook nohook;
-                tile_fft_sq<T, N, EPT, +1, 1, true, WG>(out, lds, tw, jo, 0, nohook, j);
-            } else {
-                tile_fft<T, N, EPT, +1, 1, true, WG>(out, lds, tw, jo, 0);
-            }
+            tile_fft<T, N, EPT, +1, 1, true, WG>(out, lds, tw, j, 0);
         };
         const cx<T>* P0 = planes + off;
         const cx<T>* P1 = planes + plane_stride + off;
@@ -810,14 +803,8 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
 #pragma unroll
         for (int t = 0; t < EPT; ++t) p[t] = mk<T>(-(p[t].x + za[t].x * x[t].x), -(p[t].y + za[t].y * x[t].y));
 
-        int jf = j;
-        if constexpr (OPQ) asm volatile("" : "+v"(jf));
-        if constexpr (TWQ) {
-            NoHook nohook;
-            tile_fft_sq<T, N, EPT, -1, 1, true, WG>(p, lds, tw, jf, 0, nohook, j);
-        } else {
-            tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, jf, 0);
-        }
+        const int jf = j;
+        tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, jf, 0);
         if constexpr (SP) {
             // unpack the two real-row spectra and fold them for the parity workgroups of the column pass
 #pragma unroll
@@ -1246,7 +1233,6 @@ struct Tuning {
                              // transform), 4 = two planes per transform (round 1)
     int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
-    int rows_minw;           // TCFD_ROWS_MINW: waves/SIMD the row kernel is compiled for (register cap), 0 = per size
 };
 
 struct tcfd_ns2d_plan {
@@ -1426,7 +1412,6 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->tune.pair_xcd = env_int("TCFD_PAIR_XCD", 1);
     p->tune.ablate = env_int("TCFD_ABLATE", 0);
     p->tune.rows_v = env_int("TCFD_ROWS_V", 0);
-    p->tune.rows_minw = env_int("TCFD_ROWS_MINW", 0);
     p->tune.chunk = env_int("TCFD_CHUNK", -1);
     p->tune.cols_xl = env_int("TCFD_COLS_XL", 1);
     {
@@ -1640,11 +1625,11 @@ static int launch_rows_advect4(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
-template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int OPQ = 0, int TWQ = 0>
+template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1>
 static int launch_rows_advect5(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
                                long batch, hipStream_t st) {
     using Gm = RowGeom<T, N, EPT, THR>;
-    auto kern = k_rows_advect5<T, N, EPT, THR, SP, MINW, PF, OPQ, TWQ>;
+    auto kern = k_rows_advect5<T, N, EPT, THR, SP, MINW, PF>;
     static DevOnce lds_once;
     if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
     const long npairs = batch * (N / 2);
@@ -1718,7 +1703,7 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
             return launch_rows_advect5<T, N, 8, 64, 0, 1>(p, planes, plane_stride, adv, batch, st);
     }
     if constexpr (RowGeom6<T, N, EPT, THR>::OK) {
-        if (p->tune.rows_v == 6 || (p->tune.rows_v != 5 && p->tune.rows_minw == 0 && rows_default_version<T, N>() == 6)) {
+        if (p->tune.rows_v == 6) {   // LDS-DMA staged rows: opt-in (measured slower)
             if constexpr (N >= 16) {
                 if (split) return launch_rows_advect6<T, N, EPT, THR, 1, 2>(p, planes, plane_stride, adv, batch, st);
             }
@@ -1726,29 +1711,12 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         }
     }
     if constexpr (N == 1024 && sizeof(T) == 8) {
-        if (p->tune.rows_v == 7 || (p->tune.rows_v == 0 && p->tune.rows_minw == 0)) {
-            if (split) {
-                switch (p->tune.rows_minw) {
-                    case 1: return launch_rows_advect7<T, 1, 1, 1>(p, planes, plane_stride, adv, batch, st);
-                    case 20: return launch_rows_advect7<T, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
-                    default: return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st);
-                }
-            }
+        if (p->tune.rows_v == 7 || p->tune.rows_v == 0) {   // cross-lane transforms: the default here
+            if (split) return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st);
             return launch_rows_advect7<T, 0, 2, 1>(p, planes, plane_stride, adv, batch, st);
         }
-        if (split) {
-            switch (p->tune.rows_minw) {
-                case 1: return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st);
-                case 2: return launch_rows_advect5<T, N, EPT, THR, 1, 2>(p, planes, plane_stride, adv, batch, st);
-                case 221: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 1, 1, 1>(p, planes, plane_stride, adv, batch, st);
-                case 220: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0, 1, 1>(p, planes, plane_stride, adv, batch, st);
-                case 321: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 1, 0, 1>(p, planes, plane_stride, adv, batch, st);
-                case 320: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0, 0, 1>(p, planes, plane_stride, adv, batch, st);
-                case 311: return launch_rows_advect5<T, N, EPT, THR, 1, 1, 1, 0, 1>(p, planes, plane_stride, adv, batch, st);
-                case 20: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
-                default: return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
-            }
-        }
+        // v5 at this size: two waves per SIMD, rows loaded right before use (236 VGPRs, no spills)
+        if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
     }
     if constexpr (N >= 16) {
         if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st);
