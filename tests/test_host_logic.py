@@ -115,3 +115,31 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+
+def test_composite_transforms_for_grids_with_an_odd_factor():
+    """mixed_radix.CompositeFft (n = p * 2^k through p^2 power-of-two transforms) with a torch.fft stand-in for the
+    power-of-two plan: the decomposition itself, including torch's c2r semantics on spectra that are not Hermitian."""
+    from torch_cfd_amd.mixed_radix import CompositeFft, odd_factor_split
+
+    class Pow2:
+        cdtype, rdtype = torch.complex128, torch.float64
+
+        def rfft2(self, x):
+            assert (x.shape[-1] & (x.shape[-1] - 1)) == 0
+            return torch.fft.rfft2(x)
+
+        def irfft2(self, xh):
+            return torch.fft.irfft2(xh, s=(xh.shape[-2], xh.shape[-2]))
+
+    assert odd_factor_split(1024) is None and odd_factor_split(20) is None and odd_factor_split(96) == (3, 32)
+    g = torch.Generator().manual_seed(0)
+    for n in (24, 40, 48, 56, 96):
+        p, _ = odd_factor_split(n)
+        f = CompositeFft(n, p, Pow2())
+        y = torch.randn(3, n, n, generator=g, dtype=torch.float64)
+        z = torch.complex(torch.randn(2, n, n // 2 + 1, generator=g, dtype=torch.float64),
+                          torch.randn(2, n, n // 2 + 1, generator=g, dtype=torch.float64))
+        assert (f.rfft2(y) - torch.fft.rfft2(y)).abs().max() < 1e-11
+        assert (f.irfft2(z) - torch.fft.irfft2(z, s=(n, n))).abs().max() < 1e-13

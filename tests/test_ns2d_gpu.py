@@ -431,10 +431,10 @@ def test_errors_are_loud(dev):
     w = torch.zeros(1, 16, 9, dtype=torch.complex128, device=dev, requires_grad=True)
     assert op(w, 1e-3)[0].requires_grad            # round 1 raised here; gradients now go through autograd.py
     torch.set_default_dtype(torch.float64)
-    grid = tc.Grid(shape=(24, 24), domain=((0, L), (0, L)))
+    grid = tc.Grid(shape=(20, 20), domain=((0, L), (0, L)))   # 5 * 4: the power-of-two part is below 8
     bad = tc.NavierStokes2DSpectral(1e-3, grid, solver=tc.RK4CrankNicolsonStepper()).to(dev)
-    with pytest.raises(tc._lib.TcfdError, match="power of two"):
-        bad(torch.zeros(1, 24, 13, dtype=torch.complex128, device=dev), 1e-3)
+    with pytest.raises(tc._lib.TcfdError, match="n = 20"):
+        bad(torch.zeros(1, 20, 11, dtype=torch.complex128, device=dev), 1e-3)
 
 
 class _DenseVorticityForcing(torch.nn.Module):
@@ -849,3 +849,60 @@ def test_trajectory_with_require_grad(dev):
     b = tc.get_trajectory_imex(op, w0, 1e-3, num_steps=4, record_every_steps=3, dtype=torch.complex128, require_grad=True)
     for k in a:
         assert not b[k].requires_grad and rel_l2(b[k], a[k]) < 1e-11, k
+
+
+
+# ----------------------------------------------------------------------------- grids that are not a power of two
+@pytest.mark.parametrize("n,tag,forcing", [(96, "f64", "kolmogorov"), (48, "f32", None), (80, "f64", "sincos"), (192, "f64", None)])
+def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, dev):
+    """n = p * 2^k (the reference accepts any even n, equations.py:413-422): power-of-two HIP transforms composed by
+    decimation over the odd factor + the stage loop in tensor ops (mixed_radix.py).  Transforms against torch.fft
+    semantics (non-Hermitian c2r input included), explicit terms / steps / residual / stream function / trajectory
+    against the oracle."""
+    import torch_cfd_amd as tc
+    from oracle import ns2d as O
+
+    real, cplx = REAL[tag], CPLX[tag]
+    grid, op = build_op(n, tag, forcing, dev)
+    t = oracle_tables(n, tag, forcing)
+    plan = tc.fft_plan(n, cplx, dev)
+    g = torch.Generator().manual_seed(n)
+    y = torch.randn(3, n, n, generator=g, dtype=real)
+    z = torch.complex(torch.randn(2, n, n // 2 + 1, generator=g, dtype=real), torch.randn(2, n, n // 2 + 1, generator=g, dtype=real))
+    ttol = 1e-13 if tag == "f64" else 2e-6
+    assert rel_l2(plan.rfft2(y.to(dev)), torch.fft.rfft2(y)) < ttol
+    assert rel_l2(plan.irfft2(z.to(dev)), torch.fft.irfft2(z, s=(n, n))) < ttol
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 20 + s, real)) for s in range(2)])
+    assert op._plan(w0.to(dev)).info()["composite"] in (3, 5)
+    tol = 1e-10 if tag == "f64" else 4e-6
+    assert rel_l2(op.explicit_terms(w0.to(dev)), O.explicit_terms(w0, t)) < (1e-10 if tag == "f64" else 2e-5)
+    ref, ref_dt = O.advance(w0, 1e-3, t, steps=3)
+    out, out_dt = op(w0.to(dev), 1e-3, steps=3)
+    assert out.dtype == cplx and rel_l2(out, ref) < tol
+    assert scaled_err(out_dt, ref_dt, ref / 3e-3) < tol
+    psi, res = op.stream_and_residual(out, out_dt)
+    _, psi_ref = O.stream_and_velocity(ref, t.kx, t.ky)
+    assert rel_l2(psi, psi_ref) < tol
+    assert scaled_err(res, O.residual(ref, ref_dt, t), ref_dt) < (1e-8 if tag == "f64" else 1e-3)
+    traj = tc.get_trajectory_imex(op, w0.to(dev), 1e-3, num_steps=4, record_every_steps=3, dtype=cplx)
+    ref_traj = O.trajectory(w0, 1e-3, t, num_steps=4, record_every_steps=3, dtype=cplx)
+    assert rel_l2(traj["vorticity"], ref_traj["vorticity"]) < (1e-10 if tag == "f64" else 5e-6)
+
+
+def test_odd_factor_grid_initial_condition_and_gradients(dev):
+    """The device IC generator and the differentiable step on a 96^2 grid (composite transforms underneath)."""
+    import torch_cfd_amd as tc
+    from oracle import ns2d as O
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    n = 96
+    grid, op = build_op(n, "f64", None, dev, drag=0.0)
+    w_dev = vorticity_field(grid, 4, random_state=5, device=dev)
+    assert rel_l2(w_dev, O.mcwilliams_vorticity(n, L, 4, 5, torch.float64)) < 1e-11
+    t = oracle_tables(n, "f64", None, drag=0.0)
+    w0 = torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 6, torch.float64))[None]
+    wg = w0.to(dev).requires_grad_(True)
+    op(wg, 1e-3)[0].abs().pow(2).sum().backward()
+    wc = w0.clone().requires_grad_(True)
+    O.advance(wc, 1e-3, t)[0].abs().pow(2).sum().backward()
+    assert rel_l2(wg.grad, wc.grad) < 1e-9

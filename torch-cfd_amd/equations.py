@@ -13,7 +13,9 @@ but ``NavierStokes2DSpectral.forward`` / ``explicit_terms`` / ``residual`` run t
 hand-written gfx950 kernels of ``csrc/tcfd_ns2d.hip`` through the C ABI in
 ``include/tcfd.h`` (three launches per RK stage instead of ~40 ATen launches).
 There is no CPU or eager fallback: tensors must live on a HIP device and the grid
-must be square with n = 2^k (8..2048) -- anything else raises.  The fused kernels are
+must be square with n = 2^k (8..2048: the fused kernels) or n = p * 2^k with a small
+odd p (96, 192, 384, 768, ...: power-of-two HIP transforms + tensor ops, ``mixed_radix.py``)
+-- anything else raises.  The fused kernels are
 forward-only; when gradients are asked for (a state that requires grad, trainable
 stepper coefficients) the operator steps through ``autograd.py``: the same arithmetic
 as device tensor ops around the HIP transforms and their hand-written adjoints.
@@ -203,10 +205,37 @@ class _HipPlan:
         return out
 
 
-_MESH_PLANS: Dict[tuple, _HipPlan] = {}
+_MESH_PLANS: Dict[tuple, object] = {}
 
 
-def _plan_for_mesh(kx: torch.Tensor, ky: torch.Tensor, like: torch.Tensor) -> _HipPlan:
+class _MeshTables:
+    """The table attributes the tensor-op plan reads from an operator, for the stand-alone helpers."""
+
+    smooth = False
+
+    def __init__(self, kx, ky):
+        self.kx, self.ky = kx, ky
+        self.linear_term = torch.zeros_like(kx)
+        self.filter = torch.ones_like(kx)
+
+
+def _composite_plan(op, n: int, cdtype, device, forcing_hat=None):
+    """Plan of a grid n = p * 2^k (odd p): power-of-two HIP transforms + tensor ops, see mixed_radix.py."""
+    from .mixed_radix import CompositeFft, TensorOpPlan, odd_factor_split
+
+    split = odd_factor_split(n)
+    if split is None:
+        raise _lib.TcfdError(f"n = {n}: the HIP spectral path covers n = 2^k (8..2048, fused kernels) and n = p * 2^k with a "
+                             "small odd factor p (power-of-two transforms + tensor ops)")
+    p_, m_ = split
+    return TensorOpPlan(op, CompositeFft(n, p_, fft_plan(m_, cdtype, device)), device, forcing_hat)
+
+
+def _is_pow2(n: int) -> bool:
+    return 8 <= n <= 2048 and (n & (n - 1)) == 0
+
+
+def _plan_for_mesh(kx: torch.Tensor, ky: torch.Tensor, like: torch.Tensor):
     """Table-free plan (L = 0, mask = 1) keyed on the mesh, for the stand-alone
     helpers (vorticity_to_velocity, rfft2/irfft2)."""
     n, m = kx.shape[-2:]
@@ -216,7 +245,12 @@ def _plan_for_mesh(kx: torch.Tensor, ky: torch.Tensor, like: torch.Tensor) -> _H
     key = (n, cdtype, like.device, float(kx1[1]), float(ky1[1]))
     plan = _MESH_PLANS.get(key)
     if plan is None:
-        plan = _HipPlan(n, cdtype, like.device, kx1, ky1, torch.zeros(n, m), torch.ones(n, m))
+        if _is_pow2(n):
+            plan = _HipPlan(n, cdtype, like.device, kx1, ky1, torch.zeros(n, m), torch.ones(n, m))
+        else:
+            real = _REAL_OF[cdtype]
+            plan = _composite_plan(_MeshTables(kx.detach().to(like.device, real), ky.detach().to(like.device, real)), n, cdtype,
+                                   like.device)
         _MESH_PLANS[key] = plan
     return plan
 
@@ -441,7 +475,12 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
             if self.grid.shape[0] != self.grid.shape[1] or n != self.grid.shape[0]:
                 raise ValueError("the HIP spectral path needs a square n x n grid")
             mask = self.filter if self.smooth else torch.ones_like(self.filter)
-            plan = _HipPlan(n, cdtype, like.device, self.kx[:, 0], self.ky[0, :], self.linear_term, mask, self.forcing_hat())
+            if _is_pow2(n):
+                plan = _HipPlan(n, cdtype, like.device, self.kx[:, 0], self.ky[0, :], self.linear_term, mask, self.forcing_hat())
+            else:   # n = p * 2^k: power-of-two HIP transforms + the stage loop in tensor ops (mixed_radix.py)
+                if not like.is_cuda:
+                    raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+                plan = _composite_plan(self, n, cdtype, like.device, self.forcing_hat())
             self._plans = {key: plan}  # tables changed -> drop stale plans
         return plan
 
