@@ -642,3 +642,84 @@ def test_spectral_conv_spatial_resampling(out_size, dev):
         y = layer(x.to(dev), out_mesh_size=out_size)
     assert tuple(y.shape) == (2, 5) + tuple(out_size)
     assert rel_l2(y, ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------- float64 layers (FNOBase.double())
+def _randomise(layer, scale=0.2, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p_ in layer.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g, dtype=torch.float64).to(p_.dtype) * scale)
+
+
+def _blocks(plist):
+    return [torch.view_as_complex(p_.detach().cpu().contiguous()) for p_ in plist]
+
+
+@pytest.mark.parametrize("pad,steps", [(0, 10), (1, 14), (0, 7)])
+def test_fp64_spectral_layers_against_oracle(pad, steps, dev):
+    """fp64 layers (the reference's FNOBase.double(), fno/base.py:342-349) run on the composite fp64 transforms
+    (solver rfft2 / irfft2 + tensor ops): SpectralConvS and SpectralConvT (temporal padding, resampled output steps)
+    against the oracle's torch.fft evaluation in float64, forward AND gradients."""
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float64)
+    g = torch.Generator().manual_seed(pad + steps)
+    x = torch.randn(2, 3, 16, 16, 10, generator=g, dtype=torch.float64)
+    convS = fno.SpectralConvS(3, 4, 5, 4, 3, bias=True, delta=0.4).to(dev)
+    _randomise(convS, seed=1)
+    y = convS(x.to(dev))
+    ref = OF.spectral_conv(x, _blocks(convS.weight), (5, 4, 3), _blocks(convS.bias), delta=0.4)
+    assert y.dtype == torch.float64 and rel_l2(y, ref) < 1e-12
+    convT = fno.SpectralConvT(3, 3, 5, 4, 3, delta=0.1, bias=True, temporal_padding=bool(pad)).to(dev)
+    _randomise(convT, seed=2)
+    xg = x.to(dev).requires_grad_(True)
+    yT = convT(xg, out_steps=steps)
+    xc = x.clone().requires_grad_(True)
+    refT = OF.spectral_conv_t(xc, _blocks(convT.weight), (5, 4, 3), _blocks(convT.bias), delta=0.1, out_steps=steps,
+                              temporal_padding=bool(pad))
+    assert tuple(yT.shape) == (2, 3, 16, 16, steps) and rel_l2(yT.detach(), refT.detach()) < 1e-12
+    yT.pow(2).sum().backward()
+    refT.pow(2).sum().backward()
+    assert rel_l2(xg.grad, xc.grad) < 1e-11
+
+
+def test_fp64_sfno_model_against_oracle(dev):
+    """A whole SFNO converted with .double(): spectral convolutions on the composite fp64 transforms, pointwise
+    layers through their torch modules on the device; against oracle/sfno.py evaluated in float64."""
+    from oracle import sfno as OS
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(3)
+    model = fno.SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).eval().double().to(dev)
+    assert all(p_.dtype in (torch.float64, torch.complex128) for p_ in model.parameters())
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 16, 16, 10, dtype=torch.float64)
+    with torch.no_grad():
+        y = model(x.to(dev))
+    ref = OS.sfno_forward(sd, x, (4, 4, 3), width=4, num_hidden=2, out_steps=10)
+    assert y.dtype == torch.float64 and rel_l2(y, ref) < 1e-10
+
+
+def test_fp64_helmholtz_postprocessed_layer_is_divergence_free(dev):
+    """out_dim = 2 with the Helmholtz projection between contraction and inverse transform, float64: the output
+    velocity field is divergence free to round-off (the property the reference's fp64 test pins, sfno_pytest.py:100-129)."""
+    from torch_cfd_amd import fno
+    from torch_cfd_amd.equations import fft_plan
+
+    torch.set_default_dtype(torch.float64)
+    n = 32
+    layer = fno.SpectralConvT(2, 2, 6, 6, 3, delta=0.1, bias=True, temporal_padding=True,
+                              postprocess=fno.HelmholtzProjection(n_grid=n, diam=2 * math.pi, dtype=torch.float64)).to(dev)
+    _randomise(layer, seed=4)
+    x = torch.randn(2, 2, n, n, 6, dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        y = layer(x, out_steps=8)                                             # (b, 2, n, n, 8)
+    plan = fft_plan(n, torch.complex128, dev)
+    yh = plan.rfft2(y.permute(0, 1, 4, 2, 3).contiguous())                     # (b, 2, t, n, m)
+    k = torch.fft.fftfreq(n, d=2 * math.pi / n, dtype=torch.float64).to(dev)
+    kx, ky = k[:, None], k[None, : n // 2 + 1]
+    div = 2j * math.pi * (yh[:, 0] * kx + yh[:, 1] * ky)
+    assert (div.abs().max() / yh.abs().max()).item() < 1e-12

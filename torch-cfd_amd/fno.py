@@ -120,8 +120,10 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     (Ci, Co, mx, my, mt, 2) fp32; bias: None or 4 tensors (mx, my, mt[, 2])."""
     if not v.is_cuda:
         raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+    if v.dtype == torch.float64:   # FNOBase.double() / fp64 layers (fno/base.py:342-349): composite path, see below
+        return fp64_spectral_conv(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm)
     if v.dtype != torch.float32:
-        raise TypeError(f"the HIP spectral convolution is fp32 only, got {v.dtype}")
+        raise TypeError(f"the HIP spectral convolution is fp32 (fused kernels) or fp64 (composite path), got {v.dtype}")
     if v.dim() != 5:
         raise ValueError(f"expected (b, C, X, Y, T), got {tuple(v.shape)}")
     b, ci, X, Y, T = v.shape
@@ -158,6 +160,112 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
             ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_spectral_conv")
     return out
+
+
+# ----------------------------------------------------------------------------- fp64 layers (composite path)
+def _fp64_kept_rows(n: int, mx: int, device):
+    rows = torch.cat([torch.arange(mx), torch.arange(n - mx, n)]).to(device)
+    return rows, (-rows) % n
+
+
+def fp64_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, scale: float = 1.0) -> torch.Tensor:
+    """Kept modes of rfftn(left_pad_t(v)) in float64: (b, C, n, n, T) -> (b, C, 2mx, 2my, mt) complex128.
+
+    The fused FNO kernels are fp32.  For fp64 layers the 3-D transform is composed from the solver's fp64 2-D
+    transforms (HIP rfft2 / irfft2 with their hand-written adjoints, ``autograd.py``) and small device tensor ops:
+    the short DFT in t is a matmul with a (T, mt) table, the 2-D FFT of the complex result is rfft2(Re) + i rfft2(Im)
+    with the columns beyond n/2 taken from the Hermitian mirror.  Square power-of-two grids only; differentiable."""
+    from .autograd import Rfft2
+    from .equations import fft_plan
+
+    b, c, X, Y, T = v.shape
+    mx, my, mt = modes
+    if X != Y:
+        raise NotImplementedError("fp64 spectral convolutions run on the square-grid fp64 transforms: X == Y required")
+    if 2 * my >= Y or 2 * mx > X:
+        raise ValueError("fp64 spectral convolution: need 2*modes_y < Y and 2*modes_x <= X")
+    n, Tp = X, T + t_pad
+    plan = fft_plan(n, torch.complex128, v.device)
+    kt = torch.arange(mt, device=v.device, dtype=torch.float64)
+    tt = torch.arange(T, device=v.device, dtype=torch.float64) + t_pad
+    ang = -2 * math.pi * tt[:, None] * kt[None, :] / Tp
+    a_re = (v @ torch.cos(ang)).permute(0, 1, 4, 2, 3).contiguous()            # (b, C, mt, X, Y)
+    a_im = (v @ torch.sin(ang)).permute(0, 1, 4, 2, 3).contiguous()
+    h_re, h_im = Rfft2.apply(a_re, plan), Rfft2.apply(a_im, plan)              # (b, C, mt, n, n/2+1)
+    rows, neg_rows = _fp64_kept_rows(n, mx, v.device)
+    mirror_cols = torch.arange(my, 0, -1, device=v.device)                     # ky = n - my .. n - 1  <->  n - ky = my .. 1
+
+    def kept(h):   # full-spectrum entries F[kx, ky] at the kept (kx, ky), from the half spectrum h
+        low = h[..., rows, :my]
+        high = h[..., neg_rows, :][..., mirror_cols].conj()
+        return torch.cat([low, high], dim=-1)                                  # (b, C, mt, 2mx, 2my)
+
+    vh = kept(h_re) + 1j * kept(h_im)
+    return (vh * scale).permute(0, 1, 3, 4, 2)                                 # (b, C, 2mx, 2my, mt)
+
+
+def fp64_contract(vh: torch.Tensor, weights, bias, delta: float, modes) -> torch.Tensor:
+    """The 4-corner contraction on truncated complex128 spectra (einsum per block, device ops)."""
+    mx, my, mt = modes
+    cplx = lambda w: (w if w.is_complex() else torch.view_as_complex(w.contiguous())).to(torch.complex128)
+    rows = (slice(0, mx), slice(mx, 2 * mx))
+    cols = (slice(0, my), slice(my, 2 * my))
+    co = weights[0].shape[1]
+    out = torch.zeros(vh.shape[0], co, 2 * mx, 2 * my, mt, dtype=torch.complex128, device=vh.device)
+    for iy in range(2):
+        for ix in range(2):
+            k = ix + 2 * iy
+            blk = torch.einsum("bixyt,ioxyt->boxyt", vh[:, :, rows[ix], cols[iy], :], cplx(weights[k]))
+            if bias is not None:
+                blk = blk + delta * cplx(bias[k])[None, None]
+            out[:, :, rows[ix], cols[iy], :] = blk
+    return out
+
+
+def fp64_truncated_irfftn(oh: torch.Tensor, n: int, t_out: int, t_keep: int, scale: float) -> torch.Tensor:
+    """irfftn (c2r semantics of torch in t: Im of the DC / Nyquist kt dropped) of a spectrum that is zero outside the
+    kept modes: (b, C, 2mx, 2my, mt) complex128 -> (b, C, n, n, t_keep) float64; ``scale`` relative to the
+    unnormalised inverse.  The complex 2-D inverse of each kt slice is irfft2 of its Hermitian part + i irfft2 of its
+    anti-Hermitian part."""
+    from .autograd import Irfft2
+    from .equations import fft_plan
+
+    b, c, r2, c2, mt = oh.shape
+    mx, my = r2 // 2, c2 // 2
+    plan = fft_plan(n, torch.complex128, oh.device)
+    rows, neg_rows = _fp64_kept_rows(n, mx, oh.device)
+    s = oh.permute(0, 1, 4, 2, 3)                                              # (b, C, mt, 2mx, 2my)
+    low, high = s[..., :my], s[..., my:]                                       # ky = 0..my-1 ; ky = n-my..n-1
+    shape = (b, c, mt, n, n // 2 + 1)
+    p_half = torch.zeros(shape, dtype=torch.complex128, device=oh.device)      # S[kx, ky], ky <= n/2
+    m_half = torch.zeros(shape, dtype=torch.complex128, device=oh.device)      # conj S[-kx, -ky], ky <= n/2
+    p_half[..., rows, :my] = low
+    # the mirror image lands on the rows -kx (kx = n - mx has its partner at row mx, OUTSIDE the kept rows)
+    m_half[..., neg_rows, 0] = low[..., 0].conj()
+    m_half[..., neg_rows, 1: my + 1] = high.flip(-1).conj()                    # ky = 1..my  <-  -ky = n-1 .. n-my
+    herm, anti = 0.5 * (p_half + m_half), -0.5j * (p_half - m_half)
+    z_re, z_im = Irfft2.apply(herm, plan), Irfft2.apply(anti, plan)            # (b, C, mt, n, n), each / n^2
+    kt = torch.arange(mt, device=oh.device, dtype=torch.float64)
+    tt = torch.arange(t_out - t_keep, t_out, device=oh.device, dtype=torch.float64)
+    ang = 2 * math.pi * kt[:, None] * tt[None, :] / t_out
+    ck = torch.where((kt == 0) | (2 * kt == t_out), 1.0, 2.0)[:, None]
+    out = torch.einsum("bckxy,kt->bcxyt", z_re, ck * torch.cos(ang)) - torch.einsum("bckxy,kt->bcxyt", z_im, ck * torch.sin(ang))
+    return out * (scale * n * n)
+
+
+def fp64_spectral_conv(v, weights, bias, delta, modes, t_pad=0, t_out=None, t_keep=None, norm="backward", post=None):
+    """The spectral convolution in float64 through the composite transforms above (forward and backward)."""
+    if not v.is_cuda:
+        raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+    b, ci, X, Y, T = v.shape
+    t_out = T + t_pad if t_out is None else t_out
+    t_keep = t_out if t_keep is None else t_keep
+    fs, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    vh = fp64_truncated_rfftn(v, modes, t_pad, fs)
+    oh = fp64_contract(vh, weights, bias, float(delta), modes)
+    if post is not None:
+        oh = post(oh).to(torch.complex128)
+    return fp64_truncated_irfftn(oh, X, t_out, t_keep, is_)
 
 
 def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward",
@@ -797,8 +905,13 @@ class SpectralConvT(SpectralConvS):
         if not isinstance(self.postprocess, nn.Identity):
             # spectrum post-processing (Helmholtz projection for out_dim = 2): the projection is diagonal in k,
             # so it acts on the kept modes only -- transform, contract, project, inverse-transform
+            if v.is_cuda and v.dtype == torch.float64:   # fp64 layer (the reference's fp64 Helmholtz path): composite transforms
+                post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
+                    self.postprocess, "forward_truncated") else self.postprocess
+                return fp64_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad,
+                                          out_steps + t_pad, out_steps, self.norm, post=post)
             if not v.is_cuda or v.dtype != torch.float32:
-                raise _lib.TcfdError("expected an fp32 HIP device tensor (torch-cfd_amd has no CPU fallback)")
+                raise _lib.TcfdError("expected an fp32 / fp64 HIP device tensor (torch-cfd_amd has no CPU fallback)")
             if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
                 post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
                     self.postprocess, "forward_truncated") else self.postprocess
@@ -1042,6 +1155,17 @@ class FNOBase(nn.Module):
         self.channel_expansion = channel_expansion
         self.debug = debug
         self.num_spectral_layers = num_spectral_layers
+
+    def double(self):
+        """Parameters to float64 / complex128 (fno/base.py:342-349).  An fp64 model runs its spectral convolutions on
+        the composite fp64 transforms (``fp64_spectral_conv``) and its pointwise layers through their torch modules on
+        the device; the fused fp32 kernels are not involved."""
+        for prm in self.parameters():
+            if prm.dtype == torch.float32:
+                prm.data = prm.data.to(torch.float64)
+            elif prm.dtype == torch.complex64:
+                prm.data = prm.data.to(torch.complex128)
+        return self
 
 
 class SFNO(FNOBase):
