@@ -84,7 +84,9 @@ int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* plan, int* split, int* rows_ker
  * complex128 plan (for its twiddle table). */
 int tcfd_debug_xl_fft1024(const tcfd_ns2d_plan* plan, const void* in, void* out, int count, int dir, void* stream);
 
-/* Bytes of caller-owned scratch needed by the calls below for `batch` fields. */
+/* Bytes of caller-owned scratch needed by the calls below for `batch` fields.  Batched calls run in cache-sized chunks
+ * through one chunk-sized set of fields, so this stops growing with the batch at one chunk (plus one field of the whole
+ * batch for tcfd_irfft2): 0.55 GB at 1024^2 x 64 complex128. */
 size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* plan, long batch);
 
 /* ---- RK4-CN time stepping ----------------------------------------------------

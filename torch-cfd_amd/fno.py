@@ -257,6 +257,8 @@ def fp64_spectral_conv(v, weights, bias, delta, modes, t_pad=0, t_out=None, t_ke
     """The spectral convolution in float64 through the composite transforms above (forward and backward)."""
     if not v.is_cuda:
         raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+    if any(w.dtype not in (torch.float64, torch.complex128) for w in weights):   # loud, like torch's einsum on mixed dtypes
+        raise TypeError("float64 input to a spectral convolution with float32 parameters: call .double() on the layer")
     b, ci, X, Y, T = v.shape
     t_out = T + t_pad if t_out is None else t_out
     t_keep = t_out if t_keep is None else t_keep
