@@ -122,6 +122,16 @@ __device__ __forceinline__ void group_sync() {
     }
 }
 
+// store that does not linger as a dirty line in this XCD's L2 (non-temporal hint)
+template <typename T>
+__device__ __forceinline__ void store_stream(cx<T>* p, cx<T> v) {
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    vec2 w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<vec2*>(p));
+}
+
 // called once by tile_fft after the FIRST exchange barrier of a transform (every lane of the group has then
 // consumed whatever the input registers were built from); default: nothing
 struct NoHook {

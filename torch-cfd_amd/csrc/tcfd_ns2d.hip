@@ -134,7 +134,8 @@ struct ColArgs {
     int store_h;   // 0 at the last stage of a step: the accumulator is dead (the next step starts from h = 0)
     int ablate;    // timing ablations (TCFD_ABLATE bit mask; results are WRONG when non-zero): 1 skip the
                    // transforms, 2 skip the plane stores, 4 skip the table reads, 8 skip the h traffic
-    int pair_xcd;  // block->tile map: 0 = batch fastest; 1 = adjacent half-line tiles paired on one XCD
+    int nt_planes; // plane stores with the non-temporal hint (small cache-resident problems, see launch_cols)
+    int pair_xcd;  // block->tile map: 0 = batch fastest; LG = 2 / 4: the LG tiles that share a 128-byte line on one XCD
 };
 
 // SP = 1 ("split"): the workgroup owns the rows of ONE parity q of the column (i = 2 s + q) and runs N/2-point
@@ -143,9 +144,38 @@ struct ColArgs {
 // folded sums S of the advection), rows [N/2, N) the odd parts O (resp. the twiddled differences D).
 // XL = 1 (512-point tiles of 8 columns): the transforms are xl_col_fft512 (one LDS exchange + lane transpositions);
 // register t of thread j then holds physical row xl_col_row(j) + t G instead of j + t G.
+// The twiddles of a column workgroup's transforms, read ONCE per thread: a MODE_CA workgroup runs five transforms one
+// after the other, and a table read inside every pass (behind that pass's barrier) is a memory round trip on its
+// dependency chain each time: the s = 0 entry of every pass (tile_fft_rt: the powers come from squaring) for the short
+// columns of small grids -- the latency-bound regime -- where the transform shape allows it; else nothing (table reads
+// per pass; the long-column kernels sit at their 128-register cap, and the cross-lane tiles read two entries per transform).
+template <typename T, int NT, int EPT, int XL>
+struct ColTw {
+    static constexpr bool RT = !XL && NT <= 256 && pass_tw_count<NT, EPT>() > 0 && pass_tw_single<NT, EPT>();
+    static constexpr int CNT = RT ? pass_tw_count<NT, EPT>() : 1;
+    cx<T> w[CNT];
+    __device__ __forceinline__ void load(const cx<T>* __restrict__ tw, int j) {
+        if constexpr (RT) load_pass_tw<T, NT, EPT>(w, tw, j);
+    }
+};
+template <typename T, int NT, int EPT, int DIR, int C, int XL, int XLT>
+__device__ __forceinline__ void col_fft(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>* __restrict__ tw,
+                                        const ColTw<T, NT, EPT, XLT>& ctw, int j, int c) {
+    if constexpr (XL) {   // two table entries, read per transform: 8 more live registers spill the fp64 kernels
+        const XlColTw<T> t = xl_col_load_tw<T>(tw, j);
+        xl_col_fft512<T, DIR>(x, lds, t, (int)threadIdx.x);
+    } else if constexpr (!XLT && ColTw<T, NT, EPT, XLT>::RT) {
+        NoHook nohook;
+        tile_fft_rt<T, NT, EPT, DIR, C, false, true>(x, lds, j, c, nohook, ctw.w);
+    } else {
+        tile_fft<T, NT, EPT, DIR, C, false, true>(x, lds, tw, j, c);
+    }
+}
+
 template <typename T, int N, int EPT, int C, int SP, int XL>
 __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, const T* rt_kx,
-                                            size_t wbase, int j, int c, int jc, bool valid, int q) {
+                                            size_t wbase, int j, int c, int jc, bool valid, int q,
+                                            const ColTw<T, (N >> SP), EPT, XL>& ctw) {
     constexpr int NT = N >> SP;
     constexpr int G = NT / EPT;
     constexpr T TWO_PI = (T)6.283185307179586476925286766559;
@@ -173,20 +203,17 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             if (f == 1) v = mk<T>(-v.x, -v.y);
             x[t] = valid ? v : mk<T>((T)0, (T)0);
         }
-        int jrow = j;   // physical row (mod G) of this thread's outputs
-        if constexpr (XL) {
-            if (!(a.ablate & 1)) {
-                const XlColTw<T> xtw = xl_col_load_tw<T>(a.tw, j);
-                xl_col_fft512<T, +1>(x, lds, xtw, (int)threadIdx.x);
-            }
-            jrow = xl_col_row(j);
-        } else {
-            if (!(a.ablate & 1)) tile_fft<T, NT, EPT, +1, C, false, true>(x, lds, a.tw, j, c);
-        }
+        const int jrow = XL ? xl_col_row(j) : j;   // physical row (mod G) of this thread's outputs
+        if (!(a.ablate & 1)) col_fft<T, NT, EPT, +1, C, XL, XL>(x, lds, a.tw, ctw, j, c);
         if (valid && !(a.ablate & 2)) {
             cx<T>* dst = a.planes + (size_t)f * a.plane_stride + wbase + (size_t)(SP ? q * NT : 0) * a.ldw;
+            if (a.nt_planes) {
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) dst[(size_t)(jrow + t * G) * a.ldw] = x[t];
+                for (int t = 0; t < EPT; ++t) store_stream(dst + (size_t)(jrow + t * G) * a.ldw, x[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) dst[(size_t)(jrow + t * G) * a.ldw] = x[t];
+            }
         }
     }
 }
@@ -208,8 +235,9 @@ __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&
     if (a.f_nnz > 0) {  // a handful of entries in total (1 for Kolmogorov forcing): uniform loop
         for (int e = 0; e < a.f_nnz; ++e) {
             const int r = a.f_row[e];
+            const int fc = a.f_col[e];      // all three reads of an entry before the branch: one round trip, not two
             const cx<T> v = a.f_val[e];
-            if (a.f_col[e] == jc) {
+            if (fc == jc) {
 #pragma unroll
                 for (int t = 0; t < EPT; ++t)
                     if (r == TCFD_IROW(t)) x[t] = x[t] + v;
@@ -247,12 +275,15 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
     int tile;
     long b;
     if (a.pair_xcd) {
-        // tiles narrower than a 128-byte line: the two tiles that share a line are issued 8 block
-        // ids apart, i.e. back to back on the SAME XCD (block id % 8), so the second one hits in L2
-        const unsigned q = blockIdx.x / 16, r = blockIdx.x % 16;
+        // tiles narrower than a 128-byte line: the LG = 2 or 4 tiles that share a line are issued 8 block ids apart,
+        // i.e. on the SAME XCD (block id % 8): their partial-line stores merge in that XCD's L2 into whole dirty
+        // lines before the end-of-kernel write-back (each XCD writing its own 32 bytes of a line costs a fabric
+        // transaction per piece: the plane stores were 7 of the 17 us of a 256^2 x 16 column pass)
+        const unsigned LG = (unsigned)a.pair_xcd, span = 8 * LG;
+        const unsigned q = blockIdx.x / span, r = blockIdx.x % span;
         const unsigned unit = q * 8 + (r % 8);
-        if (unit >= (unsigned)(((a.ntiles + 1) / 2) * a.batch)) return;
-        tile = 2 * (int)(unit / a.batch) + (int)(r / 8);
+        if (unit >= (unsigned)(((a.ntiles + LG - 1) / LG) * a.batch)) return;
+        tile = (int)(LG * (unit / a.batch) + r / 8);
         b = unit % a.batch;
     } else {
         tile = blockIdx.x / a.batch;
@@ -272,20 +303,30 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
     constexpr bool NEEDS_TABLES = (MODE != MODE_FWD && MODE != MODE_INV);
     T col_ky = 0, col_lin = 0, col_mask = 1;
     int f_lo = 0, f_hi = 0;
-    if constexpr (NEEDS_TABLES) {
-        for (int sl = threadIdx.x; sl < NT; sl += C * G) {  // indexed by the LOCAL row sl, spectral row IROW(sl)
-            const int i = TCFD_IROW(sl);
-            rt_kx[sl] = a.kx[i];
-            rt_lin[sl] = a.sep ? a.lin_r[i] : (T)0;
-            rt_mask[sl] = a.sep ? a.mask_r[i] : (T)1;
+    // Called AFTER the tile's own loads have been issued: the table reads (three loads whose results go to LDS, in a
+    // loop the compiler does not move loads across) then ride in the shadow of the tile's memory round trip instead
+    // of adding two of their own in front of it.  The null tables of a non-separable plan are read through `kx`.
+    auto stage_tables = [&]() {
+        if constexpr (NEEDS_TABLES) {
+            const T* lin_r = a.sep ? a.lin_r : a.kx;
+            const T* mask_r = a.sep ? a.mask_r : a.kx;
+            for (int sl = threadIdx.x; sl < NT; sl += C * G) {  // indexed by the LOCAL row sl, spectral row IROW(sl)
+                const int i = TCFD_IROW(sl);
+                const T vk = a.kx[i], vl = lin_r[i], vm = mask_r[i];
+                rt_kx[sl] = vk;
+                rt_lin[sl] = a.sep ? vl : (T)0;
+                rt_mask[sl] = a.sep ? vm : (T)1;
+            }
+            if (valid) {
+                col_ky = a.ky[jc];
+                if (a.sep) { col_lin = a.lin_c[jc]; col_mask = a.mask_c[jc]; }
+                if (a.f_ptr && a.f_nnz == 0) { f_lo = a.f_ptr[jc]; f_hi = a.f_ptr[jc + 1]; }
+            }
         }
-        if (valid) {
-            col_ky = a.ky[jc];
-            if (a.sep) { col_lin = a.lin_c[jc]; col_mask = a.mask_c[jc]; }
-            if (a.f_ptr && a.f_nnz == 0) { f_lo = a.f_ptr[jc]; f_hi = a.f_ptr[jc + 1]; }
-        }
-    }
+    };
 
+    ColTw<T, NT, EPT, XL> ctw;
+    ctw.load(a.tw, j);
     cx<T> x[EPT];
     if constexpr (MODE == MODE_A) {
         {
@@ -294,8 +335,9 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
             for (int t = 0; t < EPT; ++t)
                 x[t] = valid ? a.u_in[ub + (size_t)TCFD_IROW(j + t * G) * a.u_in_ld] : mk<T>((T)0, (T)0);
         }
+        stage_tables();
         __syncthreads();  // row tables visible
-        emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
+        emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q, ctw);
         return;
     } else {
         constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
@@ -310,14 +352,8 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
             x[t] = col_live ? a.in[inbase + (wq + (size_t)(jin + t * G)) * in_ld] : mk<T>((T)0, (T)0);
-        if constexpr (XLF) {
-            if (!(a.ablate & 1) && tile_live) {
-                const XlColTw<T> xtw = xl_col_load_tw<T>(a.tw, j);
-                xl_col_fft512<T, DIR>(x, lds, xtw, (int)threadIdx.x);
-            }
-        } else {
-            if (!(a.ablate & 1) && tile_live) tile_fft<T, NT, EPT, DIR, C, false, true>(x, lds, a.tw, j, c);
-        }
+        stage_tables();
+        if (!(a.ablate & 1) && tile_live) col_fft<T, NT, EPT, DIR, C, XLF ? 1 : 0, XL>(x, lds, a.tw, ctw, j, c);
         if constexpr (NEEDS_TABLES) __syncthreads();  // row tables visible (a one-pass transform has no barrier)
 
         if constexpr (MODE == MODE_FWD || MODE == MODE_INV) {
@@ -363,36 +399,61 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
             if (valid) {
-                apply_mask_forcing<T, N, EPT, SP>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi, q);
+                // Every global read of the update is issued before the first value is used: the reads of one thread
+                // are independent, but `h` and the state are updated in place through pointers that may alias, so
+                // a load written after an earlier element's store is not moved above it -- 2 EPT memory round trips
+                // one after the other.  In the cache-resident regimes (chunked 1024^2, small grids) a workgroup's
+                // dependency chain IS the kernel time.
                 const T lc = col_lin;
+                const size_t ub = (size_t)b * N * a.u_in_ld + jc;
+                apply_mask_forcing<T, N, EPT, SP>(a, x, j, jc, rt_mask, col_mask, f_lo, f_hi, q);
+                // UB elements per batch of reads: everything at once where the registers are there (fp32, short
+                // columns), 64 bytes' worth per array otherwise (the long-column kernels sit at the 128-register cap)
+                constexpr int UB = EPT * (int)sizeof(cx<T>) <= 64 ? EPT : 64 / (int)sizeof(cx<T>);   // 8 fp32 / 4 fp64
 #pragma unroll
-                for (int t = 0; t < EPT; ++t) {
-                    const int sl = j + t * G;
-                    const int i = TCFD_IROW(sl);
-                    const size_t gw = wbase + (wq + (size_t)sl) * a.ldw;  // h is stored parity-major when split
-                    cx<T> hn = cscale(x[t], a.fa);
-                    // pruned entries: F = 0 at every stage, so h stays 0 and is not stored at all
-                    const bool h_live = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[sl] != (T)0));
-                    if (h_live) {
-                        if (a.load_h) hn = hn + cscale(a.h[gw], a.beta);
-                        if (a.store_h) a.h[gw] = hn;
+                for (int t0 = 0; t0 < EPT; t0 += UB) {
+                    cx<T> hv[UB], uv[UB];
+                    [[maybe_unused]] cx<T> w0v[UB];
+                    T Lv[UB];
+                    bool h_live[UB];
+#pragma unroll
+                    for (int tt = 0; tt < UB; ++tt) {
+                        const int sl = j + (t0 + tt) * G;
+                        const int i = TCFD_IROW(sl);
+                        // pruned entries: F = 0 at every stage, so h stays 0 and is not stored at all
+                        h_live[tt] = !(a.ablate & 8) && (a.keep_cols == 0 || (col_live && rt_mask[sl] != (T)0));
+                        hv[tt] = (h_live[tt] && a.load_h) ? a.h[wbase + (wq + (size_t)sl) * a.ldw] : mk<T>((T)0, (T)0);
+                        uv[tt] = a.u_in[ub + (size_t)i * a.u_in_ld];
+                        Lv[tt] = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[sl] + lc : a.lin[(size_t)i * a.m + jc]);
+                        if constexpr (MODE == MODE_C) {
+                            if (a.dwdt) w0v[tt] = a.w0[(size_t)b * N * a.m + jc + (size_t)i * a.m];
+                        }
                     }
-                    const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[sl] + lc : a.lin[(size_t)i * a.m + jc]);
-                    const cx<T> u = a.u_in[(size_t)b * N * a.u_in_ld + jc + (size_t)i * a.u_in_ld];
-                    // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
-                    cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
-                    const T den = fast_rcp((T)1 - a.mud * L);
-                    x[t] = cscale(rhs, den);
-                    a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
-                    if constexpr (MODE == MODE_C) {
-                        if (a.dwdt) {   // (w_new - w_old) / (steps dt), equations.py:461-462, fused into the last stage
-                            const size_t gi = (size_t)b * N * a.m + jc + (size_t)i * a.m;
-                            a.dwdt[gi] = cscale(x[t] - a.w0[gi], a.dwdt_scale);
+#pragma unroll
+                    for (int tt = 0; tt < UB; ++tt) {
+                        const int t = t0 + tt;
+                        const int sl = j + t * G;
+                        const int i = TCFD_IROW(sl);
+                        const size_t gw = wbase + (wq + (size_t)sl) * a.ldw;  // h is stored parity-major when split
+                        const cx<T> hn = cscale(x[t], a.fa) + cscale(hv[tt], a.beta);   // hv = 0: nothing to add
+                        if (h_live[tt] && a.store_h) a.h[gw] = hn;
+                        const T L = Lv[tt];
+                        const cx<T> u = uv[tt];
+                        // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
+                        cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
+                        const T den = fast_rcp((T)1 - a.mud * L);
+                        x[t] = cscale(rhs, den);
+                        a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
+                        if constexpr (MODE == MODE_C) {
+                            if (a.dwdt) {   // (w_new - w_old) / (steps dt), equations.py:461-462, fused into the last stage
+                                const size_t gi = (size_t)b * N * a.m + jc + (size_t)i * a.m;
+                                a.dwdt[gi] = cscale(x[t] - w0v[tt], a.dwdt_scale);
+                            }
                         }
                     }
                 }
             }
-            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q);
+            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q, ctw);
         }
     }
 #undef TCFD_IROW
@@ -1213,6 +1274,11 @@ struct GraphState {
     hipEvent_t ev_out2 = nullptr, ev_rows = nullptr;
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
+    // the same step MULTI times in one graph: a graph launch costs ~10 us of idle device between replays, a sixth
+    // of a 256^2 step; long calls replay this one and finish with the single-step graph
+    static constexpr int MULTI = 16;
+    hipGraphExec_t exec_multi = nullptr;
+    hipGraph_t graph_multi = nullptr;
     // key of the captured sequence
     long batch = -1;
     int nstages = 0;
@@ -1227,8 +1293,9 @@ struct Tuning {
     int small_tiles;         // TCFD_SMALL_TILES: 4-column tiles / 64-lane row groups for small problems
     int two_wg;              // TCFD_TWO_WG: 128-VGPR cap (two workgroups per CU) for the 512-point fp64 column tiles
     int rows_blocks_per_cu;  // TCFD_ROWS_BLOCKS_PER_CU: persistent row-pass grid
-    int pair_xcd;            // TCFD_PAIR_XCD: pair the two half-line tiles of a 128-byte line on one XCD
+    int pair_xcd;            // TCFD_PAIR_XCD: put the 2 / 4 column tiles that share a 128-byte line on one XCD (0 off, 2 pairs only)
     int ablate;              // TCFD_ABLATE: timing ablations (results are WRONG when non-zero)
+    int nt_planes;           // TCFD_NT_PLANES: non-temporal plane stores (-1: for the small-tile launches only)
     int rows_v;              // TCFD_ROWS_V: 0 = per size; 6 = LDS-DMA staged rows, 5 = register-staged rows (one plane per
                              // transform), 4 = two planes per transform (round 1)
     int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
@@ -1385,6 +1452,8 @@ extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     if (p->gs) {
         if (p->gs->exec) (void)hipGraphExecDestroy(p->gs->exec);
         if (p->gs->graph) (void)hipGraphDestroy(p->gs->graph);
+        if (p->gs->exec_multi) (void)hipGraphExecDestroy(p->gs->exec_multi);
+        if (p->gs->graph_multi) (void)hipGraphDestroy(p->gs->graph_multi);
         if (p->gs->ev_in) (void)hipEventDestroy(p->gs->ev_in);
         if (p->gs->ev_out) (void)hipEventDestroy(p->gs->ev_out);
         if (p->gs->ev_out2) (void)hipEventDestroy(p->gs->ev_out2);
@@ -1411,6 +1480,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->tune.rows_blocks_per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 0);
     p->tune.pair_xcd = env_int("TCFD_PAIR_XCD", 1);
     p->tune.ablate = env_int("TCFD_ABLATE", 0);
+    p->tune.nt_planes = env_int("TCFD_NT_PLANES", -1);
     p->tune.rows_v = env_int("TCFD_ROWS_V", 0);
     p->tune.chunk = env_int("TCFD_CHUNK", -1);
     p->tune.cols_xl = env_int("TCFD_COLS_XL", 1);
@@ -1490,6 +1560,16 @@ static int set_lds(DevOnce& once, K kernel, size_t bytes) {
     return 0;
 }
 
+// tiles of C columns narrower than a 128-byte line: how many of them share a line (0: whole lines, nothing to group).
+// TCFD_PAIR_XCD = 0 switches the XCD grouping off, 2 limits it to pairs (the round-1 form).
+template <typename T, int C>
+static int line_group(const tcfd_ns2d_plan* p) {
+    constexpr int bytes = C * (int)sizeof(cx<T>);
+    if (bytes >= 128 || p->tune.pair_xcd == 0) return 0;
+    const int lg = 128 / bytes > 4 ? 4 : 128 / bytes;
+    return p->tune.pair_xcd == 2 ? 2 : lg;
+}
+
 template <typename T, int N, int MODE, int EPT, int C, int MINW = 1, int SP = 0>
 static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
     constexpr int NT = N >> SP;
@@ -1524,9 +1604,10 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
             static DevOnce lds_once_x;
             if (int rc_ = set_lds(lds_once_x, kx, lds)) return rc_;
             long blocks_x = batch * a.ntiles;
-            a.pair_xcd = (C * sizeof(cx<T>) < 128) ? p->tune.pair_xcd : 0;
+            a.pair_xcd = line_group<T, C>(p);
             a.ablate = p->tune.ablate;
-            if (a.pair_xcd) blocks_x = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
+            a.nt_planes = p->tune.nt_planes > 0;
+            if (a.pair_xcd) blocks_x = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
             ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
             hipLaunchKernelGGL(kx, dim3((unsigned)blocks_x, SP ? 2u : 1u), dim3(C * G), lds, st, a);
             HIP_TRY(hipGetLastError());
@@ -1537,9 +1618,13 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     static DevOnce lds_once;
     if (int rc_ = set_lds(lds_once, kern, lds)) return rc_;
     long blocks = batch * a.ntiles;
-    a.pair_xcd = (C * sizeof(cx<T>) < 128) ? p->tune.pair_xcd : 0;
+    a.pair_xcd = line_group<T, C>(p);
     a.ablate = p->tune.ablate;
-    if (a.pair_xcd) blocks = ((((long)(a.ntiles + 1) / 2) * batch + 7) / 8) * 16;
+    // 4-column tiles = the small, cache-resident problems: a whole pass's output would sit dirty in the L2s until the
+    // end-of-kernel write-back; streamed out while the kernel still computes, 256^2 x 16 fp32 steps 4.6 % faster
+    // (at 1024^2 the same hint costs 1-3 %)
+    a.nt_planes = p->tune.nt_planes >= 0 ? p->tune.nt_planes : (C == 4 && EPT == 4);
+    if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
     ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SP ? 2u : 1u), dim3(C * G), lds, st, a);
     HIP_TRY(hipGetLastError());
@@ -1936,20 +2021,34 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             coef.push_back(beta[k]); coef.push_back(gdt[k]); coef.push_back(mu[k]);
             coef.push_back(fa ? fa[k] : 1.0); coef.push_back(mud ? mud[k] : mu[k]); coef.push_back(base0 ? base0[k] : 0);
         }
+        auto capture = [&](int reps, hipGraph_t* graph, hipGraphExec_t* exec) -> int {
+            HIP_TRY(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+            int r = 0;
+            for (int i = 0; i < reps && !r; ++i) r = run_step(g->stream, false);         // upad -> upad
+            hipError_t e = hipStreamEndCapture(g->stream, graph);
+            if (r) return r;
+            if (e != hipSuccess) return fail(TCFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIP_TRY(hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
+            return 0;
+        };
         if (!g->exec || g->batch != batch || g->nstages != nstages || g->ws != ws || g->coef != coef) {
             if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
             if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
-            HIP_TRY(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
-            rc = run_step(g->stream, false);         // upad -> upad
-            hipError_t e = hipStreamEndCapture(g->stream, &g->graph);
-            if (rc) return rc;
-            if (e != hipSuccess) return fail(TCFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            HIP_TRY(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+            if (g->exec_multi) { (void)hipGraphExecDestroy(g->exec_multi); g->exec_multi = nullptr; }
+            if (g->graph_multi) { (void)hipGraphDestroy(g->graph_multi); g->graph_multi = nullptr; }
+            if ((rc = capture(1, &g->graph, &g->exec))) return rc;
             g->batch = batch; g->nstages = nstages; g->ws = ws; g->coef = coef;
         }
+        int interior = steps - 2;
+        if (interior >= 2 * GraphState::MULTI && !g->exec_multi &&
+            (rc = capture(GraphState::MULTI, &g->graph_multi, &g->exec_multi)))
+            return rc;
         HIP_TRY(hipEventRecord(g->ev_in, st));
         HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_in, 0));
-        for (int s = 1; s < steps - 1; ++s) HIP_TRY(hipGraphLaunch(g->exec, g->stream));
+        if (g->exec_multi)
+            for (; interior >= GraphState::MULTI; interior -= GraphState::MULTI)
+                HIP_TRY(hipGraphLaunch(g->exec_multi, g->stream));
+        for (; interior > 0; --interior) HIP_TRY(hipGraphLaunch(g->exec, g->stream));
         HIP_TRY(hipEventRecord(g->ev_out, g->stream));
         HIP_TRY(hipStreamWaitEvent(st, g->ev_out, 0));
         s0 = steps - 1;
