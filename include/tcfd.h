@@ -194,6 +194,21 @@ int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w
                        const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
                        int T, int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride,
                        const void* pe, void* stream);
+/* Spectral convolution + the pointwise block that follows it in an SFNO layer, v <- act(FFN(conv(v)) + W v)
+ * (fno/sfno.py:607-614) or the lifting tail act(v[..., -1:] + FFN(conv(v))) (:258-259), with the convolution's output
+ * kept on chip: the inverse t/y transforms of all `cout` channels of a row (b, x) and the pointwise block run in one
+ * workgroup.  Arguments: those of tcfd_fno_spectral_conv, then those of tcfd_fno_pointwise (its x is the convolution:
+ * ci = cout, w1 required, shared weights); out (batch, co_pw, X, Y, t_keep).  Bit-identical to the two calls.  Returns
+ * TCFD_EINVAL with "not instantiated" in tcfd_last_error() -- before anything is launched -- when the shape is not
+ * covered (odd t_keep, a row that does not fit a workgroup's 160 KB of LDS, widths other than 8 / 10); callers then
+ * make the two calls.  Measured SLOWER than the two calls at SFNO config 5 (one row-sized workgroup per CU), so the
+ * Python models use it only under TCFD_FNO_FUSE_TAIL=1. */
+int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* plan, const void* v, const void* const* weights,
+                                     const void* const* bias, float delta, void* out, int batch, int cin, int cout,
+                                     int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* workspace,
+                                     size_t workspace_bytes, const void* skip, const void* w1, const void* b1,
+                                     const void* w2t, const void* b2, const void* wst, const void* bs, int cm, int co_pw,
+                                     int act1, int act2, int skip_mode, int skip_T, void* stream);
 /* pe (ci, P) or NULL: when given, x is ONE channel (batch, 1, P) and the block input is x + pe[c] -- the lifting
  * operator's "input + positional encoding" (fno/sfno.py:109-113) without materialising the (batch, ci, P) tensor.
  * w2_bstride / b2_bstride: element offsets of w2t / b2 per batch element (0 = shared weights); a per-sample

@@ -723,3 +723,37 @@ def test_fp64_helmholtz_postprocessed_layer_is_divergence_free(dev):
     kx, ky = k[:, None], k[None, : n // 2 + 1]
     div = 2j * math.pi * (yh[:, 0] * kx + yh[:, 1] * ky)
     assert (div.abs().max() / yh.abs().max()).item() < 1e-12
+
+
+@pytest.mark.parametrize("width,expansion,n,T", [(10, 4, 64, 10), (8, 2, 64, 6), (10, 4, 256, 10)])
+def test_fused_layer_tail_is_bit_identical_to_the_two_kernel_path(width, expansion, n, T, dev, monkeypatch):
+    """The SFNO layer tail in ONE kernel (inverse t/y transform + pointwise block, ``tcfd_fno_spectral_conv_pointwise``)
+    against ``hip_spectral_conv`` followed by ``hip_pointwise``: same arithmetic in the same order, so exactly equal --
+    for a hidden layer (skip convolution) and for the lifting tail (broadcast of the last input slice).  The two-kernel
+    path itself is checked against the reference's goldens and the oracle above."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(width * 100 + n)
+    conv = fno.SpectralConvS(width, width, 6, 6, 3).to(dev)
+    convt = fno.SpectralConvT(width, width, 6, 6, 3, out_steps=T, bias=True).to(dev)
+    mlp = fno.PointwiseFFN(width, width, expansion * width, "GELU").to(dev)
+    w = torch.nn.Conv3d(width, width, 1).to(dev)
+    act = torch.nn.ReLU()
+    with torch.no_grad():
+        for prm in list(conv.parameters()) + list(convt.parameters()):
+            prm.mul_(1e3)   # the default gain 1e-4 would leave only the skip term visible
+        v = torch.randn(3, width, n, n, T, device=dev)
+        fused = fno.hip_conv_pointwise(conv, v, mlp, v, skip_conv=w, act2=act)
+        assert fused is not None, "hidden-layer tail was expected to be covered"
+        two = fno.hip_pointwise(conv(v), mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
+        assert torch.equal(fused, two)
+        assert rel_l2(fused, act(mlp(conv(v)) + w(v))) < 2e-6          # and the torch modules on the device
+        fused_l = fno.hip_conv_pointwise(convt, v, mlp, v, act2=act, skip_last_slice=True)
+        assert fused_l is not None
+        two_l = fno.hip_pointwise(convt(v), mlp.linear1, mlp.activation, mlp.linear2, skip=v, act2=act, skip_last_slice=True)
+        assert torch.equal(fused_l, two_l)
+    # not covered: gradients wanted, an odd number of output steps -> None before anything runs
+    assert fno.hip_conv_pointwise(conv, v.requires_grad_(), mlp, v, skip_conv=w, act2=act) is None
+    with torch.no_grad():
+        v5 = torch.randn(1, width, n, n, 5, device=dev)
+        assert fno.hip_conv_pointwise(conv, v5, mlp, v5, skip_conv=w, act2=act) is None

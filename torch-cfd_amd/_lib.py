@@ -123,6 +123,9 @@ SIGNATURES = {
                                _i, _i, _vp]),
     "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
                                 _l, _vp, _vp]),
+    "tcfd_fno_spectral_conv_pointwise": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i,
+                                              _i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _vp, _sz,
+                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_fno_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),

@@ -748,22 +748,9 @@ __device__ __forceinline__ v2f pw_act(v2f v, int act) { return v2f{pw_act(v.x, a
 __device__ __forceinline__ float pw_fma(float w, float x, float acc) { return fmaf(w, x, acc); }
 __device__ __forceinline__ v2f pw_fma(float w, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{w, w}, x, acc); }
 
-template <int CI, int CM, int CO, bool HAS_L1, int V>
-__global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
-    typedef typename PwVec<V>::type vf;
-    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * V;
-    const int b = blockIdx.y;
-    if (p >= a.P) return;
-    vf x[CI], o[CO];
-    if (a.pe) {
-        const vf v1 = *reinterpret_cast<const vf*>(a.x + (size_t)b * a.P + p);
-#pragma unroll
-        for (int i = 0; i < CI; ++i) x[i] = v1 + *reinterpret_cast<const vf*>(a.pe + (size_t)i * a.P + p);
-    } else {
-        const float* xb = a.x + (size_t)b * CI * a.P + p;
-#pragma unroll
-        for (int i = 0; i < CI; ++i) x[i] = *reinterpret_cast<const vf*>(xb + (size_t)i * a.P);
-    }
+// o = b2 + W2 . act1(W1 . x + b1)   (HAS_L1)   |   o = b2 + W2 . x   -- the block without its skip term and final activation
+template <int CI, int CM, int CO, bool HAS_L1, typename vf>
+__device__ __forceinline__ void pw_core(const PwArgs& a, int b, const vf (&x)[CI], vf (&o)[CO]) {
     const float* w2t_b = a.w2t + (size_t)b * a.w2_bstride;
     const float* b2_b = a.b2 ? a.b2 + (size_t)b * a.b2_bstride : nullptr;
 #pragma unroll
@@ -789,19 +776,45 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
             for (int c = 0; c < CO; ++c) o[c] = pw_fma(w2[c], x[m], o[c]);
         }
     }
+}
+// o += Ws . s + bs   (the 1x1x1 skip convolution)
+template <int CI, int CO, typename vf>
+__device__ __forceinline__ void pw_skip_conv(const PwArgs& a, const vf (&sv)[CI], vf (&o)[CO]) {
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+        const float* ws = a.wst + i * CO;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) o[c] = pw_fma(ws[c], sv[i], o[c]);
+    }
+    if (a.bs) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) o[c] += (vf)a.bs[c];
+    }
+}
+
+template <int CI, int CM, int CO, bool HAS_L1, int V>
+__global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
+    typedef typename PwVec<V>::type vf;
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * V;
+    const int b = blockIdx.y;
+    if (p >= a.P) return;
+    vf x[CI], o[CO];
+    if (a.pe) {
+        const vf v1 = *reinterpret_cast<const vf*>(a.x + (size_t)b * a.P + p);
+#pragma unroll
+        for (int i = 0; i < CI; ++i) x[i] = v1 + *reinterpret_cast<const vf*>(a.pe + (size_t)i * a.P + p);
+    } else {
+        const float* xb = a.x + (size_t)b * CI * a.P + p;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) x[i] = *reinterpret_cast<const vf*>(xb + (size_t)i * a.P);
+    }
+    pw_core<CI, CM, CO, HAS_L1, vf>(a, b, x, o);
     if (a.skip_mode == 1) {
         const float* sb = a.s + (size_t)b * CI * a.P + p;
+        vf sv[CI];
 #pragma unroll
-        for (int i = 0; i < CI; ++i) {
-            const vf sv = *reinterpret_cast<const vf*>(sb + (size_t)i * a.P);
-            const float* ws = a.wst + i * CO;
-#pragma unroll
-            for (int c = 0; c < CO; ++c) o[c] = pw_fma(ws[c], sv, o[c]);
-        }
-        if (a.bs) {
-#pragma unroll
-            for (int c = 0; c < CO; ++c) o[c] += (vf)a.bs[c];
-        }
+        for (int i = 0; i < CI; ++i) sv[i] = *reinterpret_cast<const vf*>(sb + (size_t)i * a.P);
+        pw_skip_conv<CI, CO, vf>(a, sv, o);
     } else if (a.skip_mode == 2) {
         const long xy = p / a.T;   // V = 2 needs an even T: both points of a lane share (x, y)
         const long sP = (a.P / a.T) * a.sT;
@@ -812,6 +825,150 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     float* ob = a.out + (size_t)b * CO * a.P + p;
 #pragma unroll
     for (int c = 0; c < CO; ++c) *reinterpret_cast<vf*>(ob + (size_t)c * a.P) = pw_act(o[c], a.act2);
+}
+
+// ------------------------------------------------------------------ inverse t/y transform + pointwise block in ONE kernel
+// The tail of an SFNO layer, v <- act(FFN(SpectralConv(v)) + W v) (fno/sfno.py:607-614) or the lifting operator's
+// act(v[..., -1:] + FFN(SpectralConvT(v))) (:258-259): k_inv_ty2 writes the convolution's output (b, C, X, Y, T) to HBM
+// and k_pointwise reads it straight back, together 2 of the layer's 5 passes over the activations.  Here ONE workgroup
+// owns the row (b, x) of ALL CI channels: it runs their inverse t/y transforms exactly as k_inv_ty2 does (slab s =
+// channel s), leaves the CI output slabs [y][t] in LDS, and feeds the pointwise block from there -- same arithmetic in
+// the same order, so the result is bit-identical to the two-kernel path.  The skip operand of a lane's first points is
+// requested before the transforms start, so that its HBM latency hides behind them.
+// MEASURED SLOWER and therefore opt-in (TCFD_FNO_FUSE_TAIL=1): at config 5 (width 10, 256 x 256 x 10) a row of 10
+// channels is 100 KB of LDS -- one 800-lane workgroup per CU, 3 waves per SIMD, its phases (spectrum in, transforms,
+// two trips of the pointwise block with their scalar weight loads) strictly one after the other: 1.29 ms per layer
+// against 0.29 + 0.59 ms for the two kernels, which run 4 resp. 8 workgroups per CU and hide exactly those latencies.
+// Saving 2 of 5 passes over the activations does not pay for losing the occupancy.
+template <int Y, int EPT, int CI, int CM, int CO>
+__global__ __launch_bounds__(1024) void k_inv_ty_pw(const cf* __restrict__ w2, PwArgs a, const float* __restrict__ pw_w1,
+                                                    const float* __restrict__ pw_b1, const float* __restrict__ pw_w2t,
+                                                    const float* __restrict__ pw_b2, const float* __restrict__ pw_wst,
+                                                    const float* __restrict__ pw_bs, const cf* __restrict__ tw_y,
+                                                    const cf* __restrict__ tw_ti, int T_out, int t_keep, int mt, int my,
+                                                    float scale, int P, int X, int Ys) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    typedef v2f vf;
+    constexpr int G = Y / EPT;
+    constexpr int NS = CI;
+    const int Q = 2 * my * mt, t0 = T_out - t_keep;
+    cf* ex = reinterpret_cast<cf*>(smem_raw);                  // [NS*P][Y] input / exchange, later [NS][Y][t_keep] floats
+    cf* win = ex + (size_t)NS * P * Y;                         // [NS][Q]
+    cf* twt = win + (size_t)NS * Q;                            // [t_keep][mt]
+    const int tr = threadIdx.x / G, j = threadIdx.x % G;
+    const int s = tr / P, p = tr - s * P;
+    const int b = blockIdx.x / X, xrow = blockIdx.x - b * X;
+    cf* lds = ex + (size_t)tr * Y;
+    const int slab_pts = Y * t_keep;                           // points of one (b, c, x) slab
+    const int n_items = slab_pts / 2;                          // packed pairs (t_keep is even)
+    const int nthr = NS * P * G;
+    // ---- skip operand of this lane's first pair
+    vf sv0[CI];
+    const bool has0 = (int)threadIdx.x < n_items;
+    if (a.skip_mode == 1 && has0) {
+        const float* sb = a.s + ((size_t)b * CI * X + xrow) * slab_pts + 2 * threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) sv0[i] = *reinterpret_cast<const vf*>(sb + (size_t)i * X * slab_pts);
+    }
+    {
+        for (int q = 0; q < NS; ++q) {
+            const cf* src = w2 + ((size_t)(b * CI + q) * X + xrow) * Q;
+            for (int i = threadIdx.x; i < Q; i += nthr) win[(size_t)q * Q + i] = src[i];
+        }
+        for (int i = threadIdx.x; i < t_keep * mt; i += nthr) twt[i] = tw_ti[(size_t)t0 * mt + i];
+        float4* z4 = reinterpret_cast<float4*>(lds);           // zero this transform's spectrum (the padding)
+#pragma unroll
+        for (int t = 0; t < EPT / 2; ++t) z4[j + t * G] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {   // as k_inv_ty2
+        const float hsc = 0.5f * scale;
+        const bool pair = 2 * p + 1 < t_keep;
+        const cf* e0 = twt + (size_t)(2 * p) * mt;
+        const cf* e1 = twt + (size_t)(pair ? 2 * p + 1 : 2 * p) * mt;
+        const cf* wq = win + (size_t)s * Q;
+        auto slot = [&](int k) { return k < my ? k : ((k >= Ys - my && k < Ys) ? k - (Ys - 2 * my) : -1); };
+        const int kmax = (Ys == Y) ? my : Y / 2;
+        for (int ky = j; ky <= kmax; ky += G) {
+            const int kyn = (Y - ky) & (Y - 1);
+            const int sa = slot(ky), sb = slot(kyn);
+            const bool ha = sa >= 0, hb = sb >= 0;
+            if (!ha && !hb) continue;      // the buffer is pre-zeroed
+            const cf* wa = wq + (size_t)(ha ? sa : 0) * mt;
+            const cf* wb = wq + (size_t)(hb ? sb : 0) * mt;
+            float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f;
+            for (int k = 0; k < mt; ++k) {
+                cf av = wa[k];
+                if (!ha) av = mk<float>(0.f, 0.f);
+                cf bv = wb[k];
+                if (!hb) bv = mk<float>(0.f, 0.f);
+                const float ux = av.x + bv.x, uy = av.y + bv.y, dx = av.x - bv.x, dy = av.y - bv.y;
+                const cf E0 = e0[k], E1 = e1[k];
+                g0x += E0.x * ux - E0.y * uy;  g0y += E0.y * dx + E0.x * dy;
+                g1x += E1.x * ux - E1.y * uy;  g1y += E1.y * dx + E1.x * dy;
+            }
+            if (!pair) { g1x = 0.f; g1y = 0.f; }
+            lds[ky] = mk<float>((g0x - g1y) * hsc, (g0y + g1x) * hsc);
+            if (kyn != ky) lds[kyn] = mk<float>((g0x + g1y) * hsc, (g1x - g0y) * hsc);
+        }
+    }
+    group_sync<false>();
+    cf x[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) x[t] = lds[j + t * G];
+    group_sync<false>();
+    tile_fft<float, Y, EPT, +1, 1, true, false>(x, lds, tw_y, j, 0);
+    __syncthreads();  // all exchanges done: the buffers become the output slabs [y][t_keep]
+    {
+        float* oslab = reinterpret_cast<float*>(ex + (size_t)s * P * Y) + (size_t)j * t_keep + 2 * p;
+#pragma unroll
+        for (int t = 0; t < EPT; ++t)
+            *reinterpret_cast<float2*>(oslab + (size_t)t * G * t_keep) = make_float2(x[t].x, x[t].y);
+    }
+    __syncthreads();
+    // ---- pointwise block on the row's Y * t_keep points, two neighbouring points per lane
+    const size_t chan_in = (size_t)P * Y * sizeof(cf) / sizeof(float);   // floats between the LDS slabs of two channels
+    const float* tile = reinterpret_cast<const float*>(ex);
+    for (int item = threadIdx.x; item < n_items; item += nthr) {
+        const int pt = 2 * item;
+        // The weights reach the FMAs through the scalar unit, as in k_pointwise.  That needs (i) the compiler's proof
+        // that the stores of an earlier trip cannot have changed them -- the tables are separate __restrict__ kernel
+        // arguments, not fields of `a` -- and (ii) the ~CI (2 CM + CO) loop-invariant scalar loads NOT hoisted out of
+        // this one- or two-trip loop (they would be spilled): an opaque zero per trip is added to the pointers.
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        a.w1 = pw_w1 + zero;
+        a.b1 = pw_b1 ? pw_b1 + zero : nullptr;
+        a.w2t = pw_w2t + zero;
+        a.b2 = pw_b2 ? pw_b2 + zero : nullptr;
+        a.wst = pw_wst ? pw_wst + zero : nullptr;
+        a.bs = pw_bs ? pw_bs + zero : nullptr;
+        vf xin[CI], o[CO];
+#pragma unroll
+        for (int i = 0; i < CI; ++i) xin[i] = *reinterpret_cast<const vf*>(tile + (size_t)i * chan_in + pt);
+        pw_core<CI, CM, CO, true, vf>(a, b, xin, o);
+        if (a.skip_mode == 1) {
+            vf sv[CI];
+            if (item == (int)threadIdx.x) {
+#pragma unroll
+                for (int i = 0; i < CI; ++i) sv[i] = sv0[i];
+            } else {
+                const float* sb = a.s + ((size_t)b * CI * X + xrow) * slab_pts + pt;
+#pragma unroll
+                for (int i = 0; i < CI; ++i) sv[i] = *reinterpret_cast<const vf*>(sb + (size_t)i * X * slab_pts);
+            }
+            pw_skip_conv<CI, CO, vf>(a, sv, o);
+        } else if (a.skip_mode == 2) {
+            const int y = pt / t_keep;
+            const size_t sP = (size_t)X * Y * a.sT;
+            const float* sb = a.s + (size_t)b * CO * sP + ((size_t)xrow * Y + y) * a.sT + (a.sT - 1);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] += (vf)sb[(size_t)c * sP];
+        }
+        float* ob = a.out + ((size_t)b * CO * X + xrow) * slab_pts + pt;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) *reinterpret_cast<vf*>(ob + (size_t)c * X * slab_pts) = pw_act(o[c], a.act2);
+    }
 }
 
 template <int CI, int CM, int CO, bool HAS_L1>
@@ -830,6 +987,88 @@ static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int Y, int CI, int CM, int CO>
+static int launch_inv_ty_pw(const tcfd_fno_plan* p, const cf* w2, const PwArgs& a, int batch, int t_keep, float scale,
+                            bool probe, hipStream_t st) {
+    constexpr int EPT = TyCfg2<Y>::EPT, G = TyCfg2<Y>::G;
+    const int P = t_keep / 2;
+    const size_t lds = ((size_t)CI * P * Y + (size_t)CI * 2 * p->my * p->mt + (size_t)t_keep * p->mt) * sizeof(cf);
+    if ((t_keep & 1) || CI * P * G > 1024 || lds > 160 * 1024)
+        return FAIL(TCFD_EINVAL, "fno: fused layer tail not instantiated (row of %d channels does not fit a workgroup)", CI);
+    if (probe) return 0;
+    auto kern = k_inv_ty_pw<Y, EPT, CI, CM, CO>;
+    int rc;
+    if ((rc = set_lds_attr(kern, lds))) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)batch * p->X)), dim3(CI * P * G), lds, st, w2, a, a.w1, a.b1, a.w2t, a.b2,
+                       a.wst, a.bs, (const cf*)p->tw_y,
+                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, p->X, p->Ys);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// probe = true: only answer whether the combination is instantiated and fits (nothing is launched)
+static int do_inv_ty_pw(const tcfd_fno_plan* p, const cf* w2, const PwArgs& a, int batch, int ci, int cm, int co, int t_keep,
+                        float scale, bool probe, hipStream_t st) {
+#define TYPW_CASE(Y_, CI_, CM_, CO_)                                                                       \
+    if (p->Y == Y_ && ci == CI_ && co == CO_ && (CM_ == 0 || cm == CM_))                                    \
+        return launch_inv_ty_pw<Y_, CI_, CM_, CO_>(p, w2, a, batch, t_keep, scale, probe, st);
+    // widths above 10 spill under the 128-register cap of the row-sized workgroup: not instantiated
+#define TYPW_WIDTHS(Y_) TYPW_CASE(Y_, 10, 40, 10) TYPW_CASE(Y_, 8, 0, 8)
+    TYPW_WIDTHS(64) TYPW_WIDTHS(256)
+#undef TYPW_WIDTHS
+#undef TYPW_CASE
+    return FAIL(TCFD_EINVAL, "fno: fused layer tail not instantiated (Y = %d, channels %d -> %d -> %d)", p->Y, ci, cm, co);
+}
+
+// Spectral convolution + the layer's pointwise block:  out = act2( W2 . act1(W1 . conv(v) + b1) + b2 + skip term ), the
+// convolution's output never leaves the chip (k_inv_ty_pw).  Arguments as tcfd_fno_spectral_conv followed by those of
+// tcfd_fno_pointwise (its `x` is the convolution, ci = cout); out is (batch, co_pw, X, Y, t_keep).  Returns TCFD_EINVAL
+// with "not instantiated" in the message -- before anything is launched -- when the combination is not covered; the
+// caller then makes the two calls.
+extern "C" int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* p, const void* v, const void* const* weights,
+                                                const void* const* bias, float delta, void* out, int batch, int cin,
+                                                int cout, int t_keep, float fwd_scale, float inv_scale, int use_mfma,
+                                                void* ws, size_t ws_bytes, const void* skip, const void* w1,
+                                                const void* b1, const void* w2t, const void* b2, const void* wst,
+                                                const void* bs, int cm, int co_pw, int act1, int act2, int skip_mode,
+                                                int skip_T, void* stream) {
+    if (!p || !v || !weights || !out || !w1 || !w2t) return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: null argument");
+    if (batch <= 0 || cin <= 0 || cout <= 0 || t_keep <= 0 || t_keep > p->T_out)
+        return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: bad sizes");
+    if (skip_mode && !skip) return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: skip input missing");
+    if (skip_mode == 2 && skip_T <= 0) return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: bad skip_T");
+    if (((uintptr_t)out | (uintptr_t)skip) % 8 != 0) return FAIL(TCFD_EINVAL, "fno: fused layer tail not instantiated (unaligned)");
+    PwArgs a;
+    a.pe = nullptr; a.x = nullptr; a.s = (const float*)skip; a.out = (float*)out;
+    a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
+    a.wst = (const float*)wst; a.bs = (const float*)bs;
+    a.P = (long)p->X * p->Y * t_keep; a.T = t_keep; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
+    a.w2_bstride = 0; a.b2_bstride = 0; a.cm = cm;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = do_inv_ty_pw(p, nullptr, a, batch, cout, cm, co_pw, t_keep, inv_scale, true, st))) return rc;
+    const size_t need = tcfd_fno_workspace_bytes(p, batch, cin, cout);
+    if (!ws || ws_bytes < need) return FAIL(TCFD_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    const size_t Q = (size_t)2 * p->my * p->mt;
+    const int cmax = std::max(cin, cout);
+    unsigned char* base = (unsigned char*)ws;
+    cf* W = (cf*)base;
+    cf* V = (cf*)(base + al256((size_t)batch * cmax * p->X * Q * sizeof(cf)));
+    cf* O = (cf*)((unsigned char*)V + al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf)));
+    if ((rc = do_fwd_ty(p, (const float*)v, W, (long)batch * cin * p->X, fwd_scale, st))) return rc;
+    if ((rc = do_fwd_x(p, W, V, (long)batch * cin, st))) return rc;
+    ContractArgs c;
+    c.vin = V; c.vout = O;
+    for (int k = 0; k < 4; ++k) {
+        c.w[k] = (const cf*)weights[k];
+        c.bias[k] = bias ? (const cf*)bias[k] : nullptr;
+    }
+    c.delta = delta; c.b = batch; c.ci = cin; c.co = cout; c.mx = p->mx; c.my = p->my; c.mt = p->mt;
+    if ((rc = do_contract(p, c, use_mfma, st))) return rc;
+    if ((rc = do_inv_x(p, O, W, (long)batch * cout, st))) return rc;
+    return do_inv_ty_pw(p, W, a, batch, cout, cm, co_pw, t_keep, inv_scale, false, st);
 }
 
 // Returns TCFD_EINVAL (with a message) for channel combinations that are not instantiated; the caller then

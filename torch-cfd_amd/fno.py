@@ -23,6 +23,7 @@ ordinary torch modules running on the same device.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 import weakref
 from typing import Dict, List, Optional, Tuple, Union
@@ -760,6 +761,85 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     return out
 
 
+def hip_conv_pointwise(conv, v: torch.Tensor, mlp, skip: torch.Tensor, skip_conv=None, act2=None,
+                       skip_last_slice: bool = False, out_steps: Optional[int] = None) -> Optional[torch.Tensor]:
+    """``act2(mlp(conv(v)) + skip_conv(skip))`` (an SFNO layer, fno/sfno.py:607-614) or ``act2(skip[..., -1:] + mlp(conv(v)))``
+    (the lifting tail, :258-259) with the convolution's output kept on chip (``tcfd_fno_spectral_conv_pointwise``:
+    inverse t/y transform and pointwise block in one kernel; bit-identical to ``hip_spectral_conv`` + ``hip_pointwise``).
+    Inference path only; returns ``None`` -- before anything runs -- when the layer is not covered (autograd, fp64,
+    post-processed or resampled convolutions, widths other than 8 / 10, rows that do not fit a workgroup) and the caller
+    makes the two calls.  NOT the default: at config 5 it is slower than the two kernels (7.5 vs 5.9 ms per forward --
+    one row-sized workgroup per CU cannot hide what 4-8 small ones do); ``TCFD_FNO_FUSE_TAIL=1`` switches the models to it."""
+    if not isinstance(mlp, PointwiseFFN) or not isinstance(conv, SpectralConvS) or not v.is_cuda or v.dtype != torch.float32:
+        return None
+    if isinstance(conv, SpectralConvT) and not isinstance(conv.postprocess, nn.Identity):
+        return None
+    lin1, lin2 = mlp.linear1, mlp.linear2
+    c1, c2 = _act_code(mlp.activation), _act_code(act2)
+    if c1 is None or c2 is None or not (_is_pointwise(lin1) and _is_pointwise(lin2)) or (
+            skip_conv is not None and not _is_pointwise(skip_conv)):
+        return None
+    mods = [m for m in (conv, lin1, lin2, skip_conv) if m is not None]
+    if torch.is_grad_enabled() and (v.requires_grad or skip.requires_grad or any(
+            p.requires_grad for m in mods for p in m.parameters())):
+        return None
+    if any(p.dtype not in (torch.float32, torch.complex64) or p.device != v.device for m in mods for p in m.parameters()):
+        return None
+    b, ci, X, Y, T = v.shape
+    mx, my, mt = conv.modes
+    weights, bias = list(conv.weight), conv._bias_list()
+    cw = weights[0].shape[1]                                     # channels of the convolution's output
+    t_pad = T if getattr(conv, "temporal_padding", False) else 0
+    if out_steps is None:
+        out_steps = getattr(conv, "out_steps", None) or T
+    t_out, t_keep = out_steps + t_pad, out_steps
+    cm, co = lin1.out_channels, lin2.out_channels
+    if lin1.in_channels != cw or lin2.in_channels != cm or b == 0 or skip.dtype != torch.float32 or skip.device != v.device:
+        return None
+    mode, sT = 0, 0
+    if skip_conv is not None:
+        if tuple(skip.shape) != (b, cw, X, Y, t_keep) or skip_conv.in_channels != cw or skip_conv.out_channels != co:
+            return None
+        mode = 1
+    elif skip_last_slice:
+        if skip.shape[1] != co or tuple(skip.shape[2:-1]) != (X, Y) or skip.shape[0] != b:
+            return None
+        mode, sT = 2, skip.shape[-1]
+
+    def as_real(w, shape):
+        w = torch.view_as_real(w.detach()) if w.is_complex() else w.detach()
+        w = w.to(torch.float32).contiguous()
+        return w if tuple(w.shape) == shape else None
+
+    ws_ = [as_real(w, (ci, cw, mx, my, mt, 2)) for w in weights]
+    bs_ = [as_real(x, (mx, my, mt, 2)) for x in bias] if bias is not None else None
+    if any(w is None for w in ws_) or (bs_ is not None and any(x is None for x in bs_)):
+        return None
+    mat = lambda c_, tr: (c_.weight.detach().reshape(c_.out_channels, c_.in_channels).t() if tr else
+                          c_.weight.detach().reshape(c_.out_channels, c_.in_channels)).contiguous()
+    vec = lambda c_: c_.bias.detach().contiguous() if (c_ is not None and c_.bias is not None) else None
+    w1, w2t = mat(lin1, False), mat(lin2, True)
+    wst = mat(skip_conv, True) if skip_conv is not None else None
+    b1, b2, bsk = vec(lin1), vec(lin2), vec(skip_conv)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    v = v.detach().contiguous()
+    skip = skip.detach().contiguous()
+    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device)
+    out = torch.empty(b, co, X, Y, t_keep, dtype=torch.float32, device=v.device)
+    ws = plan.workspace(b, ci, cw)
+    fs, is_ = _norm_scales(conv.norm, X * Y * (T + t_pad), X * Y * t_out)
+    with torch.cuda.device(v.device):
+        rc = plan.lib.tcfd_fno_spectral_conv_pointwise(
+            plan.handle, v.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None, float(conv.delta),
+            out.data_ptr(), b, ci, cw, t_keep, fs, is_, 1, ws.data_ptr(), ws.numel(),
+            skip.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst), ptr(bsk), cm, co, c1, c2, mode, sT,
+            ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+    if rc == -1 and b"not instantiated" in plan.lib.tcfd_last_error():
+        return None
+    _lib.check(rc, "tcfd_fno_spectral_conv_pointwise")
+    return out
+
+
 def _lift_table_constants(qf: torch.Tensor):
     qd = qf.reshape(qf.shape[0] if qf.dim() == 2 else qf.shape[-4], -1).double()
     return qd.sum(dim=0).float().contiguous(), qd.sum(), (qd * qd).sum()
@@ -1108,6 +1188,10 @@ class LiftingOperator(nn.Module):
             v = hip_pointwise(vp, None, None, self.proj, norm=self.norm)  # LayerNormnd folded into the projection
             if v is None:
                 v = self.proj(self.norm(vp))
+        if os.environ.get("TCFD_FNO_FUSE_TAIL", "0") == "1":   # opt-in: measured slower (see hip_conv_pointwise)
+            out = hip_conv_pointwise(self.sconv, v, self.mlp, v, act2=self.activation, skip_last_slice=True)
+            if out is not None:
+                return out
         x1 = self.sconv(v)
         if isinstance(self.mlp, PointwiseFFN):
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=v,
@@ -1207,7 +1291,12 @@ class SFNO(FNOBase):
             out_steps = self.out_steps if self.out_steps is not None else v.size(-1)
         v_res = v
         v = self.lifting_operator(v.unsqueeze(1))
+        fuse = os.environ.get("TCFD_FNO_FUSE_TAIL", "0") == "1"   # opt-in: measured slower (see hip_conv_pointwise)
         for conv, mlp, w, act in zip(self.spectral_conv, self.mlp, self.w, self.activations):
+            fused = hip_conv_pointwise(conv, v, mlp, v, skip_conv=w, act2=act) if fuse else None
+            if fused is not None:
+                v = fused
+                continue
             x1 = conv(v)
             fused = hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
             v = fused if fused is not None else act(mlp(x1) + w(v))
