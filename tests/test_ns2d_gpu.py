@@ -906,3 +906,36 @@ def test_odd_factor_grid_initial_condition_and_gradients(dev):
     wc = w0.clone().requires_grad_(True)
     O.advance(wc, 1e-3, t)[0].abs().pow(2).sum().backward()
     assert rel_l2(wg.grad, wc.grad) < 1e-9
+
+
+@pytest.mark.parametrize("n,tag,split", [(64, "f32", "0"), (128, "f64", "1"), (256, "f32", "0"), (512, "f64", "0"), (1024, "f64", "1")])
+def test_packed_nyquist_column_agrees_with_the_lone_tile(n, tag, split, dev, monkeypatch):
+    """Pruned plans (2/3-rule mask) carry column n/2 of the planes in the imaginary part of column 0 instead of
+    spending a whole column tile on it (TCFD_NYQ_PACK: 0 off, 2 every pass, 3 the opening pass only; 1 = per-size
+    default).  The STATE's Nyquist column goes through the same arithmetic either way (exactly equal); everything
+    else agrees to round-off (the transforms see Hermitian-averaged inputs).  Non-Hermitian input columns included:
+    the test field gets random imaginary parts in its DC / Nyquist columns, which c2r semantics must drop."""
+    from oracle import ns2d as O
+
+    real = REAL[tag]
+    torch.manual_seed(n)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 20 + s, real)) for s in range(3)])
+    w0[:, :, 0] += 1j * 0.1 * torch.randn(3, n, dtype=real) * w0[:, :, 0].abs().mean()
+    w0[:, :, -1] += (0.05 + 0.1j) * torch.randn(3, n, dtype=real) * w0[:, :, 1].abs().mean()
+    w0 = w0.to(dev)
+    monkeypatch.setenv("TCFD_SPLIT", split)
+    res = {}
+    for flag in ("0", "2", "3"):
+        monkeypatch.setenv("TCFD_NYQ_PACK", flag)
+        _, op = build_op(n, tag, "kolmogorov", dev)
+        assert op._plan(w0).info()["keep_cols"] > 0          # pruned: the mode applies
+        res[flag] = op(w0, 1e-3, steps=3) + (op(w0, 1e-3)[0],)
+    tols = (1e-13, 1e-11, 1e-13) if tag == "f64" else (5e-7, 2e-5, 5e-7)
+    for flag in ("2", "3"):
+        for a, b, tol in zip(res["0"], res[flag], tols):
+            assert rel_l2(a, b) < tol
+    # one step: the Nyquist column of the new state only saw element-wise arithmetic
+    assert torch.equal(res["0"][2][:, :, -1], res["2"][2][:, :, -1])
+    # and against the CPU oracle (which follows torch's c2r semantics for the non-Hermitian columns)
+    ref, _ = O.advance(w0.cpu(), 1e-3, oracle_tables(n, tag, "kolmogorov"), steps=3)
+    assert rel_l2(res["2"][0], ref) < (1e-11 if tag == "f64" else 2e-5)

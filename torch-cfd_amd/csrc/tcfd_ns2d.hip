@@ -134,6 +134,7 @@ struct ColArgs {
     int store_h;   // 0 at the last stage of a step: the accumulator is dead (the next step starts from h = 0)
     int ablate;    // timing ablations (TCFD_ABLATE bit mask; results are WRONG when non-zero): 1 skip the
                    // transforms, 2 skip the plane stores, 4 skip the table reads, 8 skip the h traffic
+    int nyq;       // 1: packed Nyquist column (see emit_planes): no lone tile for column m - 1, the lanes of column 0 own it too
     int nt_planes; // plane stores with the non-temporal hint (small cache-resident problems, see launch_cols)
     int pair_xcd;  // block->tile map: 0 = batch fastest; LG = 2 / 4: the LG tiles that share a 128-byte line on one XCD
 };
@@ -172,16 +173,45 @@ __device__ __forceinline__ void col_fft(cx<T> (&x)[EPT], cx<T>* lds, const cx<T>
     }
 }
 
+// f=0: u^ = 2 pi i ky psi   f=1: v^ = -2 pi i kx psi   f=2: dx w^ = 2 pi i kx w   f=3: dy w^ = 2 pi i ky w,
+// psi = -w / lap with lap(0,0) patched to 1 (`origin`); `us` = w^ / n^2
+template <typename T>
+__device__ __forceinline__ cx<T> plane_value(int f, cx<T> us, T kx, T ky, bool origin) {
+    constexpr T TWO_PI = (T)6.283185307179586476925286766559;
+    constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
+    if (f < 2) {
+        T lap = M4PI2 * (kx * kx + ky * ky);
+        if (origin) lap = (T)1;
+        us = cscale(us, -fast_rcp(lap));
+    }
+    const T kk = (f == 0 || f == 3) ? ky : kx;
+    cx<T> v = mul_i(cscale(us, TWO_PI * kk));
+    if (f == 1) v = mk<T>(-v.x, -v.y);
+    return v;
+}
+
+// PACKED NYQUIST COLUMN (a.nyq).  m = n/2 + 1 columns are n/2 / C full tiles plus ONE lone column, whose tile costs a
+// whole workgroup: with 4 fields of 1024^2 per chunk that makes 520 workgroups for the 512 resident slots, and the
+// 8 late ones stretch every launch by most of a workgroup's run time (measured: MODE_A 54 -> 39 us without them).
+// The row pass consumes only the REAL parts of columns 0 and m - 1 of a plane (c2r semantics: Im of the DC and
+// Nyquist coefficients of a row is dropped).  Re(IFFT(A)) = IFFT(herm A), herm A[k] = (A[k] + conj A[-k]) / 2, so
+// both columns ride through ONE transform,
+//     Z = herm(A_0) + i herm(A_nyq)   ->   IFFT(Z) = Re(IFFT A_0) + i Re(IFFT A_nyq),
+// stored in column 0: the row pass takes its Nyquist element from the imaginary part of element 0.  (With the split
+// plans the same holds per parity: the E / O half transforms and the row pass's butterfly are complex-linear.)
+// Tile 0 builds Z through the exchange buffer (free between two transforms), one row per thread of the workgroup.
+// The Nyquist column's own values wait in LDS (`un`: the rt_lin / rt_mask tables are dead by then and exactly that
+// big): registers held across the four transforms would spill the fp64 kernels.
 template <typename T, int N, int EPT, int C, int SP, int XL>
 __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u)[EPT], cx<T>* lds, const T* rt_kx,
                                             size_t wbase, int j, int c, int jc, bool valid, int q,
-                                            const ColTw<T, (N >> SP), EPT, XL>& ctw) {
+                                            const ColTw<T, (N >> SP), EPT, XL>& ctw, bool nyq_tile, const cx<T>* un) {
     constexpr int NT = N >> SP;
     constexpr int G = NT / EPT;
-    constexpr T TWO_PI = (T)6.283185307179586476925286766559;
-    constexpr T M4PI2 = (T)(-39.478417604357434475337963999505);
     const T inv_n2 = (T)1 / ((T)N * (T)N);
     const T ky = valid ? a.ky[jc] : (T)0;
+    const bool nyq_lane = nyq_tile && c == 0;
+    const T ky_n = nyq_tile ? a.ky[a.m - 1] : (T)0;
 #pragma unroll 1
     for (int f = 0; f < 4; ++f) {
         cx<T> x[EPT];
@@ -189,19 +219,33 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
         for (int t = 0; t < EPT; ++t) {
             const int sl = j + t * G;
             const int i = SP ? 2 * sl + q : sl;
-            const T kx = rt_kx[sl];
-            cx<T> us = cscale(u[t], inv_n2);
-            if (f < 2) {  // stream function: psi = -w / lap, lap(0,0) patched to 1
-                T lap = M4PI2 * (kx * kx + ky * ky);
-                if (i == 0 && jc == 0) lap = (T)1;
-                us = cscale(us, -fast_rcp(lap));
-            }
-            // f=0: u^ = 2 pi i ky psi   f=1: v^ = -2 pi i kx psi
-            // f=2: dx w^ = 2 pi i kx w  f=3: dy w^ = 2 pi i ky w
-            const T kk = (f == 0 || f == 3) ? ky : kx;
-            cx<T> v = mul_i(cscale(us, TWO_PI * kk));
-            if (f == 1) v = mk<T>(-v.x, -v.y);
+            const cx<T> v = plane_value<T>(f, cscale(u[t], inv_n2), rt_kx[sl], ky, i == 0 && jc == 0);
             x[t] = valid ? v : mk<T>((T)0, (T)0);
+        }
+        if (nyq_tile) {   // block-uniform.  Three short phases with the WHOLE workgroup (a row per thread), so that
+            cx<T>* S0 = lds;           // tile 0 does not become the launch's long pole
+            cx<T>* SZ = lds + NT;
+            if (nyq_lane) {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) S0[j + t * G] = x[t];
+            }
+            __syncthreads();
+            for (int sl = threadIdx.x; sl < NT; sl += C * G) {
+                // row -i of the column: local index of the same parity
+                const int ms = (SP && q) ? NT - 1 - sl : (NT - sl) & (NT - 1);
+                const cx<T> v0 = S0[sl], m0 = S0[ms];
+                const cx<T> vn = plane_value<T>(f, cscale(un[sl], inv_n2), rt_kx[sl], ky_n, false);
+                const cx<T> mn = plane_value<T>(f, cscale(un[ms], inv_n2), rt_kx[ms], ky_n, false);
+                const cx<T> h0 = mk<T>((T)0.5 * (v0.x + m0.x), (T)0.5 * (v0.y - m0.y));
+                const cx<T> hn = mk<T>((T)0.5 * (vn.x + mn.x), (T)0.5 * (vn.y - mn.y));
+                SZ[sl] = mk<T>(h0.x - hn.y, h0.y + hn.x);   // h0 + i hn
+            }
+            __syncthreads();
+            if (nyq_lane) {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) x[t] = SZ[j + t * G];
+            }
+            __syncthreads();
         }
         const int jrow = XL ? xl_col_row(j) : j;   // physical row (mod G) of this thread's outputs
         if (!(a.ablate & 1)) col_fft<T, NT, EPT, +1, C, XL, XL>(x, lds, a.tw, ctw, j, c);
@@ -291,6 +335,8 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
     }
     const int jc = tile * C + c;
     const bool valid = jc < a.m;
+    const bool nyq_tile = a.nyq && tile == 0;   // block-uniform: the lanes c == 0 of this workgroup also own column m - 1
+    const bool nyq_lane = nyq_tile && c == 0;
     const size_t colbase = (size_t)b * N * a.m + jc;   // element (b, 0, jc) of a caller-layout array
     const size_t wbase = (size_t)b * N * a.ldw + jc;   // same element of a workspace array
 
@@ -300,6 +346,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
     T* rt_kx = reinterpret_cast<T*>(lds + lds_elems<NT, EPT, C, false>());
     T* rt_lin = rt_kx + NT;
     T* rt_mask = rt_lin + NT;
+    cx<T>* un_lds = reinterpret_cast<cx<T>*>(rt_lin);   // [NT]: Nyquist-column state (a.nyq), overlays rt_lin + rt_mask
     constexpr bool NEEDS_TABLES = (MODE != MODE_FWD && MODE != MODE_INV);
     T col_ky = 0, col_lin = 0, col_mask = 1;
     int f_lo = 0, f_hi = 0;
@@ -337,7 +384,11 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
         }
         stage_tables();
         __syncthreads();  // row tables visible
-        emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q, ctw);
+        if (nyq_tile) {   // rt_lin / rt_mask are not used in this mode; visible after the first barrier of emit_planes
+            const cx<T>* uin = a.u_in + (size_t)b * N * a.u_in_ld + (a.m - 1);
+            for (int sl = threadIdx.x; sl < NT; sl += C * G) un_lds[sl] = uin[(size_t)TCFD_IROW(sl) * a.u_in_ld];
+        }
+        emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q, ctw, nyq_tile, un_lds);
         return;
     } else {
         constexpr bool GENERIC = (MODE == MODE_FWD || MODE == MODE_INV);
@@ -398,6 +449,22 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
             }
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
+            // packed Nyquist column (tile 0, a row per thread): its reads go out first, in the shadow of the tile's own
+            constexpr int NYQ_PER = (NT + C * G - 1) / (C * G);
+            [[maybe_unused]] cx<T> nyq_u[NYQ_PER], nyq_w0[NYQ_PER];
+            if (nyq_tile) {
+#pragma unroll
+                for (int r = 0; r < NYQ_PER; ++r) {
+                    const int sl = threadIdx.x + r * C * G;
+                    if (sl < NT) {
+                        const int i = TCFD_IROW(sl);
+                        nyq_u[r] = a.u_in[(size_t)b * N * a.u_in_ld + (a.m - 1) + (size_t)i * a.u_in_ld];
+                        if constexpr (MODE == MODE_C) {
+                            if (a.dwdt) nyq_w0[r] = a.w0[(size_t)b * N * a.m + (a.m - 1) + (size_t)i * a.m];
+                        }
+                    }
+                }
+            }
             if (valid) {
                 // Every global read of the update is issued before the first value is used: the reads of one thread
                 // are independent, but `h` and the state are updated in place through pointers that may alias, so
@@ -453,7 +520,42 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     }
                 }
             }
-            if constexpr (MODE == MODE_CA) emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q, ctw);
+            if (nyq_tile) {   // block-uniform
+                // column m - 1, a row per thread: F = 0 there (the plan is pruned: keep_cols <= m - 1), so h stays 0 and
+                // the stage is  u <- (u + mu L u) / (1 - mud L)
+                const int jn = a.m - 1;
+                const T lcn = a.sep ? a.lin_c[jn] : (T)0;
+                constexpr int PER = NYQ_PER;
+                cx<T> unew[PER];
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+                    const int sl = threadIdx.x + r * C * G;
+                    if (sl < NT) {
+                        const int i = TCFD_IROW(sl);
+                        const cx<T> uo = nyq_u[r];
+                        const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[sl] + lcn : a.lin[(size_t)i * a.m + jn]);
+                        const cx<T> rhs = uo + cscale(cscale(uo, L), a.mu);
+                        unew[r] = cscale(rhs, fast_rcp((T)1 - a.mud * L));
+                        a.u_out[(size_t)b * N * a.u_out_ld + jn + (size_t)i * a.u_out_ld] = unew[r];
+                        if constexpr (MODE == MODE_C) {
+                            if (a.dwdt) {
+                                const size_t gi = (size_t)b * N * a.m + jn + (size_t)i * a.m;
+                                a.dwdt[gi] = cscale(unew[r] - nyq_w0[r], a.dwdt_scale);
+                            }
+                        }
+                    }
+                }
+                if constexpr (MODE == MODE_CA) {
+                    __syncthreads();   // every lane is done with rt_lin / rt_mask: the Nyquist column moves in
+#pragma unroll
+                    for (int r = 0; r < PER; ++r) {
+                        const int sl = threadIdx.x + r * C * G;
+                        if (sl < NT) un_lds[sl] = unew[r];
+                    }
+                }
+            }
+            if constexpr (MODE == MODE_CA)
+                emit_planes<T, N, EPT, C, SP, XL>(a, x, lds, rt_kx, wbase, j, c, jc, valid, q, ctw, nyq_tile, un_lds);
         }
     }
 #undef TCFD_IROW
@@ -539,7 +641,9 @@ struct RawPair {
     cx<T> an, bn;  // element N/2 of both rows (only lane 0 of the group uses it)
 };
 
-template <typename T, int N, int EPT>
+// nyq (packed Nyquist column, see emit_planes): column N/2 of the planes is not there; the Nyquist element of a row
+// is the imaginary part of its element 0 and comes out of pack_herm
+template <typename T, int N, int EPT, int NYQ = 0>
 __device__ __forceinline__ void load_raw(RawPair<T, EPT>& r, const cx<T>* __restrict__ rowA,
                                          const cx<T>* __restrict__ rowB, int j) {
     constexpr int G = N / EPT;
@@ -548,14 +652,16 @@ __device__ __forceinline__ void load_raw(RawPair<T, EPT>& r, const cx<T>* __rest
         r.a[t] = rowA[j + t * G];
         r.b[t] = rowB[j + t * G];
     }
-    r.an = rowA[N / 2];
-    r.bn = rowB[N / 2];
+    if constexpr (!NYQ) {
+        r.an = rowA[N / 2];
+        r.bn = rowB[N / 2];
+    }
 }
 
 // Z[e] = A~[e] + i B~[e] (Hermitian completions, Im of DC / Nyquist dropped) in the j + t*G
 // distribution.  The upper half is the mirror image of data owned by OTHER lanes: it goes through
 // the group's LDS buffer (half an exchange) instead of being loaded from HBM a second time.
-template <typename T, int N, int EPT, bool WG>
+template <typename T, int N, int EPT, bool WG, int NYQ = 0>
 __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>& r, cx<T>* lds, int j) {
     constexpr int G = N / EPT;
     // G % EPT^2 == 0: the swizzle term of lds_addr is the same for every t, so the mirrored slots N - j - t G and
@@ -574,7 +680,8 @@ __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>
             else lds[lds_addr<EPT, 1, true>(N - k, 0)] = m;
         }
     }
-    if (j == 0) lds[lds_addr<EPT, 1, true>(N / 2, 0)] = mk<T>(r.an.x, r.bn.x);
+    if (j == 0)   // lane 0 holds element 0 in a[0] / b[0]
+        lds[lds_addr<EPT, 1, true>(N / 2, 0)] = NYQ ? mk<T>(r.a[0].y, r.b[0].y) : mk<T>(r.an.x, r.bn.x);
     group_sync<WG>();
     const cx<T>* src = lds + lds_addr<EPT, 1, true>(j, 0);
 #pragma unroll
@@ -794,7 +901,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
 // the next plane's half rows in flight -- half the live state, same loads / stores / transform count.
 // SP = 0: rows (2p, 2p+1).  SP = 1 (split column plans): rows (r, r + N/2), built from the E / O half-length column
 // transforms as  a = E + w O,  b = E - w O,  w = exp(+2 pi i r / N), and stored folded (S, D) as in k_rows_advect4.
-template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1>
+template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int NYQ = 0>
 __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_rows_advect5(
     const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
     long npairs, int ld, int kc) {
@@ -820,7 +927,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
     RawPair<T, EPT> H;
     if constexpr (PF) {
         const size_t off = row_a(pair < npairs ? pair : npairs - 1);
-        load_raw<T, N, EPT>(H, planes + off, planes + off + second, j);
+        load_raw<T, N, EPT, NYQ>(H, planes + off, planes + off + second, j);
     }
     for (long it = 0; it < iters; ++it, pair += stride) {
         const bool valid = pair < npairs;
@@ -835,7 +942,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
         cx<T> za[EPT], x[EPT], p[EPT];
         // H -> Hermitian-packed sequence -> transform; the next plane's loads are issued in between
         auto field = [&](cx<T>(&out)[EPT], const cx<T>* thisA, const cx<T>* nextA) {
-            if constexpr (!PF) load_raw<T, N, EPT>(H, thisA, thisA + second, j);
+            if constexpr (!PF) load_raw<T, N, EPT, NYQ>(H, thisA, thisA + second, j);
             if constexpr (SP) {
 #pragma unroll
                 for (int t = 0; t < EPT / 2; ++t) {
@@ -843,12 +950,14 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
                     H.b[t] = H.a[t] - o;
                     H.a[t] = H.a[t] + o;
                 }
-                const cx<T> o = cmul(H.bn, wi);
-                H.bn = H.an - o;
-                H.an = H.an + o;
+                if constexpr (!NYQ) {
+                    const cx<T> o = cmul(H.bn, wi);
+                    H.bn = H.an - o;
+                    H.an = H.an + o;
+                }
             }
-            pack_herm<T, N, EPT, WG>(out, H, lds, j);
-            if constexpr (PF) load_raw<T, N, EPT>(H, nextA, nextA + second, j);
+            pack_herm<T, N, EPT, WG, NYQ>(out, H, lds, j);
+            if constexpr (PF) load_raw<T, N, EPT, NYQ>(H, nextA, nextA + second, j);
             tile_fft<T, N, EPT, +1, 1, true, WG>(out, lds, tw, j, 0);
         };
         const cx<T>* P0 = planes + off;
@@ -905,7 +1014,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
 // The four inverse transforms leave the physical rows in the fixed permutation `pi`; the point-wise product does
 // not care, and the forward transform of the product starts from `pi` and ends in natural order.
 // LDS stores per row pair: 18 -> 8 exchange-equivalents of 16 KB; workgroup barriers per pair: ~40 -> ~20.
-template <typename T, int THR, int SP, int MINW, int PF>
+template <typename T, int THR, int SP, int MINW, int PF, int NYQ = 0>
 __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
     const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
     long npairs, int ld, int kc) {
@@ -927,7 +1036,7 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
     RawPair<T, EPT> H;
     if constexpr (PF) {
         const size_t off = row_a(pair < npairs ? pair : npairs - 1);
-        load_raw<T, N, EPT>(H, planes + off, planes + off + second, j);
+        load_raw<T, N, EPT, NYQ>(H, planes + off, planes + off + second, j);
     }
     for (long it = 0; it < iters; ++it, pair += stride) {
         const bool valid = pair < npairs;
@@ -941,7 +1050,7 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
         }
         cx<T> za[EPT], x[EPT], p[EPT];
         auto field = [&](cx<T>(&out)[EPT], const cx<T>* thisA, const cx<T>* nextA) {
-            if constexpr (!PF) load_raw<T, N, EPT>(H, thisA, thisA + second, j);
+            if constexpr (!PF) load_raw<T, N, EPT, NYQ>(H, thisA, thisA + second, j);
             if constexpr (SP) {
 #pragma unroll
                 for (int t = 0; t < EPT / 2; ++t) {
@@ -949,12 +1058,14 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
                     H.b[t] = H.a[t] - o;
                     H.a[t] = H.a[t] + o;
                 }
-                const cx<T> o = cmul(H.bn, wi);
-                H.bn = H.an - o;
-                H.an = H.an + o;
+                if constexpr (!NYQ) {
+                    const cx<T> o = cmul(H.bn, wi);
+                    H.bn = H.an - o;
+                    H.an = H.an + o;
+                }
             }
-            pack_herm<T, N, EPT, WG>(out, H, lds, j);
-            if constexpr (PF) load_raw<T, N, EPT>(H, nextA, nextA + second, j);
+            pack_herm<T, N, EPT, WG, NYQ>(out, H, lds, j);
+            if constexpr (PF) load_raw<T, N, EPT, NYQ>(H, nextA, nextA + second, j);
             xl_fft1024<T, +1, 1>(out, lds, xtw, j, nohook);
         };
         const cx<T>* P0 = planes + off;
@@ -1299,6 +1410,7 @@ struct Tuning {
     int rows_v;              // TCFD_ROWS_V: 0 = per size; 6 = LDS-DMA staged rows, 5 = register-staged rows (one plane per
                              // transform), 4 = two planes per transform (round 1)
     int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
+    int nyq_pack;            // TCFD_NYQ_PACK: packed Nyquist column in the step (1 = default where the plan allows it)
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
 };
 
@@ -1323,6 +1435,9 @@ struct tcfd_ns2d_plan {
     int f_nnz;
     int sep;        // mask and linear term are separable
     int f_sparse;   // forcing stored as CSC
+    int nyq_a, nyq_ca;   // ... in the opening pass / in the fused passes of a step (set with nyq at plan creation)
+    int nyq;        // packed Nyquist column in the step kernels (emit_planes): the plan is pruned (F = h = 0 in column
+                    // m - 1), n >= 64 (every column tile width divides n / 2) and the row kernels are v5 / v7
     int keep_cols;  // > 0: F (hence the RK accumulator h) is identically zero for columns >= keep_cols and for
                     // rows with mask_r == 0 (2/3-rule mask, forcing inside the mask): those entries of the
                     // advection / h arrays are neither written nor read.  0: no pruning.
@@ -1484,6 +1599,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->tune.rows_v = env_int("TCFD_ROWS_V", 0);
     p->tune.chunk = env_int("TCFD_CHUNK", -1);
     p->tune.cols_xl = env_int("TCFD_COLS_XL", 1);
+    p->tune.nyq_pack = env_int("TCFD_NYQ_PACK", 1);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
         p->ldw = (p->m + per_line - 1) / per_line * per_line;
@@ -1494,6 +1610,12 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
         tcfd_ns2d_plan_destroy(p);
         return rc;
     }
+    p->nyq = (p->tune.nyq_pack && n >= 64 && p->keep_cols > 0 && p->keep_cols <= p->m - 1 &&
+              (p->tune.rows_v == 0 || p->tune.rows_v == 5 || p->tune.rows_v == 7)) ? 1 : 0;
+    // per pass: the opening pass of a call (MODE_A) always gains; the fused passes (MODE_CA / MODE_C) only where tile 0's
+    // extra work does not make it the launch's long pole -- TCFD_NYQ_PACK: 1 auto, 2 every pass, 3 the opening pass only
+    p->nyq_a = p->nyq;
+    p->nyq_ca = p->nyq && (p->tune.nyq_pack == 2 || (p->tune.nyq_pack == 1 && n != 1024));
     *out = p;
     return 0;
 }
@@ -1578,6 +1700,7 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.m = p->m;
     a.ldw = p->ldw;
     a.ntiles = (p->m + C - 1) / C;
+    if (a.nyq) a.ntiles = (p->m - 1) / C;   // packed Nyquist column: no lone tile (the caller checked the plan allows it)
     a.batch = (int)batch;
     a.kx = (const T*)p->kx;
     a.ky = (const T*)p->ky;
@@ -1715,11 +1838,14 @@ static int launch_rows_advect4(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
-template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1>
+template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int NYQ = 0>
 static int launch_rows_advect5(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
-                               long batch, hipStream_t st) {
+                               long batch, hipStream_t st, int nyq = 0) {
+    if constexpr (!NYQ) {
+        if (nyq) return launch_rows_advect5<T, N, EPT, THR, SP, MINW, PF, 1>(p, planes, plane_stride, adv, batch, st, 0);
+    }
     using Gm = RowGeom<T, N, EPT, THR>;
-    auto kern = k_rows_advect5<T, N, EPT, THR, SP, MINW, PF>;
+    auto kern = k_rows_advect5<T, N, EPT, THR, SP, MINW, PF, NYQ>;
     static DevOnce lds_once;
     if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
     const long npairs = batch * (N / 2);
@@ -1734,10 +1860,13 @@ static int launch_rows_advect5(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
-template <typename T, int SP, int MINW, int PF>
+template <typename T, int SP, int MINW, int PF, int NYQ = 0>
 static int launch_rows_advect7(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
-                               long batch, hipStream_t st) {
-    auto kern = k_rows_advect7<T, 128, SP, MINW, PF>;
+                               long batch, hipStream_t st, int nyq = 0) {
+    if constexpr (!NYQ) {
+        if (nyq) return launch_rows_advect7<T, SP, MINW, PF, 1>(p, planes, plane_stride, adv, batch, st, 0);
+    }
+    auto kern = k_rows_advect7<T, 128, SP, MINW, PF, NYQ>;
     constexpr size_t lds = (size_t)(1024 + 1) * sizeof(cx<T>);   // + 1: the unpack reads slot N for lane 0 (value unused)
     const long npairs = batch * 512;
     const long blocks = rows_grid(p, npairs, 2 * MINW);   // two-wave workgroups: 2 per SIMD pair and wave slot
@@ -1780,7 +1909,7 @@ static constexpr int rows_default_version() {
 
 template <typename T, int N>
 static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
-                              hipStream_t st) {
+                              hipStream_t st, int nyq = 0) {
     constexpr int EPT = Cfg<T, N>::ROW_EPT, THR = Cfg<T, N>::ROW_THREADS;
     const bool split = use_split<T, N>(p);
     if (p->tune.rows_v == 4) {   // round-1 kernels (two planes per transform), kept for A/B measurements
@@ -1790,7 +1919,7 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
     if constexpr (N == 128 || N == 256) {
         const int force = p->tune.small_tiles;
         if (!split && (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256)))
-            return launch_rows_advect5<T, N, 8, 64, 0, 1>(p, planes, plane_stride, adv, batch, st);
+            return launch_rows_advect5<T, N, 8, 64, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
     if constexpr (RowGeom6<T, N, EPT, THR>::OK) {
         if (p->tune.rows_v == 6) {   // LDS-DMA staged rows: opt-in (measured slower)
@@ -1802,16 +1931,16 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
     }
     if constexpr (N == 1024 && sizeof(T) == 8) {
         if (p->tune.rows_v == 7 || p->tune.rows_v == 0) {   // cross-lane transforms: the default here
-            if (split) return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st);
-            return launch_rows_advect7<T, 0, 2, 1>(p, planes, plane_stride, adv, batch, st);
+            if (split) return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st, nyq);
+            return launch_rows_advect7<T, 0, 2, 1>(p, planes, plane_stride, adv, batch, st, nyq);
         }
         // v5 at this size: two waves per SIMD, rows loaded right before use (236 VGPRs, no spills)
-        if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st);
+        if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 2, 0>(p, planes, plane_stride, adv, batch, st, nyq);
     }
     if constexpr (N >= 16) {
-        if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st);
+        if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
-    return launch_rows_advect5<T, N, EPT, THR, 0, 1>(p, planes, plane_stride, adv, batch, st);
+    return launch_rows_advect5<T, N, EPT, THR, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
 }
 
 template <typename T>
@@ -1881,6 +2010,7 @@ static int step_overlap_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_
         h.dwdt = dwdt ? (cx<T>*)dwdt + oc : nullptr;
         h.planes = W.planes + ow; h.adv = W.adv + ow; h.upad = W.upad + ow; h.upad2 = W.upad2 + ow;
         h.a = ColArgs<T>{};
+        h.a.nyq = p->nyq_a;
         h.a.planes = h.planes; h.a.plane_stride = W.plane_stride; h.a.h = W.h + ow; h.a.in = h.adv;
         h.a.u_in = h.w_in; h.a.u_in_ld = p->m;
         h.u_src = h.w_in; h.u_src_ld = p->m;
@@ -1890,7 +2020,9 @@ static int step_overlap_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipStreamWaitEvent(H[i].q, g->ev_in, 0));
         if ((rc = launch_cols<T, N, MODE_A>(p, H[i].a, H[i].batch, H[i].q))) return rc;
+        H[i].a.nyq = p->nyq_ca;
     }
+    int planes_packed = p->nyq_a;
     auto cols = [&](Half& h, int k, bool last, const cx<T>* u0, int u0_ld) -> int {
         bool u0_needed_later = false;
         for (int k2 = k + 1; k2 < nstages; ++k2) u0_needed_later |= (base0 && base0[k2]);
@@ -1919,10 +2051,11 @@ static int step_overlap_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_
         const int u0_ld[2] = {H[0].u_src_ld, H[1].u_src_ld};
         for (int k = 0; k < nstages; ++k) {
             const bool last = (s == steps - 1) && (k == nstages - 1);
-            if ((rc = launch_rows_advect<T, N>(p, H[0].planes, W.plane_stride, H[0].adv, H[0].batch, H[0].q))) return rc;
+            if ((rc = launch_rows_advect<T, N>(p, H[0].planes, W.plane_stride, H[0].adv, H[0].batch, H[0].q, planes_packed))) return rc;
             HIP_TRY(hipEventRecord(g->ev_rows, H[0].q));
             HIP_TRY(hipStreamWaitEvent(H[1].q, g->ev_rows, 0));   // B stays one row pass behind A
-            if ((rc = launch_rows_advect<T, N>(p, H[1].planes, W.plane_stride, H[1].adv, H[1].batch, H[1].q))) return rc;
+            if ((rc = launch_rows_advect<T, N>(p, H[1].planes, W.plane_stride, H[1].adv, H[1].batch, H[1].q, planes_packed))) return rc;
+            planes_packed = p->nyq_ca;
             if ((rc = cols(H[0], k, last, u0[0], u0_ld[0]))) return rc;
             if ((rc = cols(H[1], k, last, u0[1], u0_ld[1]))) return rc;
         }
@@ -1955,7 +2088,10 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     a.in = W.adv;
     a.u_in = (const cx<T>*)w_in;
     a.u_in_ld = p->m;
+    a.nyq = p->nyq_a;
     if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
+    int planes_packed = p->nyq_a;   // how the planes in the workspace were written: the row pass reads them that way
+    a.nyq = p->nyq_ca;
     // the caller's (n, m) rows are not 128-byte aligned (m is odd): only the first read and the last
     // write of a call touch that layout, every stage in between uses the aligned copy `upad`
     const cx<T>* u_src = (const cx<T>*)w_in;
@@ -1969,7 +2105,8 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
         const int u0_ld = u_src_ld;
         for (int k = 0; k < nstages; ++k) {
             int r;
-            if ((r = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, q))) return r;
+            if ((r = launch_rows_advect<T, N>(p, W.planes, W.plane_stride, W.adv, batch, q, planes_packed))) return r;
+            planes_packed = p->nyq_ca;
             const bool last = final && (k == nstages - 1);
             bool u0_needed_later = false;
             for (int k2 = k + 1; k2 < nstages; ++k2) u0_needed_later |= (base0 && base0[k2]);
