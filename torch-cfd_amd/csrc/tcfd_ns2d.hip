@@ -222,7 +222,7 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             const cx<T> v = plane_value<T>(f, cscale(u[t], inv_n2), rt_kx[sl], ky, i == 0 && jc == 0);
             x[t] = valid ? v : mk<T>((T)0, (T)0);
         }
-        if (nyq_tile) {   // block-uniform.  Three short phases with the WHOLE workgroup (a row per thread), so that
+        if (nyq_tile && !(a.ablate & 64)) {   // block-uniform.  Three short phases with the WHOLE workgroup (a row per thread), so that
             cx<T>* S0 = lds;           // tile 0 does not become the launch's long pole
             cx<T>* SZ = lds + NT;
             if (nyq_lane) {
@@ -302,7 +302,9 @@ __device__ __forceinline__ void apply_mask_forcing(const ColArgs<T>& a, cx<T> (&
 #undef TCFD_IROW
 }
 
-template <typename T, int N, int EPT, int C, int MODE, int MINW, int SP = 0, int XL = 0>
+// NYQ = 1: the variant that can run with a.nyq (packed Nyquist column); kept apart because the extra code costs the
+// register-capped fp64 kernels a few spilled registers in EVERY workgroup, packed or not
+template <typename T, int N, int EPT, int C, int MODE, int MINW, int SP = 0, int XL = 0, int NYQ = 0>
 __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
     }
     const int jc = tile * C + c;
     const bool valid = jc < a.m;
-    const bool nyq_tile = a.nyq && tile == 0;   // block-uniform: the lanes c == 0 of this workgroup also own column m - 1
+    const bool nyq_tile = NYQ && a.nyq && tile == 0;   // block-uniform: the lanes c == 0 of this workgroup also own column m - 1
     const bool nyq_lane = nyq_tile && c == 0;
     const size_t colbase = (size_t)b * N * a.m + jc;   // element (b, 0, jc) of a caller-layout array
     const size_t wbase = (size_t)b * N * a.ldw + jc;   // same element of a workspace array
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                     }
                 }
             }
-            if (nyq_tile) {   // block-uniform
+            if (nyq_tile && !(a.ablate & 128)) {   // block-uniform
                 // column m - 1, a row per thread: F = 0 there (the plan is pruned: keep_cols <= m - 1), so h stays 0 and
                 // the stage is  u <- (u + mu L u) / (1 - mud L)
                 const int jn = a.m - 1;
@@ -1719,39 +1721,41 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.sep = p->sep;
     a.keep_cols = p->keep_cols;
     a.tw = (const cx<T>*)(SP ? p->tw2 : p->tw);
+    a.pair_xcd = line_group<T, C>(p);
+    a.ablate = p->tune.ablate;
+    long blocks = batch * a.ntiles;
+    if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
+    const dim3 grid((unsigned)blocks, SP ? 2u : 1u), block(C * G);
+    const int kind = MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5;
+    auto launch = [&](auto kern, DevOnce& once) -> int {
+        if (int rc_ = set_lds(once, kern, lds)) return rc_;
+        ProfScope prof(p, kind, st);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    constexpr bool NYQ_MODE = (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C);
     // 512-point tiles of 8 columns (1024^2 split plans and 512^2, fp64): cross-lane transforms unless TCFD_COLS_XL=0
     constexpr bool XL_OK = (NT == 512 && EPT == 8 && C == 8 && MODE != MODE_FWD && MODE != MODE_INV);
     if constexpr (XL_OK) {
         if (p->tune.cols_xl) {
-            auto kx = k_cols<T, N, EPT, C, MODE, MINW, SP, 1>;
-            static DevOnce lds_once_x;
-            if (int rc_ = set_lds(lds_once_x, kx, lds)) return rc_;
-            long blocks_x = batch * a.ntiles;
-            a.pair_xcd = line_group<T, C>(p);
-            a.ablate = p->tune.ablate;
             a.nt_planes = p->tune.nt_planes > 0;
-            if (a.pair_xcd) blocks_x = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
-            ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
-            hipLaunchKernelGGL(kx, dim3((unsigned)blocks_x, SP ? 2u : 1u), dim3(C * G), lds, st, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
+            static DevOnce once_x, once_xn;
+            if constexpr (NYQ_MODE) {
+                if (a.nyq) return launch(k_cols<T, N, EPT, C, MODE, MINW, SP, 1, 1>, once_xn);
+            }
+            return launch(k_cols<T, N, EPT, C, MODE, MINW, SP, 1, 0>, once_x);
         }
     }
-    auto kern = k_cols<T, N, EPT, C, MODE, MINW, SP>;
-    static DevOnce lds_once;
-    if (int rc_ = set_lds(lds_once, kern, lds)) return rc_;
-    long blocks = batch * a.ntiles;
-    a.pair_xcd = line_group<T, C>(p);
-    a.ablate = p->tune.ablate;
     // 4-column tiles = the small, cache-resident problems: a whole pass's output would sit dirty in the L2s until the
     // end-of-kernel write-back; streamed out while the kernel still computes, 256^2 x 16 fp32 steps 4.6 % faster
     // (at 1024^2 the same hint costs 1-3 %)
     a.nt_planes = p->tune.nt_planes >= 0 ? p->tune.nt_planes : (C == 4 && EPT == 4);
-    if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
-    ProfScope prof(p, MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SP ? 2u : 1u), dim3(C * G), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    static DevOnce once, once_n;
+    if constexpr (NYQ_MODE) {
+        if (a.nyq) return launch(k_cols<T, N, EPT, C, MODE, MINW, SP, 0, 1>, once_n);
+    }
+    return launch(k_cols<T, N, EPT, C, MODE, MINW, SP, 0, 0>, once);
 }
 
 #ifndef TCFD_SPLIT_A_MINW4
