@@ -911,8 +911,8 @@ def test_odd_factor_grid_initial_condition_and_gradients(dev):
 @pytest.mark.parametrize("n,tag,split", [(64, "f32", "0"), (128, "f64", "1"), (256, "f32", "0"), (512, "f64", "0"), (1024, "f64", "1")])
 def test_packed_nyquist_column_agrees_with_the_lone_tile(n, tag, split, dev, monkeypatch):
     """Pruned plans (2/3-rule mask) carry column n/2 of the planes in the imaginary part of column 0 instead of
-    spending a whole column tile on it (TCFD_NYQ_PACK: 0 off, 2 every pass, 3 the opening pass only; 1 = per-size
-    default).  The STATE's Nyquist column goes through the same arithmetic either way (exactly equal); everything
+    spending a whole column tile on it (TCFD_NYQ_PACK: 0 off, 1 / 2 every pass -- the default --, 3 the opening pass of a
+    call only).  The STATE's Nyquist column goes through the same arithmetic either way (exactly equal); everything
     else agrees to round-off (the transforms see Hermitian-averaged inputs).  Non-Hermitian input columns included:
     the test field gets random imaginary parts in its DC / Nyquist columns, which c2r semantics must drop."""
     from oracle import ns2d as O

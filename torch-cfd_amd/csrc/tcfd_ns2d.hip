@@ -311,7 +311,11 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
     constexpr int NT = N >> SP;  // transform length (half the column when the workgroup owns one parity)
     constexpr int G = NT / EPT;
     static_assert(!(SP && (MODE == MODE_FWD || MODE == MODE_INV)), "plain transforms are not split");
-    const int q = SP ? (int)blockIdx.y : 0;  // parity of the spectral rows this workgroup owns
+    // parity of the spectral rows this workgroup owns: the LOW bit of the block id, so that the two parity workgroups
+    // of a tile are dispatched next to each other -- to different XCDs.  (As blockIdx.y they were 256 ids apart, i.e.
+    // in the two slots of ONE CU: with the packed Nyquist column both long workgroups of tile 0 shared that CU.)
+    const int q = SP ? (int)(blockIdx.x & 1) : 0;
+    const unsigned bx = SP ? blockIdx.x >> 1 : blockIdx.x;
 #define TCFD_IROW(s_) (SP ? 2 * (s_) + q : (s_))
     const size_t wq = (size_t)(SP ? q * NT : 0);  // first workspace row of this parity
     const int c = threadIdx.x % C;
@@ -326,14 +330,14 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
         // lines before the end-of-kernel write-back (each XCD writing its own 32 bytes of a line costs a fabric
         // transaction per piece: the plane stores were 7 of the 17 us of a 256^2 x 16 column pass)
         const unsigned LG = (unsigned)a.pair_xcd, span = 8 * LG;
-        const unsigned q = blockIdx.x / span, r = blockIdx.x % span;
+        const unsigned q = bx / span, r = bx % span;
         const unsigned unit = q * 8 + (r % 8);
         if (unit >= (unsigned)(((a.ntiles + LG - 1) / LG) * a.batch)) return;
         tile = (int)(LG * (unit / a.batch) + r / 8);
         b = unit % a.batch;
     } else {
-        tile = blockIdx.x / a.batch;
-        b = blockIdx.x % a.batch;
+        tile = bx / a.batch;
+        b = bx % a.batch;
     }
     const int jc = tile * C + c;
     const bool valid = jc < a.m;
@@ -1614,10 +1618,9 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     }
     p->nyq = (p->tune.nyq_pack && n >= 64 && p->keep_cols > 0 && p->keep_cols <= p->m - 1 &&
               (p->tune.rows_v == 0 || p->tune.rows_v == 5 || p->tune.rows_v == 7)) ? 1 : 0;
-    // per pass: the opening pass of a call (MODE_A) always gains; the fused passes (MODE_CA / MODE_C) only where tile 0's
-    // extra work does not make it the launch's long pole -- TCFD_NYQ_PACK: 1 auto, 2 every pass, 3 the opening pass only
+    // per pass (TCFD_NYQ_PACK = 3: the opening pass of a call only, for A/B runs; the row pass reads either form)
     p->nyq_a = p->nyq;
-    p->nyq_ca = p->nyq && (p->tune.nyq_pack == 2 || (p->tune.nyq_pack == 1 && n != 1024));
+    p->nyq_ca = p->nyq && p->tune.nyq_pack != 3;
     *out = p;
     return 0;
 }
@@ -1725,7 +1728,7 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.ablate = p->tune.ablate;
     long blocks = batch * a.ntiles;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
-    const dim3 grid((unsigned)blocks, SP ? 2u : 1u), block(C * G);
+    const dim3 grid((unsigned)(blocks * (SP ? 2 : 1))), block(C * G);
     const int kind = MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5;
     auto launch = [&](auto kern, DevOnce& once) -> int {
         if (int rc_ = set_lds(once, kern, lds)) return rc_;
