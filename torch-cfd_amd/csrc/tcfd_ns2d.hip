@@ -133,7 +133,8 @@ struct ColArgs {
     int load_h;
     int store_h;   // 0 at the last stage of a step: the accumulator is dead (the next step starts from h = 0)
     int ablate;    // timing ablations (TCFD_ABLATE bit mask; results are WRONG when non-zero): 1 skip the
-                   // transforms, 2 skip the plane stores, 4 skip the table reads, 8 skip the h traffic
+                   // transforms, 2 skip the plane stores, 4 skip the table reads, 8 skip the h traffic,
+                   // 64 skip the packing of the Nyquist column into the planes, 128 skip that column's update
     int nyq;       // 1: packed Nyquist column (see emit_planes): no lone tile for column m - 1, the lanes of column 0 own it too
     int nt_planes; // plane stores with the non-temporal hint (small cache-resident problems, see launch_cols)
     int pair_xcd;  // block->tile map: 0 = batch fastest; LG = 2 / 4: the LG tiles that share a 128-byte line on one XCD
