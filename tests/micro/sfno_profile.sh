@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_sfno2
-TRAIN=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sfno2 -o trace -- python $R/tests/bench_sfno.py 2>&1 | tail -1
+TRAIN=${TRAIN:-0} timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sfno2 -o trace -- python $R/tests/bench_sfno.py 2>&1 | tail -1
 python - <<'PY'
 import csv,glob,os
 f=glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/prof_sfno2/**/*kernel_stats.csv', recursive=True)
