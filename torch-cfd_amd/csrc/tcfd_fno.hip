@@ -1403,23 +1403,26 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
 // the hidden units (z1, h, its share of z2, g1 and its share of dx -- the partial sums meet in LDS), one tile of each
 // weight-gradient product on MFMA, and a quarter of the output channels.  One staging region per workgroup instead of per
 // wave: ~4 waves per SIMD, a quarter of the weight reads per wave.  Same partial-sum layout (one row per WORKGROUP).
-template <int CI, int CM, int CO>
-__global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
+// NW waves share the 64 points of a chunk: 4 (each wave a quarter of the hidden units, one MFMA tile per wave) or 2
+// (half the hidden units, two tiles per wave: half the barrier partners, twice the staging per wave)
+template <int CI, int CM, int CO, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_pointwise_bwd4(PwBwdArgs a) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     using Wm = PwBwdW<CI, CM, CO, true>;
     constexpr int PITCH = Gm::PITCH;
     constexpr int TO = Gm::COP / 16, TB = Gm::CB / 16, TI = Gm::CIP / 16, TM = Gm::CM1 / 16;
     constexpr int RI = Wm::RI, RO = Wm::RO;
-    constexpr int MQ = CM / 4;                       // hidden units per wave
+    constexpr int MQ = CM / NW;                      // hidden units per wave
     constexpr int RED = CO > CI ? CO : CI;           // rows per wave of the cross-wave reduction scratch
-    static_assert(CM % 4 == 0 && TO == 1 && TB <= 4 && TM <= 4 && TI == 1, "k_pointwise_bwd4 geometry");
+    static_assert((NW == 2 || NW == 4) && CM % NW == 0 && TO == 1 && TB <= 4 && TM <= 4 && TI == 1, "k_pointwise_bwd4 geometry");
+    constexpr int TA_W = (TB + NW - 1) / NW, TB_W = (TM + NW - 1) / NW;   // MFMA tiles per wave: tile t belongs to wave t % NW
     typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float* Wl = reinterpret_cast<float*>(smem_raw);
     float* L0 = Wl + ((Wm::TOTAL + 3) & ~3);         // g2, later [x, 1]
     float* L1 = L0 + Gm::R0 * PITCH;                 // [h, 1, s], later g1 over h
-    float* RD = L1 + Gm::CB * PITCH;                 // [4][RED][PITCH] partial sums of z2, later of dx
+    float* RD = L1 + Gm::CB * PITCH;                 // [NW][RED][PITCH] partial sums of z2, later of dx
     for (int i = threadIdx.x; i < Wm::TOTAL; i += blockDim.x) Wl[i] = 0.f;
     __syncthreads();
     for (int i = threadIdx.x; i < CM * CI; i += blockDim.x) Wl[Wm::W1 + (i / CI) * RI + i % CI] = a.w1[i];
@@ -1438,7 +1441,11 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
     auto WSrow = [&](int i) -> const float* { return Wl + Wm::WS + i * RO; };
     auto B1at = [&](int m) -> float { return Wl[Wm::B1 + m]; };
     const int kq = lane >> 4, kc = lane & 15;
-    f4 accA = f4{0.f, 0.f, 0.f, 0.f}, accB = f4{0.f, 0.f, 0.f, 0.f};
+    f4 accA[TA_W], accB[TB_W];
+#pragma unroll
+    for (auto& v : accA) v = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (auto& v : accB) v = f4{0.f, 0.f, 0.f, 0.f};
     const long c_first = a.per_sample ? ((long)blockIdx.x % a.batch) * a.chunks_per_batch + blockIdx.x / a.batch : blockIdx.x;
     const long c_stride = a.per_sample ? gridDim.x / a.batch : gridDim.x;
     const long c_end = a.per_sample ? ((long)blockIdx.x % a.batch + 1) * a.chunks_per_batch : a.total_chunks;
@@ -1474,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) RD[(wave * RED + c) * PITCH + lane] = z2[c];
         // the constant-1 channel and the skip input rows of the second operand (wave 3 and wave 2: spread the stores)
-        if (wave == 3) L1[CM * PITCH + lane] = live ? 1.f : 0.f;
+        if (wave == NW - 1) L1[CM * PITCH + lane] = live ? 1.f : 0.f;
         float sv[CI];
         if (a.skip_mode == 1) {
             const float* sb = a.s + (size_t)b * CI * a.P + pc;
@@ -1484,7 +1491,7 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < CI; ++i) sv[i] = 0.f;
         }
-        if (wave == 2) {
+        if (wave == (NW > 2 ? 2 : 0)) {
 #pragma unroll
             for (int i = 0; i < CI; ++i) L1[(CM + 1 + i) * PITCH + lane] = sv[i];
         }
@@ -1494,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
         for (int c = 0; c < CO; ++c) {
             float v = Wl[Wm::B2 + c];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += RD[(w * RED + c) * PITCH + lane];
+            for (int w = 0; w < NW; ++w) v += RD[(w * RED + c) * PITCH + lane];
             z2[c] = v;
         }
         if (a.skip_mode == 1) {
@@ -1518,12 +1525,16 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
             for (int c = 0; c < CO; ++c) L0[c * PITCH + lane] = g2[c];
         }
         __syncthreads();
-        if (wave < TB) {   // [dW2 | db2 | dWs] tile `wave`
+#pragma unroll
+        for (int u = 0; u < TA_W; ++u) {   // [dW2 | db2 | dWs] tiles wave, wave + NW, ...
+            const int tile = wave + u * NW;
+            if (tile < TB) {
 #pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const float av = L0[kc * PITCH + 4 * q + kq];
-                const float bv = L1[(16 * wave + kc) * PITCH + 4 * q + kq];
-                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accA, 0, 0, 0);
+                for (int q = 0; q < 16; ++q) {
+                    const float av = L0[kc * PITCH + 4 * q + kq];
+                    const float bv = L1[(16 * tile + kc) * PITCH + 4 * q + kq];
+                    accA[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accA[u], 0, 0, 0);
+                }
             }
         }
         __syncthreads();   // the products have read h and g2: h rows become g1, the g2 rows become [x, 1]
@@ -1561,24 +1572,28 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
             L0[CI * PITCH + lane] = live ? 1.f : 0.f;
         }
         __syncthreads();
-        if (wave < TM) {   // [dW1 | db1] tile `wave`
+#pragma unroll
+        for (int u = 0; u < TB_W; ++u) {   // [dW1 | db1] tiles wave, wave + NW, ...
+            const int tile = wave + u * NW;
+            if (tile < TM) {
 #pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const float bv = L0[kc * PITCH + 4 * q + kq];
-                const float av = L1[(16 * wave + kc) * PITCH + 4 * q + kq];
-                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accB, 0, 0, 0);
+                for (int q = 0; q < 16; ++q) {
+                    const float bv = L0[kc * PITCH + 4 * q + kq];
+                    const float av = L1[(16 * tile + kc) * PITCH + 4 * q + kq];
+                    accB[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accB[u], 0, 0, 0);
+                }
             }
         }
-        // outputs: channel i is summed and stored by wave i % 4
+        // outputs: channel i is summed and stored by wave i % NW
         if (live) {
             if (a.dx) {
                 float* dxb = a.dx + (size_t)b * CI * a.P + p;
 #pragma unroll
                 for (int i = 0; i < CI; ++i)
-                    if ((i & 3) == wave) {
+                    if ((i % NW) == wave) {
                         float v = 0.f;
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) v += RD[(w * RED + i) * PITCH + lane];
+                        for (int w = 0; w < NW; ++w) v += RD[(w * RED + i) * PITCH + lane];
                         dxb[(size_t)i * a.P] = v;
                     }
             }
@@ -1586,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
                 float* dsb = a.ds + (size_t)b * CI * a.P + p;
 #pragma unroll
                 for (int i = 0; i < CI; ++i)
-                    if ((i & 3) == wave) {
+                    if ((i % NW) == wave) {
                         const float* ws = WSrow(i);
                         float v = 0.f;
 #pragma unroll
@@ -1597,25 +1612,33 @@ __global__ __launch_bounds__(256) void k_pointwise_bwd4(PwBwdArgs a) {
                 float* dsb = a.ds + (size_t)b * CO * a.P + p;
 #pragma unroll
                 for (int c = 0; c < CO; ++c)
-                    if ((c & 3) == wave) dsb[(size_t)c * a.P] = g2[c];
+                    if ((c % NW) == wave) dsb[(size_t)c * a.P] = g2[c];
             }
         }
         __syncthreads();   // the next chunk overwrites the staging rows and the reduction scratch
     }
     // partial sums of this workgroup: A (COP x CB) | B (CM1 x CIP), tile `wave` of each from wave `wave`
     float* out = a.partials + (size_t)blockIdx.x * Gm::TOTAL;
-    if (wave < TB) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(4 * kq + r) * Gm::CB + 16 * wave + kc] = accA[r];
+    for (int u = 0; u < TA_W; ++u) {
+        const int tile = wave + u * NW;
+        if (tile < TB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(4 * kq + r) * Gm::CB + 16 * tile + kc] = accA[u][r];
+        }
     }
-    if (wave < TM) {
-        float* o1 = out + Gm::N_A;
+    float* o1 = out + Gm::N_A;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o1[(16 * wave + 4 * kq + r) * Gm::CIP + kc] = accB[r];
+    for (int u = 0; u < TB_W; ++u) {
+        const int tile = wave + u * NW;
+        if (tile < TM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o1[(16 * tile + 4 * kq + r) * Gm::CIP + kc] = accB[u][r];
+        }
     }
 }
 
-template <int CI, int CM, int CO>
+template <int CI, int CM, int CO, int NW = 4>
 static int launch_pw_bwd4(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     using Wm = PwBwdW<CI, CM, CO, true>;
@@ -1625,12 +1648,12 @@ static int launch_pw_bwd4(PwBwdArgs a, int batch, int max_rows, int* dims, hipSt
     a.total_chunks = a.chunks_per_batch * batch;
     a.batch = batch;
     constexpr int RED = CO > CI ? CO : CI;
-    const size_t lds = ((size_t)((Wm::TOTAL + 3) & ~3) + (size_t)(Gm::ROWS + 4 * RED) * Gm::PITCH) * sizeof(float);
-    auto kern = k_pointwise_bwd4<CI, CM, CO>;
+    const size_t lds = ((size_t)((Wm::TOTAL + 3) & ~3) + (size_t)(Gm::ROWS + NW * RED) * Gm::PITCH) * sizeof(float);
+    auto kern = k_pointwise_bwd4<CI, CM, CO, NW>;
     int rc = set_lds_attr(kern, lds);
     if (rc) return rc;
     int per_cu = 0, dev = 0, cus = 256;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * NW, lds));
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     long blocks = std::min<long>({a.total_chunks, (long)max_rows, (long)std::max(per_cu, 1) * cus});
@@ -1640,7 +1663,7 @@ static int launch_pw_bwd4(PwBwdArgs a, int batch, int max_rows, int* dims, hipSt
         if (blocks < batch) blocks = batch;
         if (blocks > max_rows) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: %ld rows needed for per-sample partials, %d given", blocks, max_rows);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), lds, st, a);
     HIP_TRY(hipGetLastError());
     dims[5] = (int)blocks;
     return 0;
@@ -1707,7 +1730,11 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
     const bool l1 = cm != ci || w1 != nullptr;
 #define PWB_CASE(CI_, CM_, CO_, L1_) \
     if (ci == CI_ && cm == CM_ && co == CO_ && l1 == L1_) return launch_pw_bwd<CI_, CM_, CO_, L1_>(a, batch, max_waves, dims, st);
-    if (l1 && env_int("TCFD_PW_BWD", 4) == 4) {   // four waves per 64 points (default); 1 = one wave per 64 points
+    // TCFD_PW_BWD: 0 = default (width 10: two waves per 64 points -- 33.7 vs 35.1 ms per SFNO training step; other widths four),
+    // 2 / 4 = that many waves per 64 points, 1 = one wave per 64 points (k_pointwise_bwd)
+    const int bwd_mode = env_int("TCFD_PW_BWD", 0);
+    if (l1 && bwd_mode != 1) {
+        if (ci == 10 && cm == 40 && co == 10 && bwd_mode != 4) return launch_pw_bwd4<10, 40, 10, 2>(a, batch, max_waves, dims, st);
         if (ci == 4 && cm == 16 && co == 4) return launch_pw_bwd4<4, 16, 4>(a, batch, max_waves, dims, st);
         if (ci == 8 && cm == 32 && co == 8) return launch_pw_bwd4<8, 32, 8>(a, batch, max_waves, dims, st);
         if (ci == 10 && cm == 40 && co == 10) return launch_pw_bwd4<10, 40, 10>(a, batch, max_waves, dims, st);
