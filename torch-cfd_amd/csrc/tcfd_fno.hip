@@ -327,10 +327,11 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, flo
     }
     __syncthreads();
     const int n4 = Y * t_keep / 4;
-    float4* d4 = reinterpret_cast<float4*>(out + (size_t)base * Y * t_keep);
-    for (int q = 0; q < count; ++q) {
-        const float4* s4 = reinterpret_cast<const float4*>(ex + (size_t)q * P * Y);
-        for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[(size_t)q * n4 + i] = s4[i];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v* d4 = reinterpret_cast<f4v*>(out + (size_t)base * Y * t_keep);
+    for (int q = 0; q < count; ++q) {   // streamed out: nothing on this GPU reads it before it has left the caches
+        const f4v* s4 = reinterpret_cast<const f4v*>(ex + (size_t)q * P * Y);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) __builtin_nontemporal_store(s4[i], d4 + (size_t)q * n4 + i);
     }
 }
 
@@ -824,7 +825,8 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     }
     float* ob = a.out + (size_t)b * CO * a.P + p;
 #pragma unroll
-    for (int c = 0; c < CO; ++c) *reinterpret_cast<vf*>(ob + (size_t)c * a.P) = pw_act(o[c], a.act2);
+    for (int c = 0; c < CO; ++c)   // streamed out (non-temporal): an 0.8 GB activation tensor outlives every cache; SFNO forward 5.77 -> 5.42 ms
+        __builtin_nontemporal_store(pw_act(o[c], a.act2), reinterpret_cast<vf*>(ob + (size_t)c * a.P));
 }
 
 // ------------------------------------------------------------------ inverse t/y transform + pointwise block in ONE kernel
@@ -1594,7 +1596,7 @@ __global__ __launch_bounds__(64 * NW) void k_pointwise_bwd4(PwBwdArgs a) {
                         float v = 0.f;
 #pragma unroll
                         for (int w = 0; w < NW; ++w) v += RD[(w * RED + i) * PITCH + lane];
-                        dxb[(size_t)i * a.P] = v;
+                        __builtin_nontemporal_store(v, dxb + (size_t)i * a.P);
                     }
             }
             if (a.skip_mode == 1 && a.ds) {
@@ -1606,13 +1608,13 @@ __global__ __launch_bounds__(64 * NW) void k_pointwise_bwd4(PwBwdArgs a) {
                         float v = 0.f;
 #pragma unroll
                         for (int c = 0; c < CO; ++c) v = fmaf(ws[c], g2[c], v);
-                        dsb[(size_t)i * a.P] = v;
+                        __builtin_nontemporal_store(v, dsb + (size_t)i * a.P);
                     }
             } else if (a.skip_mode == 2 && a.ds) {
                 float* dsb = a.ds + (size_t)b * CO * a.P + p;
 #pragma unroll
                 for (int c = 0; c < CO; ++c)
-                    if ((c % NW) == wave) dsb[(size_t)c * a.P] = g2[c];
+                    if ((c % NW) == wave) __builtin_nontemporal_store(g2[c], dsb + (size_t)c * a.P);
             }
         }
         __syncthreads();   // the next chunk overwrites the staging rows and the reduction scratch
