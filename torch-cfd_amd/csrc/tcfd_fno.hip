@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(64 * NW) void k_pointwise_bwd4(PwBwdArgs a) {
                         float v = 0.f;
 #pragma unroll
                         for (int w = 0; w < NW; ++w) v += RD[(w * RED + i) * PITCH + lane];
-                        __builtin_nontemporal_store(v, dxb + (size_t)i * a.P);
+                        dxb[(size_t)i * a.P] = v;
                     }
             }
             if (a.skip_mode == 1 && a.ds) {
@@ -1608,13 +1608,13 @@ __global__ __launch_bounds__(64 * NW) void k_pointwise_bwd4(PwBwdArgs a) {
                         float v = 0.f;
 #pragma unroll
                         for (int c = 0; c < CO; ++c) v = fmaf(ws[c], g2[c], v);
-                        __builtin_nontemporal_store(v, dsb + (size_t)i * a.P);
+                        dsb[(size_t)i * a.P] = v;
                     }
             } else if (a.skip_mode == 2 && a.ds) {
                 float* dsb = a.ds + (size_t)b * CO * a.P + p;
 #pragma unroll
                 for (int c = 0; c < CO; ++c)
-                    if ((c % NW) == wave) __builtin_nontemporal_store(g2[c], dsb + (size_t)c * a.P);
+                    if ((c % NW) == wave) dsb[(size_t)c * a.P] = g2[c];
             }
         }
         __syncthreads();   // the next chunk overwrites the staging rows and the reduction scratch
