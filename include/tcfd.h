@@ -244,6 +244,13 @@ int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, vo
  * element r % batch -- what the backward of a LayerNorm folded into the convolution needs (its statistics differ per
  * sample); dx may then be NULL (only the sums are wanted). */
 
+/* Weighted squared norm of half spectra, the reduction behind SobolevLoss (fno/losses.py:263-315):
+ *   partial[b][blk] = sum_e |z[b][e]|^2 * w2[e]  over block blk's share of the `elems` complex entries of field b,
+ * accumulated in double; the caller adds the `blocks` partials of a field.  z (batch, elems) complex64 / complex128
+ * (dtype TCFD_C64 / TCFD_C128), w2 (elems) real of the matching precision, partial (batch, blocks) double. */
+int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks, int dtype,
+                         void* stream);
+
 /* STREAM-style device probe (measurement aid, SURVEY 8d "verify with a device STREAM-style probe"): `iters`
  * launches of a 16-byte-per-lane grid-stride kernel over `bytes` (a multiple of 16) of caller-owned device memory,
  * timed with HIP events on `stream`.  mode 0: copy src -> dst (2*bytes of traffic per launch); 1: read-only

@@ -757,3 +757,20 @@ def test_fused_layer_tail_is_bit_identical_to_the_two_kernel_path(width, expansi
     with torch.no_grad():
         v5 = torch.randn(1, width, n, n, 5, device=dev)
         assert fno.hip_conv_pointwise(conv, v5, mlp, v5, skip_conv=w, act2=act) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.complex64, torch.complex128])
+def test_weighted_sqnorm_kernel(dtype, dev):
+    """The one-pass reduction behind SobolevLoss against the torch expression it replaces."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(3)
+    real = torch.float32 if dtype == torch.complex64 else torch.float64
+    zh = torch.randn(5, 3, 96, 49, dtype=dtype, device=dev)
+    w2 = torch.rand(96, 49, dtype=real, device=dev) + 0.1
+    got = fno.hip_weighted_sqnorm(zh, w2)
+    ref = ((zh.real.double() ** 2 + zh.imag.double() ** 2) * w2.double()).sum(dim=(-2, -1))
+    assert got.shape == (5, 3) and got.dtype == real
+    assert torch.allclose(got.double(), ref, rtol=2e-6 if real == torch.float32 else 1e-13)
+    with pytest.raises(ValueError):
+        fno.hip_weighted_sqnorm(zh, w2[:, :-1])

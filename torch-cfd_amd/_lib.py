@@ -131,6 +131,7 @@ SIGNATURES = {
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
+    "tcfd_weighted_sqnorm": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp]),
     "tcfd_hbm_probe": (_i, [_vp, _vp, ctypes.c_size_t, _i, _i, ctypes.POINTER(ctypes.c_float), _vp]),
 }
 

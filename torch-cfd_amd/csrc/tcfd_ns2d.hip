@@ -2420,6 +2420,45 @@ extern "C" int tcfd_ns2d_velocity(const tcfd_ns2d_plan* p, const void* w, void* 
                                  : velocity_impl<float>(p, w, uh, vh, psi, batch, st);
 }
 
+// ------------------------------------------------------------------ weighted squared norm of half spectra
+// partial[b][blk] = sum over the block's share of field b of  |z[b][e]|^2 * w2[e]   (double accumulation): the
+// Fourier-domain norm of SobolevLoss (fno/losses.py:263-315) in ONE pass over the spectrum instead of five
+// element-wise / reduction launches.
+template <typename T>
+__global__ __launch_bounds__(256) void k_weighted_sqnorm(const cx<T>* __restrict__ z, const T* __restrict__ w2,
+                                                         double* __restrict__ partial, long elems) {
+    __shared__ double sh[4];
+    const long b = blockIdx.y;
+    const cx<T>* zb = z + (size_t)b * elems;
+    double acc = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < elems; e += (long)gridDim.x * 256) {
+        const cx<T> v = zb[e];
+        acc += (double)((v.x * v.x + v.y * v.y) * w2[e]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+extern "C" int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks,
+                                    int dtype, void* stream) {
+    if (!z || !w2 || !partial || batch <= 0 || elems <= 0 || blocks <= 0)
+        return fail(TCFD_EINVAL, "weighted_sqnorm: bad argument");
+    if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "weighted_sqnorm: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks, (unsigned)batch);
+    if (dtype == TCFD_C128)
+        hipLaunchKernelGGL(k_weighted_sqnorm<double>, grid, dim3(256), 0, st, (const cx<double>*)z, (const double*)w2,
+                           (double*)partial, elems);
+    else
+        hipLaunchKernelGGL(k_weighted_sqnorm<float>, grid, dim3(256), 0, st, (const cx<float>*)z, (const float*)w2,
+                           (double*)partial, elems);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int tcfd_rfft2(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, void* stream) {
     if (!p || !x || !out || batch <= 0) return fail(TCFD_EINVAL, "rfft2: bad argument");
     hipStream_t st = (hipStream_t)stream;

@@ -1309,6 +1309,29 @@ class SFNO(FNOBase):
 from .autograd import Rfft2 as _Rfft2Fn  # noqa: E402  (rfft2 on the HIP kernels with its hand-written adjoint)
 
 
+def hip_weighted_sqnorm(zh: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """``(|zh|^2 * w2).sum(dim=(-2, -1))`` for half spectra ``zh`` (*, n, m) and real weights ``w2`` (n, m) in one pass
+    over the spectrum (``tcfd_weighted_sqnorm``; double accumulation, the result comes back in ``w2.dtype``)."""
+    if not zh.is_cuda:
+        raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+    lead, elems = zh.shape[:-2], zh.shape[-2] * zh.shape[-1]
+    if tuple(w2.shape) != tuple(zh.shape[-2:]):
+        raise ValueError(f"weights {tuple(w2.shape)} for spectra {tuple(zh.shape[-2:])}")
+    cdt = zh.dtype
+    rdt = torch.float64 if cdt == torch.complex128 else torch.float32
+    zc = zh.contiguous()
+    wc = w2.to(device=zh.device, dtype=rdt).contiguous()
+    batch = max(int(zc.numel() // elems), 1)
+    blocks = max(1, min(64, (elems + 4095) // 4096))
+    partial = torch.empty(batch, blocks, dtype=torch.float64, device=zh.device)
+    with torch.cuda.device(zh.device):
+        _lib.check(_lib.load().tcfd_weighted_sqnorm(
+            zc.data_ptr(), wc.data_ptr(), partial.data_ptr(), batch, elems, blocks,
+            _lib.TCFD_C128 if cdt == torch.complex128 else _lib.TCFD_C64,
+            ctypes.c_void_p(torch.cuda.current_stream(zh.device).cuda_stream)), "tcfd_weighted_sqnorm")
+    return partial.sum(dim=-1).to(w2.dtype).reshape(lead)
+
+
 class SobolevLoss(nn.Module):
     """Fourier-domain weighted norm of (x - y), fno/losses.py:199-315, including ``freq_cutoff`` (wavenumbers above it
     are replaced by inf for negative orders and by 0 otherwise, exactly as the reference's mesh does) and every
@@ -1370,7 +1393,7 @@ class SobolevLoss(nn.Module):
                 zh = _Rfft2Fn.apply(zt, plan)
                 return ((zh.real**2 + zh.imag**2) * w2).sum(dim=(-2, -1))
             zh = plan.rfft2(zt)
-            return (zh.real**2 + zh.imag**2).mul_(w2).sum(dim=(-2, -1))
+            return hip_weighted_sqnorm(zh, w2)
 
         diff = sq_norms(x if y is None else x - y)  # the transform is linear: one rfft2 of the difference
         loss = diff.sum(dim=-1).sqrt()
