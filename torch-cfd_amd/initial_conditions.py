@@ -32,6 +32,28 @@ def _half_angular_magnitude(grid: Grid, device, real):
     return k.to(device)
 
 
+def _seeded_noise(shape, seeds) -> torch.Tensor:
+    """(len(seeds), *shape) standard-normal samples, sample i from a CPU generator seeded with seeds[i] -- the reference's
+    per-sample stream (its generators live on the CPU), so a seed reproduces the reference's field.  The generators are
+    independent: large batches are drawn by a few threads (the draw releases the GIL) straight into one buffer."""
+    out = torch.empty((len(seeds),) + tuple(shape))
+
+    def draw(i):
+        gen = torch.Generator()
+        gen.manual_seed(int(seeds[i]))
+        torch.randn(tuple(shape), generator=gen, out=out[i])
+
+    if len(seeds) < 4:
+        for i in range(len(seeds)):
+            draw(i)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(16, len(seeds))) as pool:
+            list(pool.map(draw, range(len(seeds))))
+    return out
+
+
 def vorticity_field(grid: Grid, peak_wavenumber: float = 3, random_state: int = 0, device="cuda",
                     batch_seeds=None) -> torch.Tensor:
     """(n, n) real vorticity on ``device`` (or (B, n, n) when ``batch_seeds`` lists
@@ -39,12 +61,7 @@ def vorticity_field(grid: Grid, peak_wavenumber: float = 3, random_state: int = 
     real = torch.get_default_dtype()
     n = grid.shape[0]
     seeds = [random_state] if batch_seeds is None else list(batch_seeds)
-    gen = torch.Generator()
-    noise = []
-    for s in seeds:
-        gen.manual_seed(int(s))
-        noise.append(torch.randn(grid.shape, generator=gen))
-    noise = torch.stack(noise).to(device)
+    noise = _seeded_noise(grid.shape, seeds).to(device)
     plan = fft_plan(n, _COMPLEX_OF[real], torch.device(device), diam=grid.domain[0][1] - grid.domain[0][0])
     k = _half_angular_magnitude(grid, device, real)
     filt = torch.where(k > 0, McWilliams_density(k, peak_wavenumber), torch.zeros_like(k))
@@ -84,13 +101,7 @@ def filtered_velocity_field(grid: Grid, maximum_velocity: float = 1, peak_wavenu
     n = grid.shape[0]
     h = grid.step[0]
     seeds = [random_state] if batch_seeds is None else list(batch_seeds)
-    gen = torch.Generator()
-    noise = []
-    for s in seeds:
-        for i in range(2):
-            gen.manual_seed(int(s) + i)
-            noise.append(torch.randn(grid.shape, generator=gen))
-    noise = torch.stack(noise).to(device)                      # (2B, n, n): ux, uy interleaved
+    noise = _seeded_noise(grid.shape, [int(s) + i for s in seeds for i in range(2)]).to(device)   # (2B, n, n): ux, uy interleaved
     plan = fft_plan(n, _COMPLEX_OF[real], torch.device(device), diam=grid.domain[0][1] - grid.domain[0][0])
     k = _half_angular_magnitude(grid, device, real)
     kk = torch.where(k > 0, k, torch.ones_like(k))
