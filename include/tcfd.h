@@ -78,6 +78,13 @@ int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* plan, int* separable, int* sparse_
  * row pass; rows_kernel = 6 (LDS-DMA staged row pass), 5 (register staged) or 4 (round-1 kernel). */
 int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* plan, int* split, int* rows_kernel);
 
+/* How a batched call on this plan is cut into chunks: `*fields_per_chunk` = batch elements per chunk for a call with
+ * `batch` fields (= batch when the call is not chunked), `*cache_bytes` = size of the device's memory-side last-level
+ * cache (Infinity Cache) the chunk is sized for, `*cache_source` = 0 built-in default (256 MB), 1 read from the KFD
+ * topology of the device at plan creation, 2 TCFD_CACHE_MB.  Any output pointer may be NULL. */
+int tcfd_ns2d_plan_chunking(const tcfd_ns2d_plan* plan, long batch, long* fields_per_chunk, size_t* cache_bytes,
+                            int* cache_source);
+
 /* Test hook: the cross-lane 1024-point transform of the row pass on its own (complex128, `count` sequences of
  * 1024 elements, one 128-lane group each).  dir = +1: natural-order input -> output in the kernel's internal
  * permutation (register t of lane j at out[1024 s + 128 t + j]); dir = -1: the reverse.  Needs a 1024^2
@@ -257,6 +264,14 @@ int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batc
  * sum of src (dst = 8 bytes of scratch); 2: write-only fill of dst (src unused).  *ms = average launch
  * duration.  Synchronises the stream (it is a benchmark, not part of the path). */
 int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int iters, float* ms, void* stream);
+
+/* Pitched device -> host copy on `stream`: `rows` rows of `row_bytes` bytes, source rows `src_pitch` bytes apart
+ * (device), destination rows `dst_pitch` bytes apart (host).  Asynchronous with respect to the host when the
+ * destination is page-locked.  The output side of the trajectory recorder uses it to drop one record of a batch
+ * shard into its (sample, record, y, x) slot of the host dataset while the next steps run (the reference does four
+ * blocking `.cpu()` calls per record, fno/data_gen/solvers.py:246-250). */
+int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t row_bytes,
+                           size_t rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,3 +79,173 @@ def test_gather_is_identity_without_process_group():
 
     rec = _fake_records(0, 2)
     assert gather_trajectory(rec, 2) is rec
+
+
+# ----------------------------------------------------------------------------- per-record hand-over (RecordHandover)
+def _fake_packed(start, count, rec, F=4, ns=4):
+    idx = torch.arange(start, start + count, dtype=torch.float32)[:, None, None, None]
+    f = torch.arange(F, dtype=torch.float32)[None, :, None, None]
+    yx = torch.arange(ns * ns, dtype=torch.float32).reshape(1, 1, ns, ns)
+    return (idx * 1000 + rec * 100 + f * 10 + yx / 16).contiguous()
+
+
+def _handover_worker(rank, world, port, total, batch, n_rec, q, dst):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch_cfd_amd.distributed import TRAJECTORY_FIELDS, RecordHandover, batch_layout
+
+        layout = batch_layout(total, world, batch)
+        ho = RecordHandover(TRAJECTORY_FIELDS, total, n_rec, (4, 4), torch.float32, layout, "cpu", dst=dst)
+        for start, count in layout[rank]:
+            for rec in range(n_rec):
+                ho.push(start, rec, _fake_packed(start, count, rec))
+        full = ho.finish()
+        if rank == dst:
+            ok = True
+            for f, name in enumerate(TRAJECTORY_FIELDS):
+                for rec in range(n_rec):
+                    ok &= torch.equal(full[name][:, rec], _fake_packed(0, total, rec)[:, f])
+            q.put(("ok" if ok else "mismatch", tuple(full["vorticity"].shape)))
+        else:
+            q.put(("none" if full is None else "unexpected", None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,batch,dst", [(8, 2, 0), (7, 2, 1), (5, 8, 0), (1, 4, 1)])  # several batches, ragged, empty shard
+def test_record_handover_world2(total, batch, dst):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_handover_worker, args=(r, 2, port, total, batch, 3, q, dst)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == ["none", "ok"], res
+    assert [r[1] for r in res if r[1]][0] == (total, 3, 4, 4)
+
+
+def test_record_handover_without_process_group_and_order_check():
+    from torch_cfd_amd.distributed import RecordHandover, batch_layout
+
+    layout = batch_layout(5, 1, 2)
+    assert layout == [[(0, 2), (2, 2), (4, 1)]]
+    ho = RecordHandover(("a", "b"), 5, 2, (4, 4), torch.float32, layout, "cpu")
+    with pytest.raises(ValueError, match="out of order"):
+        ho.push(2, 0, _fake_packed(2, 2, 0, F=2))
+    for start, count in layout[0]:
+        for rec in range(2):
+            ho.push(start, rec, _fake_packed(start, count, rec, F=2))
+    full = ho.finish()
+    assert torch.equal(full["b"][:, 1], _fake_packed(0, 5, 1, F=2)[:, 1])
+    ho2 = RecordHandover(("a",), 2, 1, (4, 4), torch.float32, batch_layout(2, 1, 2), "cpu")
+    with pytest.raises(RuntimeError, match="never pushed"):
+        ho2.finish()
+
+
+def _mismatch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch_cfd_amd.distributed import gather_trajectory, shard_batch
+
+        a, b = shard_batch(6, rank, world)
+        local = _fake_records(a, b + (1 if rank == 1 else 0))   # rank 1 holds one sample too many
+        try:
+            gather_trajectory(local, 6)
+            q.put("no error")
+        except ValueError as e:
+            q.put("raised" if "shard size" in str(e) else repr(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_shard_size_mismatch_raises_on_every_rank():
+    """A bad shard must not leave the other ranks blocked in their point-to-point calls."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == ["raised", "raised"], res
+
+
+def _subgroup_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch_cfd_amd.distributed import gather_trajectory, shard_batch
+
+        group = dist.new_group([1, 2])     # group ranks 0, 1 = global ranks 1, 2
+        if rank == 0:
+            q.put("outside")
+            return
+        grank = dist.get_rank(group)
+        a, b = shard_batch(5, grank, 2)
+        full = gather_trajectory(_fake_records(a, b), 5, dst=1, group=group)
+        if grank == 1:
+            ref = _fake_records(0, 5)
+            q.put("ok" if all(torch.equal(full[k], ref[k]) for k in ref) else "mismatch")
+        else:
+            q.put("none" if full is None else "unexpected")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_in_a_subgroup_addresses_peers_by_global_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == ["none", "ok", "outside"], res
+
+
+# ----------------------------------------------------------------------------- bench.py --gpus N starts its own ranks
+def _run_bench(args):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    return r, [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` with no launcher: two ranks, gloo, no kernels (--host-only), ONE JSON line."""
+    import json
+
+    r, lines = _run_bench(["--gpus", "2", "--steps", "4", "--host-only", "--scaling", scaling])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["spawned_by_bench"] is True and out["dry_run"] is True
+    assert out["scaling"] == scaling and len(out["per_rank_steps_per_s"]) == 2
+    assert out["fields_of_rank0"] == ([0, 64] if scaling == "weak" else [0, 32])
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("this box really has 64 devices")
+    r, lines = _run_bench(["--gpus", "64", "--steps", "1"])
+    assert r.returncode == 2 and not lines and b"HIP device" in r.stderr

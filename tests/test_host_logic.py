@@ -143,3 +143,121 @@ def test_composite_transforms_for_grids_with_an_odd_factor():
                           torch.randn(2, n, n // 2 + 1, generator=g, dtype=torch.float64))
         assert (f.rfft2(y) - torch.fft.rfft2(y)).abs().max() < 1e-11
         assert (f.irfft2(z) - torch.fft.irfft2(z, s=(n, n))).abs().max() < 1e-13
+
+
+# ----------------------------------------------------------------------------- caller-facing helpers of the reference
+def test_stable_time_step_bounds():
+    dx = L / 1024
+    # BASELINE config 3: advective bound 0.5 dx / 5 (6.136e-4)
+    assert tc.stable_time_step(dx=dx, dt=None, max_velocity=5.0, max_courant_number=0.5, viscosity=1e-3) == pytest.approx(6.1359e-4, rel=1e-4)
+    assert tc.stable_time_step(dx=dx, dt=1e-4, max_velocity=5.0) == 1e-4                     # the caller's dt wins when smaller
+    assert tc.stable_time_step(dx=0.1, dt=1.0, max_velocity=1e-3) == 0.1                      # implicit diffusion: dx
+    assert tc.stable_time_step(dx=0.1, dt=1.0, max_velocity=1e-3, viscosity=1.0, implicit_diffusion=False) == pytest.approx(0.01 / 4)
+
+
+def test_grid_offsets_and_axes():
+    g = tc.Grid(shape=(4, 8), domain=((0, 1), (0, 2)))
+    assert g.cell_center == (0.5, 0.5) and g.cell_faces == ((1.0, 0.5), (0.5, 1.0))
+    ax, ay = g.axes()
+    assert torch.allclose(ax, (torch.arange(4) + 0.5) / 4) and torch.allclose(ay, (torch.arange(8) + 0.5) / 4)
+    x, y = g.mesh((0, 0))
+    assert x.shape == (4, 8) and x[1, 0] == pytest.approx(0.25) and y[0, 1] == pytest.approx(0.25)
+    g.note = "callers may hang attributes on a grid, as on the reference's dataclass"
+    with pytest.raises(ValueError):
+        g.axes((0.5,))
+
+
+def test_spectral_helpers_differentiate_a_plane_wave():
+    torch.set_default_dtype(torch.float64)
+    n = 16
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    x, y = grid.mesh((0, 0))
+    f = torch.sin(2 * x + 3 * y)
+    mesh = grid.rfft_mesh()
+    fh = torch.fft.rfft2(f)
+    gx, gy = tc.spectral_grad_2d(fh, mesh)
+    assert torch.allclose(torch.fft.irfft2(gx), 2 * torch.cos(2 * x + 3 * y), atol=1e-12)
+    assert torch.allclose(torch.fft.irfft2(gy), 3 * torch.cos(2 * x + 3 * y), atol=1e-12)
+    u, v = tc.spectral_rot_2d(fh, mesh)
+    assert torch.allclose(tc.spectral_div_2d((u, v), mesh).abs().max(), torch.tensor(0.0), atol=1e-10)
+    lap = tc.spectral_laplacian_2d(mesh)
+    assert lap[0, 0] == 1 and torch.allclose(tc.spectral_curl_2d((u, v), mesh), -(lap * fh), atol=1e-9)   # curl rot = -lap
+    kx, ky = tc.fft_mesh_2d(n, L)
+    assert kx.shape == (n, n) and torch.equal(kx[:, : n // 2 + 1], mesh[0])
+
+
+def test_reference_style_user_forcing_and_solenoidal_template():
+    """A forcing written against the reference's base class overrides vorticity_eval / velocity_eval; the operator samples it
+    through forward(grid, None) exactly like a built-in one."""
+    torch.set_default_dtype(torch.float64)
+    n = 16
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+
+    class UserVorticityForcing(tc.ForcingFn):
+        def __init__(self, grid):
+            super().__init__(grid, vorticity=True)
+
+        def vorticity_eval(self, grid, vorticity=None):
+            x, y = grid.mesh((0, 0))
+            return tc.FieldArray(-4.0 * torch.cos(4 * y), (0, 0), grid)
+
+    class UserVelocityForcing(tc.ForcingFn):
+        def velocity_eval(self, grid, velocity=None):
+            x, y = grid.mesh((0, 0))
+            return tc.FieldArray(torch.sin(4 * y)), tc.FieldArray(torch.zeros_like(y))
+
+    builtin = tc.NavierStokes2DSpectral(1e-3, grid, forcing_fn=tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4)).forcing_hat()
+    for fn in (UserVorticityForcing(grid), UserVelocityForcing(grid)):
+        fh = tc.NavierStokes2DSpectral(1e-3, grid, forcing_fn=fn).forcing_hat()
+        assert torch.allclose(fh, builtin, atol=1e-9)
+
+    class MySinCos(tc.SimpleSolenoidalForcing):
+        def potential(self, x, y, s, k):
+            return s * (torch.sin(k * (x + y)) - torch.cos(k * (x + y)))
+
+        def vort_potential(self, x, y, s, k):
+            return s * (torch.cos(k * (x + y)) + torch.sin(k * (x + y)))
+
+    for vort in (True, False):
+        mine, ref = MySinCos(grid, scale=0.1, diam=L, k=2.0, vorticity=vort), tc.SinCosForcing(grid, scale=0.1, diam=L, k=2.0, vorticity=vort)
+        a, b = mine(grid, None), ref(grid, None)
+        if vort:
+            assert torch.equal(a.data, b.data)
+        else:
+            assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1].data, b[1].data)
+    # (the two forms are NOT the same force in general: the reference's momentum amplitude scale / (4 pi k) only matches the
+    #  vorticity form on the unit box, up to sign -- restated as is, golden-tested in test_oracle_golden.py)
+
+
+def test_only_this_modules_steppers_are_fused():
+    from torch_cfd_amd.equations import _is_module_stepper
+
+    assert _is_module_stepper(tc.RK4CrankNicolsonStepper()) and _is_module_stepper(tc.IMEXStepper(order=2))
+    with pytest.raises(ValueError):
+        tc.IMEXStepper(order=4)                 # order 4 is RK4CrankNicolsonStepper's
+
+    class Custom(tc.IMEXStepper):
+        def forward(self, u, dt, equation, params=None):
+            return u
+
+    class CustomSchedule(tc.RK4CrankNicolsonStepper):
+        def stage_schedule(self, params, dt, as_tensors=False):
+            return super().stage_schedule(params, dt / 2)
+
+    assert not _is_module_stepper(Custom(order=1)) and not _is_module_stepper(CustomSchedule()) and not _is_module_stepper(None)
+    patched = tc.IMEXStepper(order=1)
+    patched.stepper = lambda u, dt, eq, params=None: u      # instance-level override, as the reference's own `self.stepper =`
+    assert not _is_module_stepper(patched)
+
+
+def test_imex_schedule_keeps_trainable_parameters_attached():
+    torch.set_default_dtype(torch.float64)
+    s = tc.IMEXStepper(order=2, alpha=2 / 3, beta=0.5, requires_grad=True)
+    plain, attached = s.stage_schedule(s.params, 1e-3), s.stage_schedule(s.params, 1e-3, as_tensors=True)
+    assert all(isinstance(v, float) for vals in plain.values() for v in vals if not isinstance(v, int))
+    assert attached["mu"][0].requires_grad and attached["fa"][1].requires_grad and attached["beta"][1].requires_grad
+    for k in ("fa", "beta", "mu", "mu_den"):
+        assert [float(v) for v in attached[k]] == plain[k]
+    s1 = tc.IMEXStepper(order=1.5, alpha=0.5, requires_grad=True)
+    a1 = s1.stage_schedule(s1.params, 1e-3, as_tensors=True)
+    assert a1["mu"][0].requires_grad and a1["mu_den"][0].requires_grad

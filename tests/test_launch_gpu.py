@@ -40,10 +40,41 @@ def _torchrun(script_args, extra_env=None, timeout=600):
 
 def test_bench_under_torchrun_with_rccl():
     out = _torchrun(["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-sfno", "--no-cpu-baseline",
-                     "--no-probe"], {"BENCH_FORCE_DIST": "1"})
+                     "--no-probe", "--no-c4"], {"BENCH_FORCE_DIST": "1"})
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 10 and out["scaling"] == "weak"
-    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline"]["bound"].startswith("hbm") and 0 < out["roofline"]["frac"] < 1
     assert out["roofline_worst"]["kernel"] in out["kernels"]
+    assert out["launch"]["process_group"] is True and out["launch"]["rccl_world_size"] == 1
+    assert out["strong_scaling"]["fields_per_gpu"] == [64] and out["strong_scaling"]["value"] > 10
+    assert out["dram_bytes_per_step_est"] > 0 and out["dram_GBps_est"] < out["step_algo_GBps"]
+
+
+def test_bench_strong_scaling_through_its_own_spawner():
+    """`python bench.py --gpus 1 --scaling strong` with no launcher environment: the code path `--gpus 8` takes (the
+    spawner only starts children for N > 1; N = 1 runs in place), headline = ONE batch cut across the ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "strong", "--steps", "3", "--warmup", "1", "--no-sfno",
+                        "--no-cpu-baseline", "--no-probe", "--no-c4"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["config"]["batch_total"] == 64 and out["value"] > 10
+    assert out["strong_scaling"] is None and out["per_rank_steps_per_s"][0] == pytest.approx(out["value"], rel=1e-3)
+
+
+def test_bench_c4_ensemble_line_small():
+    """The C4 job line on one GPU with 16 samples: phases split out, dataset finite, hand-over through the pitched copies."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-sfno", "--no-cpu-baseline", "--no-probe",
+                        "--c4-samples", "16", "--batch", "8"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    c4 = out["c4_ensemble"]
+    assert "error" not in c4 and c4["finite"] is True and c4["seconds"] > 0
+    assert c4["stepping_s"] > 0 and c4["handover_tail_s"] >= 0 and c4["dataset_GB"] == pytest.approx(16 * 10 * 4 * 256 * 256 * 4 / 1e9, rel=0.01)
 
 
 def test_config4_example_under_torchrun_with_rccl():

@@ -548,9 +548,11 @@ def test_imex_steppers_golden(order, alpha, beta, dev, monkeypatch):
     wg = w0
     for _ in range(6):
         wg = op.solver.stepper(wg, 1e-3, op)
-    monkeypatch.setenv("TCFD_GRAPH", "0")
+    monkeypatch.setenv("TCFD_GRAPH", "0")      # every TCFD_* switch is read at plan creation and frozen in the plan
+    op.invalidate_plan()
     w6_plain, _ = op(w0, 1e-3, steps=6)
     monkeypatch.setenv("TCFD_GRAPH", "1")
+    op.invalidate_plan()
     w6_graph, _ = op(w0, 1e-3, steps=6)
     assert torch.equal(w6_plain, w6_graph) and rel_l2(w6_plain, wg) < 1e-12
 
@@ -707,6 +709,7 @@ def test_graph_replay_of_interior_steps_is_bit_identical(tag, dev, monkeypatch):
     outs = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("TCFD_GRAPH", flag)
+        op.invalidate_plan()               # switches are frozen per plan
         a, da = op(w0, 1e-3, steps=7)
         b, _ = op(a, 5e-4, steps=4)        # different coefficients: the graph is re-captured
         c, _ = op(b, 5e-4, steps=4)        # same key: replayed
@@ -729,6 +732,7 @@ def test_half_batch_overlap_is_bit_identical(tag, B, steps, dev, monkeypatch):
     for flag in ("0", "1"):
         monkeypatch.setenv("TCFD_OVERLAP", flag)
         monkeypatch.setenv("TCFD_GRAPH", "0")
+        op.invalidate_plan()
         w, d = op(w0, 1e-3, steps=steps)
         w2, d2 = op(w, 1e-3)
         torch.cuda.synchronize()

@@ -17,8 +17,17 @@ from .equations import (  # noqa: F401
     fft_plan,
     stable_time_step,
 )
-from .forcings import FieldArray, ForcingFn, KolmogorovForcing, SinCosForcing  # noqa: F401
+from .forcings import FieldArray, ForcingFn, KolmogorovForcing, SimpleSolenoidalForcing, SinCosForcing  # noqa: F401
 from .solvers import get_trajectory_imex  # noqa: F401
-from .spectral import brick_wall_filter_2d, vorticity_to_velocity  # noqa: F401
+from .spectral import (  # noqa: F401
+    brick_wall_filter_2d,
+    fft_mesh_2d,
+    spectral_curl_2d,
+    spectral_div_2d,
+    spectral_grad_2d,
+    spectral_laplacian_2d,
+    spectral_rot_2d,
+    vorticity_to_velocity,
+)
 
 __version__ = "0.1.0"

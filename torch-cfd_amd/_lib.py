@@ -101,6 +101,7 @@ SIGNATURES = {
     "tcfd_ns2d_plan_destroy": (None, [_vp]),
     "tcfd_ns2d_plan_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "tcfd_ns2d_plan_variant": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "tcfd_ns2d_plan_chunking": (_i, [_vp, _l, ctypes.POINTER(_l), ctypes.POINTER(_sz), ctypes.POINTER(_i)]),
     "tcfd_debug_xl_fft1024": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tcfd_ns2d_workspace_bytes": (_sz, [_vp, _l]),
     "tcfd_ns2d_step": (_i, [_vp, _vp, _vp, _vp, _l, _i, _dp, _dp, _dp, _i, _d, _vp, _sz, _vp]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     "tcfd_weighted_sqnorm": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp]),
     "tcfd_hbm_probe": (_i, [_vp, _vp, ctypes.c_size_t, _i, _i, ctypes.POINTER(ctypes.c_float), _vp]),
+    "tcfd_copy_rows_to_host": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
 }
 
 

@@ -1419,6 +1419,10 @@ struct Tuning {
     int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
     int nyq_pack;            // TCFD_NYQ_PACK: packed Nyquist column in the step (1 = default where the plan allows it)
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
+    int graph;               // TCFD_GRAPH: hipGraph replay of interior steps (-1 = when the state is <= 16 MB)
+    int overlap;             // TCFD_OVERLAP: two half batches on two streams (opt-in experiment)
+    size_t cache_bytes;      // last-level (Infinity Cache / MALL) size of the plan's device: what a chunk is sized for
+    int cache_source;        // 0 = built-in 256 MB, 1 = KFD topology of this device, 2 = TCFD_CACHE_MB
 };
 
 struct tcfd_ns2d_plan {
@@ -1587,6 +1591,49 @@ extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     delete p;
 }
 
+// Size of the memory-side last-level cache (Infinity Cache / MALL) of the CURRENT device.  hipDeviceProp_t has no field
+// for it (l2CacheSize is the per-XCD L2); the KFD topology does: the level-3 entry under
+// /sys/class/kfd/kfd/topology/nodes/<node>/caches/, the node matched to the device by PCI location.  TCFD_CACHE_MB
+// overrides; 256 MB (MI355X) when the topology cannot be read.
+static size_t last_level_cache_bytes(int* source) {
+    *source = 0;
+    const int forced = env_int("TCFD_CACHE_MB", 0);
+    if (forced > 0) { *source = 2; return (size_t)forced << 20; }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (size_t)256 << 20;
+    const long want_loc = ((long)prop.pciBusID << 8) | ((long)prop.pciDeviceID << 3);
+    auto read_props = [](const char* path, const char* const* keys, long* vals, int nk) {
+        FILE* f = fopen(path, "r");
+        if (!f) return false;
+        char key[128];
+        long long v;
+        while (fscanf(f, "%127s %lld", key, &v) == 2)
+            for (int i = 0; i < nk; ++i)
+                if (!strcmp(key, keys[i])) vals[i] = (long)v;
+        fclose(f);
+        return true;
+    };
+    for (int node = 0; node < 128; ++node) {
+        char path[256];
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+        const char* nkeys[] = {"simd_count", "location_id", "domain"};
+        long nv[3] = {0, -1, 0};
+        if (!read_props(path, nkeys, nv, 3)) break;
+        if (nv[0] <= 0 || nv[1] != want_loc || nv[2] != (long)prop.pciDomainID) continue;
+        long best = 0;
+        for (int c = 0; c < 512; ++c) {
+            snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/caches/%d/properties", node, c);
+            const char* ckeys[] = {"level", "size"};
+            long cv[2] = {0, 0};
+            if (!read_props(path, ckeys, cv, 2)) break;
+            if (cv[0] >= 3 && cv[1] > best) best = cv[1];   // size is in KB
+        }
+        if (best > 0) { *source = 1; return (size_t)best << 10; }
+    }
+    return (size_t)256 << 20;
+}
+
 extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
                                      const double* linear_term, const double* mask, const double* forcing_hat) {
     if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
@@ -1607,6 +1654,9 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     p->tune.chunk = env_int("TCFD_CHUNK", -1);
     p->tune.cols_xl = env_int("TCFD_COLS_XL", 1);
     p->tune.nyq_pack = env_int("TCFD_NYQ_PACK", 1);
+    p->tune.graph = env_int("TCFD_GRAPH", -1);
+    p->tune.overlap = env_int("TCFD_OVERLAP", 0);
+    p->tune.cache_bytes = last_level_cache_bytes(&p->tune.cache_source);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
         p->ldw = (p->m + per_line - 1) / per_line * per_line;
@@ -2083,7 +2133,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     {
         // opt-in (TCFD_OVERLAP=1): measured +2.6 % at 1024^2 x 64 fp64 -- both kernels fill the VGPR file, so the CUs
         // time-slice the two halves instead of co-running them; not worth two streams by default
-        if (batch >= 2 && env_int("TCFD_OVERLAP", 0) == 1)
+        if (batch >= 2 && p->tune.overlap == 1)
             return step_overlap_impl<T, N>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu, fa, mud, base0, steps,
                                            inv_total_dt, ws, st);
     }
@@ -2143,7 +2193,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
         return 0;
     };
     const long state_bytes = (long)batch * N * p->ldw * (long)sizeof(cx<T>);
-    const int graph_env = env_int("TCFD_GRAPH", -1);
+    const int graph_env = p->tune.graph;
     const bool profiling = p->prof && p->prof->on;
     const bool use_graph = steps >= 3 && !profiling &&
                            (graph_env == 1 || (graph_env != 0 && state_bytes <= (long)16 << 20));  // launch-bound regime
@@ -2299,6 +2349,15 @@ static int check_ws(const tcfd_ns2d_plan* p, long batch, void* ws, size_t bytes,
     return 0;
 }
 
+extern "C" int tcfd_ns2d_plan_chunking(const tcfd_ns2d_plan* p, long batch, long* fields_per_chunk, size_t* cache_bytes,
+                                       int* cache_source) {
+    if (!p || batch < 0) return fail(TCFD_EINVAL, "plan_chunking: bad argument");
+    if (fields_per_chunk) *fields_per_chunk = batch > 0 ? chunk_fields(p, batch) : 0;
+    if (cache_bytes) *cache_bytes = p->tune.cache_bytes;
+    if (cache_source) *cache_source = p->tune.cache_source;
+    return 0;
+}
+
 // Fields per chunk of a batched call.  TCFD_CHUNK > 0 forces it, 0 disables chunking, -1 (default) sizes the chunk so
 // that its working set -- 4 planes + advection + RK accumulator + padded state, 7 workspace fields per batch element --
 // fits the 256 MB Infinity Cache (measured on MI355X, steps/s per call: 1024^2 x 64 fp64 122.7 -> 129.3 at 4 fields
@@ -2309,7 +2368,8 @@ static long chunk_fields(const tcfd_ns2d_plan* p, long batch) {
     if (c == 0) return batch;
     if (c < 0) {
         const size_t per_field = 7 * (size_t)p->n * p->ldw * (p->dtype == TCFD_C128 ? 16 : 8);
-        c = (long)(((size_t)244 << 20) / per_field);
+        // 61/64 of the cache (244 of 256 MB, the measured optimum on MI355X: 4 fields of 1024^2 fp64 = 239 MB fit, 5 do not)
+        c = (long)((p->tune.cache_bytes / 64 * 61) / per_field);
         if (c < 3) return batch;
     }
     if (c >= batch) return batch;
@@ -2595,5 +2655,18 @@ extern "C" int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode
     (void)hipEventDestroy(e1);
     HIP_TRY(hipGetLastError());
     *ms = t / iters;
+    return 0;
+}
+
+// ---------------------------------------------------------------- strided device -> host copy of record slabs
+// One record of `rows` samples lands in a host array whose sample pitch is a whole trajectory: a pitched copy on the caller's
+// stream (asynchronous when the host side is page-locked), so the hand-over of a record overlaps the steps that follow it.
+extern "C" int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                                      size_t row_bytes, size_t rows, void* stream) {
+    if (!dst_host || !src_dev || row_bytes == 0 || dst_pitch < row_bytes || src_pitch < row_bytes)
+        return fail(TCFD_EINVAL, "copy_rows_to_host: bad argument");
+    if (rows == 0) return 0;
+    HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost,
+                             (hipStream_t)stream));
     return 0;
 }

@@ -18,7 +18,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from .distributed import TRAJECTORY_FIELDS, gather_trajectory, shard_batch
+from .distributed import TRAJECTORY_FIELDS
 from .equations import NavierStokes2DSpectral, RK4CrankNicolsonStepper, fft_plan
 from .grids import Grid
 from .initial_conditions import vorticity_field
@@ -47,40 +47,68 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
                                 diam: float = 2 * torch.pi, peak_wavenumber: float = 4, random_state: int = 0,
                                 subsample: int = 1, dtype: torch.dtype = torch.float32,
                                 cdtype: torch.dtype = torch.complex64, device="cuda", dst: int = 0,
-                                path: Optional[str] = None) -> Optional[Dict[str, torch.Tensor]]:
+                                path: Optional[str] = None, stats: Optional[dict] = None
+                                ) -> Optional[Dict[str, torch.Tensor]]:
     """Decaying-turbulence ensemble (McWilliams IC).  Computes in the torch default dtype (the reference driver
     sets float64), stores ``dtype`` / ``cdtype``.  Returns the dataset dict on rank ``dst`` (saved with
-    ``torch.save`` when ``path`` is given), ``None`` on the other ranks."""
+    ``torch.save`` when ``path`` is given), ``None`` on the other ranks.
+
+    Every record is post-processed (c2r, subsample, cast) on the device as soon as it exists and handed to the host
+    of ``dst`` on side streams while the next steps run (``distributed.RecordHandover``): peers -> ``dst`` over RCCL,
+    ``dst`` -> its page-locked result over PCIe.  ``stats`` (optional dict) receives the wall-clock split: ``setup_s``
+    (operator, plans, page-locked result), ``stepping_s`` (until this rank's last step has finished on the device,
+    hand-over of all earlier records running underneath) and ``handover_tail_s`` (what is left of the hand-over
+    after that: the un-hidden part of gather + D2H)."""
+    import time
+
     import torch.distributed as dist
 
+    from .distributed import RecordHandover, batch_layout
+
+    t_begin = time.perf_counter()
     device = torch.device(device)
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size() if distributed else 1
     rank = dist.get_rank() if distributed else 0
-    lo, hi = shard_batch(total_samples, rank, world)
+    layout = batch_layout(total_samples, world, batch_size)
     grid = Grid(shape=(n, n), domain=((0, diam), (0, diam)), device=device)
     op = NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=0, smooth=True, forcing_fn=None,
                                 solver=RK4CrankNicolsonStepper()).to(device)
     real = torch.get_default_dtype()
     plan = fft_plan(n, torch.complex128 if real == torch.float64 else torch.complex64, device, diam)
     ns = n // subsample
-    chunks = []
-    for start in range(lo, hi, batch_size):
-        seeds = [random_state + start + k for k in range(min(batch_size, hi - start))]
+    n_rec = len(range(0, total_steps, record_every_steps))
+    handover = RecordHandover(TRAJECTORY_FIELDS, total_samples, n_rec, (ns, ns), dtype, layout, device, dst=dst)
+    on_gpu = device.type == "cuda"
+    if on_gpu:
+        torch.cuda.synchronize(device)
+    t_setup = time.perf_counter()
+    for start, count in layout[rank]:
+        seeds = [random_state + start + k for k in range(count)]
         w = plan.rfft2(vorticity_field(grid, peak_wavenumber, batch_seeds=seeds, device=device))
         if warmup_steps > 0:
             w, _ = op._fused_steps(w, dt, warmup_steps, want_dwdt=False)
-        result = get_trajectory_imex(op, w, dt, num_steps=total_steps, record_every_steps=record_every_steps,
-                                     dtype=cdtype, to_cpu=False)
-        result = {k: spectral_to_physical(v, ns, dtype) for k, v in result.items()}
-        result["random_states"] = torch.tensor(seeds, dtype=torch.int32, device=device)
-        chunks.append(result)
-    local = {k: torch.cat([c[k] for c in chunks]) for k in chunks[0]} if chunks else {}   # empty shard: no tensors
-    # with a process group (even of one rank: torchrun --nproc-per-node 1) the hand-over goes through the collective path
-    full = gather_trajectory(local, total_samples, dst=dst, keys=DATASET_FIELDS) if distributed else local
+
+        def sink(rec, fields, start=start, count=count):
+            packed = torch.empty((count, len(TRAJECTORY_FIELDS), ns, ns), dtype=dtype, device=device)
+            for f, name in enumerate(TRAJECTORY_FIELDS):
+                packed[:, f] = spectral_to_physical(fields[name], ns, dtype)
+            handover.push(start, rec, packed)
+
+        get_trajectory_imex(op, w, dt, num_steps=total_steps, record_every_steps=record_every_steps, dtype=cdtype,
+                            to_cpu=False, record_sink=sink)
+    if on_gpu:
+        torch.cuda.current_stream(device).synchronize()
+    t_stepped = time.perf_counter()
+    full = handover.finish()
+    t_end = time.perf_counter()
+    if stats is not None:
+        stats.update(setup_s=t_setup - t_begin, stepping_s=t_stepped - t_setup, handover_tail_s=t_end - t_stepped,
+                     batches=len(layout[rank]), samples=sum(c for _, c in layout[rank]))
     if full is None:
         return None
-    full = {k: v.cpu() for k, v in full.items()}
+    full = dict(full)
+    full["random_states"] = torch.arange(random_state, random_state + total_samples, dtype=torch.int32)
     if path is not None:
         torch.save(full, path)
     return full

@@ -28,6 +28,12 @@ def shard_batch(total: int, rank: int, world_size: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def _global_rank(group, group_rank: int) -> int:
+    """``dist.P2POp`` / ``isend`` / ``irecv`` address peers by GLOBAL rank; ranks and ``dst`` of this module are
+    ranks within ``group``."""
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 def _describe(local: Dict[str, torch.Tensor]) -> List[tuple]:
     return [(k, tuple(v.shape[1:]), str(v.dtype)) for k, v in sorted(local.items())]
 
@@ -47,14 +53,19 @@ def gather_trajectory(local: Dict[str, torch.Tensor], total_batch: int, dst: int
     spans = [shard_batch(total_batch, r, world) for r in range(world)]
     lo, hi = spans[rank]
     mine = _describe(local) if keys is None else _describe({k: local[k] for k in keys if k in local})
-    every: List[Optional[list]] = [None] * world
-    dist.all_gather_object(every, mine, group=group)
-    layout = next((d for d in every if d), None)
+    sizes = sorted({int(v.shape[0]) for v in local.values()})
+    every: List[Optional[tuple]] = [None] * world
+    dist.all_gather_object(every, (mine, sizes), group=group)
+    layout = next((d for d, _ in every if d), None)
     if layout is None:
         return {} if rank == dst else None
-    for r, d in enumerate(every):
+    # every rank sees every rank's description, so a bad shard raises on ALL ranks before any point-to-point
+    # operation is posted (a one-sided error would leave the others blocked in their sends / receives)
+    for r, (d, sz) in enumerate(every):
         if d and d != layout:
             raise ValueError(f"rank {r} holds {d}, rank layout agreed on is {layout}")
+        if d and sz != [spans[r][1] - spans[r][0]]:
+            raise ValueError(f"rank {r}: local batch sizes {sz} != shard size {spans[r][1] - spans[r][0]}")
     some = next(iter(local.values())) if local else None
     device = some.device if some is not None else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
@@ -63,8 +74,6 @@ def gather_trajectory(local: Dict[str, torch.Tensor], total_batch: int, dst: int
     for key, trailing, dtype_name in layout:
         dtype = getattr(torch, dtype_name.replace("torch.", ""))
         x = local.get(key)
-        if x is not None and x.shape[0] != hi - lo:
-            raise ValueError(f"{key}: local batch {x.shape[0]} != shard size {hi - lo}")
         if rank == dst:
             full = torch.empty((total_batch,) + trailing, dtype=dtype, device=device)
             out[key] = full
@@ -73,12 +82,13 @@ def gather_trajectory(local: Dict[str, torch.Tensor], total_batch: int, dst: int
             for r, (a, b) in enumerate(spans):
                 if r != dst and b > a:
                     view = full[a:b]   # contiguous: the slice is along the leading axis
-                    ops.append(dist.P2POp(dist.irecv, torch.view_as_real(view) if view.is_complex() else view, r,
-                                          group=group))
+                    ops.append(dist.P2POp(dist.irecv, torch.view_as_real(view) if view.is_complex() else view,
+                                          _global_rank(group, r), group=group))
         elif hi > lo:
             xs = x.contiguous()
             keep.append(xs)
-            ops.append(dist.P2POp(dist.isend, torch.view_as_real(xs) if xs.is_complex() else xs, dst, group=group))
+            ops.append(dist.P2POp(dist.isend, torch.view_as_real(xs) if xs.is_complex() else xs,
+                                  _global_rank(group, dst), group=group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -97,3 +107,159 @@ def sharded_trajectory(equation, w0_local: torch.Tensor, total_batch: int, dt: f
     if full is not None and dist.is_initialized() and dist.get_backend(group) != "gloo":
         full = {k: v.cpu() for k, v in full.items()}
     return full
+
+
+# ----------------------------------------------------------------------------- per-record hand-over, overlapped
+def batch_layout(total: int, world_size: int, batch_size: int) -> List[List[Tuple[int, int]]]:
+    """Per rank, the ``(start, count)`` batches its contiguous shard of ``total`` samples is generated in (the serial
+    batch loop of fno/data_gen/data_gen_McWilliams2d.py:126-152, cut across ranks).  Every rank computes the whole
+    table, so the receiver knows what each peer is going to send without asking."""
+    if batch_size < 1:
+        raise ValueError("batch_size must be positive")
+    table = []
+    for r in range(world_size):
+        lo, hi = shard_batch(total, r, world_size)
+        table.append([(s, min(batch_size, hi - s)) for s in range(lo, hi, batch_size)])
+    return table
+
+
+class RecordHandover:
+    """Hands the post-processed records of an ensemble job to the host of rank ``dst`` WHILE the steps go on.
+
+    A record of a batch is ``(count, F, *trailing)`` real values on the device (F fields).  ``push`` is called right
+    after the record was produced on the current stream and returns at once:
+
+      * on a peer, the record goes to ``dst`` with one point-to-point send (RCCL over xGMI; the collective library
+        runs it on its own stream, ordered after the current one);
+      * on ``dst``, one receive per peer is posted for that peer's next record (all peers in one group call: seven
+        links at once), and everything that has arrived -- and ``dst``'s own record -- is copied into its
+        ``(sample, record)`` slot of the page-locked host result by pitched copies on a side stream
+        (``tcfd_copy_rows_to_host``), so PCIe runs under the next ``record_every`` steps too.
+
+    ``finish`` posts the receives still outstanding, waits, and returns ``{field: (total, n_rec, *trailing)}`` host
+    tensors on ``dst`` (``None`` elsewhere).  What a job pays at the end is the hand-over of the LAST record only.
+    No process group: the same pipeline with the device -> host stage alone.  CPU tensors (gloo, the tests): plain
+    blocking copies."""
+
+    def __init__(self, fields: Sequence[str], total: int, n_rec: int, trailing: Tuple[int, ...], dtype: torch.dtype,
+                 layout: List[List[Tuple[int, int]]], device, dst: int = 0, group: Optional[dist.ProcessGroup] = None):
+        self.fields, self.total, self.n_rec = tuple(fields), total, n_rec
+        self.trailing, self.dtype = tuple(trailing), dtype
+        self.device = torch.device(device)
+        self.group, self.dst = group, dst
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        if len(layout) != self.world:
+            raise ValueError(f"layout describes {len(layout)} ranks, the group has {self.world}")
+        self.items = [[(s, c, j) for (s, c) in batches for j in range(n_rec)] for batches in layout]
+        self.cursor = [0] * self.world
+        self.on_gpu = self.device.type == "cuda"
+        self.row_bytes = int(torch.tensor([], dtype=dtype).element_size())
+        for d in self.trailing:
+            self.row_bytes *= d
+        self._keep: list = []          # device buffers a copy or a send still reads
+        self._sends: list = []
+        self.host: Optional[Dict[str, torch.Tensor]] = None
+        if self.rank == dst:
+            self.host = {f: torch.empty((total, n_rec) + self.trailing, dtype=dtype, pin_memory=self.on_gpu)
+                         for f in self.fields}
+        if self.on_gpu:
+            from . import _lib
+
+            self._lib = _lib
+            self._clib = _lib.load()
+            self.side = torch.cuda.Stream(device=self.device)
+
+    # -- dst side
+    def _land(self, buf: torch.Tensor, start: int, count: int, rec: int, work=None):
+        """Copy ``buf`` (count, F, *trailing) into host[f][start:start+count, rec] for every field."""
+        if not self.on_gpu:
+            if work is not None:
+                work.wait()
+            for f, name in enumerate(self.fields):
+                self.host[name][start:start + count, rec].copy_(buf[:, f])
+            return
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.side):
+            if work is not None:
+                work.wait()                      # orders the side stream behind the receive, the host does not block
+            else:
+                self.side.wait_stream(main)      # own record: produced on the caller's stream
+            F = len(self.fields)
+            import ctypes
+
+            for f, name in enumerate(self.fields):
+                h = self.host[name]
+                rc = self._clib.tcfd_copy_rows_to_host(
+                    h[start, rec].data_ptr(), self.n_rec * self.row_bytes, buf[:, f].data_ptr(), F * self.row_bytes,
+                    self.row_bytes, count, ctypes.c_void_p(self.side.cuda_stream))
+                self._lib.check(rc, "tcfd_copy_rows_to_host")
+        self._keep.append(buf)
+
+    def _post_receives(self):
+        """One receive per peer that still has a record to send (its next one), all in one group call."""
+        ops, meta = [], []
+        for r in range(self.world):
+            if r == self.dst or self.cursor[r] >= len(self.items[r]):
+                continue
+            s, c, j = self.items[r][self.cursor[r]]
+            self.cursor[r] += 1
+            stage = torch.empty((c, len(self.fields)) + self.trailing, dtype=self.dtype, device=self.device)
+            ops.append(dist.P2POp(dist.irecv, stage, _global_rank(self.group, r), group=self.group))
+            meta.append((stage, s, c, j))
+        if not ops:
+            return False
+        works = dist.batch_isend_irecv(ops)
+        if len(works) == len(meta):
+            for w, (stage, s, c, j) in zip(works, meta):
+                self._land(stage, s, c, j, work=w)
+        else:   # one coalesced work object for the whole group
+            for i, (stage, s, c, j) in enumerate(meta):
+                self._land(stage, s, c, j, work=works[0] if i == 0 else _Done())
+        return True
+
+    # -- every rank
+    def push(self, start: int, rec: int, packed: torch.Tensor):
+        mine = self.items[self.rank]
+        k = self.cursor[self.rank]
+        if k >= len(mine) or mine[k][0] != start or mine[k][2] != rec:
+            raise ValueError(f"rank {self.rank}: record (start {start}, index {rec}) pushed out of order; "
+                             f"expected {mine[k] if k < len(mine) else 'nothing'}")
+        count = mine[k][1]
+        want = (count, len(self.fields)) + self.trailing
+        if tuple(packed.shape) != want or packed.dtype != self.dtype or not packed.is_contiguous():
+            raise ValueError(f"record must be a contiguous {self.dtype} tensor of shape {want}, got "
+                             f"{tuple(packed.shape)} {packed.dtype}")
+        self.cursor[self.rank] += 1
+        if self.rank == self.dst:
+            self._land(packed, start, count, rec)
+            if self.world > 1:
+                self._post_receives()
+        else:
+            self._sends.append((dist.isend(packed, _global_rank(self.group, self.dst), group=self.group), packed))
+
+    def finish(self) -> Optional[Dict[str, torch.Tensor]]:
+        if self.cursor[self.rank] != len(self.items[self.rank]):
+            raise RuntimeError(f"rank {self.rank}: {len(self.items[self.rank]) - self.cursor[self.rank]} records were "
+                               "never pushed")
+        if self.rank == self.dst:
+            while self.world > 1 and self._post_receives():
+                pass
+            if self.on_gpu:
+                self.side.synchronize()
+            self._keep.clear()
+            return self.host
+        for work, _ in self._sends:
+            work.wait()
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._sends.clear()
+        return None
+
+
+class _Done:
+    """Stand-in for the members of a coalesced group whose single work object was already waited on."""
+
+    def wait(self):
+        return True

@@ -42,13 +42,14 @@ _REAL_OF = {torch.complex64: torch.float32, torch.complex128: torch.float64}
 def stable_time_step(dx: float = None, dt: float = None, max_velocity: float = 1.0,
                      max_courant_number: float = 0.5, viscosity: float = 1e-3,
                      implicit_diffusion: bool = True, ndim: int = 2) -> float:
-    """CFL-limited time step: min(diffusion limit, advection limit, dt)."""
-    dt_diffusion = dx
-    if not implicit_diffusion:
-        dt_diffusion = dx**2 / (viscosity * 2 ** (ndim))
-    dt_advection = max_courant_number * dx / max_velocity
-    dt = dt_advection if dt is None else dt
-    return min(dt_diffusion, dt_advection, dt)
+    """Largest admissible step: the smallest of the caller's ``dt`` (if any), the advective CFL bound
+    ``C dx / v_max`` and the diffusive bound -- ``dx^2 / (2^ndim nu)`` for explicit diffusion, just ``dx`` when
+    diffusion is treated implicitly (torch_cfd/equations.py:35-64)."""
+    bounds = [max_courant_number * dx / max_velocity,
+              dx if implicit_diffusion else dx * dx / (viscosity * 2**ndim)]
+    if dt is not None:
+        bounds.append(dt)
+    return min(bounds)
 
 
 # ----------------------------------------------------------------------------- HIP plan wrapper
@@ -313,7 +314,8 @@ class IMEXStepper(nn.Module):
     def __init__(self, order: float = 2, alpha: float = 0.5, beta: Optional[float] = 0.5,
                  requires_grad: bool = False, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if order not in (1, 1.5, 2, 4):
+        if order not in (1, 1.5, 2, 4) or (order == 4 and type(self) is IMEXStepper):
+            # order 4 is RK4CrankNicolsonStepper's; the reference's base class would be left without a stepper
             raise ValueError(f"IMEXStepper: unsupported order {order}")
         self.order = order
         self._set_params({"alpha": torch.tensor(alpha), "beta": torch.tensor(beta)}, requires_grad=requires_grad)
@@ -322,15 +324,20 @@ class IMEXStepper(nn.Module):
         self.params = nn.ParameterDict({k: nn.Parameter(v, requires_grad=requires_grad) for k, v in params.items()})
         self.requires_grad = requires_grad
 
-    def stage_schedule(self, params: Params, dt: float) -> Dict[str, list]:
+    def stage_schedule(self, params: Params, dt: float, as_tensors: bool = False) -> Dict[str, list]:
         """Per-stage scalars, each rounded the way the reference's 0-dim tensor arithmetic rounds it
-        (``(1 - alpha) * dt`` is a default-dtype tensor product there, equations.py:174-228)."""
-        alpha = params["alpha"].detach().cpu()
+        (``(1 - alpha) * dt`` is a default-dtype tensor product there, equations.py:174-228).  ``as_tensors`` keeps
+        the entries that depend on ``alpha`` / ``beta`` as 0-dim tensors attached to the parameters, so a trainable
+        scheme (``requires_grad=True``) receives gradients when the step runs in its differentiable form."""
+        if as_tensors:
+            alpha, num = params["alpha"], (lambda t: t)
+        else:
+            alpha, num = params["alpha"].detach().cpu(), (lambda t: t.item())
         if self.order in (1, 1.5):
-            return {"fa": [1.0], "beta": [0.0], "gdt": [float(dt)], "mu": [((1 - alpha) * dt).item()],
-                    "mu_den": [(alpha * dt).item()], "base0": [0]}
-        half = (params["beta"].detach().cpu() * dt).item()   # Crank-Nicolson weight of both stages
-        return {"fa": [1.0, alpha.item()], "beta": [0.0, (1 - alpha).item()], "gdt": [float(dt)] * 2,
+            return {"fa": [1.0], "beta": [0.0], "gdt": [float(dt)], "mu": [num((1 - alpha) * dt)],
+                    "mu_den": [num(alpha * dt)], "base0": [0]}
+        half = num((params["beta"] if as_tensors else params["beta"].detach().cpu()) * dt)   # Crank-Nicolson weight of both stages
+        return {"fa": [1.0, num(alpha * 1)], "beta": [0.0, num(1 - alpha)], "gdt": [float(dt)] * 2,
                 "mu": [half, half], "mu_den": [half, half], "base0": [0, 1]}
 
     def stepper(self, u, dt, equation, params=None):
@@ -339,10 +346,22 @@ class IMEXStepper(nn.Module):
 
     def forward(self, u, dt, equation, params=None):
         params = self.params if params is None else params
-        if isinstance(equation, NavierStokes2DSpectral):
+        if isinstance(equation, NavierStokes2DSpectral) and _is_module_stepper(self):
             out, _ = equation._fused_steps(u, dt, 1, params, want_dwdt=False, stepper=self)
             return out
         return self.stepper(u, dt, equation, params)
+
+
+def _is_module_stepper(solver) -> bool:
+    """True when ``solver`` steps exactly as this module's schemes do, i.e. its stage schedule may go to the fused
+    kernels.  A user subclass that overrides ``forward`` / ``stepper`` / ``stage_schedule`` is a different scheme:
+    it is called as ``solver(u, dt, equation)`` (its explicit terms still run on HIP), never replaced silently."""
+    if not isinstance(solver, IMEXStepper):
+        return False
+    cls = type(solver)
+    own_schedules = (IMEXStepper.stage_schedule, RK4CrankNicolsonStepper.stage_schedule)
+    return (cls.forward is IMEXStepper.forward and cls.stepper is IMEXStepper.stepper
+            and cls.stage_schedule in own_schedules and "stepper" not in vars(solver) and "forward" not in vars(solver))
 
 
 _CARPENTER_KENNEDY = {   # 5-stage low-storage RK4 (2N storage), the reference's default weights (equations.py:294-317)
@@ -377,7 +396,8 @@ class RK4CrankNicolsonStepper(IMEXStepper):
         return ([be[k].item() for k in stages], [(ga[k] * dt).item() for k in stages],
                 [(0.5 * dt * (al[k + 1] - al[k])).item() for k in stages])
 
-    def stage_schedule(self, params: Params, dt: float) -> Dict[str, list]:
+    def stage_schedule(self, params: Params, dt: float, as_tensors: bool = False) -> Dict[str, list]:
+        # (trainable RK coefficients do not come through here: autograd.rk_crank_nicolson_steps reads the tensors)
         beta, gdt, mu = self.stage_scalars(params, dt)
         return {"beta": beta, "gdt": gdt, "mu": mu, "fa": None, "mu_den": None, "base0": None}
 
@@ -503,8 +523,10 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
         forcing = self._forcing_on(w)
         if isinstance(stepper, RK4CrankNicolsonStepper):
             out = ad.rk_crank_nicolson_steps(self, plan, w, dt, steps, params, forcing)
-        else:
-            out = ad.scheduled_steps(self, plan, w, steps, stepper.stage_schedule(params, dt), forcing)
+        else:   # alpha / beta stay tensors: a trainable IMEX scheme gets its gradients (as the reference's 0-dim arithmetic gives)
+            sched = stepper.stage_schedule(params, dt, as_tensors=True)
+            sched = {k: [v.to(w.device) if torch.is_tensor(v) else v for v in vals] for k, vals in sched.items()}
+            out = ad.scheduled_steps(self, plan, w, steps, sched, forcing)
         out = out.reshape(lead)
         return out, ((out - vort_hat) / (steps * dt) if want_dwdt else None)
 
@@ -558,7 +580,7 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
         """``vort_hat``: (B, n, m), (B, T, n, m) or (n, m) half spectrum.  Returns the state after ``steps`` steps and
         ``(new - old) / (steps * dt)``.  With a stepper of this module all stages of all steps run fused in the HIP
         kernels; a foreign ``solver(u, dt, equation)`` callable is looped over (its explicit terms still run on HIP)."""
-        if isinstance(self.solver, IMEXStepper):
+        if _is_module_stepper(self.solver):
             return self._fused_steps(vort_hat, dt, steps)
         if self.solver is None:
             raise TypeError("NavierStokes2DSpectral.forward needs a solver (e.g. RK4CrankNicolsonStepper())")

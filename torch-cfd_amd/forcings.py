@@ -71,15 +71,27 @@ class ForcingFn(nn.Module):
     def curl(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError(f"{type(self).__name__} has no vorticity-equation form")
 
-    def forward(self, grid: Optional[Grid] = None, field=None):
+    # The reference's extension points (torch_cfd/forcings.py:97-116): a user forcing written against the reference
+    # overrides ``velocity_eval(grid, velocity)`` and / or ``vorticity_eval(grid, vorticity)`` and returns sampled
+    # data; ``forward`` dispatches on ``self.vorticity`` exactly as there.  The built-in family implements the two
+    # hooks once, here, on top of ``momentum`` / ``curl``.
+    def velocity_eval(self, grid: Optional[Grid], velocity=None):
         grid = self.grid if grid is None else grid
         off_x, off_y = self.offsets
-        if self.vorticity:
-            x, y = grid.mesh(off_x)
-            return FieldArray(self.curl(x, y), off_x, grid)
         (x, _), (_, y) = grid.mesh(off_x), grid.mesh(off_y)
         fx, fy = self.momentum(x, y)
         return FieldArray(fx, off_x, grid), FieldArray(fy, off_y, grid)
+
+    def vorticity_eval(self, grid: Optional[Grid], vorticity=None):
+        grid = self.grid if grid is None else grid
+        off_x = self.offsets[0]
+        x, y = grid.mesh(off_x)
+        return FieldArray(self.curl(x, y), off_x, grid)
+
+    def forward(self, grid: Optional[Grid] = None, velocity=None, vorticity=None):
+        if self.vorticity:
+            return self.vorticity_eval(grid, vorticity)
+        return self.velocity_eval(grid, velocity)
 
 
 class KolmogorovForcing(ForcingFn):
@@ -105,21 +117,44 @@ class KolmogorovForcing(ForcingFn):
         return -self.scale * k * torch.cos(k * s)
 
 
-class SinCosForcing(ForcingFn):
-    """The FNO-paper forcing ``scale * (sin(k (x + y)) + cos(k (x + y)))`` on the vorticity equation (the default
-    here as in the reference, ``vorticity=True``).  Its momentum form is the solenoidal pair ``(g, -g)`` with
-    ``g = a (sin(k (x + y)) - cos(k (x + y)))``, ``a = scale / (4 pi wave_number)``; ``swap_xy`` flips its sign."""
+class SimpleSolenoidalForcing(ForcingFn):
+    """Template of a divergence-free forcing given by ONE scalar profile (torch_cfd/forcings.py:220-297): the momentum
+    form is the pair ``(g, -g)`` with ``g = potential(x, y, a, k)``, ``a = scale / (4 pi wave_number)``, and the force
+    on the vorticity equation is ``vort_potential(x, y, scale, k)``, ``k`` the angular wavenumber.  ``swap_xy`` flips
+    the sign of the pair.  Subclasses supply the two profiles (plain functions of ``(x, y, amplitude, k)``)."""
 
-    def __init__(self, grid: Grid, scale: float = 0.1, diam: float = 1.0, k: float = 1.0, swap_xy: bool = False,
+    def __init__(self, grid: Grid, scale: float = 1, diam: float = 1.0, k: float = 1.0, swap_xy: bool = False,
                  vorticity: bool = True, offsets=None, device=None, **unused):
         super().__init__(grid, scale=scale, wave_number=k, diam=diam, swap_xy=swap_xy, vorticity=vorticity,
                          offsets=offsets, device=device)
 
+    def potential(self, x, y, s, k):
+        raise NotImplementedError(f"{type(self).__name__}.potential")
+
+    def vort_potential(self, x, y, s, k):
+        raise NotImplementedError(f"{type(self).__name__}.vort_potential")
+
     def momentum(self, x, y):
-        phase = self.angular_wavenumber * (x + y)
-        g = self.scale / (4 * math.pi * self.wave_number) * (torch.sin(phase) - torch.cos(phase))
+        g = self.potential(x, y, self.scale / (4 * math.pi * self.wave_number), self.angular_wavenumber)
         return (-g, g) if self.swap_xy else (g, -g)
 
     def curl(self, x, y):
-        phase = self.angular_wavenumber * (x + y)
-        return self.scale * (torch.cos(phase) + torch.sin(phase))
+        return self.vort_potential(x, y, self.scale, self.angular_wavenumber)
+
+
+class SinCosForcing(SimpleSolenoidalForcing):
+    """The FNO-paper forcing ``scale * (sin(k (x + y)) + cos(k (x + y)))`` on the vorticity equation (the default
+    here as in the reference, ``vorticity=True``); momentum profile ``a (sin(k (x + y)) - cos(k (x + y)))``."""
+
+    def __init__(self, grid: Grid, scale: float = 0.1, diam: float = 1.0, k: float = 1.0, swap_xy: bool = False,
+                 vorticity: bool = True, offsets=None, device=None, **unused):
+        super().__init__(grid, scale=scale, diam=diam, k=k, swap_xy=swap_xy, vorticity=vorticity, offsets=offsets,
+                         device=device)
+
+    def potential(self, x, y, s, k):
+        phase = k * (x + y)
+        return s * (torch.sin(phase) - torch.cos(phase))
+
+    def vort_potential(self, x, y, s, k):
+        phase = k * (x + y)
+        return s * (torch.cos(phase) + torch.sin(phase))

@@ -38,8 +38,6 @@ class Grid:
     """``shape`` samples on the periodic box ``domain``; sample i of axis a sits at
     ``lo_a + (i + offset_a) * step_a`` (offset 1/2 = cell centres, 0 = cell corners)."""
 
-    __slots__ = ("shape", "domain", "step", "device")
-
     def __init__(self, shape, step=None, domain=None, device="cpu"):
         self.shape = tuple(int(n) for n in shape)
         if any(n <= 0 for n in self.shape):
@@ -54,13 +52,27 @@ class Grid:
     def ndim(self):
         return len(self.shape)
 
+    @property
+    def cell_center(self):
+        """Offset (in cells) of the cell centres: 1/2 along every axis."""
+        return (0.5,) * self.ndim
+
+    @property
+    def cell_faces(self):
+        """Per axis a, the offset of the face a cell shares with its upper neighbour along a: 1 there, 1/2 elsewhere
+        (the staggered positions the reference's forcings default to, torch_cfd/grids.py:117-121)."""
+        return tuple(tuple(1.0 if b == a else 0.5 for b in range(self.ndim)) for a in range(self.ndim))
+
+    def axes(self, offset=None):
+        """1-D sample positions per axis, shifted by ``offset`` cells (default: cell centres)."""
+        offset = self.cell_center if offset is None else tuple(offset)
+        if len(offset) != self.ndim:
+            raise ValueError(f"Grid.axes: offset {offset} for a {self.ndim}-D grid")
+        return tuple(lo + (torch.arange(n) + o) * h for (lo, _), n, o, h in zip(self.domain, self.shape, offset, self.step))
+
     def mesh(self, offset=None):
         """Coordinate arrays (``indexing='ij'``) of the samples shifted by ``offset`` cells (default 1/2)."""
-        offset = (0.5,) * self.ndim if offset is None else tuple(offset)
-        if len(offset) != self.ndim:
-            raise ValueError(f"Grid.mesh: offset {offset} for a {self.ndim}-D grid")
-        lines = [lo + (torch.arange(n) + o) * h for (lo, _), n, o, h in zip(self.domain, self.shape, offset, self.step)]
-        return tuple(c.to(self.device) for c in torch.meshgrid(*lines, indexing="ij"))
+        return tuple(c.to(self.device) for c in torch.meshgrid(*self.axes(offset), indexing="ij"))
 
     # -- wavenumbers (ordinal: cycles per unit length; the kernels multiply by 2 pi)
     def fft_axes(self):

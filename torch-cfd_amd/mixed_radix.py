@@ -153,7 +153,8 @@ class TensorOpPlan:
         lap = (-4 * torch.pi**2 * (kx**2 + ky**2)).clone()
         lap[..., 0, 0] = 1
         psi = -w3 / lap
-        return (2j * torch.pi * ky * psi, -2j * torch.pi * kx * psi), psi
+        shape = w.shape     # same shapes as the power-of-two plan and the reference: (n, m) in -> (n, m) out
+        return ((2j * torch.pi * ky * psi).reshape(shape), (-2j * torch.pi * kx * psi).reshape(shape)), psi.reshape(shape)
 
     def stream_residual(self, w, wt, want_psi=True, want_res=True):
         psi = res = None

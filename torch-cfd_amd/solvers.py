@@ -14,11 +14,11 @@ from __future__ import annotations
 
 import math
 from datetime import datetime
-from typing import Dict
+from typing import Callable, Dict, Optional
 
 import torch
 
-from .equations import ImplicitExplicitODE, RK4CrankNicolsonStepper
+from .equations import ImplicitExplicitODE, _is_module_stepper
 
 TQDM_ITERS = 200
 
@@ -34,11 +34,15 @@ def get_trajectory_imex(
     require_grad: bool = False,
     dtype: torch.dtype = torch.complex64,
     to_cpu: bool = True,
+    record_sink: Optional[Callable[[int, Dict[str, torch.Tensor]], None]] = None,
 ) -> Dict[str, torch.Tensor]:
     """w0 (*, n, m) half spectrum -> dict(vorticity, stream, vort_t, residual),
     each (*, n_t, n, m) complex ``dtype`` with one snapshot after every step whose
     0-based index is a multiple of ``record_every_steps``.  ``to_cpu=False`` keeps
-    the stacks on the device (used by the multi-GPU gather)."""
+    the stacks on the device (used by the multi-GPU gather).  With a ``record_sink`` nothing is stacked: every
+    record goes to ``record_sink(index, {name: (*, n, m) complex dtype})`` as soon as it exists (device tensors on the
+    current stream) and the function returns ``{}`` -- the ensemble driver post-processes and hands records over while
+    the following steps run (``data_gen.py``, ``distributed.RecordHandover``)."""
     # require_grad: the reference marks w / dw/dt of every step as requiring grad and records DETACHED copies
     # (solvers.py:224-250); here the steps then run through the differentiable path (torch-cfd_amd/autograd.py)
     if require_grad:
@@ -46,7 +50,8 @@ def get_trajectory_imex(
     n_rec = len(range(0, num_steps, record_every_steps))
     lead, (n, m) = tuple(w0.shape[:-2]), w0.shape[-2:]
     names = ("vorticity", "stream", "vort_t", "residual")
-    out = {k: torch.empty(*lead, n_rec, n, m, dtype=dtype, device=w0.device) for k in names}
+    out = {} if record_sink is not None else {k: torch.empty(*lead, n_rec, n, m, dtype=dtype, device=w0.device)
+                                              for k in names}
     tqdm_iters = num_steps if TQDM_ITERS > num_steps else TQDM_ITERS
     update_every = max(num_steps // tqdm_iters, 1)
     bar = None
@@ -56,7 +61,8 @@ def get_trajectory_imex(
         bar = tqdm(total=num_steps)
     w = w0
     rec = 0
-    fused = bar is None and not require_grad and isinstance(getattr(equation, "solver", None), RK4CrankNicolsonStepper)
+    fused = (bar is None and not require_grad and hasattr(equation, "_fused_steps")
+             and _is_module_stepper(getattr(equation, "solver", None)))
     t_step = 0
     while t_step < num_steps:
         if fused and t_step % record_every_steps != 0:
@@ -74,8 +80,11 @@ def get_trajectory_imex(
             bar.update(update_every)
         if t_step % record_every_steps == 0:
             psi, res = equation.stream_and_residual(w.detach(), dwdt.detach())
-            for key, val in zip(names, (w.detach(), psi, dwdt.detach(), res)):
-                out[key][..., rec, :, :].copy_(val)  # casts to `dtype` on the device
+            if record_sink is not None:
+                record_sink(rec, {key: val.to(dtype) for key, val in zip(names, (w.detach(), psi, dwdt.detach(), res))})
+            else:
+                for key, val in zip(names, (w.detach(), psi, dwdt.detach(), res)):
+                    out[key][..., rec, :, :].copy_(val)  # casts to `dtype` on the device
             rec += 1
         t_step += 1
     if bar is not None:

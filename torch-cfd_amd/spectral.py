@@ -49,3 +49,51 @@ def vorticity_to_velocity(grid: Grid, w_hat: torch.Tensor,
     if tuple(kx.shape[-2:]) != tuple(w_hat.shape[-2:]):
         raise ValueError(f"wavenumber mesh {tuple(kx.shape[-2:])} does not match the spectrum {tuple(w_hat.shape[-2:])}")
     return _plan_for_mesh(kx, ky, w_hat).velocity(w_hat)
+
+
+# ----------------------------------------------------------------------------- k-space helpers callers name directly
+# Plain tensor expressions on whatever device their arguments live on (torch_cfd/spectral.py:29-75).  The operator
+# itself never calls them -- the same arithmetic is fused into the HIP kernels -- they are here so that scripts written
+# against the reference (diagnostics, custom forcings, post-processing) keep working.
+_TWO_PI_I = 2j * torch.pi
+
+
+def fft_mesh_2d(n: int, diam: float, device=None):
+    """Full (n, n) wavenumber mesh (cycles per unit length), ``indexing='ij'``."""
+    k = torch.fft.fftfreq(n, d=diam / n)
+    kx, ky = torch.meshgrid(k, k, indexing="ij")
+    return kx.to(device), ky.to(device)
+
+
+def spectral_laplacian_2d(fft_mesh, device=None) -> torch.Tensor:
+    """Symbol of the Laplacian, ``-(2 pi)^2 |k|^2``, with the (0, 0) entry set to 1 so that it can be divided by."""
+    kx, ky = fft_mesh
+    lap = -((2 * torch.pi) ** 2) * (kx.abs() ** 2 + ky.abs() ** 2)
+    lap[..., 0, 0] = 1
+    return lap.to(device)
+
+
+def spectral_grad_2d(f_hat: torch.Tensor, rfft_mesh):
+    """(d/dx, d/dy) of a scalar half spectrum."""
+    kx, ky = rfft_mesh
+    return _TWO_PI_I * kx * f_hat, _TWO_PI_I * ky * f_hat
+
+
+def spectral_rot_2d(psi_hat: torch.Tensor, rfft_mesh):
+    """Velocity of a stream function: (d psi / dy, -d psi / dx)."""
+    dx, dy = spectral_grad_2d(psi_hat, rfft_mesh)
+    return dy, -dx
+
+
+def spectral_curl_2d(vel_hat, rfft_mesh) -> torch.Tensor:
+    """Scalar curl dv/dx - du/dy of a velocity pair of half spectra."""
+    u_hat, v_hat = vel_hat
+    kx, ky = rfft_mesh
+    return _TWO_PI_I * (kx * v_hat - ky * u_hat)
+
+
+def spectral_div_2d(vel_hat, rfft_mesh) -> torch.Tensor:
+    """Divergence du/dx + dv/dy of a velocity pair of half spectra."""
+    u_hat, v_hat = vel_hat
+    kx, ky = rfft_mesh
+    return _TWO_PI_I * (kx * u_hat + ky * v_hat)
