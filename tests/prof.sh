@@ -5,7 +5,7 @@ cd /root/repo
 export TMPDIR=/tmp
 out=/root/repo/gpurun_out/prof_$tag
 mkdir -p $out
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-sfno --no-probe $@"
+ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-sfno --no-probe --no-c4 $@"
 CMD=${PROF_CMD:-python bench.py $ARGS}   # PROF_CMD="python tests/bench_fno.py" profiles something else
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- $CMD > $out/trace.log 2>&1
 i=0

@@ -774,3 +774,15 @@ def test_weighted_sqnorm_kernel(dtype, dev):
     assert torch.allclose(got.double(), ref, rtol=2e-6 if real == torch.float32 else 1e-13)
     with pytest.raises(ValueError):
         fno.hip_weighted_sqnorm(zh, w2[:, :-1])
+
+
+def test_weighted_sqnorm_batch_beyond_65535(dev):
+    """b * T of a loss input is not bounded by the 65535 rows of grid.y: the batch rides in grid.x."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(0)
+    z = torch.randn(70000, 8, 5, dtype=torch.complex64, device=dev)
+    w2 = torch.rand(8, 5, device=dev)
+    got = fno.hip_weighted_sqnorm(z, w2)
+    ref = (z.abs().double() ** 2 * w2.double()).sum(dim=(-2, -1))
+    assert got.shape == (70000,) and rel_l2(got, ref) < 1e-6

@@ -842,6 +842,67 @@ def test_trainable_rk_coefficients_receive_gradients(dev):
     assert rel_l2(g, fd) < 1e-6
 
 
+@pytest.mark.parametrize("order,alpha", [(2, 2 / 3), (1.5, 0.5)])
+def test_trainable_imex_parameters_receive_gradients(order, alpha, dev):
+    """IMEXStepper(requires_grad=True): alpha / beta are 0-dim tensors in the reference's step (equations.py:174-228) and
+    receive gradients there; here the differentiable path keeps them attached (stage_schedule(as_tensors=True)).  Checked
+    against central differences of the FUSED forward step, with a state that requires grad too (the silent case)."""
+    import torch_cfd_amd as tc
+    from oracle import ns2d as O
+
+    torch.set_default_dtype(torch.float64)
+    n, dt = 32, 2e-3
+    grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+    op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, solver=tc.IMEXStepper(order=order, alpha=alpha, beta=0.5,
+                                                                                requires_grad=True)).to(dev)
+    w0 = torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 1, torch.float64))[None].to(dev).requires_grad_(True)
+    out, _ = op(w0, dt, steps=2)
+    out.abs().pow(2).sum().backward()
+    names = ("alpha", "beta") if order == 2 else ("alpha",)
+    for name in names:
+        g = op.solver.params[name].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs() > 0, name
+        eps, vals = 1e-5, []
+        with torch.no_grad():
+            for sgn in (+1, -1):
+                op.solver.params[name] += sgn * eps
+                op._coef_cache = None
+                vals.append(op(w0.detach(), dt, steps=2)[0].abs().pow(2).sum().item())   # no grad: fused kernels
+                op.solver.params[name] -= sgn * eps
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(g.item() - fd) <= 1e-6 * abs(fd), (name, g.item(), fd)
+    assert w0.grad is not None and torch.isfinite(torch.view_as_real(w0.grad)).all()
+
+
+def test_user_stepper_subclass_is_not_replaced_by_the_fused_schedule(dev):
+    """A subclass that overrides forward() is a different scheme: NavierStokes2DSpectral.forward loops over it."""
+    import torch_cfd_amd as tc
+
+    class HalfStep(tc.RK4CrankNicolsonStepper):
+        def forward(self, u, dt, equation, params=None):
+            return super().forward(u, dt / 2, equation, params)
+
+    _, op = build_op(32, "f64", "kolmogorov", dev)
+    g = load_golden("ns2d_trajectory.npz")
+    w0 = torch.from_numpy(g["f64_w0"]).to(dev)
+    ref, _ = op(w0, 5e-4, steps=2)
+    op.solver = HalfStep().to(dev)
+    got, dwdt = op(w0, 1e-3, steps=2)
+    assert rel_l2(got, ref) < 1e-13 and rel_l2(dwdt, (ref - w0) / 2e-3) < 1e-10
+
+
+def test_velocity_keeps_the_input_shape_on_composite_grids(dev):
+    import torch_cfd_amd as tc
+
+    torch.set_default_dtype(torch.float64)
+    for n in (96, 64):
+        grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
+        for shape in ((n, n // 2 + 1), (2, 3, n, n // 2 + 1)):
+            w = torch.randn(*shape, dtype=torch.complex128, device=dev)
+            (u, v), psi = tc.vorticity_to_velocity(grid, w)
+            assert u.shape == v.shape == psi.shape == w.shape, (n, shape, u.shape)
+
+
 def test_trajectory_with_require_grad(dev):
     """get_trajectory_imex(require_grad=True) (fno/data_gen/solvers.py:199): same records as without."""
     import torch_cfd_amd as tc

@@ -2486,12 +2486,14 @@ extern "C" int tcfd_ns2d_velocity(const tcfd_ns2d_plan* p, const void* w, void* 
 // element-wise / reduction launches.
 template <typename T>
 __global__ __launch_bounds__(256) void k_weighted_sqnorm(const cx<T>* __restrict__ z, const T* __restrict__ w2,
-                                                         double* __restrict__ partial, long elems) {
+                                                         double* __restrict__ partial, long elems, int blocks) {
     __shared__ double sh[4];
-    const long b = blockIdx.y;
+    // one-dimensional grid of batch * blocks workgroups (grid.y stops at 65535 fields; b * T of a loss has no such bound)
+    const long b = blockIdx.x / blocks;
+    const int blk = blockIdx.x - (unsigned)(b * blocks);
     const cx<T>* zb = z + (size_t)b * elems;
     double acc = 0.0;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < elems; e += (long)gridDim.x * 256) {
+    for (long e = (long)blk * 256 + threadIdx.x; e < elems; e += (long)blocks * 256) {
         const cx<T> v = zb[e];
         acc += (double)((v.x * v.x + v.y * v.y) * w2[e]);
     }
@@ -2499,7 +2501,7 @@ __global__ __launch_bounds__(256) void k_weighted_sqnorm(const cx<T>* __restrict
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 extern "C" int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks,
@@ -2507,14 +2509,15 @@ extern "C" int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial
     if (!z || !w2 || !partial || batch <= 0 || elems <= 0 || blocks <= 0)
         return fail(TCFD_EINVAL, "weighted_sqnorm: bad argument");
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "weighted_sqnorm: bad dtype %d", dtype);
+    if ((double)batch * blocks >= 2147483647.0) return fail(TCFD_EINVAL, "weighted_sqnorm: batch * blocks exceeds the grid limit");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks, (unsigned)batch);
+    const dim3 grid((unsigned)(batch * blocks));
     if (dtype == TCFD_C128)
         hipLaunchKernelGGL(k_weighted_sqnorm<double>, grid, dim3(256), 0, st, (const cx<double>*)z, (const double*)w2,
-                           (double*)partial, elems);
+                           (double*)partial, elems, blocks);
     else
         hipLaunchKernelGGL(k_weighted_sqnorm<float>, grid, dim3(256), 0, st, (const cx<float>*)z, (const float*)w2,
-                           (double*)partial, elems);
+                           (double*)partial, elems, blocks);
     HIP_TRY(hipGetLastError());
     return 0;
 }
