@@ -427,15 +427,17 @@ def test_sfno_training_step_gradients_golden(dev):
     (10, 40, 10, True, 1, "ReLU"), (10, 40, 10, True, 1, "GELU"), (10, 40, 10, True, 0, "SiLU"), (8, 32, 8, True, 1, "Tanh"),
     (10, 10, 1, False, 0, None), (10, 10, 10, False, 1, "ReLU"), (4, 16, 4, True, 1, "ReLU"),
     (10, 40, 10, True, 2, "GELU"), (4, 16, 4, True, 2, "ReLU"),
+    (6, 24, 6, True, 1, "ReLU"), (12, 48, 12, True, 0, "GELU"), (14, 56, 14, True, 1, "SiLU"), (10, 40, 10, True, 0, None),
 ])
-def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, dev):
+@pytest.mark.parametrize("X", [7, 6])   # P = 630 (not a multiple of 4: the LDS-staged kernels) / 540 (P % 16 = 12: the all-MFMA kernel, ragged last group)
+def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, X, dev):
     """tcfd_fno_pointwise_bwd (input / skip gradients + MFMA-accumulated weight and bias gradients) against torch
-    autograd of the same block written with einsums in float64; ragged point count (P % 64 != 0)."""
+    autograd of the same block written with einsums in float64; ragged point counts."""
     import torch.nn as nn
     from torch_cfd_amd import fno
 
     torch.manual_seed(ci * 100 + co)
-    shape = (3, ci, 7, 9, 10)      # P = 630
+    shape = (3, ci, X, 9, 10)
     lin1 = nn.Conv3d(ci, cm, 1).to(dev) if two else None
     lin2 = nn.Conv3d(cm, co, 1).to(dev)
     skc = nn.Conv3d(ci, co, 1).to(dev) if mode == 1 else None
@@ -444,7 +446,7 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
     x = torch.randn(*shape, device=dev, requires_grad=True)
     s = torch.randn(*shape, device=dev, requires_grad=True) if mode == 1 else None
     if mode == 2:   # lifting tail: the last time slice of a (b, co, X, Y, 6) tensor is broadcast over t
-        s = torch.randn(3, co, 7, 9, 6, device=dev, requires_grad=True)
+        s = torch.randn(3, co, X, 9, 6, device=dev, requires_grad=True)
     out = fno.hip_pointwise(x, lin1, a1, lin2, skip=s, skip_conv=skc, act2=a2, skip_last_slice=(mode == 2))
     assert out is not None and out.grad_fn is not None
     t = torch.randn_like(out)
@@ -786,3 +788,30 @@ def test_weighted_sqnorm_batch_beyond_65535(dev):
     got = fno.hip_weighted_sqnorm(z, w2)
     ref = (z.abs().double() ** 2 * w2.double()).sum(dim=(-2, -1))
     assert got.shape == (70000,) and rel_l2(got, ref) < 1e-6
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pointwise_backward_kernels_agree(mode, dev, monkeypatch):
+    """The all-MFMA backward (default) against the LDS-staged two-/four-wave kernels on the same inputs (TCFD_PW_BWD)."""
+    import torch.nn as nn
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(5)
+    ci, cm, co = 10, 40, 10
+    lin1, lin2 = nn.Conv3d(ci, cm, 1).to(dev), nn.Conv3d(cm, co, 1).to(dev)
+    skc = nn.Conv3d(ci, co, 1).to(dev) if mode == 1 else None
+    x = torch.randn(2, ci, 16, 12, 10, device=dev)
+    s = torch.randn(2, ci, 16, 12, 10, device=dev) if mode == 1 else torch.randn(2, co, 16, 12, 6, device=dev)
+    dout = torch.randn(2, co, 16, 12, 10, device=dev)
+    spec = (True, nn.GELU(), nn.GELU(), mode, None)
+    res = {}
+    for flag in ("5", "2", "4"):
+        monkeypatch.setenv("TCFD_PW_BWD", flag)
+        res[flag] = fno._hip_pointwise_backward(spec, dout, x, s, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
+                                                skc.weight if skc else None, skc.bias if skc else None, None, None)
+        torch.cuda.synchronize()
+    for flag in ("2", "4"):
+        for got, ref in zip(res["5"], res[flag]):
+            assert (got is None) == (ref is None)
+            if got is not None:
+                assert rel_l2(got, ref) < 5e-6

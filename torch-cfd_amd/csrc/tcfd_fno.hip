@@ -1640,6 +1640,325 @@ __global__ __launch_bounds__(64 * NW) void k_pointwise_bwd4(PwBwdArgs a) {
     }
 }
 
+// activation and its derivative of a set of D tiles, the switch on the (run-time) activation OUTSIDE the element loops:
+// one uniform branch per call instead of one per element
+template <int ACT>
+__device__ __forceinline__ void pw_act_pair(float z, float& h, float& d) {
+    if constexpr (ACT == 1) { h = z > 0.f ? z : 0.f; d = z > 0.f ? 1.f : 0.f; }
+    else if constexpr (ACT == 2) {
+        const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+        h = z * cdf;
+        d = cdf + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+    } else if constexpr (ACT == 3) { const float sg = 1.f / (1.f + __expf(-z)); h = z * sg; d = sg * (1.f + z * (1.f - sg)); }
+    else if constexpr (ACT == 4) { const float t = tanhf(z); h = t; d = 1.f - t * t; }
+    else { h = z; d = 1.f; }
+}
+template <int N, typename V4>
+__device__ __forceinline__ void pw_act_tiles(const V4 (&z)[N], V4 (&h)[N], V4 (&d)[N], int act) {
+#define PW_ACT_ALL(ACT_)                                                   \
+    _Pragma("unroll") for (int t = 0; t < N; ++t)                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                    \
+            float hv, dv;                                                  \
+            pw_act_pair<ACT_>(z[t][r], hv, dv);                            \
+            h[t][r] = hv;                                                  \
+            d[t][r] = dv;                                                  \
+        }
+    switch (act) {
+        case 1: PW_ACT_ALL(1) break;
+        case 2: PW_ACT_ALL(2) break;
+        case 3: PW_ACT_ALL(3) break;
+        case 4: PW_ACT_ALL(4) break;
+        default: PW_ACT_ALL(0) break;
+    }
+#undef PW_ACT_ALL
+}
+
+// ------------------------------------------------------------------ two-layer backward, everything on MFMA
+// k_pointwise_bwd4 spends its time in the LDS pipe (weights, channel-major staging of the points for the weight-gradient
+// products, cross-wave reductions: ~1500 DS instructions and 5 workgroup barriers per 64 points).  Here a wave owns 16
+// points at a time and NOTHING goes through LDS: the weights live in registers as MFMA operand fragments, and every
+// product of the block -- forward recompute, input gradients, weight gradients -- is a chain of v_mfma_f32_16x16x4_f32
+// whose D registers are fed straight back as operands.
+//
+// Lane l = (q, c) = (l >> 4, l & 15).  The instruction takes A[row c][k q] and B[k q][col c] from lane (q, c) and leaves
+// D[row 4q + r][col c] in register r.  Hence a D tile of a matrix M (rows R, columns C) IS, register r by register r,
+//   * the B operand of  X . M   (k-step r contracts over rows {4q + r})                 -> D tile of X M
+//   * the A operand of  M^T . Y (same k-steps)                                          -> D tile of M^T Y
+// provided the other operand's fragment lists its k index in the same order (weights: laid out that way once, at kernel
+// start).  Both contract over M's ROW index.  The block needs contractions over channels (the chain z1 -> z2 -> g2 -> dh
+// -> dx) and over points (weight gradients = sums over points of outer products), so every intermediate is produced in
+// two orientations:
+//   "O1"  rows = channels, cols = the 16 points     z1 = W1' [x;1],  z2 = W2 h + Ws' [s;1],  dh = W2^T g2
+//   "OT"  rows = the 16 points, cols = channels     z1^T = [x;1]^T W1'^T (same fragments, operands swapped),
+//                                                   g2^T = g2^T I (identity fragment), dh^T = g2^T W2,
+//                                                   dx^T = g1^T W1, ds^T = g2^T Ws           (O1 tiles as A operands)
+// and the weight gradients are  dW2 += (g2^T)^T h^T,  [dWs | db2] += (g2^T)^T [s;1]^T,  [dW1 | db1] += (g1^T)^T [x;1]^T
+// with OT tiles as both operands.  Biases ride as a constant-1 channel.  105 MFMAs per 16 points at width 10 (52 for the
+// chain, 25 for the second orientation, 28 for the weight gradients): the kernel is bound by the matrix pipe (~1.8 ms for
+// the (32, 10, 256, 256, 10) activations of config 5) instead of 4.3 ms of LDS issue.  Inputs are read in the two
+// fragment layouts they are needed in ([ch 4j + q][pt c]: 64-byte rows; [ch c][pt 4q .. 4q + 3]: 16-byte lanes), the
+// second read of a line hits the vector cache; dx / ds leave as 16-byte lanes.  One row of partial sums per wave.
+template <int CI, int CM, int CO, int MODE, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void k_pointwise_bwd_mfma(PwBwdArgs a) {
+    using Gm = PwBwdGeom<CI, CM, CO, true>;
+    constexpr int KI = (CI + 1 + 3) / 4;        // k-steps over [x ; 1]
+    constexpr int TM = (CM + 15) / 16;          // 16-row tiles of the hidden layer
+    static_assert(CI + 1 <= 16 && CO <= 16 && TM <= 4, "k_pointwise_bwd_mfma geometry");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    constexpr int mode = MODE;                  // = a.skip_mode (compile time: the loads must be straight-line code)
+    // ---- weight fragments (registers, for the whole kernel)
+    float W1a[TM][KI], W2a[TM][4], Wsa[KI], Idf[4], W2b[TM][4], W1b[TM][4], Wsb[4];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int hid = 16 * t + c;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int k = 4 * j + q;
+            float v = 0.f;
+            if (hid < CM) v = k < CI ? a.w1[hid * CI + k] : ((k == CI && a.b1) ? a.b1[hid] : 0.f);
+            W1a[t][j] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hq = 16 * t + 4 * q + r, cq = 4 * q + r;
+            W2a[t][r] = (c < CO && hq < CM) ? a.w2t[hq * CO + c] : 0.f;          // W2[co c][hid 16t+4q+r]
+            W2b[t][r] = (cq < CO && hid < CM) ? a.w2t[hid * CO + cq] : 0.f;      // W2[co 4q+r][hid 16t+c]
+            W1b[t][r] = (hq < CM && c < CI) ? a.w1[hq * CI + c] : 0.f;           // W1[hid 16t+4q+r][ci c]
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const int k = 4 * j + q;
+        float v = 0.f;
+        if (c < CO) {
+            if (k < CI) v = mode == 1 ? a.wst[k * CO + c] : 0.f;
+            else if (k == CI) v = (a.b2 ? a.b2[c] : 0.f) + ((mode == 1 && a.bs) ? a.bs[c] : 0.f);
+        }
+        Wsa[j] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Idf[r] = c == 4 * q + r ? 1.f : 0.f;
+        Wsb[r] = (mode == 1 && 4 * q + r < CO && c < CI) ? a.wst[c * CO + 4 * q + r] : 0.f;
+    }
+    f4 accW2[TM], accW1[TM], accWs = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TM; ++t) accW2[t] = accW1[t] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int gpb = (int)((a.P + 15) / 16);                 // groups of 16 points per batch element (the launcher checks
+    const int total = gpb * a.batch;                        // that the group count fits 31 bits)
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), wstride = gridDim.x * 4;
+
+    struct In {
+        float xa[KI], sa[KI], dz[4], sl[4];
+        f4 xb, sb;
+    };
+    // Loads go through buffer descriptors (one per tensor, built from the kernel arguments): a lane that has nothing to
+    // read -- padding channel, point beyond P -- passes an offset beyond the buffer and gets 0 from the bounds check.  No
+    // lane condition ever guards a load, so the loads of the NEXT group are straight-line code the compiler counts
+    // (s_waitcnt vmcnt(N) at the first use, one iteration later).  With plain conditional loads every load sat in its
+    // own exec-masked branch and the prefetch ended in s_waitcnt vmcnt(0) in front of the current group's first MFMA:
+    // 3.5 ms per launch, every iteration paid a memory round trip.
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0x80000000u;                        // the launcher checks that every tensor is < 2 GiB
+    const unsigned P4 = (unsigned)a.P * 4u;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((size_t)a.batch * CI * a.P * 4), 0x00020000);
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, (int)((size_t)a.batch * CO * a.P * 4), 0x00020000);
+    const size_t s_bytes = mode == 1 ? (size_t)a.batch * CI * a.P * 4 : (mode == 2 ? (size_t)a.batch * CO * (a.P / a.T) * a.sT * 4 : 0);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mode ? a.s : a.x), 0, (int)s_bytes, 0x00020000);
+    // per-lane constants of the two layouts: channel row offsets (or OOB) and the constant-1 channel
+    unsigned ka_off[KI];
+    float ka_one[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const int k = 4 * j + q;
+        ka_off[j] = k < CI ? (unsigned)k * P4 : OOB;
+        ka_one[j] = k == CI ? 1.f : 0.f;
+    }
+    const unsigned cb_off = c < CI ? (unsigned)c * P4 : OOB;
+    const float cb_one = c == CI ? 1.f : 0.f;
+    unsigned co_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) co_off[r] = 4 * q + r < CO ? (unsigned)(4 * q + r) * P4 : OOB;
+    const unsigned sP4 = mode == 2 ? (unsigned)((a.P / a.T) * a.sT) * 4u : 0u;
+    auto load = [&](int G, In& in) {
+        const int b = G / gpb;
+        const unsigned p0 = (unsigned)(G - b * gpb) * 16u;
+        const unsigned pa = p0 + c, pb = p0 + 4 * q;
+        const bool live_a = pa < (unsigned)a.P, live_b = pb < (unsigned)a.P;   // P % 4 == 0: a 16-byte lane is all live or all dead
+        const unsigned base_i = (unsigned)b * CI * P4, base_o = (unsigned)b * CO * P4;
+        const unsigned oa = live_a ? base_i + pa * 4u : OOB, ob = live_b ? base_i + pb * 4u : OOB;
+        const float one_b = live_b ? cb_one : 0.f;
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+            in.xa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, 0)) + ka_one[j];
+        {
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, 0);
+            in.xb = f4{__uint_as_float(v.x) + one_b, __uint_as_float(v.y) + one_b, __uint_as_float(v.z) + one_b, __uint_as_float(v.w) + one_b};
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < KI; ++j)
+                in.sa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, 0)) + ka_one[j];
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, 0);
+            in.sb = f4{__uint_as_float(v.x) + one_b, __uint_as_float(v.y) + one_b, __uint_as_float(v.z) + one_b, __uint_as_float(v.w) + one_b};
+        } else {
+#pragma unroll
+            for (int j = 0; j < KI; ++j) in.sa[j] = ka_one[j];
+            in.sb = f4{one_b, one_b, one_b, one_b};
+        }
+        const unsigned od = live_a ? base_o + pa * 4u : OOB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            in.dz[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, 0));
+            in.sl[r] = 0.f;
+        }
+        if constexpr (MODE == 2) {
+            const unsigned pc = live_a ? pa : (unsigned)a.P - 1u;
+            const unsigned os = (unsigned)b * CO * sP4 + ((pc / (unsigned)a.T) * (unsigned)a.sT + (unsigned)(a.sT - 1)) * 4u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                in.sl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * q + r < CO ? (unsigned)(4 * q + r) * sP4 + os : OOB, 0, 0));
+        }
+    };
+#define PW_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
+    In cur;
+    load(wid < total ? wid : total - 1, cur);
+    for (int G = wid; G < total; G += wstride) {
+        In nxt;
+        load(G + wstride < total ? G + wstride : total - 1, nxt);   // unconditional (clamped): no branch around the prefetch
+        __builtin_amdgcn_sched_barrier(0);                          // ... and issued HERE, a whole iteration ahead of their use
+        const int b = G / gpb;
+        const long pb = (long)(G - b * gpb) * 16 + 4 * q;
+        const bool live_b = pb < a.P;
+        // Issue order: independent matrix work is placed between a product and the element-wise step that consumes it,
+        // so the wave has MFMAs in flight while it runs its VALU part (a wave issues in order).
+        // ---- z1 in both orientations (the same two fragments, operands swapped)
+        f4 h[TM], d1[TM], hT[TM], dT[TM];
+        {
+            f4 z[TM], zT[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                z[t] = zT[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < KI; ++j) z[t] = PW_MFMA(W1a[t][j], cur.xa[j], z[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int j = 0; j < KI; ++j) zT[t] = PW_MFMA(cur.xa[j], W1a[t][j], zT[t]);
+            pw_act_tiles<TM>(z, h, d1, a.act1);
+            // ---- O1: z2 = [Ws | b] [s ; 1] + W2 h  (the skip part first: it does not wait for the activation)
+            f4 z2 = f4{cur.sl[0], cur.sl[1], cur.sl[2], cur.sl[3]};
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < KI; ++j) z2 = PW_MFMA(Wsa[j], cur.sa[j], z2);
+            } else {
+                z2 = PW_MFMA(Wsa[CI / 4], cur.sa[CI / 4], z2);        // only the constant-1 channel (the bias) is there
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z2 = PW_MFMA(W2a[t][r], h[t][r], z2);
+            pw_act_tiles<TM>(zT, hT, dT, a.act1);                      // under the z2 chain
+            f4 zz[1] = {z2}, hh[1], dd[1];
+            pw_act_tiles<1>(zz, hh, dd, a.act2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z2[r] = cur.dz[r] * dd[0][r];
+            // g2 now lives in z2's registers
+            // ---- everything that needs only g2: dh (O1), dh^T and g2^T (OT)
+            f4 dh[TM], dhT[TM], g2T = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                dh[t] = dhT[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[t] = PW_MFMA(W2b[t][r], z2[r], dh[t]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g2T = PW_MFMA(z2[r], Idf[r], g2T);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dhT[t] = PW_MFMA(z2[r], W2b[t][r], dhT[t]);
+            // ---- dx^T, ds^T from the O1 tiles as A operands
+            f4 dxT = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dxT = PW_MFMA(dh[t][r] * d1[t][r], W1b[t][r], dxT);
+            if constexpr (MODE == 1) {
+                if (a.ds) {
+                    f4 dsT = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dsT = PW_MFMA(z2[r], Wsb[r], dsT);
+                    if (c < CI && live_b) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + c) * a.P + pb) = dsT;
+                }
+            } else if constexpr (MODE == 2) {
+                if (a.ds && c < CO && live_b) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CO + c) * a.P + pb) = g2T;
+            }
+            // ---- weight gradients: contractions over the 16 points, OT tiles on both sides
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accWs = PW_MFMA(g2T[r], cur.sb[r], accWs);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accW2[t] = PW_MFMA(g2T[r], hT[t][r], accW2[t]);
+                    accW1[t] = PW_MFMA(dhT[t][r] * dT[t][r], cur.xb[r], accW1[t]);
+                }
+            if (a.dx && c < CI && live_b)
+                *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + c) * a.P + pb) = dxT;
+        }
+        cur = nxt;
+    }
+#undef PW_MFMA
+    // ---- this wave's row of partial sums: A (COP x CB) = [dW2 | db2 | dWs],  B (CM1 x CIP) = [dW1 | db1]
+    float* out = a.partials + (size_t)wid * Gm::TOTAL;
+    float* o1 = out + Gm::N_A;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * t + c < CM) out[(4 * q + r) * Gm::CB + 16 * t + c] = accW2[t][r];
+            if (c <= CI) o1[(16 * t + 4 * q + r) * Gm::CIP + c] = accW1[t][r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (c <= CI) out[(4 * q + r) * Gm::CB + CM + (c == CI ? 0 : 1 + c)] = accWs[r];
+}
+
+template <int CI, int CM, int CO, int MODE, int OCC = 2>
+static int launch_pw_bwd_mfma_m(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
+    using Gm = PwBwdGeom<CI, CM, CO, true>;
+    dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
+    if (!a.x) return 0;
+    a.batch = batch;
+    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE, OCC>;
+    int per_cu = 0, dev = 0, cus = 256;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const long groups = ((a.P + 15) / 16) * batch;
+    if (groups >= (1L << 30)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: %ld groups of 16 points exceed the kernel's index range", groups);
+    if ((size_t)batch * (CI > CO ? CI : CO) * (size_t)a.P * 4 >= ((size_t)1 << 31))
+        return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: tensors of 2 GiB and more are beyond the kernel's 32-bit buffer offsets");
+    long blocks = std::min<long>({(groups + 3) / 4, (long)max_rows / 4, (long)std::max(per_cu, 1) * cus});
+    if (blocks < 1) blocks = 1;
+    // every wave writes its row, also one that found no work; rows beyond the grid are not touched
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    dims[5] = (int)(blocks * 4);
+    return 0;
+}
+
+template <int CI, int CM, int CO>
+static int launch_pw_bwd_mfma(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
+    if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1>(a, batch, max_rows, dims, st);
+    if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2>(a, batch, max_rows, dims, st);
+    return launch_pw_bwd_mfma_m<CI, CM, CO, 0>(a, batch, max_rows, dims, st);
+}
+
 template <int CI, int CM, int CO, int NW = 4>
 static int launch_pw_bwd4(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
@@ -1734,7 +2053,15 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
     if (ci == CI_ && cm == CM_ && co == CO_ && l1 == L1_) return launch_pw_bwd<CI_, CM_, CO_, L1_>(a, batch, max_waves, dims, st);
     // TCFD_PW_BWD: 0 = default (width 10: two waves per 64 points -- 33.7 vs 35.1 ms per SFNO training step; other widths four),
     // 2 / 4 = that many waves per 64 points, 1 = one wave per 64 points (k_pointwise_bwd)
+    // 0 (default) / 5: the all-MFMA kernel (k_pointwise_bwd_mfma) wherever it applies; 1 / 2 / 4 select the older kernels
     const int bwd_mode = env_int("TCFD_PW_BWD", 0);
+    if (l1 && !per_sample && (bwd_mode == 0 || bwd_mode == 5) && P % 4 == 0 && max_waves >= 4 &&
+        (size_t)batch * (size_t)(ci > co ? ci : co) * (size_t)P * 4 < ((size_t)1 << 31)) {   // 32-bit buffer offsets
+#define PWM_CASE(CI_, CM_, CO_) \
+    if (ci == CI_ && cm == CM_ && co == CO_) return launch_pw_bwd_mfma<CI_, CM_, CO_>(a, batch, max_waves, dims, st);
+        PWM_CASE(4, 16, 4) PWM_CASE(6, 24, 6) PWM_CASE(8, 32, 8) PWM_CASE(10, 40, 10) PWM_CASE(12, 48, 12) PWM_CASE(14, 56, 14)
+#undef PWM_CASE
+    }
     if (l1 && bwd_mode != 1) {
         if (ci == 10 && cm == 40 && co == 10 && bwd_mode != 4) return launch_pw_bwd4<10, 40, 10, 2>(a, batch, max_waves, dims, st);
         if (ci == 4 && cm == 16 && co == 4) return launch_pw_bwd4<4, 16, 4>(a, batch, max_waves, dims, st);

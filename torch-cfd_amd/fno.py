@@ -520,7 +520,8 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     ds = torch.empty_like(sk) if mode == 1 else (torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=dev)
                                                  if mode == 2 else None)
     max_waves = 2048
-    partials = torch.empty(max_waves, per_row, dtype=torch.float32, device=dev)
+    # zeros: the all-MFMA kernel writes only the entries of a row that mean something (one row per wave)
+    partials = torch.zeros(max_waves, per_row, dtype=torch.float32, device=dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise_bwd(ptr(xs), ptr(sk), ptr(dz), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t), ptr(b2v),
