@@ -12,7 +12,7 @@ x = torch.randn(32, ci, 256, 256, 10, device=dev)
 s = torch.randn_like(x)
 dout = torch.randn_like(x)
 res = {}
-for act in ("ReLU", "GELU"):
+for act in os.environ.get("ACTS", "ReLU,GELU").split(","):
     spec = (True, getattr(nn, act)(), getattr(nn, act)(), 1, None)
     for flag in sys.argv[1:] or ["5", "2", "4"]:
         os.environ["TCFD_PW_BWD"] = flag

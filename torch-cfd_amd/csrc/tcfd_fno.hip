@@ -1698,8 +1698,12 @@ __device__ __forceinline__ void pw_act_tiles(const V4 (&z)[N], V4 (&h)[N], V4 (&
 // the (32, 10, 256, 256, 10) activations of config 5) instead of 4.3 ms of LDS issue.  Inputs are read in the two
 // fragment layouts they are needed in ([ch 4j + q][pt c]: 64-byte rows; [ch c][pt 4q .. 4q + 3]: 16-byte lanes), the
 // second read of a line hits the vector cache; dx / ds leave as 16-byte lanes.  One row of partial sums per wave.
-template <int CI, int CM, int CO, int MODE, int OCC = 2>
-__global__ __launch_bounds__(256, OCC) void k_pointwise_bwd_mfma(PwBwdArgs a) {
+// Measured at config 5 (ReLU, per launch): LDS-staged two-wave kernel 3.83 ms -> first version 4.95 (a switch on the run-time
+// activation per element) -> 3.51 (one switch per tile set) -> 3.02 (buffer loads: the prefetch stays in flight) -> 2.87
+// (sched_barrier behind the prefetch) -> 2.82 (issue order).  Three waves per SIMD (weights re-read from LDS, 168 registers)
+// gain nothing (3.06): what is left is the ~40-cycle gap every time a product's D tile turns into the next product's operand.
+template <int CI, int CM, int CO, int MODE>
+__global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     constexpr int KI = (CI + 1 + 3) / 4;        // k-steps over [x ; 1]
     constexpr int TM = (CM + 15) / 16;          // 16-row tiles of the hidden layer
@@ -1928,13 +1932,13 @@ __global__ __launch_bounds__(256, OCC) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         if (c <= CI) out[(4 * q + r) * Gm::CB + CM + (c == CI ? 0 : 1 + c)] = accWs[r];
 }
 
-template <int CI, int CM, int CO, int MODE, int OCC = 2>
+template <int CI, int CM, int CO, int MODE>
 static int launch_pw_bwd_mfma_m(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
     if (!a.x) return 0;
     a.batch = batch;
-    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE, OCC>;
+    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE>;
     int per_cu = 0, dev = 0, cus = 256;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
     HIP_TRY(hipGetDevice(&dev));
