@@ -214,6 +214,26 @@ def test_config5_full_size_against_oracle(dev):
     assert math.isfinite(float(loss_full))
 
 
+def test_config5_twenty_output_steps_against_oracle(dev):
+    """BASELINE configs[4] shape with out_steps = 20 (twice the latent steps: the output convolution's inverse transform
+    resamples in t, fno/sfno.py:313-328): a two-sample slice of the (32, 256, 256, 20) output against oracle/sfno.py."""
+    from oracle import sfno as OS
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(32, 256, 256, 10, generator=g)
+    with torch.no_grad():
+        out = model(x.to(dev), out_steps=20)
+    assert out.shape == (32, 256, 256, 20) and torch.isfinite(out).all()
+    ref = OS.sfno_forward(sd, x[7:9], (24, 24, 5), width=10, num_hidden=3, out_steps=20)
+    assert rel_l2(out[7:9], ref) < 1e-5
+
+
 @pytest.mark.parametrize("order", [0, -1, 1])
 @pytest.mark.parametrize("rel", [0, 1])
 def test_sobolev_loss_golden(order, rel, dev):

@@ -341,6 +341,42 @@ def test_config3_full_size_batch_consistency(dev):
     assert torch.equal(F * op.filter, F)
 
 
+@pytest.mark.parametrize("tag,tol", [("f64", 1e-10), ("f32", 1e-5)])
+def test_1024_ten_steps_in_one_call_against_oracle(tag, tol, dev):
+    """1024^2, B = 2, TEN steps through forward(w, dt, steps=10) (the chunked multi-step path of the headline size)
+    against the oracle: fp64 1e-10, fp32 the stated ten-step tolerance 1e-5."""
+    from oracle import ns2d as O
+
+    n, dt = 1024, 6.136e-4
+    real = REAL[tag]
+    grid, op = build_op(n, tag, "kolmogorov", dev)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, real)) for s in range(2)])
+    out, dwdt = op(w0.to(dev), dt, steps=10)
+    t = oracle_tables(n, tag, "kolmogorov")
+    ref, ref_dt = O.advance(w0, dt, t, steps=10)
+    assert rel_l2(out, ref) < tol
+    assert scaled_err(dwdt, ref_dt, ref / (10 * dt)) < tol
+
+
+def test_config3_steps_in_one_call_equal_per_call_steps(dev):
+    """BASELINE configs[2] size (1024^2, B = 64, fp64): forward(w, dt, steps=3) -- every chunk runs its three steps back
+    to back, the state stays on die -- must equal three forward(w, dt) calls bit for bit, dw/dt to round-off."""
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.initial_conditions import vorticity_field
+
+    n, B, dt = 1024, 64, 6.136e-4
+    grid, op = build_op(n, "f64", "kolmogorov", dev)
+    plan = tc.fft_plan(n, torch.complex128, dev)
+    w0 = torch.cat([plan.rfft2(vorticity_field(grid, 4, batch_seeds=list(range(i, i + 8)), device=dev))
+                    for i in range(0, B, 8)])
+    fused, dw_fused = op(w0, dt, steps=3)
+    w = w0
+    for _ in range(3):
+        w, _ = op(w, dt)
+    assert torch.equal(fused, w)
+    assert rel_l2(dw_fused, (w - w0) / (3 * dt)) < 1e-12
+
+
 def test_config4_shard_full_size(dev):
     """BASELINE configs[3], one GPU's shard: McWilliams decaying turbulence, 512^2, 64 fields, fp64, unforced, dt = 1e-3,
     ICs generated on the device (seeds 0..63).  12 steps through the trajectory API (fused steps between records):
