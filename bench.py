@@ -243,7 +243,38 @@ def sfno_config5(dev):
         per_step.append(e0.elapsed_time(e1))
     t_train = sorted(per_step)[len(per_step) // 2]
     algo_gb = 21.5 * 32 * 10 * 256 * 256 * 10 * 4 / 1e9
-    return {"workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
+    # roofline of the dominant kernel of the forward (k_pointwise<10,40,10>: FFN + skip conv + activation of a hidden layer
+    # in one pass, 4 launches = 2.3 of the 5.4 ms): it reads the spectral-conv output and the layer input and writes the
+    # next activation -- 3 A_H of algorithmic bytes per launch; timed in isolation with events on torch's
+    # current stream, which is the stream the library launches on
+    roof = None
+    try:
+        A_H = 32 * 10 * 256 * 256 * 10 * 4
+        x1, v = torch.randn(32, 10, 256, 256, 10, device=dev), torch.randn(32, 10, 256, 256, 10, device=dev)
+        mlp, w, act = model.mlp[0], model.w[0], model.activations[0]
+        with torch.no_grad():
+            blk = lambda: fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
+            assert blk() is not None
+            t_blk = timeit(blk, 20)
+            # the backward of the same block (k_pointwise_bwd_mfma): reads x, skip, dout, writes dx, dskip = 5 A_H
+            spec = (True, mlp.activation, act, 1, None)
+            bwd = lambda: fno._hip_pointwise_backward(spec, x1, v, v, mlp.linear1.weight, mlp.linear1.bias, mlp.linear2.weight,
+                                                      mlp.linear2.bias, w.weight, w.bias, None, None)
+            t_bwd = timeit(bwd, 10)
+        del x1, v
+        ach = 3 * A_H / (t_blk * 1e-3) / 1e9
+        roof = {"kernel": "k_pointwise<10,40,10> (FFN + skip conv + activation of one hidden layer)", "bound": "hbm",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "algo_bytes_per_launch": 3 * A_H, "avg_launch_ms": round(t_blk, 4), "launches_per_forward": 4,
+                "traffic": None,
+                "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
+                                    "algo_bytes_per_launch": 5 * A_H, "avg_launch_ms": round(t_bwd, 4),
+                                    "achieved": round(5 * A_H / (t_bwd * 1e-3) / 1e9, 1),
+                                    "frac": round(5 * A_H / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "note": "matrix-pipe bound: 105 v_mfma_f32_16x16x4_f32 per 16 points = 1.8 ms of MFMA time per launch"}}
+    except Exception as e:
+        roof = {"error": repr(e)}
+    return {"roofline": roof, "workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
             "forward_ms": round(t_fwd, 3), "forward_plus_loss_ms": round(t_all, 3), "train_step_ms": round(t_train, 2),
             "train_step_ms_each": [round(t, 2) for t in per_step],
             "samples_per_s": round(32 / (t_all * 1e-3), 1), "algo_GB": round(algo_gb, 2),

@@ -286,7 +286,8 @@ def test_sobolev_loss_fft_norms_and_cutoff(norm, dev):
         assert float(loss(x.to(dev), y.to(dev))) == pytest.approx(float(ref), rel=2e-5)
 
 
-@pytest.mark.parametrize("width,act", [(10, "ReLU"), (32, "GELU"), (8, "SiLU"), (20, "Tanh")])
+@pytest.mark.parametrize("width,act", [(10, "ReLU"), (32, "GELU"), (8, "SiLU"), (20, "Tanh"), (7, "ReLU"), (13, "GELU"), (31, "ReLU"),
+                                       (48, "GELU"), (64, "ReLU")])
 def test_fused_pointwise_block_matches_torch_modules(width, act, dev):
     """tcfd_fno_pointwise vs the same layer evaluated with torch modules (PointwiseFFN + skip conv + act),
     the lifting tail (last-slice broadcast) and the single-convolution forms."""
@@ -311,9 +312,9 @@ def test_fused_pointwise_block_matches_torch_modules(width, act, dev):
         assert out is not None and rel_l2(out, red(v)) < 2e-6
         out = fno.hip_pointwise(v, None, None, w)
         assert out is not None and rel_l2(out, w(v)) < 2e-6
-        # not instantiated -> None (the caller keeps its torch modules)
-        odd = torch.nn.Conv3d(7, 7, 1).to(dev)
-        assert fno.hip_pointwise(torch.randn(1, 7, 8, 8, 4, device=dev), None, None, odd) is None
+        # not instantiated (wider than 64 channels) -> None (the caller keeps its torch modules)
+        wide = torch.nn.Conv3d(72, 72, 1).to(dev)
+        assert fno.hip_pointwise(torch.randn(1, 72, 8, 8, 4, device=dev), None, None, wide) is None
 
 
 def test_spectral_conv_t_with_helmholtz_postprocess_golden(dev):

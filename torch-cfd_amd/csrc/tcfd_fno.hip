@@ -980,13 +980,16 @@ static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
     // (width 32 keeps one point per lane: two need > 128 VGPRs and lose more in occupancy than they gain; 20: +5 %)
     const bool pairs = (CI <= env_int("TCFD_PW_PAIR_MAXC", 20)) && (a.P % 2 == 0) && (a.skip_mode != 2 || a.T % 2 == 0) &&
                        (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.pe | (uintptr_t)(a.skip_mode == 1 ? a.s : nullptr)) % 8 == 0);
-    if (pairs) {
-        dim3 grid((unsigned)((a.P / 2 + 255) / 256), (unsigned)batch);
-        hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 2>), grid, dim3(256), 0, st, a);
-    } else {
-        dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)batch);
-        hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 1>), grid, dim3(256), 0, st, a);
+    if constexpr (CI <= 20) {      // (the packed form is not even compiled for wider layers)
+        if (pairs) {
+            dim3 grid((unsigned)((a.P / 2 + 255) / 256), (unsigned)batch);
+            hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 2>), grid, dim3(256), 0, st, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
     }
+    dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 1>), grid, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1094,8 +1097,9 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
 #define PW_CASE(CI_, CM_, CO_)                                                             \
     if (ci == CI_ && cm == CM_ && co == CO_)                                                \
         return l1 ? launch_pw<CI_, CM_, CO_, true>(a, batch, st) : launch_pw<CI_, CM_, CO_, false>(a, batch, st);
-    // the reference's default expansion (4 x width) with a compile-time trip count, then ANY hidden width for every even
-    // width up to 32 (SpaceTimePositionalEncoding needs an even width > 3; fno/sfno.py:607-614 accepts any):
+    // the reference's default expansion (4 x width) with a compile-time trip count, then ANY hidden width for every
+    // width up to 32 -- odd ones too: fno/sfno.py:607-614 and PointwiseFFN accept any, only SpaceTimePositionalEncoding
+    // wants an even width > 3 -- and 36 / 40 / 48 / 64 (one point per lane, the channels still fit the register file):
     // the channel counts index register arrays and stay template parameters, the hidden width is a loop bound
 #define PW_ANY(W_)                                                                         \
     if (ci == W_ && co == W_ && l1) return launch_pw<W_, 0, W_, true>(a, batch, st);
@@ -1103,12 +1107,18 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
         PW_CASE(4, 16, 4) PW_CASE(8, 32, 8) PW_CASE(10, 40, 10) PW_CASE(16, 64, 16) PW_CASE(20, 80, 20) PW_CASE(32, 128, 32)
         PW_ANY(4) PW_ANY(6) PW_ANY(8) PW_ANY(10) PW_ANY(12) PW_ANY(14) PW_ANY(16) PW_ANY(18) PW_ANY(20) PW_ANY(24) PW_ANY(28)
         PW_ANY(32)
+        PW_ANY(3) PW_ANY(5) PW_ANY(7) PW_ANY(9) PW_ANY(11) PW_ANY(13) PW_ANY(15) PW_ANY(17) PW_ANY(19) PW_ANY(21) PW_ANY(22)
+        PW_ANY(23) PW_ANY(25) PW_ANY(26) PW_ANY(27) PW_ANY(29) PW_ANY(30) PW_ANY(31) PW_ANY(36) PW_ANY(40) PW_ANY(48) PW_ANY(64)
     } else {
         if (cm != ci) return FAIL(TCFD_EINVAL, "fno_pointwise: single layer needs cm == ci");
         PW_CASE(4, 4, 4) PW_CASE(4, 4, 1) PW_CASE(8, 8, 8) PW_CASE(8, 8, 1) PW_CASE(10, 10, 10) PW_CASE(10, 10, 1)
         PW_CASE(16, 16, 16) PW_CASE(16, 16, 1) PW_CASE(20, 20, 20) PW_CASE(20, 20, 1) PW_CASE(32, 32, 32) PW_CASE(32, 32, 1)
         PW_CASE(6, 6, 6) PW_CASE(6, 6, 1) PW_CASE(12, 12, 12) PW_CASE(12, 12, 1) PW_CASE(14, 14, 14) PW_CASE(14, 14, 1)
         PW_CASE(18, 18, 18) PW_CASE(18, 18, 1) PW_CASE(24, 24, 24) PW_CASE(24, 24, 1) PW_CASE(28, 28, 28) PW_CASE(28, 28, 1)
+#define PW_ONE(W_) PW_CASE(W_, W_, W_) PW_CASE(W_, W_, 1)
+        PW_ONE(3) PW_ONE(5) PW_ONE(7) PW_ONE(9) PW_ONE(11) PW_ONE(13) PW_ONE(15) PW_ONE(17) PW_ONE(19) PW_ONE(21) PW_ONE(22)
+        PW_ONE(23) PW_ONE(25) PW_ONE(26) PW_ONE(27) PW_ONE(29) PW_ONE(30) PW_ONE(31) PW_ONE(36) PW_ONE(40) PW_ONE(48) PW_ONE(64)
+#undef PW_ONE
     }
 #undef PW_CASE
 #undef PW_ANY

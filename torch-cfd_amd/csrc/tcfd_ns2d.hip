@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <limits>
 #include <mutex>
 #include <vector>
@@ -1614,23 +1615,32 @@ static size_t last_level_cache_bytes(int* source) {
         fclose(f);
         return true;
     };
+    // Pass 1: the node whose PCI location is this device's.  Pass 2 (containers hide the GPU nodes' `properties` files but not
+    // their cache entries): every node that lists a level-3 cache -- the GPUs of one box are of one kind, so the smallest
+    // level-3 size found is this device's (and the safe choice if they were not).
+    long any_l3 = 0;
     for (int node = 0; node < 128; ++node) {
         char path[256];
         snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
         const char* nkeys[] = {"simd_count", "location_id", "domain"};
-        long nv[3] = {0, -1, 0};
-        if (!read_props(path, nkeys, nv, 3)) break;
-        if (nv[0] <= 0 || nv[1] != want_loc || nv[2] != (long)prop.pciDomainID) continue;
+        long nv[3] = {-1, -1, 0};
+        const bool props = read_props(path, nkeys, nv, 3);
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/caches", node);
+        if (!props && access(path, F_OK) != 0) { if (node > 16) break; else continue; }
+        if (props && nv[0] == 0) continue;       // a CPU node
         long best = 0;
-        for (int c = 0; c < 512; ++c) {
+        for (int c = 0; c < 1024; ++c) {
             snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/caches/%d/properties", node, c);
             const char* ckeys[] = {"level", "size"};
             long cv[2] = {0, 0};
             if (!read_props(path, ckeys, cv, 2)) break;
             if (cv[0] >= 3 && cv[1] > best) best = cv[1];   // size is in KB
         }
-        if (best > 0) { *source = 1; return (size_t)best << 10; }
+        if (best <= 0) continue;
+        if (props && nv[1] == want_loc && nv[2] == (long)prop.pciDomainID) { *source = 1; return (size_t)best << 10; }
+        if (any_l3 == 0 || best < any_l3) any_l3 = best;
     }
+    if (any_l3 > 0) { *source = 1; return (size_t)any_l3 << 10; }
     return (size_t)256 << 20;
 }
 

@@ -76,8 +76,8 @@ _WARNED = set()
 
 
 def _note_torch_modules(what: str):
-    """The fused pointwise kernels cover even widths <= 32 (any expansion); other channel counts run the layer's own
-    torch modules ON THE DEVICE (never the oracle / CPU) -- said once, not silently."""
+    """The fused pointwise kernels cover every width <= 32 and 36 / 40 / 48 / 64 (any expansion); other channel counts run
+    the layer's own torch modules ON THE DEVICE (never the oracle / CPU) -- said once, not silently."""
     if what not in _WARNED:
         _WARNED.add(what)
         import warnings
