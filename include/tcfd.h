@@ -147,7 +147,7 @@ int tcfd_rfft2(const tcfd_ns2d_plan* plan, const void* x_real, void* out_hat, lo
 int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, void* workspace,
                 size_t workspace_bytes, void* stream);
 
-/* ---- FNO / SFNO spectral convolution (fp32) ---------------------------------------
+/* ---- FNO / SFNO spectral convolution (fp32 and fp64) -------------------------------
  * Replaces SpectralConv.forward (fno/base.py:229-237) with SpectralConvS.spectral_conv
  * (fno/sfno.py:364-391), SpectralConvT.forward (fno/sfno.py:433-457) and
  * SpectralConv3d.forward (fno/fno3d.py:86-116):
@@ -155,13 +155,16 @@ int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, l
  * with pruned transforms (only the 2mx x 2my x mt kept modes are produced / consumed).
  *   plan: grid (X, Y) powers of two in [8, 1024]; T_in input steps, t_pad zeros prepended
  *         (SpectralConvT temporal_padding), T_out = irfftn length in t, modes (mx, my, mt).
- *   v        (batch, cin, X, Y, T_in) fp32         out (batch, cout, X, Y, t_keep) fp32
- *   weights  4 pointers, each (cin, cout, mx, my, mt) interleaved complex64, block order
+ *   precision: a plan is fp32 (TCFD_C64: real data fp32, spectra / weights complex64 -- tcfd_fno_plan_create and
+ *         _resample) or fp64 (TCFD_C128, tcfd_fno_plan_create_dtype: FNOBase.double(), fno/base.py:342-349); every
+ *         array of a call has the plan's precision.  Scalars (delta, scales) are double in both cases.
+ *   v        (batch, cin, X, Y, T_in) real          out (batch, cout, X, Y, t_keep) real
+ *   weights  4 pointers, each (cin, cout, mx, my, mt) interleaved complex, block order
  *            ix + 2*iy = [lo-x lo-y, hi-x lo-y, lo-x hi-y, hi-x hi-y]  (sfno.py:374-386; the
  *            complex weights1..4 of fno3d.py:36-79 have the same memory layout)
- *   bias     NULL or 4 pointers (mx, my, mt) complex64, added as delta * bias (sfno.py:388-390)
+ *   bias     NULL or 4 pointers (mx, my, mt) complex, added as delta * bias (sfno.py:388-390)
  *   fwd_scale / inv_scale   norm="backward": 1 and 1/(X*Y*T_out)
- *   use_mfma 1: per-mode products on v_mfma_f32_16x16x4_f32; 0: plain VALU kernel */
+ *   use_mfma 1: per-mode products on v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64; 0: plain VALU kernel */
 typedef struct tcfd_fno_plan tcfd_fno_plan;
 int tcfd_fno_plan_create(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt);
 /* Plan of an INVERSE transform onto a grid (X, Y) of a truncated spectrum taken from a grid (Xs, Ys): what
@@ -170,23 +173,26 @@ int tcfd_fno_plan_create(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad
  * Only tcfd_fno_inverse_trunc may be called with such a plan. */
 int tcfd_fno_plan_create_resample(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt,
                                   int Xs, int Ys);
+/* The general constructor: as _resample (Xs = X, Ys = Y for an ordinary plan) with the precision, TCFD_C64 or TCFD_C128. */
+int tcfd_fno_plan_create_dtype(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt,
+                               int Xs, int Ys, int dtype);
 void tcfd_fno_plan_destroy(tcfd_fno_plan* plan);
 size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* plan, int batch, int cin, int cout);
 int tcfd_fno_spectral_conv(const tcfd_fno_plan* plan, const void* v, const void* const* weights,
-                           const void* const* bias, float delta, void* out, int batch, int cin, int cout,
-                           int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* workspace,
+                           const void* const* bias, double delta, void* out, int batch, int cin, int cout,
+                           int t_keep, double fwd_scale, double inv_scale, int use_mfma, void* workspace,
                            size_t workspace_bytes, void* stream);
 /* The two halves of the convolution on their own, for layers that post-process the spectrum between contraction
  * and inverse transform (SpectralConvT(postprocess=HelmholtzProjection), fno/sfno.py:449):
- *   forward_trunc: v (batch, c, X, Y, T_in) fp32 -> vh (batch, c, 2mx, 2my, mt) complex64, kept modes only
- *   inverse_trunc: vh -> out (batch, c, X, Y, t_keep) fp32.  Workspace: tcfd_fno_workspace_bytes(plan, batch, c, c). */
-int tcfd_fno_forward_trunc(const tcfd_fno_plan* plan, const void* v, void* vh, int batch, int c, float fwd_scale,
+ *   forward_trunc: v (batch, c, X, Y, T_in) real -> vh (batch, c, 2mx, 2my, mt) complex, kept modes only
+ *   inverse_trunc: vh -> out (batch, c, X, Y, t_keep) real.  Workspace: tcfd_fno_workspace_bytes(plan, batch, c, c). */
+int tcfd_fno_forward_trunc(const tcfd_fno_plan* plan, const void* v, void* vh, int batch, int c, double fwd_scale,
                            void* workspace, size_t workspace_bytes, void* stream);
 int tcfd_fno_inverse_trunc(const tcfd_fno_plan* plan, const void* vh, void* out, int batch, int c, int t_keep,
-                           float inv_scale, void* workspace, size_t workspace_bytes, void* stream);
-/* The contraction alone on truncated spectra (batch, c, 2mx, 2my, mt) complex64 (tests). */
-int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, float delta,
-                      void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,
+                           double inv_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The contraction alone on truncated spectra (batch, c, 2mx, 2my, mt), dtype TCFD_C64 / TCFD_C128 (tests). */
+int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, double delta,
+                      void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma, int dtype,
                       void* stream);
 
 /* Fused pointwise block of an SFNO layer (fp32, channel-major (batch, C, P) tensors, P = X*Y*T):
@@ -201,6 +207,12 @@ int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w
                        const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
                        int T, int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride,
                        const void* pe, void* stream);
+/* The same block in float64 (every array double; no positional-encoding input; w2_bstride / b2_bstride as in
+ * tcfd_fno_pointwise: per-batch-element offsets of w2t / b2, 0 = shared): what an SFNO converted
+ * with .double() (fno/base.py:342-349) runs.  Widths 4, 6, 8, 10, 12, 16, 20, 24, 32, any hidden width. */
+int tcfd_fno_pointwise_f64(const void* x, const void* skip, void* out, const void* w1, const void* b1, const void* w2t,
+                           const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P, int T,
+                           int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride, void* stream);
 /* Spectral convolution + the pointwise block that follows it in an SFNO layer, v <- act(FFN(conv(v)) + W v)
  * (fno/sfno.py:607-614) or the lifting tail act(v[..., -1:] + FFN(conv(v))) (:258-259), with the convolution's output
  * kept on chip: the inverse t/y transforms of all `cout` channels of a row (b, x) and the pointwise block run in one
@@ -223,6 +235,8 @@ int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* plan, const void* v, c
  * tcfd_row_moments: sum and sum of squares (double, stats[rows][2]) of every row of a (rows, L) fp32 matrix --
  * the statistics of LayerNormnd / GroupNorm(1 group) with the rows cut across many workgroups. */
 int tcfd_row_moments(const void* x, void* stats, int rows, long L, void* stream);
+/* The same for float64 rows. */
+int tcfd_row_moments_f64(const void* x, void* stats, int rows, long L, void* stream);
 
 /* ---- per-launch event timing (measurement aid; no reference counterpart) -------
  * Between profile_begin and profile_end every kernel the plan launches is

@@ -128,6 +128,14 @@ def test_contraction_mfma_equals_valu_and_oracle(dev):
     c = fno.hip_contract(vh.to(dev), [x.to(dev) for x in w], None, 1.0, modes, use_mfma=False)
     assert rel_l2(c, ref) < 1e-6
     assert rel_l2(a, ref) < 1e-6
+    # the same in float64: v_mfma_f64_16x16x4_f64 against the VALU kernel and the oracle (complex128), with a bias
+    vd = vh.to(torch.complex128)
+    wd = [x.to(torch.complex128) for x in w]
+    bd = [torch.view_as_complex(torch.randn(*modes, 2, generator=g, dtype=torch.float64)) for _ in range(4)]
+    ref64 = OF.spectral_contract(vd, wd, modes, bias=bd, delta=0.3)
+    a64 = fno.hip_contract(vd.to(dev), [x.to(dev) for x in wd], [x.to(dev) for x in bd], 0.3, modes, use_mfma=True)
+    c64 = fno.hip_contract(vd.to(dev), [x.to(dev) for x in wd], [x.to(dev) for x in bd], 0.3, modes, use_mfma=False)
+    assert a64.dtype == torch.complex128 and rel_l2(c64, ref64) < 1e-14 and rel_l2(a64, ref64) < 1e-14
 
 
 def test_linearity_and_zero_input(dev):
@@ -681,9 +689,10 @@ def _blocks(plist):
 
 @pytest.mark.parametrize("pad,steps", [(0, 10), (1, 14), (0, 7)])
 def test_fp64_spectral_layers_against_oracle(pad, steps, dev):
-    """fp64 layers (the reference's FNOBase.double(), fno/base.py:342-349) run on the composite fp64 transforms
-    (solver rfft2 / irfft2 + tensor ops): SpectralConvS and SpectralConvT (temporal padding, resampled output steps)
-    against the oracle's torch.fft evaluation in float64, forward AND gradients."""
+    """fp64 layers (the reference's FNOBase.double(), fno/base.py:342-349) run the fused kernels instantiated for
+    double: SpectralConvS and SpectralConvT (temporal padding, resampled output steps) against the oracle's torch.fft
+    evaluation in float64, forward AND gradients; and against round 2's composite path (solver rfft2 / irfft2 + tensor
+    ops), an independent evaluation on the device."""
     from oracle import fno as OF
     from torch_cfd_amd import fno
 
@@ -695,6 +704,9 @@ def test_fp64_spectral_layers_against_oracle(pad, steps, dev):
     y = convS(x.to(dev))
     ref = OF.spectral_conv(x, _blocks(convS.weight), (5, 4, 3), _blocks(convS.bias), delta=0.4)
     assert y.dtype == torch.float64 and rel_l2(y, ref) < 1e-12
+    with torch.no_grad():
+        comp = fno.fp64_spectral_conv(x.to(dev), list(convS.weight), convS._bias_list(), convS.delta, convS.modes)
+    assert rel_l2(y, comp) < 1e-12
     convT = fno.SpectralConvT(3, 3, 5, 4, 3, delta=0.1, bias=True, temporal_padding=bool(pad)).to(dev)
     _randomise(convT, seed=2)
     xg = x.to(dev).requires_grad_(True)
@@ -709,8 +721,8 @@ def test_fp64_spectral_layers_against_oracle(pad, steps, dev):
 
 
 def test_fp64_sfno_model_against_oracle(dev):
-    """A whole SFNO converted with .double(): spectral convolutions on the composite fp64 transforms, pointwise
-    layers through their torch modules on the device; against oracle/sfno.py evaluated in float64."""
+    """A whole SFNO converted with .double(): spectral convolutions and pointwise blocks on the fp64 instantiation of
+    the fused kernels; against oracle/sfno.py evaluated in float64."""
     from oracle import sfno as OS
     from torch_cfd_amd import fno
 
@@ -836,3 +848,69 @@ def test_pointwise_backward_kernels_agree(mode, dev, monkeypatch):
             assert (got is None) == (ref is None)
             if got is not None:
                 assert rel_l2(got, ref) < 5e-6
+
+
+@pytest.mark.parametrize("width,mode,act", [(10, 1, "GELU"), (4, 2, "ReLU"), (8, 0, "SiLU"), (32, 1, "Tanh")])
+def test_fp64_pointwise_block_matches_torch_modules(width, mode, act, dev):
+    """tcfd_fno_pointwise_f64 against the layer's own torch modules in float64 (two-layer block with skip convolution /
+    last-slice broadcast / no skip, and the single-convolution forms)."""
+    import torch.nn as nn
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(width + mode)
+    mlp = fno.PointwiseFFN(width, width, 3 * width, act).double().to(dev)
+    w = nn.Conv3d(width, width, 1).double().to(dev)
+    red = nn.Conv3d(width, 1, 1).double().to(dev)
+    a2 = getattr(nn, act)()
+    x1 = torch.randn(2, width, 12, 8, 10, dtype=torch.float64, device=dev)
+    v = torch.randn(2, width, 12, 8, 10, dtype=torch.float64, device=dev)
+    vin = torch.randn(2, width, 12, 8, 7, dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        core = mlp.linear2(mlp.activation(mlp.linear1(x1)))
+        if mode == 1:
+            ref, out = a2(core + w(v)), fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=a2)
+        elif mode == 2:
+            ref = a2(vin[..., -1:] + core)
+            out = fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=vin, act2=a2, skip_last_slice=True)
+        else:
+            ref, out = a2(core), fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, act2=a2)
+        assert out is not None and out.dtype == torch.float64 and rel_l2(out, ref) < 1e-13
+        out = fno.hip_pointwise(v, None, None, red)
+        assert out is not None and rel_l2(out, red(v)) < 1e-13
+        out = fno.hip_pointwise(v, None, None, w)
+        assert out is not None and rel_l2(out, w(v)) < 1e-13
+
+
+def test_fp64_forward_cost_against_fp32_at_config5_shape(dev):
+    """SFNO(24, 24, 5, width 10).double() on (8, 256, 256, 10): every layer on the fp64 kernels (no torch-module warning),
+    agrees with the fp32 model to fp32 round-off, and costs a small multiple of it (fp64 moves twice the bytes and the
+    pointwise block has no packed math)."""
+    import warnings
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(0)
+    m32 = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4).to(dev).eval()
+    m64 = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4).to(dev).eval()
+    m64.load_state_dict(m32.state_dict())
+    m64 = m64.double()
+    x = torch.randn(8, 256, 256, 10, device=dev)
+
+    def timed(m, inp):
+        with torch.no_grad():
+            y = m(inp)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                y = m(inp)
+            e1.record()
+            torch.cuda.synchronize()
+        return y, e0.elapsed_time(e1) / 3
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # "uses its torch modules" would raise here
+        y64, t64 = timed(m64, x.double())
+    y32, t32 = timed(m32, x)
+    assert y64.dtype == torch.float64 and rel_l2(y32, y64) < 2e-5
+    print(f"fp32 {t32:.2f} ms, fp64 {t64:.2f} ms, ratio {t64 / t32:.2f}")
+    assert t64 < 3.0 * t32          # measured 1.9 (B = 8) .. 2.2 (B = 32)

@@ -15,7 +15,8 @@
 //   k_inv_ty2  c2r step in t on the kept ky, then zero-padded Y-point inverse FFTs (two output steps per transform)
 //                                                                  -> (b,C,X,Y,T_keep)
 //
-// fp32 only (SpectralConv3d is cfloat-only in the reference).
+// fp32 and fp64 (the kernels are templates on the real type; SpectralConv3d itself is cfloat-only in the reference,
+// SURVEY a16, FNOBase.double() makes SpectralConvS / T / SFNO run in float64, fno/base.py:342-349).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -49,11 +50,13 @@ struct tcfd_fno_plan {
                    // torch's irfftn(s = other size) pads / trims the spectrum ARRAY at its end, so the high block keeps
                    // its array indices [Xs - mx, Xs) / [Ys - my, Ys) in a transform of length X / Y (fno/base.py:229-237)
     int Tp;        // padded input length  T_in + t_pad (the rfft length in t)
-    cf* tw_x;      // [X]   exp(-2 pi i k / X)
-    cf* tw_y;      // [Y]
-    cf* tw_tf;     // [mt][Tp]   forward:  exp(-2 pi i kt t / Tp)
-    cf* tw_ti;     // [T_out][mt] inverse: c_kt * exp(+2 pi i kt t / T_out), c = 1 (kt = 0 or Nyquist) else 2
+    int dtype;     // TCFD_C64: fp32 data / complex64 spectra; TCFD_C128: fp64 / complex128 (FNOBase.double(), fno/base.py:342-349)
+    void* tw_x;    // [X]   exp(-2 pi i k / X)            (complex of the plan's precision, as all four tables)
+    void* tw_y;    // [Y]
+    void* tw_tf;   // [mt][Tp]   forward:  exp(-2 pi i kt t / Tp)
+    void* tw_ti;   // [T_out][mt] inverse: c_kt * exp(+2 pi i kt t / T_out), c = 1 (kt = 0 or Nyquist) else 2
 };
+static size_t csize(const tcfd_fno_plan* p) { return p->dtype == TCFD_C128 ? 16 : 8; }
 
 static bool pow2(int n) { return n >= 8 && n <= 1024 && (n & (n - 1)) == 0; }
 
@@ -64,12 +67,13 @@ static int upload_vec(void** dst, const std::vector<V>& h) {
     return 0;
 }
 
-static std::vector<cf> unit_roots(int n) {
-    std::vector<cf> w(n);
+template <typename T>
+static std::vector<cx<T>> unit_roots(int n) {
+    std::vector<cx<T>> w(n);
     for (int t = 0; t < n; ++t) {
         const long double a = -2.0L * 3.141592653589793238462643383279502884L * t / n;
-        w[t].x = (float)cosl(a);
-        w[t].y = (float)sinl(a);
+        w[t].x = (T)cosl(a);
+        w[t].y = (T)sinl(a);
     }
     return w;
 }
@@ -87,9 +91,42 @@ extern "C" int tcfd_fno_plan_create(tcfd_fno_plan** out, int X, int Y, int T_in,
     return tcfd_fno_plan_create_resample(out, X, Y, T_in, t_pad, T_out, mx, my, mt, X, Y);
 }
 
+template <typename T>
+static int fill_tables(tcfd_fno_plan* p) {
+    const int Tp = p->Tp, mt = p->mt, T_out = p->T_out;
+    std::vector<cx<T>> tf((size_t)mt * Tp), ti((size_t)T_out * mt);
+    const long double PI2 = 2.0L * 3.141592653589793238462643383279502884L;
+    for (int k = 0; k < mt; ++k)
+        for (int t = 0; t < Tp; ++t) {
+            const long double a = -PI2 * (long double)((long)k * t % Tp) / Tp;
+            tf[(size_t)k * Tp + t].x = (T)cosl(a);
+            tf[(size_t)k * Tp + t].y = (T)sinl(a);
+        }
+    for (int t = 0; t < T_out; ++t)
+        for (int k = 0; k < mt; ++k) {
+            // c2r: x[t] = sum_k c_k Re( X_k e^{+2 pi i k t / T} ), Im(X_0) and Im(X_Nyquist) ignored
+            const bool edge = (k == 0) || (2 * k == T_out);
+            const long double a = PI2 * (long double)((long)k * t % T_out) / T_out;
+            const T c = edge ? (T)1 : (T)2;
+            ti[(size_t)t * mt + k].x = c * (T)cosl(a);
+            ti[(size_t)t * mt + k].y = edge ? (T)0 : c * (T)sinl(a);
+        }
+    int rc;
+    if ((rc = upload_vec(&p->tw_x, unit_roots<T>(p->X))) || (rc = upload_vec(&p->tw_y, unit_roots<T>(p->Y))) ||
+        (rc = upload_vec(&p->tw_tf, tf)) || (rc = upload_vec(&p->tw_ti, ti)))
+        return rc;
+    return 0;
+}
+
 extern "C" int tcfd_fno_plan_create_resample(tcfd_fno_plan** out, int X, int Y, int T_in, int t_pad, int T_out, int mx,
                                              int my, int mt, int Xs, int Ys) {
+    return tcfd_fno_plan_create_dtype(out, X, Y, T_in, t_pad, T_out, mx, my, mt, Xs, Ys, TCFD_C64);
+}
+
+extern "C" int tcfd_fno_plan_create_dtype(tcfd_fno_plan** out, int X, int Y, int T_in, int t_pad, int T_out, int mx,
+                                          int my, int mt, int Xs, int Ys, int dtype) {
     if (!out) return FAIL(TCFD_EINVAL, "fno_plan_create: null argument");
+    if (dtype != TCFD_C64 && dtype != TCFD_C128) return FAIL(TCFD_EINVAL, "fno_plan_create: bad dtype %d", dtype);
     if (!pow2(X) || !pow2(Y)) return FAIL(TCFD_EINVAL, "fno_plan_create: X=%d, Y=%d must be powers of two in [8, 1024]", X, Y);
     if (T_in < 1 || t_pad < 0 || T_out < 1 || mx < 1 || my < 1 || mt < 1)
         return FAIL(TCFD_EINVAL, "fno_plan_create: bad sizes");
@@ -104,26 +141,9 @@ extern "C" int tcfd_fno_plan_create_resample(tcfd_fno_plan** out, int X, int Y, 
     p->X = X; p->Y = Y; p->T_in = T_in; p->t_pad = t_pad; p->T_out = T_out;
     p->mx = mx; p->my = my; p->mt = mt; p->Tp = Tp;
     p->Xs = Xs; p->Ys = Ys;
-    std::vector<cf> tf((size_t)mt * Tp), ti((size_t)T_out * mt);
-    const long double PI2 = 2.0L * 3.141592653589793238462643383279502884L;
-    for (int k = 0; k < mt; ++k)
-        for (int t = 0; t < Tp; ++t) {
-            const long double a = -PI2 * (long double)((long)k * t % Tp) / Tp;
-            tf[(size_t)k * Tp + t].x = (float)cosl(a);
-            tf[(size_t)k * Tp + t].y = (float)sinl(a);
-        }
-    for (int t = 0; t < T_out; ++t)
-        for (int k = 0; k < mt; ++k) {
-            // c2r: x[t] = sum_k c_k Re( X_k e^{+2 pi i k t / T} ), Im(X_0) and Im(X_Nyquist) ignored
-            const bool edge = (k == 0) || (2 * k == T_out);
-            const long double a = PI2 * (long double)((long)k * t % T_out) / T_out;
-            const float c = edge ? 1.f : 2.f;
-            ti[(size_t)t * mt + k].x = c * (float)cosl(a);
-            ti[(size_t)t * mt + k].y = edge ? 0.f : c * (float)sinl(a);
-        }
-    int rc;
-    if ((rc = upload_vec((void**)&p->tw_x, unit_roots(X))) || (rc = upload_vec((void**)&p->tw_y, unit_roots(Y))) ||
-        (rc = upload_vec((void**)&p->tw_tf, tf)) || (rc = upload_vec((void**)&p->tw_ti, ti))) {
+    p->dtype = dtype;
+    const int rc = dtype == TCFD_C128 ? fill_tables<double>(p) : fill_tables<float>(p);
+    if (rc) {
         tcfd_fno_plan_destroy(p);
         return rc;
     }
@@ -138,9 +158,9 @@ extern "C" size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* p, int batch, in
     if (!p) return 0;
     const size_t Q = (size_t)2 * p->my * p->mt;
     const int cmax = std::max(cin, cout);
-    const size_t w = al256((size_t)batch * cmax * p->X * Q * sizeof(cf));        // W1 / W2 (shared)
-    const size_t v = al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf));    // truncated input spectrum
-    const size_t o = al256((size_t)batch * cout * 2 * p->mx * Q * sizeof(cf));   // truncated output spectrum
+    const size_t w = al256((size_t)batch * cmax * p->X * Q * csize(p));        // W1 / W2 (shared)
+    const size_t v = al256((size_t)batch * cin * 2 * p->mx * Q * csize(p));    // truncated input spectrum
+    const size_t o = al256((size_t)batch * cout * 2 * p->mx * Q * csize(p));   // truncated output spectrum
     return w + v + o;
 }
 
@@ -156,21 +176,24 @@ extern "C" size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* p, int batch, in
 //              and two output steps ride through one complex IFFT:  H_p = G[.][t0+2p] + i G[.][t0+2p+1].
 // A workgroup owns NS consecutive slabs; thread = (transform tr = s*P + p, lane j of its G-lane group), G <= 64 so
 // every transform lives inside one wave and the exchange needs no workgroup barrier.
-template <int Y>
+template <int Y, typename T = float>
 struct TyCfg2 {
-    static constexpr int EPT = Y >= 256 ? 16 : (Y >= 64 ? 8 : (Y >= 16 ? 4 : 2));
+    static constexpr int EPT0 = Y >= 256 ? 16 : (Y >= 64 ? 8 : (Y >= 16 ? 4 : 2));
+    static constexpr int EPT = (sizeof(T) == 8 && EPT0 > 8) ? 8 : EPT0;      // fp64: 16 complex doubles per lane are 64 VGPRs of data alone
     static constexpr int G = Y / EPT;
 };
+typedef unsigned int b128 __attribute__((ext_vector_type(4)));     // 16 bytes of anything (slab copies)
 
-template <int Y, int EPT>
-__global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, cf* __restrict__ w1,
-                                                  const cf* __restrict__ tw_y, const cf* __restrict__ tw_tf, int T_in,
-                                                  int t_pad, int mt, int my, float scale, int P, int NS, long slabs,
+template <typename T, int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>* __restrict__ w1,
+                                                  const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_tf, int T_in,
+                                                  int t_pad, int mt, int my, T scale, int P, int NS, long slabs,
                                                   unsigned mt_magic) {
+    typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
     const int Tp = T_in + t_pad, Q = 2 * my * mt;
-    const size_t per = (size_t)Y * T_in * 4 > (size_t)P * Y * sizeof(cf) ? (size_t)Y * T_in * 4 : (size_t)P * Y * sizeof(cf);
+    const size_t per = (size_t)Y * T_in * sizeof(T) > (size_t)P * Y * sizeof(cf) ? (size_t)Y * T_in * sizeof(T) : (size_t)P * Y * sizeof(cf);
     unsigned char* slabs_b = smem_raw;                                            // [NS] slab, later [P][Y] spectra
     cf* twt = reinterpret_cast<cf*>(smem_raw + (size_t)NS * per);                  // [mt][Tp]
     const int tr = threadIdx.x / G, j = threadIdx.x % G;
@@ -179,10 +202,10 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, c
     const int count = (int)(slabs - base < NS ? slabs - base : NS);
     const size_t slab_elems = (size_t)Y * T_in;
     {
-        const float4* s4 = reinterpret_cast<const float4*>(v + (size_t)base * slab_elems);
-        const int n4 = (int)(slab_elems / 4);
+        const b128* s4 = reinterpret_cast<const b128*>(v + (size_t)base * slab_elems);
+        const int n4 = (int)(slab_elems * sizeof(T) / 16);
         for (int q = 0; q < count; ++q) {
-            float4* d4 = reinterpret_cast<float4*>(slabs_b + (size_t)q * per);
+            b128* d4 = reinterpret_cast<b128*>(slabs_b + (size_t)q * per);
             for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[(size_t)q * n4 + i];
         }
         for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
@@ -190,32 +213,29 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, c
     __syncthreads();
     cf x[EPT];
     {   // slabs past the end of the batch (last workgroup only) transform stale LDS; nothing of theirs is stored
-        const float* sl = reinterpret_cast<const float*>(slabs_b + (size_t)s * per) + (size_t)j * T_in + 2 * p;
+        const T* sl = reinterpret_cast<const T*>(slabs_b + (size_t)s * per) + (size_t)j * T_in + 2 * p;
         if ((T_in & 1) == 0) {
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) {
-                const float2 r = *reinterpret_cast<const float2*>(sl + (size_t)t * G * T_in);
-                x[t] = mk<float>(r.x, r.y);
-            }
+            for (int t = 0; t < EPT; ++t) x[t] = *reinterpret_cast<const cf*>(sl + (size_t)t * G * T_in);
         } else {
             const bool pair = 2 * p + 1 < T_in;
 #pragma unroll
             for (int t = 0; t < EPT; ++t) {
-                const float* r = sl + (size_t)t * G * T_in;
-                x[t] = mk<float>(r[0], pair ? r[1] : 0.f);
+                const T* r = sl + (size_t)t * G * T_in;
+                x[t] = mk<T>(r[0], pair ? r[1] : (T)0);
             }
         }
     }
     __syncthreads();  // every transform of the slab has its input: the slab bytes become the exchange buffers
     cf* lds = reinterpret_cast<cf*>(slabs_b + (size_t)s * per) + (size_t)p * Y;
-    tile_fft<float, Y, EPT, -1, 1, true, false>(x, lds, tw_y, j, 0);
+    tile_fft<T, Y, EPT, -1, 1, true, false>(x, lds, tw_y, j, 0);
 #pragma unroll
     for (int t = 0; t < EPT; ++t) lds[j + t * G] = x[t];   // Z_p in natural order, read by the whole slab below
     __syncthreads();
     // v^[-ky][t] = conj v^[ky][t] (real input): one task (ky in [0, my], kt) produces out[ky][kt] and out[-ky][kt]
     // from four real sums.  The slab's P*G lanes stride over the (my+1)*mt tasks.
     if (s < count) {
-        const float hsc = 0.5f * scale;
+        const T hsc = (T)0.5 * scale;
         cf* dst = w1 + (size_t)(base + s) * Q;
         const cf* zbase = reinterpret_cast<const cf*>(slabs_b + (size_t)s * per);
         const int ntask = (my + 1) * mt;
@@ -224,12 +244,12 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, c
             const int kt = task - ky * mt;
             const int kyn = (Y - ky) & (Y - 1);
             const cf* w = twt + (size_t)kt * Tp + t_pad;
-            float sce = 0.f, sdf = 0.f, scf = 0.f, sde = 0.f;
+            T sce = 0, sdf = 0, scf = 0, sde = 0;
             for (int pp = 0; pp < P; ++pp) {
                 const cf za = zbase[(size_t)pp * Y + ky], zb = zbase[(size_t)pp * Y + kyn];
                 // 2 v^[ky][2pp] = za + conj zb ;  2 v^[ky][2pp+1] = -i (za - conj zb)
-                const float c0 = za.x + zb.x, d0 = za.y - zb.y;
-                const float c1 = za.y + zb.y, d1 = zb.x - za.x;
+                const T c0 = za.x + zb.x, d0 = za.y - zb.y;
+                const T c1 = za.y + zb.y, d1 = zb.x - za.x;
                 const cf w0 = w[2 * pp];
                 sce += c0 * w0.x; sdf += d0 * w0.y; scf += c0 * w0.y; sde += d0 * w0.x;
                 if (2 * pp + 1 < T_in) {
@@ -237,16 +257,17 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const float* __restrict__ v, c
                     sce += c1 * w1v.x; sdf += d1 * w1v.y; scf += c1 * w1v.y; sde += d1 * w1v.x;
                 }
             }
-            if (ky < my) dst[(size_t)ky * mt + kt] = mk<float>((sce - sdf) * hsc, (scf + sde) * hsc);
-            if (ky >= 1) dst[(size_t)(2 * my - ky) * mt + kt] = mk<float>((sce + sdf) * hsc, (scf - sde) * hsc);
+            if (ky < my) dst[(size_t)ky * mt + kt] = mk<T>((sce - sdf) * hsc, (scf + sde) * hsc);
+            if (ky >= 1) dst[(size_t)(2 * my - ky) * mt + kt] = mk<T>((sce + sdf) * hsc, (scf - sde) * hsc);
         }
     }
 }
 
-template <int Y, int EPT>
-__global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, float* __restrict__ out,
-                                                  const cf* __restrict__ tw_y, const cf* __restrict__ tw_ti, int T_out,
-                                                  int t_keep, int mt, int my, float scale, int P, int NS, long slabs, int Ys) {
+template <typename T, int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, T* __restrict__ out,
+                                                  const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_ti, int T_out,
+                                                  int t_keep, int mt, int my, T scale, int P, int NS, long slabs, int Ys) {
+    typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
     const int Q = 2 * my * mt, t0 = T_out - t_keep;
@@ -262,15 +283,14 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, flo
         const cf* src = w2 + (size_t)base * Q;
         for (int i = threadIdx.x; i < count * Q; i += blockDim.x) win[i] = src[i];
         for (int i = threadIdx.x; i < t_keep * mt; i += blockDim.x) twt[i] = tw_ti[(size_t)t0 * mt + i];
-        float4* z4 = reinterpret_cast<float4*>(lds);           // zero this transform's spectrum (the padding)
 #pragma unroll
-        for (int t = 0; t < EPT / 2; ++t) z4[j + t * G] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < EPT; ++t) lds[j + t * G] = mk<T>((T)0, (T)0);   // zero this transform's spectrum (the padding)
     }
     __syncthreads();
     // G[-ky][t] = conj G[ky][t]: the transform's own lanes stride over ky in [0, my] and fill H_p[ky], H_p[-ky].
     // With a = W[ky][k], b = W[-ky][k], u = a + b, d = a - b:  a E + conj(b E) = (E.x u.x - E.y u.y) + i (E.y d.x + E.x d.y)
     if (s < count) {
-        const float hsc = 0.5f * scale;
+        const T hsc = (T)0.5 * scale;
         const bool pair = 2 * p + 1 < t_keep;
         const cf* e0 = twt + (size_t)(2 * p) * mt;
         const cf* e1 = twt + (size_t)(pair ? 2 * p + 1 : 2 * p) * mt;
@@ -287,21 +307,21 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, flo
             if (!ha && !hb) continue;      // the buffer is pre-zeroed
             const cf* wa = wq + (size_t)(ha ? sa : 0) * mt;
             const cf* wb = wq + (size_t)(hb ? sb : 0) * mt;
-            float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f;
+            T g0x = 0, g0y = 0, g1x = 0, g1y = 0;
             for (int k = 0; k < mt; ++k) {
                 cf a = wa[k];
-                if (!ha) a = mk<float>(0.f, 0.f);
+                if (!ha) a = mk<T>((T)0, (T)0);
                 cf b = wb[k];
-                if (!hb) b = mk<float>(0.f, 0.f);
-                const float ux = a.x + b.x, uy = a.y + b.y, dx = a.x - b.x, dy = a.y - b.y;
+                if (!hb) b = mk<T>((T)0, (T)0);
+                const T ux = a.x + b.x, uy = a.y + b.y, dx = a.x - b.x, dy = a.y - b.y;
                 const cf E0 = e0[k], E1 = e1[k];
                 g0x += E0.x * ux - E0.y * uy;  g0y += E0.y * dx + E0.x * dy;
                 g1x += E1.x * ux - E1.y * uy;  g1y += E1.y * dx + E1.x * dy;
             }
-            if (!pair) { g1x = 0.f; g1y = 0.f; }
+            if (!pair) { g1x = 0; g1y = 0; }
             // H[ky] = G0 + i G1 ;  H[-ky] = conj G0 + i conj G1
-            lds[ky] = mk<float>((g0x - g1y) * hsc, (g0y + g1x) * hsc);
-            if (kyn != ky) lds[kyn] = mk<float>((g0x + g1y) * hsc, (g1x - g0y) * hsc);
+            lds[ky] = mk<T>((g0x - g1y) * hsc, (g0y + g1x) * hsc);
+            if (kyn != ky) lds[kyn] = mk<T>((g0x + g1y) * hsc, (g1x - g0y) * hsc);
         }
     }
     group_sync<false>();
@@ -309,37 +329,36 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cf* __restrict__ w2, flo
 #pragma unroll
     for (int t = 0; t < EPT; ++t) x[t] = lds[j + t * G];
     group_sync<false>();
-    tile_fft<float, Y, EPT, +1, 1, true, false>(x, lds, tw_y, j, 0);
+    tile_fft<T, Y, EPT, +1, 1, true, false>(x, lds, tw_y, j, 0);
     __syncthreads();  // all exchanges done: the buffers become the output slabs [y][t_keep]
-    float* oslab = reinterpret_cast<float*>(ex + (size_t)s * P * Y) + (size_t)j * t_keep + 2 * p;
+    T* oslab = reinterpret_cast<T*>(ex + (size_t)s * P * Y) + (size_t)j * t_keep + 2 * p;
     if ((t_keep & 1) == 0) {
 #pragma unroll
-        for (int t = 0; t < EPT; ++t)
-            *reinterpret_cast<float2*>(oslab + (size_t)t * G * t_keep) = make_float2(x[t].x, x[t].y);
+        for (int t = 0; t < EPT; ++t) *reinterpret_cast<cf*>(oslab + (size_t)t * G * t_keep) = x[t];
     } else {
         const bool pair = 2 * p + 1 < t_keep;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            float* o = oslab + (size_t)t * G * t_keep;
+            T* o = oslab + (size_t)t * G * t_keep;
             o[0] = x[t].x;
             if (pair) o[1] = x[t].y;
         }
     }
     __syncthreads();
-    const int n4 = Y * t_keep / 4;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v* d4 = reinterpret_cast<f4v*>(out + (size_t)base * Y * t_keep);
+    const int n4 = (int)((size_t)Y * t_keep * sizeof(T) / 16);
+    b128* d4 = reinterpret_cast<b128*>(out + (size_t)base * Y * t_keep);
     for (int q = 0; q < count; ++q) {   // streamed out: nothing on this GPU reads it before it has left the caches
-        const f4v* s4 = reinterpret_cast<const f4v*>(ex + (size_t)q * P * Y);
+        const b128* s4 = reinterpret_cast<const b128*>(ex + (size_t)q * P * Y);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) __builtin_nontemporal_store(s4[i], d4 + (size_t)q * n4 + i);
     }
 }
 
 // ------------------------------------------------------------------ x transforms on (X, Q) column tiles
 // FWD: in (b*c, X, Q) -> out (b*c, 2mx, Q) kept rows;  INV: in (b*c, 2mx, Q) -> out (b*c, X, Q)
-template <int X, int EPT, int C, bool FWD>
-__global__ __launch_bounds__(C*(X / EPT)) void k_x(const cf* __restrict__ in, cf* __restrict__ out,
-                                                   const cf* __restrict__ tw_x, int Q, int mx, int ntiles, int Xs) {
+template <typename T, int X, int EPT, int C, bool FWD>
+__global__ __launch_bounds__(C*(X / EPT)) void k_x(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+                                                   const cx<T>* __restrict__ tw_x, int Q, int mx, int ntiles, int Xs) {
+    typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);
     constexpr int G = X / EPT;
@@ -353,15 +372,15 @@ __global__ __launch_bounds__(C*(X / EPT)) void k_x(const cf* __restrict__ in, cf
     for (int t = 0; t < EPT; ++t) {
         const int kx = j + t * G;
         if constexpr (FWD) {
-            x[t] = valid ? in[(bc * X + kx) * Q + q] : mk<float>(0.f, 0.f);
+            x[t] = valid ? in[(bc * X + kx) * Q + q] : mk<T>((T)0, (T)0);
         } else {
             int kxi = -1;   // array index kx of a length-X spectrum cut out of / padded from one of length Xs
             if (kx < mx) kxi = kx;
             else if (kx >= Xs - mx && kx < Xs) kxi = kx - (Xs - 2 * mx);
-            x[t] = (valid && kxi >= 0) ? in[(bc * 2 * mx + kxi) * Q + q] : mk<float>(0.f, 0.f);
+            x[t] = (valid && kxi >= 0) ? in[(bc * 2 * mx + kxi) * Q + q] : mk<T>((T)0, (T)0);
         }
     }
-    tile_fft<float, X, EPT, FWD ? -1 : +1, C, false, true>(x, lds, tw_x, j, c);
+    tile_fft<T, X, EPT, FWD ? -1 : +1, C, false, true>(x, lds, tw_x, j, c);
     if (valid) {
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
@@ -379,19 +398,23 @@ __global__ __launch_bounds__(C*(X / EPT)) void k_x(const cf* __restrict__ in, cf
 }
 
 // ------------------------------------------------------------------ contraction
-struct ContractArgs {
-    const cf* vin;        // (b, ci, 2mx, 2my, mt)
-    cf* vout;             // (b, co, 2mx, 2my, mt)
-    const cf* w[4];       // (ci, co, mx, my, mt)  block index ix + 2*iy
-    const cf* bias[4];    // (mx, my, mt) or null
-    float delta;
+template <typename T>
+struct ContractArgsT {
+    const cx<T>* vin;     // (b, ci, 2mx, 2my, mt)
+    cx<T>* vout;          // (b, co, 2mx, 2my, mt)
+    const cx<T>* w[4];    // (ci, co, mx, my, mt)  block index ix + 2*iy
+    const cx<T>* bias[4]; // (mx, my, mt) or null
+    T delta;
     int b, ci, co, mx, my, mt;
 };
+typedef ContractArgsT<float> ContractArgs;
 
 // Plain VALU form: one thread per (batch, out channel, mode); lanes run along the modes so both the
 // spectrum and the weight reads are contiguous.  Used for shapes the MFMA kernel does not cover and
 // as its cross-check.
-__global__ void k_contract_valu(ContractArgs a) {
+template <typename T>
+__global__ void k_contract_valu(ContractArgsT<T> a) {
+    typedef cx<T> cf;
     const int M = 4 * a.mx * a.my * a.mt;  // kept modes per (b, channel)
     const long total = (long)a.b * a.co * M;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -406,7 +429,7 @@ __global__ void k_contract_valu(ContractArgs a) {
         const int wm = ((kxi - ix * a.mx) * a.my + (kyi - iy * a.my)) * a.mt + kt;  // mode inside the block
         const int MB = a.mx * a.my * a.mt;
         const cf* w = a.w[blk];
-        float re = 0.f, im = 0.f;
+        T re = 0, im = 0;
         for (int i = 0; i < a.ci; ++i) {
             const cf xv = a.vin[((long)bb * a.ci + i) * M + mode];
             const cf wv = w[((long)i * a.co + o) * MB + wm];
@@ -418,7 +441,7 @@ __global__ void k_contract_valu(ContractArgs a) {
             re += a.delta * bv.x;
             im += a.delta * bv.y;
         }
-        a.vout[idx] = mk<float>(re, im);
+        a.vout[idx] = mk<T>(re, im);
     }
 }
 
@@ -428,9 +451,18 @@ __global__ void k_contract_valu(ContractArgs a) {
 // (block, kx, ky-run), the spectrum slice [b][ci][NM] and the weight slice [ci][co][NM] in LDS with
 // coalesced loads (lanes along the contiguous mode axis), then its waves sweep the modes.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// one K-step of four: fp32 on v_mfma_f32_16x16x4_f32, fp64 on v_mfma_f64_16x16x4_f64 (same operand layout; the result
+// rows are interleaved differently, see the store below)
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+template <typename T> struct Acc4 { typedef f32x4 type; };
+template <> struct Acc4<double> { typedef f64x4 type; };
 
-template <int NM>
-__global__ __launch_bounds__(256) void k_contract_mfma(ContractArgs a) {
+template <typename T, int NM>
+__global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
+    typedef cx<T> cf;
+    typedef typename Acc4<T>::type acc4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int M = 4 * a.mx * a.my * a.mt;
     const int MB = a.mx * a.my * a.mt;
@@ -448,7 +480,7 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgs a) {
     const int ix = blk & 1, iy = blk >> 1;
     const cf* w = a.w[blk];
     // zero fill (padding) then stage
-    for (int i = threadIdx.x; i < NM * (bp * cip + cip * cop); i += blockDim.x) As[i] = mk<float>(0.f, 0.f);
+    for (int i = threadIdx.x; i < NM * (bp * cip + cip * cop); i += blockDim.x) As[i] = mk<T>((T)0, (T)0);
     __syncthreads();
     for (int i = threadIdx.x; i < a.b * a.ci * NM; i += blockDim.x) {
         const int mm = i % NM, rest = i / NM;
@@ -470,30 +502,31 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgs a) {
     for (int work = wave; work < NM * mt_tiles * nt_tiles; work += nwaves) {
         const int mm = work / (mt_tiles * nt_tiles);
         const int mtile = (work / nt_tiles) % mt_tiles, ntile = work % nt_tiles;
-        f32x4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0}, ir = {0, 0, 0, 0};
+        acc4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0}, ir = {0, 0, 0, 0};
         const cf* Am = As + (size_t)mm * bp * cip;
         const cf* Bm = Bs + (size_t)mm * cip * cop;
         for (int k0 = 0; k0 < cip; k0 += 4) {
             // A operand: lane l holds A[m = l & 15][k = l >> 4];  B operand: B[k = l >> 4][n = l & 15]
             const cf av = Am[(size_t)(mtile * 16 + (lane & 15)) * cip + k0 + (lane >> 4)];
             const cf bv = Bm[(size_t)(k0 + (lane >> 4)) * cop + ntile * 16 + (lane & 15)];
-            rr = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, rr, 0, 0, 0);
-            ii = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, ii, 0, 0, 0);
-            ri = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.y, ri, 0, 0, 0);
-            ir = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.x, ir, 0, 0, 0);
+            rr = mfma4(av.x, bv.x, rr);
+            ii = mfma4(av.y, bv.y, ii);
+            ri = mfma4(av.x, bv.y, ri);
+            ir = mfma4(av.y, bv.x, ir);
         }
         // C/D layout: col n = lane & 15, row m = (lane >> 4) * 4 + r
         const int wm = wm0 + mm;
         const int kt = wm % a.mt, ky = (wm / a.mt) % a.my, kx = wm / (a.mt * a.my);
         const int mode = ((kx + ix * a.mx) * 2 * a.my + (ky + iy * a.my)) * a.mt + kt;
         const int o = ntile * 16 + (lane & 15);
-        cf bias = mk<float>(0.f, 0.f);
+        cf bias = mk<T>((T)0, (T)0);
         if (a.bias[blk]) bias = cscale(a.bias[blk][wm], a.delta);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int bb = mtile * 16 + (lane >> 4) * 4 + r;
+            // result rows: f32 16x16x4 keeps rows 4 (l >> 4) + r in register r, f64 16x16x4 rows 4 r + (l >> 4)
+            const int bb = mtile * 16 + (sizeof(T) == 8 ? 4 * r + (lane >> 4) : (lane >> 4) * 4 + r);
             if (bb < a.b && o < a.co)
-                a.vout[((long)bb * a.co + o) * M + mode] = mk<float>(rr[r] - ii[r] + bias.x, ri[r] + ir[r] + bias.y);
+                a.vout[((long)bb * a.co + o) * M + mode] = mk<T>(rr[r] - ii[r] + bias.x, ri[r] + ir[r] + bias.y);
         }
     }
 }
@@ -507,17 +540,18 @@ static int set_lds_attr(K kernel, size_t bytes) {
     return 0;
 }
 
-template <int X, bool FWD>
-static int launch_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
+template <typename T, int X, bool FWD>
+static int launch_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
+    typedef cx<T> ct;
     constexpr int EPT = X >= 512 ? 16 : (X >= 64 ? 8 : 4);
-    constexpr int C = 16;  // 16 complex64 = one 128-byte line
+    constexpr int C = 128 / (int)sizeof(ct);  // 16 complex64 / 8 complex128 = one 128-byte line
     const int Q = 2 * p->my * p->mt;
     const int ntiles = (Q + C - 1) / C;
-    constexpr size_t lds = (size_t)lds_elems<X, EPT, C, false>() * sizeof(cf);
-    auto kern = k_x<X, EPT, C, FWD>;
+    constexpr size_t lds = (size_t)lds_elems<X, EPT, C, false>() * sizeof(ct);
+    auto kern = k_x<T, X, EPT, C, FWD>;
     int rc = set_lds_attr(kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(bc * ntiles)), dim3(C * (X / EPT)), lds, st, in, out, (const cf*)p->tw_x, Q,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(bc * ntiles)), dim3(C * (X / EPT)), lds, st, in, out, (const ct*)p->tw_x, Q,
                        p->mx, ntiles, FWD ? X : p->Xs);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -527,10 +561,9 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
-
-template <int Y>
+template <typename T, int Y>
 static int ty2_geometry(int P, int* NS) {
-    constexpr int G = TyCfg2<Y>::G;
+    constexpr int G = TyCfg2<Y, T>::G;
     if (P * G > 1024) return FAIL(TCFD_EINVAL, "fno: %d packed time pairs x %d lanes exceed a workgroup", P, G);
     int ns = env_int("TCFD_FNO_NS", 0);
     if (ns <= 0) ns = std::max(1, std::min(8, 256 / (P * G)));
@@ -539,45 +572,49 @@ static int ty2_geometry(int P, int* NS) {
     return 0;
 }
 
-template <int Y>
-static int launch_fwd_ty2(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float scale, hipStream_t st) {
-    constexpr int EPT = TyCfg2<Y>::EPT, G = TyCfg2<Y>::G;
+template <typename T, int Y>
+static int launch_fwd_ty2(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, T scale, hipStream_t st) {
+    typedef cx<T> ct;
+    constexpr int EPT = TyCfg2<Y, T>::EPT, G = TyCfg2<Y, T>::G;
     const int P = (p->T_in + 1) / 2;
     int NS, rc;
-    if ((rc = ty2_geometry<Y>(P, &NS))) return rc;
-    const size_t per = std::max((size_t)Y * p->T_in * 4, (size_t)P * Y * sizeof(cf));
+    if ((rc = ty2_geometry<T, Y>(P, &NS))) return rc;
+    if (((size_t)Y * p->T_in * sizeof(T)) % 16 != 0) return FAIL(TCFD_EINVAL, "fno: slab of %d x %d values is not a multiple of 16 bytes", Y, p->T_in);
+    const size_t per = std::max((size_t)Y * p->T_in * sizeof(T), (size_t)P * Y * sizeof(ct));
     size_t lds;
     for (;; --NS) {
-        lds = (size_t)NS * per + (size_t)p->mt * p->Tp * sizeof(cf);
+        lds = (size_t)NS * per + (size_t)p->mt * p->Tp * sizeof(ct);
         if (lds <= 160 * 1024 || NS == 1) break;
     }
     if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T=%d)", Y, p->T_in);
-    auto kern = k_fwd_ty2<Y, EPT>;
+    auto kern = k_fwd_ty2<T, Y, EPT>;
     if ((rc = set_lds_attr(kern, lds))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, v, w1, (const cf*)p->tw_y,
-                       (const cf*)p->tw_tf, p->T_in, p->t_pad, p->mt, p->my, scale, P, NS, slabs,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, v, w1, (const ct*)p->tw_y,
+                       (const ct*)p->tw_tf, p->T_in, p->t_pad, p->mt, p->my, scale, P, NS, slabs,
                        p->mt > 1 ? (unsigned)(((1ull << 32) + p->mt - 1) / p->mt) : 0u);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int Y>
-static int launch_inv_ty2(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float scale,
+template <typename T, int Y>
+static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T scale,
                           hipStream_t st) {
-    constexpr int EPT = TyCfg2<Y>::EPT, G = TyCfg2<Y>::G;
+    typedef cx<T> ct;
+    constexpr int EPT = TyCfg2<Y, T>::EPT, G = TyCfg2<Y, T>::G;
     const int P = (t_keep + 1) / 2;
     int NS, rc;
-    if ((rc = ty2_geometry<Y>(P, &NS))) return rc;
+    if ((rc = ty2_geometry<T, Y>(P, &NS))) return rc;
+    if (((size_t)Y * t_keep * sizeof(T)) % 16 != 0) return FAIL(TCFD_EINVAL, "fno: slab of %d x %d values is not a multiple of 16 bytes", Y, t_keep);
     size_t lds;
     for (;; --NS) {
-        lds = ((size_t)NS * P * Y + (size_t)NS * 2 * p->my * p->mt + (size_t)t_keep * p->mt) * sizeof(cf);
+        lds = ((size_t)NS * P * Y + (size_t)NS * 2 * p->my * p->mt + (size_t)t_keep * p->mt) * sizeof(ct);
         if (lds <= 160 * 1024 || NS == 1) break;
     }
     if (lds > 160 * 1024) return FAIL(TCFD_EINVAL, "fno: slab does not fit LDS (Y=%d, T_out=%d)", Y, p->T_out);
-    auto kern = k_inv_ty2<Y, EPT>;
+    auto kern = k_inv_ty2<T, Y, EPT>;
     if ((rc = set_lds_attr(kern, lds))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const cf*)p->tw_y,
-                       (const cf*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const ct*)p->tw_y,
+                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -595,44 +632,82 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cf* w2, float* out, long
         default: return FAIL(TCFD_EINVAL, "unsupported transform length %d", n); \
     }
 
-static int do_fwd_ty(const tcfd_fno_plan* p, const float* v, cf* w1, long slabs, float s, hipStream_t st) {
-    DISPATCH_POW2(p->Y, (launch_fwd_ty2<N_>(p, v, w1, slabs, s, st)));
+template <typename T>
+static int do_fwd_ty(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, T s, hipStream_t st) {
+    DISPATCH_POW2(p->Y, (launch_fwd_ty2<T, N_>(p, v, w1, slabs, s, st)));
 }
-static int do_inv_ty(const tcfd_fno_plan* p, const cf* w2, float* out, long slabs, int t_keep, float s, hipStream_t st) {
-    DISPATCH_POW2(p->Y, (launch_inv_ty2<N_>(p, w2, out, slabs, t_keep, s, st)));
+template <typename T>
+static int do_inv_ty(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T s, hipStream_t st) {
+    DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st)));
 }
-static int do_fwd_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
-    DISPATCH_POW2(p->X, (launch_x<N_, true>(p, in, out, bc, st)));
+template <typename T>
+static int do_fwd_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
+    DISPATCH_POW2(p->X, (launch_x<T, N_, true>(p, in, out, bc, st)));
 }
-static int do_inv_x(const tcfd_fno_plan* p, const cf* in, cf* out, long bc, hipStream_t st) {
-    DISPATCH_POW2(p->X, (launch_x<N_, false>(p, in, out, bc, st)));
+template <typename T>
+static int do_inv_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
+    DISPATCH_POW2(p->X, (launch_x<T, N_, false>(p, in, out, bc, st)));
 }
 
-static int do_contract(const tcfd_fno_plan* p, ContractArgs a, int use_mfma, hipStream_t st) {
+template <typename T>
+static int do_contract(ContractArgsT<T> a, int use_mfma, hipStream_t st) {
     const int MB = a.mx * a.my * a.mt;
     constexpr int NM = 8;
     const int cip = (a.ci + 3) & ~3, bp = (a.b + 15) & ~15, cop = (a.co + 15) & ~15;
-    const size_t lds = (size_t)NM * ((size_t)bp * cip + (size_t)cip * cop) * sizeof(cf);
+    const size_t lds = (size_t)NM * ((size_t)bp * cip + (size_t)cip * cop) * sizeof(cx<T>);
     if (use_mfma && MB % NM == 0 && lds <= 150 * 1024) {
-        auto kern = k_contract_mfma<NM>;
+        auto kern = k_contract_mfma<T, NM>;
         int rc = set_lds_attr(kern, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(4 * MB / NM)), dim3(256), lds, st, a);
     } else {
         const long total = (long)a.b * a.co * 4 * MB;
         const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_contract_valu, dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_contract_valu<T>, dim3(blocks), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// Full spectral convolution.  v (b, ci, X, Y, T_in) fp32 -> out (b, co, X, Y, t_keep) fp32 (the last t_keep of
-// the T_out reconstructed steps).  weights[k] (ci, co, mx, my, mt, 2) fp32, bias[k] (mx, my, mt, 2) or NULL.
+template <typename T>
+static ContractArgsT<T> contract_args(const void* vin, void* vout, const void* const* weights, const void* const* bias,
+                                      double delta, int batch, int cin, int cout, int mx, int my, int mt) {
+    ContractArgsT<T> a;
+    a.vin = (const cx<T>*)vin; a.vout = (cx<T>*)vout;
+    for (int k = 0; k < 4; ++k) {
+        a.w[k] = (const cx<T>*)weights[k];
+        a.bias[k] = bias ? (const cx<T>*)bias[k] : nullptr;
+    }
+    a.delta = (T)delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
+    return a;
+}
+
+template <typename T>
+static int spectral_conv_impl(const tcfd_fno_plan* p, const void* v, const void* const* weights, const void* const* bias,
+                              double delta, void* out, int batch, int cin, int cout, int t_keep, double fwd_scale,
+                              double inv_scale, int use_mfma, void* ws, hipStream_t st) {
+    typedef cx<T> ct;
+    const size_t Q = (size_t)2 * p->my * p->mt;
+    const int cmax = std::max(cin, cout);
+    unsigned char* base = (unsigned char*)ws;
+    ct* W = (ct*)base;
+    ct* V = (ct*)(base + al256((size_t)batch * cmax * p->X * Q * sizeof(ct)));
+    ct* O = (ct*)((unsigned char*)V + al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(ct)));
+    int rc;
+    if ((rc = do_fwd_ty<T>(p, (const T*)v, W, (long)batch * cin * p->X, (T)fwd_scale, st))) return rc;
+    if ((rc = do_fwd_x<T>(p, W, V, (long)batch * cin, st))) return rc;
+    if ((rc = do_contract<T>(contract_args<T>(V, O, weights, bias, delta, batch, cin, cout, p->mx, p->my, p->mt), use_mfma, st)))
+        return rc;
+    if ((rc = do_inv_x<T>(p, O, W, (long)batch * cout, st))) return rc;
+    return do_inv_ty<T>(p, W, (T*)out, (long)batch * cout * p->X, t_keep, (T)inv_scale, st);
+}
+
+// Full spectral convolution.  v (b, ci, X, Y, T_in) real -> out (b, co, X, Y, t_keep) real (the last t_keep of the T_out
+// reconstructed steps) in the plan's precision.  weights[k] (ci, co, mx, my, mt, 2), bias[k] (mx, my, mt, 2) or NULL.
 // fwd_scale / inv_scale: normalisation of rfftn / irfftn ("backward": 1 and 1/(X*Y*T_out)).
 extern "C" int tcfd_fno_spectral_conv(const tcfd_fno_plan* p, const void* v, const void* const* weights,
-                                      const void* const* bias, float delta, void* out, int batch, int cin, int cout,
-                                      int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* ws,
+                                      const void* const* bias, double delta, void* out, int batch, int cin, int cout,
+                                      int t_keep, double fwd_scale, double inv_scale, int use_mfma, void* ws,
                                       size_t ws_bytes, void* stream) {
     if (!p || !v || !weights || !out) return FAIL(TCFD_EINVAL, "fno_spectral_conv: null argument");
     if (batch <= 0 || cin <= 0 || cout <= 0 || t_keep <= 0 || t_keep > p->T_out)
@@ -640,66 +715,56 @@ extern "C" int tcfd_fno_spectral_conv(const tcfd_fno_plan* p, const void* v, con
     const size_t need = tcfd_fno_workspace_bytes(p, batch, cin, cout);
     if (!ws || ws_bytes < need) return FAIL(TCFD_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const size_t Q = (size_t)2 * p->my * p->mt;
-    const int cmax = std::max(cin, cout);
-    unsigned char* base = (unsigned char*)ws;
-    cf* W = (cf*)base;
-    cf* V = (cf*)(base + al256((size_t)batch * cmax * p->X * Q * sizeof(cf)));
-    cf* O = (cf*)((unsigned char*)V + al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf)));
-    int rc;
-    if ((rc = do_fwd_ty(p, (const float*)v, W, (long)batch * cin * p->X, fwd_scale, st))) return rc;
-    if ((rc = do_fwd_x(p, W, V, (long)batch * cin, st))) return rc;
-    ContractArgs a;
-    a.vin = V; a.vout = O;
-    for (int k = 0; k < 4; ++k) {
-        a.w[k] = (const cf*)weights[k];
-        a.bias[k] = bias ? (const cf*)bias[k] : nullptr;
-    }
-    a.delta = delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = p->mx; a.my = p->my; a.mt = p->mt;
-    if ((rc = do_contract(p, a, use_mfma, st))) return rc;
-    if ((rc = do_inv_x(p, O, W, (long)batch * cout, st))) return rc;
-    return do_inv_ty(p, W, (float*)out, (long)batch * cout * p->X, t_keep, inv_scale, st);
+    return p->dtype == TCFD_C128
+               ? spectral_conv_impl<double>(p, v, weights, bias, delta, out, batch, cin, cout, t_keep, fwd_scale, inv_scale, use_mfma, ws, st)
+               : spectral_conv_impl<float>(p, v, weights, bias, delta, out, batch, cin, cout, t_keep, fwd_scale, inv_scale, use_mfma, ws, st);
 }
 
 // The two halves of the spectral convolution on their own, for layers that post-process the spectrum between
 // the contraction and the inverse transform (SpectralConvT(postprocess=HelmholtzProjection), fno/sfno.py:449):
-//   forward_trunc : v (batch, c, X, Y, T_in) fp32  -> vh (batch, c, 2mx, 2my, mt) complex64 (kept modes only)
-//   inverse_trunc : vh (batch, c, 2mx, 2my, mt)    -> out (batch, c, X, Y, t_keep) fp32
+//   forward_trunc : v (batch, c, X, Y, T_in) real  -> vh (batch, c, 2mx, 2my, mt) complex (kept modes only)
+//   inverse_trunc : vh (batch, c, 2mx, 2my, mt)    -> out (batch, c, X, Y, t_keep) real
 // Workspace: tcfd_fno_workspace_bytes(plan, batch, c, c).
-extern "C" int tcfd_fno_forward_trunc(const tcfd_fno_plan* p, const void* v, void* vh, int batch, int c, float fwd_scale,
+extern "C" int tcfd_fno_forward_trunc(const tcfd_fno_plan* p, const void* v, void* vh, int batch, int c, double fwd_scale,
                                       void* ws, size_t ws_bytes, void* stream) {
     if (!p || !v || !vh || batch <= 0 || c <= 0) return FAIL(TCFD_EINVAL, "fno_forward_trunc: bad argument");
     if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = do_fwd_ty(p, (const float*)v, (cf*)ws, (long)batch * c * p->X, fwd_scale, st))) return rc;
-    return do_fwd_x(p, (const cf*)ws, (cf*)vh, (long)batch * c, st);
+    if (p->dtype == TCFD_C128) {
+        if ((rc = do_fwd_ty<double>(p, (const double*)v, (cx<double>*)ws, (long)batch * c * p->X, fwd_scale, st))) return rc;
+        return do_fwd_x<double>(p, (const cx<double>*)ws, (cx<double>*)vh, (long)batch * c, st);
+    }
+    if ((rc = do_fwd_ty<float>(p, (const float*)v, (cf*)ws, (long)batch * c * p->X, (float)fwd_scale, st))) return rc;
+    return do_fwd_x<float>(p, (const cf*)ws, (cf*)vh, (long)batch * c, st);
 }
 
 extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
-                                      float inv_scale, void* ws, size_t ws_bytes, void* stream) {
+                                      double inv_scale, void* ws, size_t ws_bytes, void* stream) {
     if (!p || !vh || !out || batch <= 0 || c <= 0 || t_keep <= 0 || t_keep > p->T_out)
         return FAIL(TCFD_EINVAL, "fno_inverse_trunc: bad argument");
     if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = do_inv_x(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
-    return do_inv_ty(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, inv_scale, st);
+    if (p->dtype == TCFD_C128) {
+        if ((rc = do_inv_x<double>(p, (const cx<double>*)vh, (cx<double>*)ws, (long)batch * c, st))) return rc;
+        return do_inv_ty<double>(p, (const cx<double>*)ws, (double*)out, (long)batch * c * p->X, t_keep, inv_scale, st);
+    }
+    if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
+    return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st);
 }
 
-// Contraction alone on caller-provided truncated spectra (tests, MFMA vs VALU cross-check).
-extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, float delta,
+// Contraction alone on caller-provided truncated spectra (tests, MFMA vs VALU cross-check); dtype TCFD_C64 / TCFD_C128.
+extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, double delta,
                                  void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,
-                                 void* stream) {
+                                 int dtype, void* stream) {
     if (!vin || !weights || !vout) return FAIL(TCFD_EINVAL, "fno_contract: null argument");
-    ContractArgs a;
-    a.vin = (const cf*)vin; a.vout = (cf*)vout;
-    for (int k = 0; k < 4; ++k) {
-        a.w[k] = (const cf*)weights[k];
-        a.bias[k] = bias ? (const cf*)bias[k] : nullptr;
-    }
-    a.delta = delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
-    return do_contract(nullptr, a, use_mfma, (hipStream_t)stream);
+    if (dtype == TCFD_C128)
+        return do_contract<double>(contract_args<double>(vin, vout, weights, bias, delta, batch, cin, cout, mx, my, mt), use_mfma,
+                                   (hipStream_t)stream);
+    if (dtype != TCFD_C64) return FAIL(TCFD_EINVAL, "fno_contract: bad dtype %d", dtype);
+    return do_contract<float>(contract_args<float>(vin, vout, weights, bias, delta, batch, cin, cout, mx, my, mt), use_mfma,
+                              (hipStream_t)stream);
 }
 
 
@@ -1040,6 +1105,7 @@ extern "C" int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* p, const vo
                                                 const void* bs, int cm, int co_pw, int act1, int act2, int skip_mode,
                                                 int skip_T, void* stream) {
     if (!p || !v || !weights || !out || !w1 || !w2t) return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: null argument");
+    if (p->dtype != TCFD_C64) return FAIL(TCFD_EINVAL, "fno: fused layer tail not instantiated (fp32 plans only)");
     if (batch <= 0 || cin <= 0 || cout <= 0 || t_keep <= 0 || t_keep > p->T_out)
         return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: bad sizes");
     if (skip_mode && !skip) return FAIL(TCFD_EINVAL, "fno_spectral_conv_pointwise: skip input missing");
@@ -1062,17 +1128,11 @@ extern "C" int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* p, const vo
     cf* W = (cf*)base;
     cf* V = (cf*)(base + al256((size_t)batch * cmax * p->X * Q * sizeof(cf)));
     cf* O = (cf*)((unsigned char*)V + al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(cf)));
-    if ((rc = do_fwd_ty(p, (const float*)v, W, (long)batch * cin * p->X, fwd_scale, st))) return rc;
-    if ((rc = do_fwd_x(p, W, V, (long)batch * cin, st))) return rc;
-    ContractArgs c;
-    c.vin = V; c.vout = O;
-    for (int k = 0; k < 4; ++k) {
-        c.w[k] = (const cf*)weights[k];
-        c.bias[k] = bias ? (const cf*)bias[k] : nullptr;
-    }
-    c.delta = delta; c.b = batch; c.ci = cin; c.co = cout; c.mx = p->mx; c.my = p->my; c.mt = p->mt;
-    if ((rc = do_contract(p, c, use_mfma, st))) return rc;
-    if ((rc = do_inv_x(p, O, W, (long)batch * cout, st))) return rc;
+    if ((rc = do_fwd_ty<float>(p, (const float*)v, W, (long)batch * cin * p->X, fwd_scale, st))) return rc;
+    if ((rc = do_fwd_x<float>(p, W, V, (long)batch * cin, st))) return rc;
+    if ((rc = do_contract<float>(contract_args<float>(V, O, weights, bias, delta, batch, cin, cout, p->mx, p->my, p->mt), use_mfma, st)))
+        return rc;
+    if ((rc = do_inv_x<float>(p, O, W, (long)batch * cout, st))) return rc;
     return do_inv_ty_pw(p, W, a, batch, cout, cm, co_pw, t_keep, inv_scale, false, st);
 }
 
@@ -1123,6 +1183,116 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
 #undef PW_CASE
 #undef PW_ANY
     return FAIL(TCFD_EINVAL, "fno_pointwise: channels (%d -> %d -> %d) not instantiated", ci, cm, co);
+}
+
+
+// ------------------------------------------------------------------ the same block in float64 (FNOBase.double())
+// One point per lane, channels in registers, weights lane-uniform through the scalar unit; fp64 VALU has no packed form
+// and half the rate, so the block is compute bound here (width 10: 1800 DFMA per point) -- it exists so that an SFNO
+// converted with .double() (fno/base.py:342-349) stays on hand-written kernels end to end, not for speed.
+struct PwArgsD {
+    const double *x, *s, *w1, *b1, *w2t, *b2, *wst, *bs;
+    double* out;
+    long P;
+    long w2_bstride, b2_bstride;   // per-batch-element offsets of w2t / b2 (0: shared): a folded LayerNorm rides in the single-layer form
+    int T, sT, act1, act2, skip_mode, cm;
+};
+__device__ __forceinline__ double pw_act(double v, int act) {
+    switch (act) {
+        case 1: return v > 0.0 ? v : 0.0;
+        case 2: return 0.5 * v * (1.0 + erf(v * 0.70710678118654752440));
+        case 3: return v / (1.0 + exp(-v));
+        case 4: return tanh(v);
+        default: return v;
+    }
+}
+template <int CI, int CO, bool HAS_L1>
+__global__ __launch_bounds__(256) void k_pointwise_f64(PwArgsD a) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long b = blockIdx.y;
+    if (p >= a.P) return;
+    double x[CI], o[CO];
+    const double* xb = a.x + (size_t)b * CI * a.P + p;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+    const double* w2t_b = a.w2t + (size_t)b * a.w2_bstride;
+    const double* b2_b = a.b2 ? a.b2 + (size_t)b * a.b2_bstride : nullptr;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) o[c] = b2_b ? b2_b[c] : 0.0;
+    if constexpr (HAS_L1) {
+        for (int m = 0; m < a.cm; ++m) {
+            double z = a.b1 ? a.b1[m] : 0.0;
+            const double* w1 = a.w1 + (size_t)m * CI;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) z = fma(w1[i], x[i], z);
+            const double h = pw_act(z, a.act1);
+            const double* w2 = w2t_b + (size_t)m * CO;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] = fma(w2[c], h, o[c]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const double* w2 = w2t_b + (size_t)i * CO;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] = fma(w2[c], x[i], o[c]);
+        }
+    }
+    if (a.skip_mode == 1) {
+        const double* sb = a.s + (size_t)b * CI * a.P + p;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const double sv = sb[(size_t)i * a.P];
+            const double* ws = a.wst + (size_t)i * CO;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] = fma(ws[c], sv, o[c]);
+        }
+        if (a.bs) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) o[c] += a.bs[c];
+        }
+    } else if (a.skip_mode == 2) {
+        const long sP = (a.P / a.T) * a.sT;
+        const double* sb = a.s + (size_t)b * CO * sP + (p / a.T) * a.sT + (a.sT - 1);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) o[c] += sb[(size_t)c * sP];
+    }
+    double* ob = a.out + (size_t)b * CO * a.P + p;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) ob[(size_t)c * a.P] = pw_act(o[c], a.act2);
+}
+
+// float64 form of tcfd_fno_pointwise (no positional-encoding input, shared weights).  Instantiated for the widths
+// 4, 6, 8, 10, 12, 16, 20, 24, 32 (any hidden width) and their single-convolution forms W -> W, W -> 1.
+extern "C" int tcfd_fno_pointwise_f64(const void* x, const void* skip, void* out, const void* w1, const void* b1,
+                                      const void* w2t, const void* b2, const void* wst, const void* bs, int batch,
+                                      int ci, int cm, int co, long P, int T, int skip_T, int act1, int act2,
+                                      int skip_mode, long w2_bstride, long b2_bstride, void* stream) {
+    if (!x || !out || !w2t || batch <= 0 || P <= 0) return FAIL(TCFD_EINVAL, "fno_pointwise_f64: bad argument");
+    if (skip_mode && !skip) return FAIL(TCFD_EINVAL, "fno_pointwise_f64: skip input missing");
+    if (skip_mode == 1 && !wst) return FAIL(TCFD_EINVAL, "fno_pointwise_f64: skip weights missing");
+    if (skip_mode == 2 && (T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise_f64: bad T");
+    PwArgsD a;
+    a.x = (const double*)x; a.s = (const double*)skip; a.out = (double*)out; a.w1 = (const double*)w1;
+    a.b1 = (const double*)b1; a.w2t = (const double*)w2t; a.b2 = (const double*)b2; a.wst = (const double*)wst;
+    a.bs = (const double*)bs; a.P = P; a.T = T; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode; a.cm = cm;
+    a.w2_bstride = w2_bstride; a.b2_bstride = b2_bstride;
+    const bool l1 = w1 != nullptr;
+    if (!l1 && cm != ci) return FAIL(TCFD_EINVAL, "fno_pointwise_f64: single layer needs cm == ci");
+    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)batch);
+    hipStream_t st = (hipStream_t)stream;
+#define PWD(CI_, CO_)                                                                                      \
+    if (ci == CI_ && co == CO_) {                                                                           \
+        if (l1) hipLaunchKernelGGL((k_pointwise_f64<CI_, CO_, true>), grid, dim3(256), 0, st, a);           \
+        else hipLaunchKernelGGL((k_pointwise_f64<CI_, CO_, false>), grid, dim3(256), 0, st, a);             \
+        HIP_TRY(hipGetLastError());                                                                         \
+        return 0;                                                                                           \
+    }
+#define PWD_W(W_) PWD(W_, W_) PWD(W_, 1)
+    PWD_W(4) PWD_W(6) PWD_W(8) PWD_W(10) PWD_W(12) PWD_W(16) PWD_W(20) PWD_W(24) PWD_W(32)
+#undef PWD_W
+#undef PWD
+    return FAIL(TCFD_EINVAL, "fno_pointwise_f64: channels (%d -> %d -> %d) not instantiated", ci, cm, co);
 }
 
 
@@ -2134,6 +2304,49 @@ __global__ __launch_bounds__(256) void k_row_moments(const float* __restrict__ x
         atomicAdd(&stats[2 * row], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
         atomicAdd(&stats[2 * row + 1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
     }
+}
+
+// the same for float64 rows (plain double accumulation)
+__global__ __launch_bounds__(256) void k_row_moments_f64(const double* __restrict__ x, double* __restrict__ stats, long L,
+                                                         int chunks) {
+    __shared__ double sh[2][4];
+    const int row = blockIdx.y, chunk = blockIdx.x;
+    const long per = ((L + chunks - 1) / chunks + 1) & ~1L;
+    const long lo = (long)chunk * per, hi = lo + per < L ? lo + per : L;
+    const double* r = x + (size_t)row * L;
+    double s1 = 0.0, s2 = 0.0;
+    if ((L & 1) == 0) {
+        for (long i = lo + (long)threadIdx.x * 2; i < hi; i += 256 * 2) {
+            const double2 v = *reinterpret_cast<const double2*>(r + i);
+            s1 += v.x + v.y;
+            s2 += v.x * v.x + v.y * v.y;
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) { const double v = r[i]; s1 += v; s2 += v * v; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+    }
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * row], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&stats[2 * row + 1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    }
+}
+
+extern "C" int tcfd_row_moments_f64(const void* x, void* stats, int rows, long L, void* stream) {
+    if (!x || !stats || rows <= 0 || L <= 0) return FAIL(TCFD_EINVAL, "row_moments_f64: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(stats, 0, (size_t)rows * 2 * sizeof(double), st));
+    int chunks = (int)std::min<long>(std::max<long>(L / (256 * 2 * 8), 1), 2048 / std::max(rows, 1) + 1);
+    hipLaunchKernelGGL(k_row_moments_f64, dim3((unsigned)chunks, (unsigned)rows), dim3(256), 0, st, (const double*)x,
+                       (double*)stats, L, chunks);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // stats (rows, 2) double, zeroed by this call (memset node on the stream) before the accumulation.

@@ -40,21 +40,22 @@ ActivationType = Union[str]
 
 # ----------------------------------------------------------------------------- HIP plan cache
 class _FnoPlan:
-    def __init__(self, key, device):
+    def __init__(self, key, device, real: torch.dtype = torch.float32):
         """key = (X, Y, T_in, t_pad, T_out, mx, my, mt[, Xs, Ys]); the two extra entries make it the inverse plan of a
-        RESAMPLING layer (spectrum taken on an Xs x Ys grid, transformed onto X x Y; ``tcfd_fno_plan_create_resample``)."""
+        RESAMPLING layer (spectrum taken on an Xs x Ys grid, transformed onto X x Y).  ``real`` is the precision of the
+        plan's tables and of every array passed with it: float32 (complex64 spectra) or float64 (complex128)."""
         X, Y, T_in, t_pad, T_out, mx, my, mt = key[:8]
         self.lib = _lib.load()
         self.key = tuple(key[:8])
         self.device = torch.device(device)
+        self.real = real
+        self.cplx = torch.complex128 if real == torch.float64 else torch.complex64
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            if len(key) == 10:
-                rc = self.lib.tcfd_fno_plan_create_resample(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt,
-                                                            key[8], key[9])
-            else:
-                rc = self.lib.tcfd_fno_plan_create(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt)
-        _lib.check(rc, "tcfd_fno_plan_create")
+            Xs, Ys = (key[8], key[9]) if len(key) == 10 else (X, Y)
+            rc = self.lib.tcfd_fno_plan_create_dtype(ctypes.byref(handle), X, Y, T_in, t_pad, T_out, mx, my, mt, Xs, Ys,
+                                                     _lib.TCFD_C128 if real == torch.float64 else _lib.TCFD_C64)
+        _lib.check(rc, "tcfd_fno_plan_create_dtype")
         self.handle = handle
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._fin = weakref.finalize(self, self.lib.tcfd_fno_plan_destroy, handle)
@@ -86,11 +87,15 @@ def _note_torch_modules(what: str):
                       "this layer uses its torch modules on the device (slower, same result)", stacklevel=3)
 
 
-def _plan(key, device) -> _FnoPlan:
-    full = key + (torch.device(device),)
+def _real_of(dtype: torch.dtype) -> torch.dtype:
+    return torch.float64 if dtype in (torch.float64, torch.complex128) else torch.float32
+
+
+def _plan(key, device, real: torch.dtype = torch.float32) -> _FnoPlan:
+    full = key + (torch.device(device), real)
     p = _PLANS.get(full)
     if p is None:
-        p = _FnoPlan(key, device)
+        p = _FnoPlan(key, device, real)
         _PLANS[full] = p
     return p
 
@@ -117,14 +122,18 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
                       use_mfma: bool = True) -> torch.Tensor:
     """irfftn(contract(rfftn(left_pad_t(v, t_pad))), s=(X, Y, t_out))[..., -t_keep:] on the HIP kernels.
 
-    v (b, Ci, X, Y, T) fp32 HIP tensor; weights: 4 tensors (Ci, Co, mx, my, mt) complex64 or
-    (Ci, Co, mx, my, mt, 2) fp32; bias: None or 4 tensors (mx, my, mt[, 2])."""
+    v (b, Ci, X, Y, T) fp32 or fp64 HIP tensor (fp64: FNOBase.double(), fno/base.py:342-349 -- the same kernels,
+    instantiated for double); weights: 4 tensors (Ci, Co, mx, my, mt) complex or (Ci, Co, mx, my, mt, 2) real of the
+    SAME precision; bias: None or 4 tensors (mx, my, mt[, 2])."""
     if not v.is_cuda:
         raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
-    if v.dtype == torch.float64:   # FNOBase.double() / fp64 layers (fno/base.py:342-349): composite path, see below
-        return fp64_spectral_conv(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm)
-    if v.dtype != torch.float32:
-        raise TypeError(f"the HIP spectral convolution is fp32 (fused kernels) or fp64 (composite path), got {v.dtype}")
+    if v.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"the HIP spectral convolution is fp32 or fp64, got {v.dtype}")
+    real = v.dtype
+    if real == torch.float64 and any(_real_of(w.dtype) != real for w in weights):   # loud, like torch's einsum on mixed dtypes
+        raise TypeError("float64 input to a spectral convolution with float32 parameters: call .double() on the layer")
+    # (float32 data through a layer whose parameters are float64 -- built under a float64 default dtype -- computes in
+    #  float32: the parameters are cast, as in round 2)
     if v.dim() != 5:
         raise ValueError(f"expected (b, C, X, Y, T), got {tuple(v.shape)}")
     b, ci, X, Y, T = v.shape
@@ -137,21 +146,21 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
         return hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma)
     v = v.detach().contiguous()
     if b == 0:   # empty batch, like the reference's tensor ops
-        return torch.empty(0, co, X, Y, t_keep, dtype=torch.float32, device=v.device)
+        return torch.empty(0, co, X, Y, t_keep, dtype=real, device=v.device)
 
     def as_real(w, shape):
         w = w.detach()
         if w.is_complex():
             w = torch.view_as_real(w)
-        w = w.to(torch.float32).contiguous()
+        w = w.to(real).contiguous()
         if tuple(w.shape) != shape:
             raise ValueError(f"weight/bias shape {tuple(w.shape)} != {shape}")
         return w
 
     ws_ = [as_real(w, (ci, co, mx, my, mt, 2)) for w in weights]
     bs_ = [as_real(x, (mx, my, mt, 2)) for x in bias] if bias is not None else None
-    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device)
-    out = torch.empty(b, co, X, Y, t_keep, dtype=torch.float32, device=v.device)
+    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device, real)
+    out = torch.empty(b, co, X, Y, t_keep, dtype=real, device=v.device)
     ws = plan.workspace(b, ci, co)
     fs, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     with torch.cuda.device(v.device):
@@ -163,7 +172,7 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     return out
 
 
-# ----------------------------------------------------------------------------- fp64 layers (composite path)
+# ----------------------------------------------------------------------------- fp64 by composition (cross-check of the fp64 kernels)
 def _fp64_kept_rows(n: int, mx: int, device):
     rows = torch.cat([torch.arange(mx), torch.arange(n - mx, n)]).to(device)
     return rows, (-rows) % n
@@ -172,7 +181,8 @@ def _fp64_kept_rows(n: int, mx: int, device):
 def fp64_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, scale: float = 1.0) -> torch.Tensor:
     """Kept modes of rfftn(left_pad_t(v)) in float64: (b, C, n, n, T) -> (b, C, 2mx, 2my, mt) complex128.
 
-    The fused FNO kernels are fp32.  For fp64 layers the 3-D transform is composed from the solver's fp64 2-D
+    Round 2's fp64 path, kept as an independent cross-check of the fp64 instantiation of the fused kernels (the
+    layers no longer call it): the 3-D transform is composed from the solver's fp64 2-D
     transforms (HIP rfft2 / irfft2 with their hand-written adjoints, ``autograd.py``) and small device tensor ops:
     the short DFT in t is a matmul with a (T, mt) table, the 2-D FFT of the complex result is rfft2(Re) + i rfft2(Im)
     with the columns beyond n/2 taken from the Hermitian mirror.  Square power-of-two grids only; differentiable."""
@@ -273,14 +283,14 @@ def fp64_spectral_conv(v, weights, bias, delta, modes, t_pad=0, t_out=None, t_ke
 
 def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward",
                         scale: Optional[float] = None):
-    """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) fp32 -> (b, C, 2mx, 2my, mt) complex64, plus the plan.
-    ``scale`` overrides the normalisation factor of ``norm``."""
+    """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) real -> (b, C, 2mx, 2my, mt) complex of the same precision
+    (fp32 / fp64), plus the plan.  ``scale`` overrides the normalisation factor of ``norm``."""
     b, c, X, Y, T = v.shape
     mx, my, mt = modes
     t_out = T + t_pad if t_out is None else t_out
-    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device)
-    v = v.detach().contiguous()
-    vh = torch.empty(b, c, 2 * mx, 2 * my, mt, dtype=torch.complex64, device=v.device)
+    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device, _real_of(v.dtype))
+    v = v.detach().to(plan.real).contiguous()
+    vh = torch.empty(b, c, 2 * mx, 2 * my, mt, dtype=plan.cplx, device=v.device)
     ws = plan.workspace(b, c, c)
     fs, _ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     fs = fs if scale is None else float(scale)
@@ -298,8 +308,8 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
     b, c = vh.shape[:2]
     if tuple(vh.shape[2:]) != (2 * mx, 2 * my, mt) or not vh.is_complex():
         raise ValueError(f"expected a complex (b, C, {2 * mx}, {2 * my}, {mt}) truncated spectrum, got {tuple(vh.shape)} {vh.dtype}")
-    vh = vh.detach().to(torch.complex64).contiguous()   # e.g. a float64 post-processing table promotes to complex128
-    out = torch.empty(b, c, X, Y, t_keep, dtype=torch.float32, device=vh.device)
+    vh = vh.detach().to(plan.cplx).contiguous()   # e.g. a float64 post-processing table promotes an fp32 layer's spectrum
+    out = torch.empty(b, c, X, Y, t_keep, dtype=plan.real, device=vh.device)
     ws = plan.workspace(b, c, c)
     _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     is_ = is_ if scale is None else float(scale)
@@ -311,27 +321,31 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
 
 
 def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -> torch.Tensor:
-    """The 4-corner contraction alone on truncated spectra (b, Ci, 2mx, 2my, mt) complex64."""
+    """The 4-corner contraction alone on truncated spectra (b, Ci, 2mx, 2my, mt) complex64 / complex128; the precision of
+    the SPECTRUM decides, the weights are cast to it."""
     b, ci = vh.shape[:2]
     mx, my, mt = modes
     co = weights[0].shape[1]
-    vh = vh.detach().to(torch.complex64).contiguous()
-    f32 = lambda t: (torch.view_as_real(t) if t.is_complex() else t).detach().to(device=vh.device, dtype=torch.float32).contiguous()
+    real = _real_of(vh.dtype)
+    cplx = torch.complex128 if real == torch.float64 else torch.complex64
+    vh = vh.detach().to(cplx).contiguous()
+    f32 = lambda t: (torch.view_as_real(t) if t.is_complex() else t).detach().to(device=vh.device, dtype=real).contiguous()
     ws_ = [f32(w) for w in weights]
     bs_ = [f32(x) for x in bias] if bias is not None else None
-    out = torch.empty(b, co, 2 * mx, 2 * my, mt, dtype=torch.complex64, device=vh.device)
+    out = torch.empty(b, co, 2 * mx, 2 * my, mt, dtype=cplx, device=vh.device)
     lib = _lib.load()
     with torch.cuda.device(vh.device):
         rc = lib.tcfd_fno_contract(vh.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None,
                                    float(delta), out.data_ptr(), b, ci, co, mx, my, mt, 1 if use_mfma else 0,
+                                   _lib.TCFD_C128 if real == torch.float64 else _lib.TCFD_C64,
                                    ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_contract")
     return out
 
 
-def _c2r_weights(mt: int, T: int, device) -> torch.Tensor:
+def _c2r_weights(mt: int, T: int, device, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """Multiplicity of the kept time modes in a length-T c2r transform: 1 for kt = 0 and the Nyquist mode, else 2."""
-    c = torch.full((mt,), 2.0, dtype=torch.float32, device=device)
+    c = torch.full((mt,), 2.0, dtype=_real_of(dtype), device=device)
     c[0] = 1.0
     if T % 2 == 0 and T // 2 < mt:
         c[T // 2] = 1.0
@@ -361,8 +375,8 @@ class _FwdTruncFn(torch.autograd.Function):
         (b, c, X, Y, T), modes, t_pad, t_out, norm = ctx.cfg
         Tp = T + t_pad
         fs, _ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
-        plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device)       # its inverse reconstructs Tp steps
-        zh = (z / _c2r_weights(modes[2], Tp, z.device)).contiguous()
+        plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device, _real_of(z.dtype))       # its inverse reconstructs Tp steps
+        zh = (z / _c2r_weights(modes[2], Tp, z.device, z.dtype)).contiguous()
         return hip_truncated_irfftn(zh, plan, T, scale=fs), None, None, None, None
 
 
@@ -372,7 +386,7 @@ class _InvTruncFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, oh, plan_key, t_keep, norm):
-        plan = _plan(plan_key, oh.device)
+        plan = _plan(plan_key, oh.device, _real_of(oh.dtype))
         ctx.cfg = (plan_key, t_keep, norm)
         return hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
 
@@ -381,7 +395,7 @@ class _InvTruncFn(torch.autograd.Function):
         (X, Y, T, t_pad, t_out, mx, my, mt), t_keep, norm = ctx.cfg
         _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
         gh, _ = hip_truncated_rfftn(dy.contiguous(), (mx, my, mt), t_pad=t_out - t_keep, t_out=t_out, scale=is_)
-        return gh * _c2r_weights(mt, t_out, dy.device), None, None, None
+        return gh * _c2r_weights(mt, t_out, dy.device, dy.dtype), None, None, None
 
 
 class _ContractFn(torch.autograd.Function):
@@ -431,7 +445,7 @@ def hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_k
     vh = _FwdTruncFn.apply(v, tuple(modes), t_pad, t_out, norm)
     oh = _ContractFn.apply(vh, float(delta), tuple(modes), use_mfma, bias is not None, *params)
     if post is not None:
-        oh = post(oh).to(torch.complex64)
+        oh = post(oh).to(vh.dtype)        # a float64 projection table promotes an fp32 layer's spectrum: back to the layer's
     return _InvTruncFn.apply(oh, (X, Y, T, t_pad, t_out) + tuple(modes), t_keep, norm)
 
 
@@ -668,16 +682,19 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     combination is not covered (channel counts, activation type, dtype, autograd) -- the caller then runs its
     torch modules."""
     c1, c2 = _act_code(act1), _act_code(act2)
-    if (c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32 or not _is_pointwise(lin2)
+    if (c1 is None or c2 is None or not x.is_cuda or x.dtype not in (torch.float32, torch.float64) or not _is_pointwise(lin2)
             or (lin1 is not None and not _is_pointwise(lin1)) or (skip_conv is not None and not _is_pointwise(skip_conv))):
         return None
+    real = x.dtype
     for mod in (lin1, lin2, skip_conv, norm):
         for prm in (mod.parameters() if mod is not None else ()):
-            if prm.dtype != torch.float32 or prm.device != x.device:   # torch's own conv raises on this too
-                raise TypeError(f"fp32 input on {x.device} but a {prm.dtype} parameter on {prm.device}: build / move the "
-                                "layer in float32 on the input's device")
-    if skip is not None and (skip.dtype != torch.float32 or skip.device != x.device):
-        raise TypeError("the skip input must be float32 on the same device as x")
+            if prm.dtype != real or prm.device != x.device:   # torch's own conv raises on this too
+                raise TypeError(f"{real} input on {x.device} but a {prm.dtype} parameter on {prm.device}: build / move the "
+                                "layer in the input's precision on the input's device")
+    if skip is not None and (skip.dtype != real or skip.device != x.device):
+        raise TypeError("the skip input must have the precision and the device of x")
+    if real == torch.float64:
+        return _hip_pointwise_f64(x, lin1, c1, lin2, skip, skip_conv, c2, skip_last_slice, norm)
     if torch.is_grad_enabled():
         mods = [m for m in (lin1, lin2, skip_conv, norm) if m is not None]
         tensors = [x, skip] + [p for m in mods for p in m.parameters()]
@@ -759,6 +776,66 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
         _note_torch_modules(f"pointwise block {ci} -> {cm} -> {co}")
         return None
     _lib.check(rc, "tcfd_fno_pointwise")
+    return out
+
+
+def _hip_pointwise_f64(x, lin1, c1, lin2, skip, skip_conv, c2, skip_last_slice, norm=None) -> Optional[torch.Tensor]:
+    """The block in float64 (``tcfd_fno_pointwise_f64``); forward only -- under autograd (or for a width that is not
+    instantiated) ``None``: the layer's torch modules then run, on the device.  ``norm`` (LayerNormnd in front of a
+    single convolution): statistics from ``tcfd_row_moments_f64``, normalisation + affine folded into per-sample weights."""
+    mods = [m for m in (lin1, lin2, skip_conv, norm) if m is not None]
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [x, skip] + [p for m in mods for p in m.parameters()]):
+        return None
+    b, ci = x.shape[:2]
+    co = lin2.out_channels
+    cm = lin1.out_channels if lin1 is not None else ci
+    if lin2.in_channels != cm or (lin1 is not None and lin1.in_channels != ci):
+        return None
+    P, T = x[0, 0].numel(), x.shape[-1]
+    mode, s_t, sT = 0, None, 0
+    if skip_conv is not None:
+        if skip is None or skip.shape != x.shape or skip_conv.in_channels != ci or skip_conv.out_channels != co:
+            return None
+        mode, s_t = 1, skip.detach().contiguous()
+    elif skip_last_slice:
+        if skip is None or skip.shape[1] != co or skip.shape[2:-1] != x.shape[2:-1]:
+            return None
+        mode, s_t, sT = 2, skip.detach().contiguous(), skip.shape[-1]
+    x = x.detach().contiguous()
+    out = torch.empty(b, co, *x.shape[2:], dtype=torch.float64, device=x.device)
+    mat = lambda conv, tr: (lambda w: (w.t() if tr else w).contiguous())(conv.weight.detach().reshape(conv.out_channels, conv.in_channels))
+    w1 = mat(lin1, False) if lin1 is not None else None
+    w2t = mat(lin2, True)
+    wst = mat(skip_conv, True) if skip_conv is not None else None
+    bias = lambda c: c.bias.detach().contiguous() if (c is not None and c.bias is not None) else None
+    b1, b2, bs = bias(lin1), bias(lin2), bias(skip_conv)
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    w2_bs = b2_bs = 0
+    if norm is not None:   # W'_b[c, o] = W[o, c] gamma_c rstd_b ,  b'_b[o] = bias[o] + sum_c W[o, c] (beta_c - gamma_c mu_b rstd_b)
+        if lin1 is not None or norm.num_groups != 1 or norm.num_channels != ci:
+            return None
+        L = ci * P
+        stats = torch.empty(b, 2, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.tcfd_row_moments_f64(x.data_ptr(), stats.data_ptr(), b, L, stream), "tcfd_row_moments_f64")
+        mu = stats[:, 0] / L
+        rstd = torch.rsqrt((stats[:, 1] / L - mu * mu).clamp_min(0) + norm.eps)
+        gamma = norm.weight.detach() if norm.weight is not None else torch.ones(ci, dtype=torch.float64, device=x.device)
+        beta = norm.bias.detach() if norm.bias is not None else torch.zeros(ci, dtype=torch.float64, device=x.device)
+        W = lin2.weight.detach().reshape(co, ci)
+        w2t = (W.t()[None] * (gamma[None, :, None] * rstd[:, None, None])).contiguous()                 # (b, ci, co)
+        fb = (beta[None, :] - gamma[None, :] * (mu * rstd)[:, None]) @ W.t()
+        b2 = (fb + lin2.bias.detach()[None] if lin2.bias is not None else fb).contiguous()              # (b, co)
+        w2_bs, b2_bs = ci * co, co
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(x.device):
+        rc = lib.tcfd_fno_pointwise_f64(x.data_ptr(), ptr(s_t), out.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst),
+                                        ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs, stream)
+    if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+        _note_torch_modules(f"float64 pointwise block {ci} -> {cm} -> {co}")
+        return None
+    _lib.check(rc, "tcfd_fno_pointwise_f64")
     return out
 
 
@@ -967,7 +1044,7 @@ class SpectralConvS(SpectralConv):
         mx, my, mt = self.modes
         vh, _ = hip_truncated_rfftn(v, self.modes, norm=self.norm)
         oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
-        inv = _plan((Xo, Yo, T, 0, To, mx, my, mt, X, Y), v.device)
+        inv = _plan((Xo, Yo, T, 0, To, mx, my, mt, X, Y), v.device, _real_of(v.dtype))
         _, scale = _norm_scales(self.norm, X * Y * T, Xo * Yo * To)
         return hip_truncated_irfftn(oh, inv, To, scale=scale)
 
@@ -988,12 +1065,7 @@ class SpectralConvT(SpectralConvS):
         if not isinstance(self.postprocess, nn.Identity):
             # spectrum post-processing (Helmholtz projection for out_dim = 2): the projection is diagonal in k,
             # so it acts on the kept modes only -- transform, contract, project, inverse-transform
-            if v.is_cuda and v.dtype == torch.float64:   # fp64 layer (the reference's fp64 Helmholtz path): composite transforms
-                post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
-                    self.postprocess, "forward_truncated") else self.postprocess
-                return fp64_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad,
-                                          out_steps + t_pad, out_steps, self.norm, post=post)
-            if not v.is_cuda or v.dtype != torch.float32:
+            if not v.is_cuda or v.dtype not in (torch.float32, torch.float64):
                 raise _lib.TcfdError("expected an fp32 / fp64 HIP device tensor (torch-cfd_amd has no CPU fallback)")
             if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
                 post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
@@ -1244,9 +1316,8 @@ class FNOBase(nn.Module):
         self.num_spectral_layers = num_spectral_layers
 
     def double(self):
-        """Parameters to float64 / complex128 (fno/base.py:342-349).  An fp64 model runs its spectral convolutions on
-        the composite fp64 transforms (``fp64_spectral_conv``) and its pointwise layers through their torch modules on
-        the device; the fused fp32 kernels are not involved."""
+        """Parameters to float64 / complex128 (fno/base.py:342-349).  An fp64 model runs the SAME fused kernels as an
+        fp32 one, instantiated for double (transforms, contraction on v_mfma_f64_16x16x4_f64, pointwise block)."""
         for prm in self.parameters():
             if prm.dtype == torch.float32:
                 prm.data = prm.data.to(torch.float64)
