@@ -958,12 +958,16 @@ def test_trajectory_with_require_grad(dev):
 
 
 # ----------------------------------------------------------------------------- grids that are not a power of two
-@pytest.mark.parametrize("n,tag,forcing", [(96, "f64", "kolmogorov"), (48, "f32", None), (80, "f64", "sincos"), (192, "f64", None)])
-def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, dev):
-    """n = p * 2^k (the reference accepts any even n, equations.py:413-422): power-of-two HIP transforms composed by
-    decimation over the odd factor + the stage loop in tensor ops (mixed_radix.py).  Transforms against torch.fft
-    semantics (non-Hermitian c2r input included), explicit terms / steps / residual / stream function / trajectory
-    against the oracle."""
+@pytest.mark.parametrize("n,tag,forcing,fused", [
+    (96, "f64", "kolmogorov", True), (192, "f64", None, True), (384, "f32", "kolmogorov", True), (768, "f64", "sincos", True),
+    (96, "f32", None, True), (768, "f32", None, True),
+    (48, "f32", None, False), (80, "f64", "sincos", False)])
+def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, fused, dev):
+    """n = p * 2^k (the reference accepts any even n, equations.py:413-422).  n = 3 * 2^k (96 .. 768) runs the FUSED
+    column / row kernels (radix-12 first pass: 4-point transforms, twelfth-root twiddles, 3-point transforms in
+    registers); other small odd factors the power-of-two HIP transforms composed by decimation over the odd factor + the
+    stage loop in tensor ops (mixed_radix.py).  Transforms against torch.fft semantics (non-Hermitian c2r input
+    included), explicit terms / steps / residual / stream function / trajectory against the oracle."""
     import torch_cfd_amd as tc
     from oracle import ns2d as O
 
@@ -978,7 +982,8 @@ def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, dev):
     assert rel_l2(plan.rfft2(y.to(dev)), torch.fft.rfft2(y)) < ttol
     assert rel_l2(plan.irfft2(z.to(dev)), torch.fft.irfft2(z, s=(n, n))) < ttol
     w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 20 + s, real)) for s in range(2)])
-    assert op._plan(w0.to(dev)).info()["composite"] in (3, 5)
+    info = op._plan(w0.to(dev)).info()
+    assert ("composite" in info) == (not fused) and (fused or info["composite"] in (3, 5))
     tol = 1e-10 if tag == "f64" else 4e-6
     assert rel_l2(op.explicit_terms(w0.to(dev)), O.explicit_terms(w0, t)) < (1e-10 if tag == "f64" else 2e-5)
     ref, ref_dt = O.advance(w0, 1e-3, t, steps=3)

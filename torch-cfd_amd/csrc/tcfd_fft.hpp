@@ -102,6 +102,79 @@ struct Dft<1, DIR, T> {
     static __device__ __forceinline__ void run(cx<T> (&)[1]) {}
 };
 
+// ---- radix 3 (grids n = 3 * 2^k: 96, 192, 384, 768) ----------------------------------------------------------------
+// three-point DFT of (a, b, c) in place: y_p = a + w^p b + w^2p c, w = exp(DIR 2 pi i / 3) = -1/2 + DIR i sqrt(3)/2
+template <int DIR, typename T>
+__device__ __forceinline__ void dft3(cx<T>& a, cx<T>& b, cx<T>& c) {
+    constexpr T S3 = (T)0.86602540378443864676;   // sqrt(3) / 2
+    const cx<T> t1 = b + c;
+    const cx<T> t2 = mk<T>(a.x - (T)0.5 * t1.x, a.y - (T)0.5 * t1.y);
+    const cx<T> d = cscale(b - c, S3);
+    const cx<T> r = DIR > 0 ? mul_i(d) : mul_mi(d);          // DIR i sqrt(3)/2 (b - c)
+    a = a + t1;
+    b = t2 + r;
+    c = t2 - r;
+}
+template <int DIR, typename T>
+struct Dft<3, DIR, T> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[3]) { dft3<DIR, T>(v[0], v[1], v[2]); }
+};
+// v <- v * exp(DIR 2 pi i M / 12) for compile-time M in [0, 12)
+template <int M, int DIR, typename T>
+__device__ __forceinline__ cx<T> rot12(cx<T> v) {
+    constexpr int m = ((M % 12) + 12) % 12;
+    if constexpr (m == 0) return v;
+    else if constexpr (m == 3) return DIR > 0 ? mul_i(v) : mul_mi(v);
+    else if constexpr (m == 6) return mk<T>(-v.x, -v.y);
+    else if constexpr (m == 9) return DIR > 0 ? mul_mi(v) : mul_i(v);
+    else {
+        constexpr double C30 = 0.86602540378443864676, C60 = 0.5;
+        // cos / sin of m * 30 degrees
+        constexpr double cc = m == 1 ? C30 : m == 2 ? C60 : m == 4 ? -C60 : m == 5 ? -C30 : m == 7 ? -C30 : m == 8 ? -C60 : m == 10 ? C60 : C30;
+        constexpr double ss = m == 1 ? C60 : m == 2 ? C30 : m == 4 ? C30 : m == 5 ? C60 : m == 7 ? -C60 : m == 8 ? -C30 : m == 10 ? -C30 : -C60;
+        constexpr T c = (T)cc, sn = (T)ss * (T)DIR;
+        return mk<T>(v.x * c - v.y * sn, v.x * sn + v.y * c);
+    }
+}
+// 12 = 4 x 3 (decimation in time over the factor 3): E_s = DFT4(v[3k + s]), twiddle W12^(s q), then 3-point DFTs
+// over s give X[q + 4 p], p = 0..2
+template <int DIR, typename T>
+struct Dft<12, DIR, T> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[12]) {
+        cx<T> e0[4], e1[4], e2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e0[k] = v[3 * k]; e1[k] = v[3 * k + 1]; e2[k] = v[3 * k + 2]; }
+        Dft<4, DIR, T>::run(e0);
+        Dft<4, DIR, T>::run(e1);
+        Dft<4, DIR, T>::run(e2);
+        tw<0>(v, e0, e1, e2);
+    }
+    template <int Q>
+    static __device__ __forceinline__ void tw(cx<T> (&v)[12], cx<T> (&e0)[4], cx<T> (&e1)[4], cx<T> (&e2)[4]) {
+        if constexpr (Q < 4) {
+            cx<T> a = e0[Q], b = rot12<Q, DIR, T>(e1[Q]), c = rot12<2 * Q, DIR, T>(e2[Q]);
+            dft3<DIR, T>(a, b, c);
+            v[Q] = a;
+            v[Q + 4] = b;
+            v[Q + 8] = c;
+            tw<Q + 1>(v, e0, e1, e2);
+        }
+    }
+};
+
+__host__ __device__ constexpr bool is_pow2c(int n) { return n > 0 && (n & (n - 1)) == 0; }
+// Radix of the Stockham pass that starts with Ns transformed elements per sub-sequence: the whole register set (EPT) while
+// it divides what is left, then the largest power of two that divides both.  For power-of-two N this is min(EPT, rest);
+// for N = 3 * 2^k with EPT = 12 it gives 12, 4, 4, ... (768 = 12 * 4 * 4 * 4: three exchanges, like 1024 = 8 * 8 * 8 * 2).
+template <int N, int EPT, int Ns>
+__host__ __device__ constexpr int pass_radix() {
+    constexpr int REM = N / Ns;
+    if (REM % EPT == 0) return EPT;
+    for (int r = 16; r >= 2; r >>= 1)
+        if (EPT % r == 0 && REM % r == 0) return r;
+    return REM;
+}
+
 // ---- synchronisation flavour of one transform group -------------------------
 // SYNC = 1: lanes of a group span several waves -> workgroup barrier (__syncthreads).
 // SYNC = 0: the group lives inside one wave: LDS is in-order per wave, so only
@@ -146,7 +219,10 @@ __device__ __forceinline__ int lds_addr(int e, int c) {
     // (consecutive lanes <-> consecutive elements) only gets permuted inside aligned EPT-element blocks and
     // stays conflict free.  (A one-element pad per EPT block fixes the stores too, but makes every 16-byte
     // READ two-way conflicted: measured 28 % LDS conflict cycles in the row kernel.)
-    if constexpr (PAD) e ^= (e / EPT) % EPT;
+    if constexpr (PAD) {
+        if constexpr ((EPT & (EPT - 1)) == 0) e ^= (e / EPT) % EPT;
+        else e = e - e % EPT + (e % EPT + e / EPT) % EPT;   // EPT not a power of two (12): a rotation instead of the XOR
+    }
     return e * C + c;
 }
 template <int N, int EPT, int C, bool PAD>
@@ -203,13 +279,15 @@ template <typename T, int N, int EPT, int DIR, int C, bool PAD, int WGSYNC, int 
           int P = 0>
 struct Passes {
     static constexpr int REM = N / Ns;
-    static constexpr int R = REM >= EPT ? EPT : REM;
+    static constexpr int R = pass_radix<N, EPT, Ns>();
     static constexpr int Q = EPT / R;
+    static constexpr bool P2 = is_pow2c(N) && is_pow2c(EPT);   // the closed-form swizzle addresses and twiddle chains below
+    static_assert(P2 || TWSQ == 0, "squared / register twiddles are for power-of-two transforms");
     static constexpr int G = N / EPT;
     static constexpr bool LAST = (Ns * R == N);
     // sub-butterfly s of a pass with Q > 1: k_s = k_0 + s G when nothing wraps, i.e. the twiddle is the s = 0 one
     // turned by s * G * N / (Ns R) table steps; usable when that is a whole number of sixteenths of a turn
-    static constexpr bool CHAIN = TWSQ && Q > 1 && (Q * G <= Ns) && ((16 * G) % (Ns * R) == 0) &&
+    static constexpr bool CHAIN = P2 && TWSQ && Q > 1 && (Q * G <= Ns) && ((16 * G) % (Ns * R) == 0) &&
                                   ((Q - 1) * ((16 * G) / (Ns * R)) < 8);
     static constexpr int STEP16 = CHAIN ? (16 * G) / (Ns * R) : 0;
 
@@ -230,7 +308,7 @@ struct Passes {
         if constexpr (!LAST) {
             group_sync<WGSYNC>();
             if constexpr (Ns == 1) hook();
-            if constexpr (PAD && C == 1 && G % (EPT * EPT) == 0) {
+            if constexpr (P2 && PAD && C == 1 && G % (EPT * EPT) == 0) {
                 // the swizzle term ((e / EPT) % EPT) is the same for e = j + t G: one address, constant offsets
                 const cx<T>* src = lds + lds_addr<EPT, 1, true>(j, 0);
 #pragma unroll
@@ -250,14 +328,14 @@ struct Passes {
                                                  int c, int jt, cx<T>& w_first) {
         if constexpr (S < Q) {
             const int jb = j + S * G;
-            const int k = jb & (Ns - 1);
+            const int k = jb % Ns;                 // (a mask for power-of-two Ns: Ns is a compile-time constant)
             cx<T> v[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = x[S + Q * r];
             if constexpr (Ns > 1) {
                 // v[r] *= W^(r*base): only the log2(R) powers W^(base*2^b) are needed; every v[r]
                 // is multiplied by the ones whose bit is set in r (keeps 1 twiddle live instead of R)
-                const int base = ((jt + S * G) & (Ns - 1)) * (N / (Ns * R));
+                const int base = ((jt + S * G) % Ns) * (N / (Ns * R));
                 if constexpr (TWSQ) {
                     cx<T> w;
                     if constexpr (CHAIN && S > 0) {
@@ -290,7 +368,7 @@ struct Passes {
             if constexpr (LAST) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) x[S + Q * r] = v[r];
-            } else if constexpr (PAD && C == 1 && Q == 1 && (Ns == 1 || Ns == EPT || Ns % (EPT * EPT) == 0)) {
+            } else if constexpr (P2 && PAD && C == 1 && Q == 1 && (Ns == 1 || Ns == EPT || Ns % (EPT * EPT) == 0)) {
                 // The swizzled slot of element e_r = o + r Ns, o = (jb - k) R + k, in closed form (R = EPT here):
                 //   Ns = 1      : (e/EPT) % EPT = jb % EPT            -> jb R + (r ^ (jb % EPT))
                 //   Ns = EPT    : (e/EPT) % EPT = r                   -> (jb - k) R + r EPT + (k ^ r)

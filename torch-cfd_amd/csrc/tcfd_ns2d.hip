@@ -72,6 +72,15 @@ TCFD_CFG(float, 256, 16, 16, 16, 256)
 TCFD_CFG(float, 512, 8, 16, 8, 256)
 TCFD_CFG(float, 1024, 16, 8, 16, 256)
 TCFD_CFG(float, 2048, 16, 8, 16, 256)
+// n = 3 * 2^k: twelve elements per lane (radix 12 = 4 x 3 in registers, then radix-4 passes), plain Stockham tiles
+TCFD_CFG(double, 96, 12, 32, 12, 256)
+TCFD_CFG(double, 192, 12, 16, 12, 256)
+TCFD_CFG(double, 384, 12, 8, 12, 256)
+TCFD_CFG(double, 768, 12, 8, 12, 256)
+TCFD_CFG(float, 96, 12, 32, 12, 256)
+TCFD_CFG(float, 192, 12, 16, 12, 256)
+TCFD_CFG(float, 384, 12, 16, 12, 256)
+TCFD_CFG(float, 768, 12, 16, 12, 256)
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -154,7 +163,7 @@ struct ColArgs {
 // per pass; the long-column kernels sit at their 128-register cap, and the cross-lane tiles read two entries per transform).
 template <typename T, int NT, int EPT, int XL>
 struct ColTw {
-    static constexpr bool RT = !XL && NT <= 256 && pass_tw_count<NT, EPT>() > 0 && pass_tw_single<NT, EPT>();
+    static constexpr bool RT = !XL && NT <= 256 && is_pow2c(NT) && is_pow2c(EPT) && pass_tw_count<NT, EPT>() > 0 && pass_tw_single<NT, EPT>();
     static constexpr int CNT = RT ? pass_tw_count<NT, EPT>() : 1;
     cx<T> w[CNT];
     __device__ __forceinline__ void load(const cx<T>* __restrict__ tw, int j) {
@@ -234,7 +243,7 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
             __syncthreads();
             for (int sl = threadIdx.x; sl < NT; sl += C * G) {
                 // row -i of the column: local index of the same parity
-                const int ms = (SP && q) ? NT - 1 - sl : (NT - sl) & (NT - 1);
+                const int ms = (SP && q) ? NT - 1 - sl : (NT - sl) % NT;
                 const cx<T> v0 = S0[sl], m0 = S0[ms];
                 const cx<T> vn = plane_value<T>(f, cscale(un[sl], inv_n2), rt_kx[sl], ky_n, false);
                 const cx<T> mn = plane_value<T>(f, cscale(un[ms], inv_n2), rt_kx[ms], ky_n, false);
@@ -611,7 +620,7 @@ __device__ __forceinline__ void unpack_store_pair(const cx<T> (&x)[EPT], cx<T>* 
     for (int t = 0; t < EPT / 2; ++t) {
         const int k = j + t * G;
         const cx<T> A = x[t];
-        const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
+        const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) % N, 0)];
         const cx<T> S = mk<T>(A.x + Bm.x, A.y - Bm.y);  // A + conj(B) = 2 X0
         const cx<T> D = mk<T>(A.x - Bm.x, A.y + Bm.y);  // A - conj(B) = 2 i X1
         if (valid && k < kc) {  // kc: columns the consumer reads (2/3-rule pruning)
@@ -881,7 +890,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
         for (int t = 0; t < EPT / 2; ++t) {
             const int k = j + t * G;
             const cx<T> A = p[t];
-            const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
+            const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) % N, 0)];
             const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of row r
             const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of row r + N/2
             if (valid && k < kc) {
@@ -995,7 +1004,7 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_ro
             for (int t = 0; t < EPT / 2; ++t) {
                 const int k = jf + t * G;
                 const cx<T> A = p[t];
-                const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) & (N - 1), 0)];
+                const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) % N, 0)];
                 const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of row r
                 const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of row r + N/2
                 if (valid && k < kc) {
@@ -1151,7 +1160,7 @@ struct RowGeom6 {
     static constexpr int XBUF = N + 2;
     static constexpr size_t GROUP_BYTES = (size_t)(XBUF + 2 * SROW) * sizeof(cx<T>);
     static constexpr size_t LDS_BYTES = GROUP_BYTES * GROUPS;
-    static constexpr bool OK = (G % 64 == 0) && (ROWB % (1024 * (WAVES > 0 ? WAVES : 1)) == 0) && pass_tw_single<N, EPT>();
+    static constexpr bool OK = is_pow2c(N) && is_pow2c(EPT) && (G % 64 == 0) && (ROWB % (1024 * (WAVES > 0 ? WAVES : 1)) == 0) && pass_tw_single<N, EPT>();
 };
 
 template <typename T, int N, int EPT, int THR, int SP, int MINW>
@@ -1455,7 +1464,9 @@ struct tcfd_ns2d_plan {
                     // advection / h arrays are neither written nor read.  0: no pruning.
 };
 
-static bool supported_n(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 0; }
+static bool supported_n(int n) {
+    return (n >= 8 && n <= 2048 && (n & (n - 1)) == 0) || n == 96 || n == 192 || n == 384 || n == 768;   // 2^k and 3 * 2^k
+}
 
 template <typename T>
 static int upload(void** dst, const std::vector<T>& host) {
@@ -1647,7 +1658,7 @@ static size_t last_level_cache_bytes(int* source) {
 extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
                                      const double* linear_term, const double* mask, const double* forcing_hat) {
     if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
-    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048]", n);
+    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048] (or 96, 192, 384, 768)", n);
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "plan_create: bad dtype %d", dtype);
     tcfd_ns2d_plan* p = new tcfd_ns2d_plan();   // value-initialised: every pointer / flag starts at zero
     p->n = n;
@@ -1677,7 +1688,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
         tcfd_ns2d_plan_destroy(p);
         return rc;
     }
-    p->nyq = (p->tune.nyq_pack && n >= 64 && p->keep_cols > 0 && p->keep_cols <= p->m - 1 &&
+    p->nyq = (p->tune.nyq_pack && n >= 64 && (n & (n - 1)) == 0 && p->keep_cols > 0 && p->keep_cols <= p->m - 1 &&
               (p->tune.rows_v == 0 || p->tune.rows_v == 5 || p->tune.rows_v == 7)) ? 1 : 0;
     // per pass (TCFD_NYQ_PACK = 3: the opening pass of a call only, for A/B runs; the row pass reads either form)
     p->nyq_a = p->nyq;
@@ -1831,7 +1842,7 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
 template <typename T, int N>
 static bool use_split(const tcfd_ns2d_plan* p) {
     const int force = p->tune.split;
-    if (N < 16) return false;
+    if (N < 16 || !is_pow2c(N)) return false;
     if (force >= 0) return force != 0;
     return N == 1024;   // fp64: 7.99 vs 8.6 ms/step; fp32 (16-column, 128-byte tiles of 512 rows): 5.61 vs 6.05 ms/step
 }
@@ -1850,6 +1861,9 @@ static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, 
 
 template <typename T, int N, int MODE>
 static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
+    if constexpr (!is_pow2c(N))   // n = 3 * 2^k: one plan, plain Stockham tiles
+        return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
+    else
     if constexpr (MODE != MODE_FWD && MODE != MODE_INV) {
         if (use_split<T, N>(p)) return launch_cols_split<T, N, MODE>(p, a, batch, st);
     }
@@ -1979,6 +1993,9 @@ template <typename T, int N>
 static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
                               hipStream_t st, int nyq = 0) {
     constexpr int EPT = Cfg<T, N>::ROW_EPT, THR = Cfg<T, N>::ROW_THREADS;
+    if constexpr (!is_pow2c(N)) {   // n = 3 * 2^k: the software-pipelined two-planes-per-transform kernel, generic in N and EPT
+        return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
+    } else {
     const bool split = use_split<T, N>(p);
     if (p->tune.rows_v == 4) {   // round-1 kernels (two planes per transform), kept for A/B measurements
         if (split) return launch_rows_advect4<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
@@ -2009,6 +2026,7 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
     return launch_rows_advect5<T, N, EPT, THR, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
+    }
 }
 
 template <typename T>
@@ -2341,6 +2359,10 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
         case 512: { constexpr int N_ = 512; return CALL; }                \
         case 1024: { constexpr int N_ = 1024; return CALL; }              \
         case 2048: { constexpr int N_ = 2048; return CALL; }              \
+        case 96: { constexpr int N_ = 96; return CALL; }                  \
+        case 192: { constexpr int N_ = 192; return CALL; }                \
+        case 384: { constexpr int N_ = 384; return CALL; }                \
+        case 768: { constexpr int N_ = 768; return CALL; }                \
         default: return fail(TCFD_EINVAL, "unsupported n=%d", n);         \
     }
 #define TCFD_DISPATCH(p, CALL)                                            \
