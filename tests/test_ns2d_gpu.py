@@ -593,7 +593,7 @@ def test_imex_steppers_golden(order, alpha, beta, dev, monkeypatch):
     assert torch.equal(w6_plain, w6_graph) and rel_l2(w6_plain, wg) < 1e-12
 
 
-@pytest.mark.parametrize("n,tag", [(16, "f64"), (64, "f32"), (256, "f64"), (512, "f32")])
+@pytest.mark.parametrize("n,tag", [(16, "f64"), (64, "f32"), (256, "f64"), (512, "f32"), (192, "f64"), (384, "f32"), (768, "f64")])
 def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
     """The radix-2 split of the column transform (default at 1024^2 fp64) can be forced on or off for any
     n >= 16; both plans must give the same step and the same explicit terms."""

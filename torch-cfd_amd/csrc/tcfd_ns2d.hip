@@ -1431,6 +1431,7 @@ struct Tuning {
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
     int graph;               // TCFD_GRAPH: hipGraph replay of interior steps (-1 = when the state is <= 16 MB)
     int overlap;             // TCFD_OVERLAP: two half batches on two streams (opt-in experiment)
+    int round_fields;        // n = 3 * 2^k: fields whose column tiles fill the resident workgroup slots exactly once (0: not used)
     size_t cache_bytes;      // last-level (Infinity Cache / MALL) size of the plan's device: what a chunk is sized for
     int cache_source;        // 0 = built-in 256 MB, 1 = KFD topology of this device, 2 = TCFD_CACHE_MB
 };
@@ -1655,6 +1656,8 @@ static size_t last_level_cache_bytes(int* source) {
     return (size_t)256 << 20;
 }
 
+static int fill_round_fields(tcfd_ns2d_plan* p);   // (needs the size dispatch, defined below)
+
 extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
                                      const double* linear_term, const double* mask, const double* forcing_hat) {
     if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
@@ -1688,6 +1691,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
         tcfd_ns2d_plan_destroy(p);
         return rc;
     }
+    (void)fill_round_fields(p);
     p->nyq = (p->tune.nyq_pack && n >= 64 && (n & (n - 1)) == 0 && p->keep_cols > 0 && p->keep_cols <= p->m - 1 &&
               (p->tune.rows_v == 0 || p->tune.rows_v == 5 || p->tune.rows_v == 7)) ? 1 : 0;
     // per pass (TCFD_NYQ_PACK = 3: the opening pass of a call only, for A/B runs; the row pass reads either form)
@@ -1842,9 +1846,9 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
 template <typename T, int N>
 static bool use_split(const tcfd_ns2d_plan* p) {
     const int force = p->tune.split;
-    if (N < 16 || !is_pow2c(N)) return false;
+    if (N < 16 || (!is_pow2c(N) && N != 192 && N != 384 && N != 768)) return false;   // (96 / 2 = 48 has no tile configuration)
     if (force >= 0) return force != 0;
-    return N == 1024;   // fp64: 7.99 vs 8.6 ms/step; fp32 (16-column, 128-byte tiles of 512 rows): 5.61 vs 6.05 ms/step
+    return N == 1024;   // (768: split 160 vs plain 181 steps/s at one round of workgroups per launch)   // fp64: 7.99 vs 8.6 ms/step; fp32 (16-column, 128-byte tiles of 512 rows): 5.61 vs 6.05 ms/step
 }
 
 template <typename T, int N, int MODE>
@@ -1861,9 +1865,12 @@ static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, 
 
 template <typename T, int N, int MODE>
 static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
-    if constexpr (!is_pow2c(N))   // n = 3 * 2^k: one plan, plain Stockham tiles
+    if constexpr (!is_pow2c(N)) {   // n = 3 * 2^k: Stockham tiles (no cross-lane / packed-Nyquist variants), whole or split
+        if constexpr (N != 96 && MODE != MODE_FWD && MODE != MODE_INV) {
+            if (use_split<T, N>(p)) return launch_cols_split<T, N, MODE>(p, a, batch, st);
+        }
         return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
-    else
+    } else
     if constexpr (MODE != MODE_FWD && MODE != MODE_INV) {
         if (use_split<T, N>(p)) return launch_cols_split<T, N, MODE>(p, a, batch, st);
     }
@@ -1993,8 +2000,21 @@ template <typename T, int N>
 static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv, long batch,
                               hipStream_t st, int nyq = 0) {
     constexpr int EPT = Cfg<T, N>::ROW_EPT, THR = Cfg<T, N>::ROW_THREADS;
-    if constexpr (!is_pow2c(N)) {   // n = 3 * 2^k: the software-pipelined two-planes-per-transform kernel, generic in N and EPT
-        return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
+    if constexpr (!is_pow2c(N)) {
+        // n = 3 * 2^k: v5 (one plane per transform, next plane's rows in flight, one wave per SIMD); at 768^2 fp64 per 7-field
+        // chunk launch: 43 us, against 53 for v3 (two planes per transform, TCFD_ROWS_V=4) and 124 for v5 capped at two waves
+        // per SIMD (twelve complex fp64 per array spill there)
+        const bool split3 = use_split<T, N>(p);
+        if (p->tune.rows_v == 4) {
+            if constexpr (N != 96) {
+                if (split3) return launch_rows_advect4<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
+            }
+            return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
+        }
+        if constexpr (N != 96) {
+            if (split3) return launch_rows_advect5<T, N, EPT, THR, 1, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
+        }
+        return launch_rows_advect5<T, N, EPT, THR, 0, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
     } else {
     const bool split = use_split<T, N>(p);
     if (p->tune.rows_v == 4) {   // round-1 kernels (two planes per transform), kept for A/B measurements
@@ -2390,6 +2410,26 @@ extern "C" int tcfd_ns2d_plan_chunking(const tcfd_ns2d_plan* p, long batch, long
     return 0;
 }
 
+// n = 3 * 2^k: how many fields make ONE round of resident column workgroups.  These plans run whole-column Stockham tiles
+// (768^2 fp64: 107 KB of LDS = one 512-lane workgroup per CU, 49 tiles per field): a cache-sized chunk of 7 fields is 343
+// workgroups = 1.34 rounds, 5 fields are 245 = one round -- 157 -> 181 steps/s.
+template <typename T, int N>
+static int round_fields_impl(tcfd_ns2d_plan* p) {
+    if constexpr (is_pow2c(N)) {
+        p->tune.round_fields = 0;
+    } else {
+        constexpr int EPT = Cfg<T, N>::COL_EPT, C = Cfg<T, N>::COLS;
+        constexpr size_t lds = (size_t)lds_elems<N, EPT, C, false>() * sizeof(cx<T>) + 3 * (size_t)N * sizeof(T);
+        constexpr int threads = C * (N / EPT);
+        const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / lds), by_thr = std::max(1, 1024 / threads);
+        const int per_cu = std::min(std::min(by_lds, by_thr), 2);      // the column kernels use > 128 registers at EPT = 12
+        const int tiles = (p->m + C - 1) / C;
+        p->tune.round_fields = std::max(1, 256 * per_cu / tiles);
+    }
+    return 0;
+}
+static int fill_round_fields(tcfd_ns2d_plan* p) { TCFD_DISPATCH(p, (round_fields_impl<T_, N_>(p))); }
+
 // Fields per chunk of a batched call.  TCFD_CHUNK > 0 forces it, 0 disables chunking, -1 (default) sizes the chunk so
 // that its working set -- 4 planes + advection + RK accumulator + padded state, 7 workspace fields per batch element --
 // fits the 256 MB Infinity Cache (measured on MI355X, steps/s per call: 1024^2 x 64 fp64 122.7 -> 129.3 at 4 fields
@@ -2403,6 +2443,7 @@ static long chunk_fields(const tcfd_ns2d_plan* p, long batch) {
         // 61/64 of the cache (244 of 256 MB, the measured optimum on MI355X: 4 fields of 1024^2 fp64 = 239 MB fit, 5 do not)
         c = (long)((p->tune.cache_bytes / 64 * 61) / per_field);
         if (c < 3) return batch;
+        if (p->tune.round_fields > 0 && c > p->tune.round_fields) c = c / p->tune.round_fields * p->tune.round_fields;   // whole rounds
     }
     if (c >= batch) return batch;
     const long nchunks = (batch + c - 1) / c;
