@@ -961,12 +961,13 @@ def test_trajectory_with_require_grad(dev):
 @pytest.mark.parametrize("n,tag,forcing,fused", [
     (96, "f64", "kolmogorov", True), (192, "f64", None, True), (384, "f32", "kolmogorov", True), (768, "f64", "sincos", True),
     (96, "f32", None, True), (768, "f32", None, True),
-    (48, "f32", None, False), (80, "f64", "sincos", False)])
+    (80, "f64", "sincos", True), (160, "f32", "kolmogorov", True), (320, "f64", None, True), (640, "f64", "kolmogorov", True), (640, "f32", None, True),
+    (48, "f32", None, False), (48, "f64", "sincos", False)])
 def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, fused, dev):
-    """n = p * 2^k (the reference accepts any even n, equations.py:413-422).  n = 3 * 2^k (96 .. 768) runs the FUSED
-    column / row kernels (radix-12 first pass: 4-point transforms, twelfth-root twiddles, 3-point transforms in
-    registers); other small odd factors the power-of-two HIP transforms composed by decimation over the odd factor + the
-    stage loop in tensor ops (mixed_radix.py).  Transforms against torch.fft semantics (non-Hermitian c2r input
+    """n = p * 2^k (the reference accepts any even n, equations.py:413-422).  n = 3 * 2^k (96 .. 768) and n = 5 * 2^k
+    (80 .. 640) run the FUSED column / row kernels (radix-12 / radix-20 first pass: 4-point transforms, twiddles, 3- / 5-point
+    transforms in registers); other sizes with a small odd factor (48, 112, ...) the power-of-two HIP transforms composed by
+    decimation over the odd factor + the stage loop in tensor ops (mixed_radix.py).  Transforms against torch.fft semantics (non-Hermitian c2r input
     included), explicit terms / steps / residual / stream function / trajectory against the oracle."""
     import torch_cfd_amd as tc
     from oracle import ns2d as O

@@ -162,6 +162,78 @@ struct Dft<12, DIR, T> {
     }
 };
 
+// ---- radix 5 (grids n = 5 * 2^k: 80, 160, 320, 640) ----------------------------------------------------------------
+// cos(2 pi m / 20), m = 0..19 (sin is the same table shifted by a quarter turn)
+__host__ __device__ constexpr double cos20(int m) {
+    constexpr double t[20] = {1.0, 0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410,
+                              0.0, -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212,
+                              -1.0, -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410,
+                              0.0, 0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212};
+    return t[((m % 20) + 20) % 20];
+}
+// v <- v * exp(DIR 2 pi i M / 20)
+template <int M, int DIR, typename T>
+__device__ __forceinline__ cx<T> rot20(cx<T> v) {
+    constexpr int m = ((M % 20) + 20) % 20;
+    if constexpr (m == 0) return v;
+    else if constexpr (m == 5) return DIR > 0 ? mul_i(v) : mul_mi(v);
+    else if constexpr (m == 10) return mk<T>(-v.x, -v.y);
+    else if constexpr (m == 15) return DIR > 0 ? mul_mi(v) : mul_i(v);
+    else {
+        constexpr T c = (T)cos20(m), sn = (T)cos20(m - 5) * (T)DIR;     // sin(x) = cos(x - pi/2)
+        return mk<T>(v.x * c - v.y * sn, v.x * sn + v.y * c);
+    }
+}
+// five-point DFT in place: y_p = sum_s w^(p s) v_s, w = exp(DIR 2 pi i / 5)
+template <int DIR, typename T>
+__device__ __forceinline__ void dft5(cx<T>& a, cx<T>& b, cx<T>& c, cx<T>& d, cx<T>& e) {
+    constexpr T C1 = (T)0.30901699437494742410, C2 = (T)-0.80901699437494742410;     // cos 72, cos 144
+    constexpr T S1 = (T)0.95105651629515357212, S2 = (T)0.58778525229247312917;      // sin 72, sin 144
+    const cx<T> t1 = b + e, t2 = c + d, t3 = b - e, t4 = c - d;
+    const cx<T> m1 = mk<T>(a.x + C1 * t1.x + C2 * t2.x, a.y + C1 * t1.y + C2 * t2.y);
+    const cx<T> m2 = mk<T>(a.x + C2 * t1.x + C1 * t2.x, a.y + C2 * t1.y + C1 * t2.y);
+    const cx<T> n1 = mk<T>(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
+    const cx<T> n2 = mk<T>(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+    const cx<T> r1 = DIR > 0 ? mul_i(n1) : mul_mi(n1), r2 = DIR > 0 ? mul_i(n2) : mul_mi(n2);
+    a = a + t1 + t2;
+    b = m1 + r1;
+    e = m1 - r1;
+    c = m2 + r2;
+    d = m2 - r2;
+}
+template <int DIR, typename T>
+struct Dft<5, DIR, T> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[5]) { dft5<DIR, T>(v[0], v[1], v[2], v[3], v[4]); }
+};
+// 20 = 4 x 5: E_s = DFT4(v[5k + s]), twiddle W20^(s q), five-point DFTs over s give X[q + 4 p], p = 0..4
+template <int DIR, typename T>
+struct Dft<20, DIR, T> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[20]) {
+        cx<T> e[5][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int s = 0; s < 5; ++s) e[s][k] = v[5 * k + s];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) Dft<4, DIR, T>::run(e[s]);
+        tw<0>(v, e);
+    }
+    template <int Q>
+    static __device__ __forceinline__ void tw(cx<T> (&v)[20], cx<T> (&e)[5][4]) {
+        if constexpr (Q < 4) {
+            cx<T> a = e[0][Q], b = rot20<Q, DIR, T>(e[1][Q]), c = rot20<2 * Q, DIR, T>(e[2][Q]),
+                  d = rot20<3 * Q, DIR, T>(e[3][Q]), f = rot20<4 * Q, DIR, T>(e[4][Q]);
+            dft5<DIR, T>(a, b, c, d, f);
+            v[Q] = a;
+            v[Q + 4] = b;
+            v[Q + 8] = c;
+            v[Q + 12] = d;
+            v[Q + 16] = f;
+            tw<Q + 1>(v, e);
+        }
+    }
+};
+
 __host__ __device__ constexpr bool is_pow2c(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // Radix of the Stockham pass that starts with Ns transformed elements per sub-sequence: the whole register set (EPT) while
 // it divides what is left, then the largest power of two that divides both.  For power-of-two N this is min(EPT, rest);
@@ -221,7 +293,7 @@ __device__ __forceinline__ int lds_addr(int e, int c) {
     // READ two-way conflicted: measured 28 % LDS conflict cycles in the row kernel.)
     if constexpr (PAD) {
         if constexpr ((EPT & (EPT - 1)) == 0) e ^= (e / EPT) % EPT;
-        else e = e - e % EPT + (e % EPT + e / EPT) % EPT;   // EPT not a power of two (12): a rotation instead of the XOR
+        else e = e - e % EPT + (e % EPT + e / EPT) % EPT;   // EPT not a power of two (12, 20): a rotation instead of the XOR
     }
     return e * C + c;
 }

@@ -81,6 +81,15 @@ TCFD_CFG(float, 96, 12, 32, 12, 256)
 TCFD_CFG(float, 192, 12, 16, 12, 256)
 TCFD_CFG(float, 384, 12, 16, 12, 256)
 TCFD_CFG(float, 768, 12, 16, 12, 256)
+// n = 5 * 2^k: twenty elements per lane (radix 20 = 4 x 5 in registers, then radix 4 / 2)
+TCFD_CFG(double, 80, 20, 32, 20, 256)
+TCFD_CFG(double, 160, 20, 16, 20, 256)
+TCFD_CFG(double, 320, 20, 8, 20, 256)
+TCFD_CFG(double, 640, 20, 8, 20, 256)
+TCFD_CFG(float, 80, 20, 32, 20, 256)
+TCFD_CFG(float, 160, 20, 16, 20, 256)
+TCFD_CFG(float, 320, 20, 16, 20, 256)
+TCFD_CFG(float, 640, 20, 16, 20, 256)
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -1466,7 +1475,8 @@ struct tcfd_ns2d_plan {
 };
 
 static bool supported_n(int n) {
-    return (n >= 8 && n <= 2048 && (n & (n - 1)) == 0) || n == 96 || n == 192 || n == 384 || n == 768;   // 2^k and 3 * 2^k
+    return (n >= 8 && n <= 2048 && (n & (n - 1)) == 0) || n == 96 || n == 192 || n == 384 || n == 768 ||   // 2^k, 3 * 2^k
+           n == 80 || n == 160 || n == 320 || n == 640;                                                    // and 5 * 2^k
 }
 
 template <typename T>
@@ -1661,7 +1671,7 @@ static int fill_round_fields(tcfd_ns2d_plan* p);   // (needs the size dispatch, 
 extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
                                      const double* linear_term, const double* mask, const double* forcing_hat) {
     if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
-    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048] (or 96, 192, 384, 768)", n);
+    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048] (or 96 / 192 / 384 / 768, 80 / 160 / 320 / 640)", n);
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "plan_create: bad dtype %d", dtype);
     tcfd_ns2d_plan* p = new tcfd_ns2d_plan();   // value-initialised: every pointer / flag starts at zero
     p->n = n;
@@ -1866,7 +1876,7 @@ static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, 
 template <typename T, int N, int MODE>
 static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
     if constexpr (!is_pow2c(N)) {   // n = 3 * 2^k: Stockham tiles (no cross-lane / packed-Nyquist variants), whole or split
-        if constexpr (N != 96 && MODE != MODE_FWD && MODE != MODE_INV) {
+        if constexpr ((N == 192 || N == 384 || N == 768) && MODE != MODE_FWD && MODE != MODE_INV) {
             if (use_split<T, N>(p)) return launch_cols_split<T, N, MODE>(p, a, batch, st);
         }
         return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
@@ -2005,13 +2015,14 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         // chunk launch: 43 us, against 53 for v3 (two planes per transform, TCFD_ROWS_V=4) and 124 for v5 capped at two waves
         // per SIMD (twelve complex fp64 per array spill there)
         const bool split3 = use_split<T, N>(p);
+        constexpr bool SPLIT_OK = (N == 192 || N == 384 || N == 768);
         if (p->tune.rows_v == 4) {
-            if constexpr (N != 96) {
+            if constexpr (SPLIT_OK) {
                 if (split3) return launch_rows_advect4<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
             }
             return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
         }
-        if constexpr (N != 96) {
+        if constexpr (SPLIT_OK) {
             if (split3) return launch_rows_advect5<T, N, EPT, THR, 1, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
         }
         return launch_rows_advect5<T, N, EPT, THR, 0, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
@@ -2383,6 +2394,10 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
         case 192: { constexpr int N_ = 192; return CALL; }                \
         case 384: { constexpr int N_ = 384; return CALL; }                \
         case 768: { constexpr int N_ = 768; return CALL; }                \
+        case 80: { constexpr int N_ = 80; return CALL; }                  \
+        case 160: { constexpr int N_ = 160; return CALL; }                \
+        case 320: { constexpr int N_ = 320; return CALL; }                \
+        case 640: { constexpr int N_ = 640; return CALL; }                \
         default: return fail(TCFD_EINVAL, "unsupported n=%d", n);         \
     }
 #define TCFD_DISPATCH(p, CALL)                                            \
