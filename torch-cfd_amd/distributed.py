@@ -237,7 +237,11 @@ class RecordHandover:
             if self.world > 1:
                 self._post_receives()
         else:
-            self._sends.append((dist.isend(packed, _global_rank(self.group, self.dst), group=self.group), packed))
+            # through batch_isend_irecv like the receiving side: ProcessGroupNCCL runs batched point-to-point operations on
+            # the group's communicator and unbatched ones on a separate two-rank communicator -- a batched receive and an
+            # unbatched send would never meet
+            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, packed, _global_rank(self.group, self.dst), group=self.group)])
+            self._sends.append((works, packed))
 
     def finish(self) -> Optional[Dict[str, torch.Tensor]]:
         if self.cursor[self.rank] != len(self.items[self.rank]):
@@ -250,8 +254,9 @@ class RecordHandover:
                 self.side.synchronize()
             self._keep.clear()
             return self.host
-        for work, _ in self._sends:
-            work.wait()
+        for works, _ in self._sends:
+            for work in works:
+                work.wait()
         if self.on_gpu:
             torch.cuda.current_stream(self.device).synchronize()
         self._sends.clear()
