@@ -126,6 +126,16 @@ int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* plan, const void* w_in, void* w_ou
 int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* plan, const void* w, void* out, long batch,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Vector-Jacobian product of the explicit terms (what torch autograd builds from the ~40 ops of
+ * NavierStokes2DSpectral._explicit_terms, torch_cfd/equations.py:413-438, when a state requires grad).  With
+ * F(w) = mask . rfft2(-(dxw u + dyw v)) and a cotangent g of F:  the caller passes gm = mask * g / c  (c = 1 on the DC
+ * and Nyquist columns of the half spectrum, 2 elsewhere: the adjoint of the r2c transform) and receives the four half
+ * spectra X_f (xout: (4, batch, n, m), f = u^, v^, dxw^, dyw^ as in the forward's planes); the cotangent of w is
+ *     wbar = -(c / n^2) * sum_f conj(a_f) X_f ,   a_0 = -2 pi i ky / lap, a_1 = 2 pi i kx / lap, a_2 = 2 pi i kx, a_3 = 2 pi i ky
+ * (lap = -4 pi^2 |k|^2 with lap(0,0) := 1).  Workspace as tcfd_ns2d_explicit_terms. */
+int tcfd_ns2d_explicit_terms_vjp(const tcfd_ns2d_plan* plan, const void* w, const void* gm, void* xout, long batch,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* psi = -w/lap and residual = w_t - F(w) - L w in one call: the record step of
  * get_trajectory_imex (fno/data_gen/solvers.py:245-247, torch_cfd/spectral.py:113,
  * equations.py:405-411).  Either output may be NULL. */

@@ -848,6 +848,35 @@ def test_differentiable_step_matches_fused_step_and_cpu_autograd(dev):
     assert rel_l2(wg2.grad, wc2.grad) < 1e-10
 
 
+@pytest.mark.parametrize("n,tag,B,forcing", [(64, "f64", 3, "kolmogorov"), (256, "f32", 2, None), (1024, "f64", 6, "kolmogorov"),
+                                            (96, "f64", 2, "sincos"), (160, "f64", 2, None), (512, "f64", 20, None)])
+def test_fused_vjp_of_the_explicit_terms_matches_the_tensor_op_path(n, tag, B, forcing, dev, monkeypatch):
+    """tcfd_ns2d_explicit_terms_vjp (one row pass with five c2r / four products / four r2c per row pair) against the
+    tensor-op backward through the hand-written transform adjoints (TCFD_FUSED_VJP=0): same cotangent of w for a random
+    complex cotangent of F; sizes with split plans (1024: the VJP uses whole-column tiles), several chunks per call
+    (1024 x 6, 512 x 20), radix-3 / radix-5 grids, fp32."""
+    from oracle import ns2d as O
+
+    real = REAL[tag]
+    grid, op = build_op(n, tag, forcing, dev)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 40 + s, real)) for s in range(min(B, 3))])
+    w0 = w0.repeat((B + w0.shape[0] - 1) // w0.shape[0], 1, 1)[:B].contiguous()
+    w0 = w0 * (1 + 0.1 * torch.arange(B, dtype=real)[:, None, None])
+    g = torch.Generator().manual_seed(n)
+    cot = torch.complex(torch.randn(B, n, n // 2 + 1, generator=g, dtype=real), torch.randn(B, n, n // 2 + 1, generator=g, dtype=real)).to(dev)
+    grads, vals = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_FUSED_VJP", flag)
+        w = w0.to(dev).requires_grad_(True)
+        F = op.explicit_terms(w)
+        vals[flag] = F.detach()
+        (F * cot.conj()).real.sum().backward()
+        grads[flag] = w.grad
+    tol = 1e-11 if tag == "f64" else 2e-5
+    assert rel_l2(vals["1"], vals["0"]) < (1e-12 if tag == "f64" else 2e-5)
+    assert rel_l2(grads["1"], grads["0"]) < tol
+
+
 def test_trainable_rk_coefficients_receive_gradients(dev):
     """RK4CrankNicolsonStepper(requires_grad=True): d loss / d gammas from the differentiable path against central
     differences of the FUSED forward step (two different code paths must agree)."""

@@ -108,6 +108,7 @@ SIGNATURES = {
     "tcfd_ns2d_step_imex": (_i, [_vp, _vp, _vp, _vp, _l, _i, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(_i), _i, _d, _vp, _sz,
                                  _vp]),
     "tcfd_ns2d_explicit_terms": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_ns2d_explicit_terms_vjp": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _sz, _vp]),
     "tcfd_ns2d_stream_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _sz, _vp]),
     "tcfd_ns2d_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),

@@ -10,8 +10,10 @@ hand-written transforms:
     X = rfft2(y)                                                     grad y = n^2 irfft2(grad X / c)
 
 with c = 1 on the DC and Nyquist columns of the half spectrum and 2 elsewhere (the c2r transform counts the interior
-columns twice, the r2c transform once).  Nothing here touches torch.fft or the CPU; it is the slow path (a stage is
-~25 launches instead of 2) and exists for gradients only.
+columns twice, the r2c transform once).  Nothing here touches torch.fft or the CPU.  Since round 3 the explicit terms and
+their vector-Jacobian product run on the fused kernels (``FusedExplicitTerms``: 3 launches forward, ~10 backward); what is
+left in tensor ops is the Runge-Kutta / Crank-Nicolson bookkeeping of a stage (a handful of element-wise launches), which is
+also what lets trainable coefficients receive gradients.
 """
 from __future__ import annotations
 
@@ -54,8 +56,66 @@ class Irfft2(torch.autograd.Function):
         return Rfft2.apply(g, plan) * scale, None
 
 
+class FusedExplicitTerms(torch.autograd.Function):
+    """F(w) on the fused kernels (3 launches) with its vector-Jacobian product on the fused kernels too
+    (``tcfd_ns2d_explicit_terms_vjp``: the opening column pass of the forward + one column inverse transform, ONE row pass with
+    five c2r / four products / four r2c per row pair, four column transforms) instead of ~25 tensor-op launches each way.
+
+    F(w) = M . R(-(I(a2 w) I(a0 w) + I(a3 w) I(a1 w))) + f with a0 = -2 pi i ky / lap (u), a1 = 2 pi i kx / lap (v),
+    a2 = 2 pi i kx (dx w), a3 = 2 pi i ky (dy w).  With the transform adjoints of this module (R^T g = n^2 I(g / c),
+    I^T y = (c / n^2) R(y)):  nbar = R^T(M g) and  wbar = -(c / n^2) sum_f conj(a_f) R(nbar . partner_f)."""
+
+    @staticmethod
+    def forward(ctx, w_hat, op, plan):
+        ctx.op, ctx.plan = op, plan
+        ctx.save_for_backward(w_hat)
+        return plan.explicit_terms(w_hat).reshape(w_hat.shape)
+
+    @staticmethod
+    def _tables(op, plan, device):
+        key = (plan.cdtype, device, op.smooth) + tuple((t.data_ptr(), t._version) for t in (op.kx, op.ky, op.filter))
+        cached = getattr(plan, "_vjp_tables", None)
+        if cached is None or cached[0] != key:
+            real = plan.rdtype
+            kx, ky = op.kx.to(device=device, dtype=real), op.ky.to(device=device, dtype=real)
+            lap = (-4 * torch.pi**2 * (kx**2 + ky**2)).clone()
+            lap[..., 0, 0] = 1
+            two_pi_i = 2j * torch.pi
+            a = torch.stack([-two_pi_i * ky / lap, two_pi_i * kx / lap, two_pi_i * kx, two_pi_i * ky * torch.ones_like(kx)]).to(plan.cdtype)
+            c = _column_weights(plan, kx)
+            mask = op.filter.to(device=device, dtype=real) if op.smooth else torch.ones_like(kx)
+            pre = (mask / c).to(real)                                   # gm = g * mask / c
+            post = (-(c / float(plan.n * plan.n)) * a.conj()).contiguous()   # (4, n, m): wbar = sum_f post_f X_f
+            cached = (key, pre, post)
+            plan._vjp_tables = cached
+        return cached[1], cached[2]
+
+    @staticmethod
+    def backward(ctx, g):
+        (w_hat,) = ctx.saved_tensors
+        pre, post = FusedExplicitTerms._tables(ctx.op, ctx.plan, g.device)
+        lead = w_hat.shape
+        w3 = w_hat.reshape(-1, ctx.plan.n, ctx.plan.m)
+        gm = (g.reshape(w3.shape) * pre).contiguous()
+        X = ctx.plan.explicit_terms_vjp(w3, gm)                          # (4, B, n, m)
+        wbar = (X * post[:, None]).sum(dim=0)
+        return wbar.reshape(lead), None, None
+
+
+def _fused_vjp_ok(plan) -> bool:
+    import os
+
+    return hasattr(plan, "explicit_terms_vjp") and os.environ.get("TCFD_FUSED_VJP", "1") != "0"
+
+
 def explicit_terms(op, plan, w_hat: torch.Tensor, forcing_hat) -> torch.Tensor:
-    """F(w) = mask * rfft2(-(dx w * u + dy w * v)) + f^  with  psi = -w / lap,  (u, v) = (dy psi, -dx psi)."""
+    """F(w) = mask * rfft2(-(dx w * u + dy w * v)) + f^  with  psi = -w / lap,  (u, v) = (dy psi, -dx psi).  On the fused
+    grids (power-of-two, 3 * 2^k, 5 * 2^k plans) through ``FusedExplicitTerms``; the tensor-op form below serves the composite
+    grids and as the cross-check (``TCFD_FUSED_VJP=0``)."""
+    if _fused_vjp_ok(plan):
+        if torch.is_grad_enabled() and w_hat.requires_grad:
+            return FusedExplicitTerms.apply(w_hat, op, plan)
+        return plan.explicit_terms(w_hat).reshape(w_hat.shape)     # nothing to differentiate: the plain fused sweep
     kx, ky = op.kx.to(w_hat.device), op.ky.to(w_hat.device)
     two_pi_i = 2j * torch.pi
     lap = -4 * torch.pi**2 * (kx**2 + ky**2)

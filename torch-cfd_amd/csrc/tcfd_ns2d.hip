@@ -917,6 +917,60 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_adv
     }
 }
 
+// ---- row pass of the VECTOR-JACOBIAN PRODUCT of the explicit terms -----------------------------------------------
+// F(w) = M . R( -(dxw u + dyw v) ) [+ f],  u, v, dxw, dyw = I(a_f w).  For a cotangent g:  nbar = R^T(M g) is a real field
+// (plane 4 holds the column-transformed M g / c), and the cotangents of the four inverse transforms are nbar times the
+// PARTNER of each factor:   Y0 = nbar dxw (-> u^),  Y1 = nbar dyw (-> v^),  Y2 = nbar u (-> dxw^),  Y3 = nbar v (-> dyw^).
+// One group per row pair, two rows per complex transform as in v5: five c2r, four products, four r2c; the Y rows replace
+// the plane rows they were computed from (a pair's rows belong to its group alone).  Plain (non-split) plane layout.
+template <typename T, int N, int EPT, int THR>
+__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_vjp(cx<T>* __restrict__ planes, size_t plane_stride,
+                                                                                 const cx<T>* __restrict__ gplane,
+                                                                                 const cx<T>* __restrict__ tw, long npairs, int ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT, THR>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    const long stride = (long)gridDim.x * Gm::GROUPS;
+    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
+    const long iters = (npairs + stride - 1) / stride;   // every group runs the same number of iterations (workgroup barriers)
+    for (long it = 0; it < iters; ++it, pair += stride) {
+        const bool valid = pair < npairs;
+        const long cur = valid ? pair : npairs - 1;
+        const size_t off = (size_t)cur * 2 * (size_t)ld;
+        RawPair<T, EPT> H;
+        auto field = [&](cx<T>(&out)[EPT], const cx<T>* rowA) {
+            load_raw<T, N, EPT>(H, rowA, rowA + ld, j);
+            pack_herm<T, N, EPT, WG>(out, H, lds, j);
+            tile_fft<T, N, EPT, +1, 1, true, WG>(out, lds, tw, j, 0);
+        };
+        auto emit = [&](const cx<T>(&nb)[EPT], const cx<T>(&fld)[EPT], cx<T>* rowA) {
+            cx<T> y[EPT];
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) y[t] = mk<T>(nb[t].x * fld[t].x, nb[t].y * fld[t].y);
+            tile_fft<T, N, EPT, -1, 1, true, WG>(y, lds, tw, j, 0);
+            unpack_store_pair<T, N, EPT>(y, lds, rowA, rowA + ld, j, valid);
+        };
+        cx<T> nb[EPT], fa[EPT], fb[EPT];
+        cx<T>* P0 = planes + off;
+        cx<T>* P1 = planes + plane_stride + off;
+        cx<T>* P2 = planes + 2 * plane_stride + off;
+        cx<T>* P3 = planes + 3 * plane_stride + off;
+        field(nb, gplane + off);
+        field(fa, P2);          // dx w
+        field(fb, P0);          // u
+        emit(nb, fa, P0);       // Y0 = nbar dxw
+        emit(nb, fb, P2);       // Y2 = nbar u
+        field(fa, P3);          // dy w
+        field(fb, P1);          // v
+        emit(nb, fa, P1);       // Y1 = nbar dyw
+        emit(nb, fb, P3);       // Y3 = nbar v
+    }
+}
+
 // ---- row pass, one plane per transform ("v5") --------------------------------------------------
 // The kernels above ride two PLANES of one row through a complex transform, so the transformed velocity rows
 // of BOTH rows of a pair stay live while the gradient planes are transformed (z1r, z1s, x, p + two half quads:
@@ -2538,6 +2592,75 @@ extern "C" int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* p, const void* w, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     return explicit_chunked(p, w, out, nullptr, nullptr, false, batch, ws, st);
+}
+
+// Vector-Jacobian product of the explicit terms (the backward of tcfd_ns2d_explicit_terms): from the state w and the
+// pre-weighted cotangent gm = mask * g / c it produces the four half spectra  X_f = rfft2(Y_f)  (k_rows_vjp), which the caller
+// combines:  wbar = -(c / n^2) sum_f conj(a_f) X_f.  Three kinds of launches per chunk: the opening column pass of the forward
+// (w -> 4 planes) + the column inverse transform of gm, the row pass above, four generic column forward transforms.
+template <typename T, int N>
+static int explicit_vjp_impl(const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, size_t x_field_stride,
+                             long batch, void* ws, hipStream_t st) {
+    Ws<T> W = carve<T>(p, ws, batch);
+    int rc;
+    ColArgs<T> a{};
+    a.planes = W.planes;
+    a.plane_stride = W.plane_stride;
+    a.u_in = (const cx<T>*)w;
+    a.u_in_ld = p->m;
+    a.nyq = 0;    // whole-column tiles, every column present (the row pass reads the plain layout)
+    if ((rc = launch_cols_v<T, N, MODE_A, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st))) return rc;
+    ColArgs<T> g{};
+    g.in = (const cx<T>*)gm;
+    g.out = W.adv;
+    g.in_ld = p->m;
+    g.out_ld = p->ldw;
+    g.scale = (T)1;
+    if ((rc = launch_cols<T, N, MODE_INV>(p, g, batch, st))) return rc;
+    {
+        constexpr int EPT = Cfg<T, N>::ROW_EPT, THR = Cfg<T, N>::ROW_THREADS;
+        using Gm = RowGeom<T, N, EPT, THR>;
+        auto kern = k_rows_vjp<T, N, EPT, THR>;
+        static DevOnce lds_once;
+        if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
+        const long npairs = batch * (N / 2);
+        const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, 4);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, W.planes, W.plane_stride,
+                           (const cx<T>*)W.adv, (const cx<T>*)p->tw, npairs, p->ldw);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int f = 0; f < 4; ++f) {
+        ColArgs<T> c{};
+        c.in = W.planes + (size_t)f * W.plane_stride;
+        c.out = (cx<T>*)xout + (size_t)f * x_field_stride;
+        c.in_ld = p->ldw;
+        c.out_ld = p->m;
+        c.scale = (T)1;
+        if ((rc = launch_cols<T, N, MODE_FWD>(p, c, batch, st))) return rc;
+    }
+    return 0;
+}
+static int explicit_vjp_dispatch(const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, size_t xs, long batch,
+                                 void* ws, hipStream_t st) {
+    TCFD_DISPATCH(p, (explicit_vjp_impl<T_, N_>(p, w, gm, xout, xs, batch, ws, st)));
+}
+
+extern "C" int tcfd_ns2d_explicit_terms_vjp(const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, long batch,
+                                            void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !w || !gm || !xout || batch <= 0) return fail(TCFD_EINVAL, "explicit_terms_vjp: bad argument");
+    int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = (p->dtype == TCFD_C128 ? 16 : 8) * (size_t)p->n * p->m;
+    const size_t xs = (size_t)batch * p->n * p->m;            // elements between the four outputs
+    const long chunk = chunk_fields(p, batch);
+    for (long b0 = 0; b0 < batch; b0 += chunk) {
+        const long nb = std::min(chunk, batch - b0);
+        rc = explicit_vjp_dispatch(p, (const unsigned char*)w + (size_t)b0 * esz, (const unsigned char*)gm + (size_t)b0 * esz,
+                                   (unsigned char*)xout + (size_t)b0 * esz, xs, nb, ws, st);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* p, const void* w, const void* wt, void* psi,

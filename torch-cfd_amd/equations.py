@@ -154,6 +154,21 @@ class _HipPlan:
         _lib.check(rc, "tcfd_ns2d_explicit_terms")
         return out
 
+    def explicit_terms_vjp(self, w, gm):
+        """The four half spectra X_f of ``tcfd_ns2d_explicit_terms_vjp`` for the state ``w`` and the pre-weighted cotangent
+        ``gm`` = mask * g / c: shape (4, *w.shape)."""
+        w, batch = self._prep(w)
+        gm, _ = self._prep(gm)
+        out = torch.empty((4,) + tuple(w.shape), dtype=w.dtype, device=w.device)
+        if batch == 0:
+            return out
+        ws = self.workspace(batch)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tcfd_ns2d_explicit_terms_vjp(self.handle, w.data_ptr(), gm.data_ptr(), out.data_ptr(), batch,
+                                                       ws.data_ptr(), ws.numel(), self._stream())
+        _lib.check(rc, "tcfd_ns2d_explicit_terms_vjp")
+        return out
+
     def stream_residual(self, w, wt, want_psi=True, want_res=True):
         w, batch = self._prep(w)
         wt_, _ = self._prep(wt)
@@ -512,8 +527,16 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
         return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
     def _forcing_on(self, like: torch.Tensor):
-        fh = self.forcing_hat()
-        return None if fh is None else fh.to(device=like.device, dtype=self._plan(like).cdtype)
+        """The forcing spectrum on the device, sampled once per plan (the plan is rebuilt when the forcing's fingerprint or a
+        table changes): sampling it again on every differentiable call cost a CPU rfft2 of the grid each time (30-50 ms at
+        1024^2 -- more than the step)."""
+        plan = self._plan(like)
+        cached = getattr(plan, "_forcing_dev", None)
+        if cached is None:
+            fh = self.forcing_hat()
+            cached = (None if fh is None else fh.to(device=like.device, dtype=plan.cdtype),)
+            plan._forcing_dev = cached
+        return cached[0]
 
     def _autograd_steps(self, vort_hat, dt, steps, params, stepper, want_dwdt):
         from . import autograd as ad
