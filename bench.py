@@ -76,6 +76,9 @@ def parse(argv=None):
                     help="weak: --batch fields per GPU; strong: --batch fields in total, cut across the GPUs")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 ensemble job (512 samples of 512^2 over the ranks)")
     ap.add_argument("--c4-samples", type=int, default=512)
+    ap.add_argument("--c4-only", action="store_true",
+                    help="run ONLY the C4 ensemble job and print its JSON (what a multi-rank run starts as a separate job)")
+    ap.add_argument("--c4-timeout", type=float, default=420.0, help="seconds the separate C4 job of a multi-rank run may take")
     ap.add_argument("--host-only", action="store_true",
                     help="launcher / timing / reduction path only, on CPU over gloo with a no-op step (no kernels): "
                          "what the CPU test of the N-rank spawner runs")
@@ -395,11 +398,70 @@ def c4_ensemble(dev, world, rank, total):
             "note": "max over ranks of each phase; handover_tail_s = gather + D2H left after the last step finished"}
 
 
+LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+              "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "BENCH_SPAWNED", "BENCH_FORCE_DIST", "TORCHELASTIC_RUN_ID",
+              "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")
+
+
+def c4_as_separate_job(world, samples, timeout):
+    """The C4 ensemble job of a multi-rank run, started by rank 0 as its OWN set of `world` ranks (this script with --c4-only,
+    through the spawner above) with a time limit: its hand-over uses point-to-point RCCL traffic that the step benchmark does
+    not, and whatever happens to it -- an error, a hang -- must not take the scaling measurement down with it.  The parent
+    ranks idle meanwhile (their GPUs are shared with the job: a few GB of their 288)."""
+    import signal
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--c4-only", "--c4-samples", str(samples)]
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)      # the job's own process group (start_new_session): the spawner and its ranks
+            proc.communicate()
+            return {"error": f"the separate C4 job did not finish within {timeout:.0f} s and was stopped"}
+        lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return {"error": f"the separate C4 job exited with status {proc.returncode}"}
+        return json.loads(lines[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def c4_only_main(args):
+    """`--c4-only`: the C4 job alone, one JSON object on stdout (rank 0)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("nccl", device_id=dev)
+    res = c4_ensemble(dev, world, rank, args.c4_samples)
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))       # no launcher: this process only starts the ranks and forwards the status
+    if args.c4_only:
+        return c4_only_main(args)
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on stdout (flushed at exit,
     # i.e. AFTER anything Python prints): keep a private handle on the real stdout for the JSON line and point fd 1 at
     # stderr for everything else (libraries, warnings, the banner).
@@ -426,7 +488,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
+    # host-side barrier for the wait on the separate C4 job (an RCCL barrier would keep a spinning kernel on every waiting GPU)
+    host_group = dist.new_group(backend="gloo") if (use_dist and world > 1) else None
 
     import torch_cfd_amd as tc
     from torch_cfd_amd.distributed import shard_batch
@@ -674,12 +740,18 @@ def main():
         "hbm_probe": probe,
     }
     if not args.no_c4:
-        try:
-            out["c4_ensemble"] = c4_ensemble(dev, world, rank, args.c4_samples)
-        except Exception as e:
-            if use_dist:
-                raise           # a rank that left a collective job must not leave the others waiting
-            out["c4_ensemble"] = {"error": repr(e)}
+        if world > 1 or os.environ.get("BENCH_C4_SEPARATE") == "1":   # (the env switch exercises this path on one GPU)
+            # a job of its own (see c4_as_separate_job): rank 0 starts it and waits, the other ranks wait on the host
+            torch.cuda.empty_cache()
+            if rank == 0:
+                out["c4_ensemble"] = c4_as_separate_job(world, args.c4_samples, args.c4_timeout)
+            if host_group is not None:
+                dist.barrier(group=host_group)
+        else:
+            try:
+                out["c4_ensemble"] = c4_ensemble(dev, world, rank, args.c4_samples)
+            except Exception as e:
+                out["c4_ensemble"] = {"error": repr(e)}
         torch.set_default_dtype(real)
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_sfno:

@@ -64,6 +64,27 @@ def test_bench_strong_scaling_through_its_own_spawner():
     assert out["strong_scaling"] is None and out["per_rank_steps_per_s"][0] == pytest.approx(out["value"], rel=1e-3)
 
 
+def test_bench_c4_job_as_a_separate_process_tree():
+    """What a multi-rank bench does with the C4 job: rank 0 starts it as its own set of ranks (`--c4-only` through the
+    spawner) with a time limit and reads its JSON -- exercised here with one rank (BENCH_C4_SEPARATE=1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BENCH_C4_SEPARATE"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-sfno", "--no-cpu-baseline", "--no-probe",
+                        "--c4-samples", "8", "--batch", "4"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    c4 = json.loads(lines[0])["c4_ensemble"]
+    assert "error" not in c4 and c4["finite"] is True and c4["seconds"] > 0
+    # and a job that cannot finish in time is stopped, the bench line survives
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-sfno", "--no-cpu-baseline", "--no-probe",
+                        "--c4-samples", "64", "--batch", "4", "--c4-timeout", "0.5"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert "did not finish" in out["c4_ensemble"]["error"] and out["value"] > 10
+
+
 def test_bench_c4_ensemble_line_small():
     """The C4 job line on one GPU with 16 samples: phases split out, dataset finite, hand-over through the pitched copies."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
