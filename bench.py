@@ -488,6 +488,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the host-side group must not depend on the hostname resolving
         import datetime
 
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
