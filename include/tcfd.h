@@ -50,6 +50,9 @@ typedef enum {
 typedef enum { TCFD_C64 = 0, TCFD_C128 = 1 } tcfd_dtype;
 
 typedef struct tcfd_ns2d_plan tcfd_ns2d_plan;
+typedef struct tcfd_fno_plan tcfd_fno_plan;
+
+#ifndef TCFD_H_TYPES_ONLY   /* (the library's second compilation unit wants the types without the prototypes) */
 
 const char* tcfd_last_error(void);
 int tcfd_version(void);
@@ -175,7 +178,6 @@ int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, l
  *   bias     NULL or 4 pointers (mx, my, mt) complex, added as delta * bias (sfno.py:388-390)
  *   fwd_scale / inv_scale   norm="backward": 1 and 1/(X*Y*T_out)
  *   use_mfma 1: per-mode products on v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64; 0: plain VALU kernel */
-typedef struct tcfd_fno_plan tcfd_fno_plan;
 int tcfd_fno_plan_create(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt);
 /* Plan of an INVERSE transform onto a grid (X, Y) of a truncated spectrum taken from a grid (Xs, Ys): what
  * SpectralConv.forward(v, out_mesh_size) does through irfftn(s = out_mesh_size) (fno/base.py:229-237) -- torch pads or
@@ -296,6 +298,8 @@ int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int iters
  * blocking `.cpu()` calls per record, fno/data_gen/solvers.py:246-250). */
 int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t row_bytes,
                            size_t rows, void* stream);
+
+#endif /* TCFD_H_TYPES_ONLY */
 
 #ifdef __cplusplus
 }

@@ -22,12 +22,29 @@
 #include <mutex>
 #include <vector>
 
+// ---- compilation units ---------------------------------------------------------------------------------------------------
+// This file is compiled TWICE, in parallel (torch-cfd_amd/_lib.py): unit 0 (-DTCFD_UNIT=0) holds the C ABI and every
+// float64 kernel instantiation, unit 1 (-DTCFD_UNIT=1) the float32 instantiations behind seven `*_f32` entry points that unit
+// 0's (dtype, n) dispatch forwards to.  Built without the macro it is one unit with both.  (A single unit took 7 minutes of
+// hipcc once the 3 * 2^k and 5 * 2^k grids joined; in unit 1 the ABI functions are compiled as unused statics.)
+#ifndef TCFD_UNIT
+#define TCFD_UNIT (-1)
+#endif
+#if TCFD_UNIT == 1
+#define TCFD_H_TYPES_ONLY
+#define TCFD_API [[maybe_unused]] static
+#else
+#define TCFD_API extern "C"
+#endif
 #include "../../include/tcfd.h"
 #include "tcfd_fft.hpp"
 
 using namespace tcfd;
 
 // ------------------------------------------------------------------ errors
+#if TCFD_UNIT == 1
+int tcfd_set_error(int code, const char* fmt, ...);   // unit 0's
+#else
 static thread_local char g_err[512] = "";
 int tcfd_set_error(int code, const char* fmt, ...) {  // shared with tcfd_fno.hip
     va_list ap;
@@ -36,6 +53,7 @@ int tcfd_set_error(int code, const char* fmt, ...) {  // shared with tcfd_fno.hi
     va_end(ap);
     return code;
 }
+#endif
 #define fail(...) tcfd_set_error(__VA_ARGS__)
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -43,8 +61,10 @@ int tcfd_set_error(int code, const char* fmt, ...) {  // shared with tcfd_fno.hi
         if (e_ != hipSuccess) return fail(TCFD_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+#if TCFD_UNIT != 1
 extern "C" const char* tcfd_last_error(void) { return g_err; }
 extern "C" int tcfd_version(void) { return 1; }
+#endif
 
 // ------------------------------------------------------------------ per-size configuration
 // COL_EPT / ROW_EPT = elements per lane of one transform in the column / row kernels,
@@ -81,6 +101,8 @@ TCFD_CFG(float, 96, 12, 32, 12, 256)
 TCFD_CFG(float, 192, 12, 16, 12, 256)
 TCFD_CFG(float, 384, 12, 16, 12, 256)
 TCFD_CFG(float, 768, 12, 16, 12, 256)
+TCFD_CFG(double, 1536, 12, 4, 12, 256)     // 4 (8) columns: a whole-column tile of 8 (16) would not fit the LDS
+TCFD_CFG(float, 1536, 12, 8, 12, 256)
 // n = 5 * 2^k: twenty elements per lane (radix 20 = 4 x 5 in registers, then radix 4 / 2)
 TCFD_CFG(double, 80, 20, 32, 20, 256)
 TCFD_CFG(double, 160, 20, 16, 20, 256)
@@ -90,6 +112,8 @@ TCFD_CFG(float, 80, 20, 32, 20, 256)
 TCFD_CFG(float, 160, 20, 16, 20, 256)
 TCFD_CFG(float, 320, 20, 16, 20, 256)
 TCFD_CFG(float, 640, 20, 16, 20, 256)
+TCFD_CFG(double, 1280, 20, 4, 20, 256)
+TCFD_CFG(float, 1280, 20, 8, 20, 256)
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -1530,7 +1554,7 @@ struct tcfd_ns2d_plan {
 
 static bool supported_n(int n) {
     return (n >= 8 && n <= 2048 && (n & (n - 1)) == 0) || n == 96 || n == 192 || n == 384 || n == 768 ||   // 2^k, 3 * 2^k
-           n == 80 || n == 160 || n == 320 || n == 640;                                                    // and 5 * 2^k
+           n == 1536 || n == 80 || n == 160 || n == 320 || n == 640 || n == 1280;                         // and 5 * 2^k
 }
 
 template <typename T>
@@ -1642,7 +1666,7 @@ static int plan_fill(tcfd_ns2d_plan* p, const double* kx, const double* ky, cons
     return 0;
 }
 
-extern "C" void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
+TCFD_API void tcfd_ns2d_plan_destroy(tcfd_ns2d_plan* p) {
     if (!p) return;
     void* ptrs[] = {p->tw, p->tw2, p->kx, p->ky, p->lin, p->mask, p->forcing, p->mask_r, p->mask_c,
                     p->lin_r, p->lin_c, p->f_ptr, p->f_row, p->f_val, p->f_col};
@@ -1722,10 +1746,10 @@ static size_t last_level_cache_bytes(int* source) {
 
 static int fill_round_fields(tcfd_ns2d_plan* p);   // (needs the size dispatch, defined below)
 
-extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
+TCFD_API int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const double* kx, const double* ky,
                                      const double* linear_term, const double* mask, const double* forcing_hat) {
     if (!out || !kx || !ky || !linear_term || !mask) return fail(TCFD_EINVAL, "plan_create: null argument");
-    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048] (or 96 / 192 / 384 / 768, 80 / 160 / 320 / 640)", n);
+    if (!supported_n(n)) return fail(TCFD_EINVAL, "plan_create: n=%d is not a power of two in [8, 2048] (or 3 * 2^k in 96..1536, 5 * 2^k in 80..1280)", n);
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return fail(TCFD_EINVAL, "plan_create: bad dtype %d", dtype);
     tcfd_ns2d_plan* p = new tcfd_ns2d_plan();   // value-initialised: every pointer / flag starts at zero
     p->n = n;
@@ -1765,7 +1789,7 @@ extern "C" int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, con
     return 0;
 }
 
-extern "C" int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* p, int* separable, int* sparse_forcing, int* keep_cols) {
+TCFD_API int tcfd_ns2d_plan_info(const tcfd_ns2d_plan* p, int* separable, int* sparse_forcing, int* keep_cols) {
     if (!p) return fail(TCFD_EINVAL, "plan_info: null plan");
     if (separable) *separable = p->sep;
     if (sparse_forcing) *sparse_forcing = p->f_sparse;
@@ -1784,7 +1808,7 @@ static long chunk_fields(const tcfd_ns2d_plan* p, long batch);
 // Scratch of the batched calls.  They run chunk by chunk through ONE chunk-sized set of 8 fields (h, adv, 4 planes,
 // line-aligned state, second state), so the need does not grow with the batch beyond one chunk -- except for irfft2,
 // which stages ONE field of the whole batch.  (1024^2 x 64 fp64: 0.55 GB instead of the 4.4 GB of an unchunked step.)
-extern "C" size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
+TCFD_API size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
     if (!p || batch <= 0) return 0;
     return std::max(8 * field_bytes(p, chunk_fields(p, batch)), field_bytes(p, batch));
 }
@@ -1910,7 +1934,7 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
 template <typename T, int N>
 static bool use_split(const tcfd_ns2d_plan* p) {
     const int force = p->tune.split;
-    if (N < 16 || (!is_pow2c(N) && N != 192 && N != 384 && N != 768)) return false;   // (96 / 2 = 48 has no tile configuration)
+    if (N < 16 || !is_pow2c(N)) return false;   // n = 3 * 2^k / 5 * 2^k: whole-column tiles only (split measured slower at 768: 160 vs 181 steps/s)
     if (force >= 0) return force != 0;
     return N == 1024;   // (768: split 160 vs plain 181 steps/s at one round of workgroups per launch)   // fp64: 7.99 vs 8.6 ms/step; fp32 (16-column, 128-byte tiles of 512 rows): 5.61 vs 6.05 ms/step
 }
@@ -1929,10 +1953,7 @@ static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, 
 
 template <typename T, int N, int MODE>
 static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
-    if constexpr (!is_pow2c(N)) {   // n = 3 * 2^k: Stockham tiles (no cross-lane / packed-Nyquist variants), whole or split
-        if constexpr ((N == 192 || N == 384 || N == 768) && MODE != MODE_FWD && MODE != MODE_INV) {
-            if (use_split<T, N>(p)) return launch_cols_split<T, N, MODE>(p, a, batch, st);
-        }
+    if constexpr (!is_pow2c(N)) {   // n = 3 * 2^k / 5 * 2^k: whole-column Stockham tiles (no split / cross-lane / packed-Nyquist variants)
         return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
     } else
     if constexpr (MODE != MODE_FWD && MODE != MODE_INV) {
@@ -2065,20 +2086,9 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
                               hipStream_t st, int nyq = 0) {
     constexpr int EPT = Cfg<T, N>::ROW_EPT, THR = Cfg<T, N>::ROW_THREADS;
     if constexpr (!is_pow2c(N)) {
-        // n = 3 * 2^k: v5 (one plane per transform, next plane's rows in flight, one wave per SIMD); at 768^2 fp64 per 7-field
-        // chunk launch: 43 us, against 53 for v3 (two planes per transform, TCFD_ROWS_V=4) and 124 for v5 capped at two waves
-        // per SIMD (twelve complex fp64 per array spill there)
-        const bool split3 = use_split<T, N>(p);
-        constexpr bool SPLIT_OK = (N == 192 || N == 384 || N == 768);
-        if (p->tune.rows_v == 4) {
-            if constexpr (SPLIT_OK) {
-                if (split3) return launch_rows_advect4<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
-            }
-            return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
-        }
-        if constexpr (SPLIT_OK) {
-            if (split3) return launch_rows_advect5<T, N, EPT, THR, 1, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
-        }
+        // n = 3 * 2^k / 5 * 2^k: v5 (one plane per transform, next plane's rows in flight, one wave per SIMD); at 768^2 fp64 per
+        // 7-field chunk launch: 43 us, against 53 for v3 (two planes per transform) and 124 for v5 capped at two waves per
+        // SIMD (twelve complex fp64 per array spill there).  Only this one variant is instantiated for these sizes.
         return launch_rows_advect5<T, N, EPT, THR, 0, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
     } else {
     const bool split = use_split<T, N>(p);
@@ -2452,10 +2462,32 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
         case 160: { constexpr int N_ = 160; return CALL; }                \
         case 320: { constexpr int N_ = 320; return CALL; }                \
         case 640: { constexpr int N_ = 640; return CALL; }                \
+        case 1536: { constexpr int N_ = 1536; return CALL; }              \
+        case 1280: { constexpr int N_ = 1280; return CALL; }              \
         default: return fail(TCFD_EINVAL, "unsupported n=%d", n);         \
     }
-#define TCFD_DISPATCH(p, CALL)                                            \
-    do {                                                                  \
+// TCFD_DISPATCHED(name, (parameters), (arguments), call): defines `static int name(parameters)` that runs `call` with T_ / N_
+// bound to the plan's precision and grid size.  In a two-unit build the float32 half lives in unit 1 as `name_f32`.
+#if TCFD_UNIT == 1
+#define TCFD_DISPATCHED(NAME, PARAMS, ARGS, CALL)                         \
+    int NAME##_f32 PARAMS {                                               \
+        using T_ = float;                                                 \
+        TCFD_DISPATCH_N(T_, (p)->n, CALL)                                 \
+    }                                                                     \
+    [[maybe_unused]] static int NAME PARAMS { return NAME##_f32 ARGS; }
+#elif TCFD_UNIT == 0
+#define TCFD_DISPATCHED(NAME, PARAMS, ARGS, CALL)                         \
+    int NAME##_f32 PARAMS;                                                \
+    static int NAME PARAMS {                                              \
+        if ((p)->dtype == TCFD_C128) {                                    \
+            using T_ = double;                                            \
+            TCFD_DISPATCH_N(T_, (p)->n, CALL)                             \
+        }                                                                 \
+        return NAME##_f32 ARGS;                                           \
+    }
+#else
+#define TCFD_DISPATCHED(NAME, PARAMS, ARGS, CALL)                         \
+    static int NAME PARAMS {                                              \
         if ((p)->dtype == TCFD_C128) {                                    \
             using T_ = double;                                            \
             TCFD_DISPATCH_N(T_, (p)->n, CALL)                             \
@@ -2463,14 +2495,15 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
             using T_ = float;                                             \
             TCFD_DISPATCH_N(T_, (p)->n, CALL)                             \
         }                                                                 \
-    } while (0)
+    }
+#endif
 
 static int check_ws(const tcfd_ns2d_plan* p, long batch, void* ws, size_t bytes, size_t need) {
     if (!ws || bytes < need) return fail(TCFD_EWORKSPACE, "workspace %zu B < required %zu B", bytes, need);
     return 0;
 }
 
-extern "C" int tcfd_ns2d_plan_chunking(const tcfd_ns2d_plan* p, long batch, long* fields_per_chunk, size_t* cache_bytes,
+TCFD_API int tcfd_ns2d_plan_chunking(const tcfd_ns2d_plan* p, long batch, long* fields_per_chunk, size_t* cache_bytes,
                                        int* cache_source) {
     if (!p || batch < 0) return fail(TCFD_EINVAL, "plan_chunking: bad argument");
     if (fields_per_chunk) *fields_per_chunk = batch > 0 ? chunk_fields(p, batch) : 0;
@@ -2497,7 +2530,7 @@ static int round_fields_impl(tcfd_ns2d_plan* p) {
     }
     return 0;
 }
-static int fill_round_fields(tcfd_ns2d_plan* p) { TCFD_DISPATCH(p, (round_fields_impl<T_, N_>(p))); }
+TCFD_DISPATCHED(fill_round_fields, (tcfd_ns2d_plan * p), (p), (round_fields_impl<T_, N_>(p)))
 
 // Fields per chunk of a batched call.  TCFD_CHUNK > 0 forces it, 0 disables chunking, -1 (default) sizes the chunk so
 // that its working set -- 4 planes + advection + RK accumulator + padded state, 7 workspace fields per batch element --
@@ -2519,14 +2552,15 @@ static long chunk_fields(const tcfd_ns2d_plan* p, long batch) {
     return (batch + nchunks - 1) / nchunks;
 }
 
-static int chunk_dispatch(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages,
-                          const double* beta, const double* gdt, const double* mu_num, const double* fa,
-                          const double* mu_den, const int* base0, int steps, double inv_total_dt, void* ws, hipStream_t st) {
-    TCFD_DISPATCH(p, (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps,
-                                         inv_total_dt, ws, st)));
-}
+TCFD_DISPATCHED(chunk_dispatch,
+                (const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch, int nstages, const double* beta,
+                 const double* gdt, const double* mu_num, const double* fa, const double* mu_den, const int* base0, int steps,
+                 double inv_total_dt, void* ws, hipStream_t st),
+                (p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps, inv_total_dt, ws, st),
+                (step_impl<T_, N_>(p, w_in, w_out, dwdt, batch, nstages, beta, gdt, mu_num, fa, mu_den, base0, steps,
+                                   inv_total_dt, ws, st)))
 
-extern "C" int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
+TCFD_API int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
                                    int nstages, const double* fa, const double* beta, const double* gdt,
                                    const double* mu_num, const double* mu_den, const int* base0, int steps,
                                    double inv_total_dt, void* ws, size_t ws_bytes, void* stream) {
@@ -2557,17 +2591,17 @@ extern "C" int tcfd_ns2d_step_imex(const tcfd_ns2d_plan* p, const void* w_in, vo
                           st);
 }
 
-extern "C" int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
+TCFD_API int tcfd_ns2d_step(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, void* dwdt, long batch,
                               int nstages, const double* beta, const double* gdt, const double* mu, int steps,
                               double inv_total_dt, void* ws, size_t ws_bytes, void* stream) {
     return tcfd_ns2d_step_imex(p, w_in, w_out, dwdt, batch, nstages, nullptr, beta, gdt, mu, nullptr, nullptr, steps,
                                inv_total_dt, ws, ws_bytes, stream);
 }
 
-static int explicit_dispatch(const tcfd_ns2d_plan* p, const void* w, void* out, const void* wt, void* psi, bool residual,
-                             long batch, void* ws, hipStream_t st) {
-    TCFD_DISPATCH(p, (explicit_impl<T_, N_>(p, w, out, wt, psi, residual, batch, ws, st)));
-}
+TCFD_DISPATCHED(explicit_dispatch,
+                (const tcfd_ns2d_plan* p, const void* w, void* out, const void* wt, void* psi, bool residual, long batch, void* ws,
+                 hipStream_t st),
+                (p, w, out, wt, psi, residual, batch, ws, st), (explicit_impl<T_, N_>(p, w, out, wt, psi, residual, batch, ws, st)))
 // F(w) / residual sweeps chunk by chunk like the steps (the planes of a chunk stay on die between the two passes)
 static int explicit_chunked(const tcfd_ns2d_plan* p, const void* w, void* out, const void* wt, void* psi, bool residual,
                             long batch, void* ws, hipStream_t st) {
@@ -2585,7 +2619,7 @@ static int explicit_chunked(const tcfd_ns2d_plan* p, const void* w, void* out, c
     return 0;
 }
 
-extern "C" int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* p, const void* w, void* out, long batch, void* ws,
+TCFD_API int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* p, const void* w, void* out, long batch, void* ws,
                                         size_t ws_bytes, void* stream) {
     if (!p || !w || !out || batch <= 0) return fail(TCFD_EINVAL, "explicit_terms: bad argument");
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
@@ -2640,12 +2674,11 @@ static int explicit_vjp_impl(const tcfd_ns2d_plan* p, const void* w, const void*
     }
     return 0;
 }
-static int explicit_vjp_dispatch(const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, size_t xs, long batch,
-                                 void* ws, hipStream_t st) {
-    TCFD_DISPATCH(p, (explicit_vjp_impl<T_, N_>(p, w, gm, xout, xs, batch, ws, st)));
-}
+TCFD_DISPATCHED(explicit_vjp_dispatch,
+                (const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, size_t xs, long batch, void* ws, hipStream_t st),
+                (p, w, gm, xout, xs, batch, ws, st), (explicit_vjp_impl<T_, N_>(p, w, gm, xout, xs, batch, ws, st)))
 
-extern "C" int tcfd_ns2d_explicit_terms_vjp(const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, long batch,
+TCFD_API int tcfd_ns2d_explicit_terms_vjp(const tcfd_ns2d_plan* p, const void* w, const void* gm, void* xout, long batch,
                                             void* ws, size_t ws_bytes, void* stream) {
     if (!p || !w || !gm || !xout || batch <= 0) return fail(TCFD_EINVAL, "explicit_terms_vjp: bad argument");
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
@@ -2663,7 +2696,7 @@ extern "C" int tcfd_ns2d_explicit_terms_vjp(const tcfd_ns2d_plan* p, const void*
     return 0;
 }
 
-extern "C" int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* p, const void* w, const void* wt, void* psi,
+TCFD_API int tcfd_ns2d_stream_residual(const tcfd_ns2d_plan* p, const void* w, const void* wt, void* psi,
                                          void* residual, long batch, void* ws, size_t ws_bytes, void* stream) {
     if (!p || !w || batch <= 0 || (residual && !wt)) return fail(TCFD_EINVAL, "stream_residual: bad argument");
     int rc = check_ws(p, batch, ws, ws_bytes, tcfd_ns2d_workspace_bytes(p, batch));
@@ -2683,7 +2716,7 @@ static int velocity_impl(const tcfd_ns2d_plan* p, const void* w, void* uh, void*
     return 0;
 }
 
-extern "C" int tcfd_ns2d_velocity(const tcfd_ns2d_plan* p, const void* w, void* uh, void* vh, void* psi, long batch,
+TCFD_API int tcfd_ns2d_velocity(const tcfd_ns2d_plan* p, const void* w, void* uh, void* vh, void* psi, long batch,
                                   void* stream) {
     if (!p || !w || batch <= 0) return fail(TCFD_EINVAL, "velocity: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -2715,7 +2748,7 @@ __global__ __launch_bounds__(256) void k_weighted_sqnorm(const cx<T>* __restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-extern "C" int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks,
+TCFD_API int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks,
                                     int dtype, void* stream) {
     if (!z || !w2 || !partial || batch <= 0 || elems <= 0 || blocks <= 0)
         return fail(TCFD_EINVAL, "weighted_sqnorm: bad argument");
@@ -2733,19 +2766,22 @@ extern "C" int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial
     return 0;
 }
 
-extern "C" int tcfd_rfft2(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, void* stream) {
+TCFD_DISPATCHED(rfft2_dispatch, (const tcfd_ns2d_plan* p, const void* x, void* out, long batch, hipStream_t st), (p, x, out, batch, st),
+                (rfft2_impl<T_, N_>(p, x, out, batch, st)))
+TCFD_DISPATCHED(irfft2_dispatch, (const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, hipStream_t st),
+                (p, xh, out, batch, ws, st), (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)))
+
+TCFD_API int tcfd_rfft2(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, void* stream) {
     if (!p || !x || !out || batch <= 0) return fail(TCFD_EINVAL, "rfft2: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    TCFD_DISPATCH(p, (rfft2_impl<T_, N_>(p, x, out, batch, st)));
+    return rfft2_dispatch(p, x, out, batch, (hipStream_t)stream);
 }
 
-extern "C" int tcfd_irfft2(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, size_t ws_bytes,
+TCFD_API int tcfd_irfft2(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, size_t ws_bytes,
                            void* stream) {
     if (!p || !xh || !out || batch <= 0) return fail(TCFD_EINVAL, "irfft2: bad argument");
     int rc = check_ws(p, batch, ws, ws_bytes, field_bytes(p, batch));
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    TCFD_DISPATCH(p, (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)));
+    return irfft2_dispatch(p, xh, out, batch, ws, (hipStream_t)stream);
 }
 
 template <typename T, int N>
@@ -2762,9 +2798,11 @@ static int variant_impl(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
     return 0;
 }
 
-extern "C" int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
+TCFD_DISPATCHED(variant_dispatch, (const tcfd_ns2d_plan* p, int* split, int* rows_kernel), (p, split, rows_kernel),
+                (variant_impl<T_, N_>(p, split, rows_kernel)))
+TCFD_API int tcfd_ns2d_plan_variant(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
     if (!p) return fail(TCFD_EINVAL, "plan_variant: null plan");
-    TCFD_DISPATCH(p, (variant_impl<T_, N_>(p, split, rows_kernel)));
+    return variant_dispatch(p, split, rows_kernel);
 }
 
 // ------------------------------------------------------------------ test hook: the cross-lane transform alone
@@ -2786,7 +2824,7 @@ __global__ __launch_bounds__(128) void k_debug_xl(const cx<double>* __restrict__
     for (int t = 0; t < 8; ++t) out[(size_t)blockIdx.x * 1024 + 128 * t + j] = x[t];
 }
 
-extern "C" int tcfd_debug_xl_fft1024(const tcfd_ns2d_plan* p, const void* in, void* out, int count, int dir, void* stream) {
+TCFD_API int tcfd_debug_xl_fft1024(const tcfd_ns2d_plan* p, const void* in, void* out, int count, int dir, void* stream) {
     if (!p || !in || !out || count <= 0 || (dir != 1 && dir != -1)) return fail(TCFD_EINVAL, "debug_xl_fft1024: bad argument");
     if (p->n != 1024 || p->dtype != TCFD_C128) return fail(TCFD_EINVAL, "debug_xl_fft1024: needs a 1024^2 complex128 plan");
     hipStream_t st = (hipStream_t)stream;
@@ -2801,7 +2839,7 @@ extern "C" int tcfd_debug_xl_fft1024(const tcfd_ns2d_plan* p, const void* in, vo
 }
 
 // ------------------------------------------------------------------ profiling side-car
-extern "C" int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* p, int max_records) {
+TCFD_API int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* p, int max_records) {
     if (!p || max_records <= 0) return fail(TCFD_EINVAL, "profile_begin: bad argument");
     if (!p->prof) p->prof = new ProfState();
     for (auto& r : p->prof->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -2812,7 +2850,7 @@ extern "C" int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* p, int max_records) {
     return 0;
 }
 
-extern "C" int tcfd_ns2d_profile_end(tcfd_ns2d_plan* p, int capacity, int* count, int* kinds, float* ms) {
+TCFD_API int tcfd_ns2d_profile_end(tcfd_ns2d_plan* p, int capacity, int* count, int* kinds, float* ms) {
     if (!p || !p->prof || !count) return fail(TCFD_EINVAL, "profile_end: profiling was not started");
     ProfState* ps = p->prof;
     ps->on = false;
@@ -2831,6 +2869,7 @@ extern "C" int tcfd_ns2d_profile_end(tcfd_ns2d_plan* p, int capacity, int* count
     return 0;
 }
 
+#if TCFD_UNIT != 1   // (a non-template kernel: one definition in the library)
 // ---------------------------------------------------------------- HBM probe (bench.py reports it beside the 8 TB/s spec)
 __global__ __launch_bounds__(256) void k_probe(const double2* __restrict__ src, double2* __restrict__ dst, size_t n16,
                                                int mode) {
@@ -2848,7 +2887,7 @@ __global__ __launch_bounds__(256) void k_probe(const double2* __restrict__ src, 
     }
 }
 
-extern "C" int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int iters, float* ms, void* stream) {
+TCFD_API int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int iters, float* ms, void* stream) {
     if (!dst || (mode != 2 && !src) || !ms || bytes < 16 || bytes % 16 || iters < 1 || mode < 0 || mode > 2)
         return fail(TCFD_EINVAL, "hbm_probe: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -2872,10 +2911,12 @@ extern "C" int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode
     return 0;
 }
 
+#endif
+
 // ---------------------------------------------------------------- strided device -> host copy of record slabs
 // One record of `rows` samples lands in a host array whose sample pitch is a whole trajectory: a pitched copy on the caller's
 // stream (asynchronous when the host side is page-locked), so the hand-over of a record overlaps the steps that follow it.
-extern "C" int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+TCFD_API int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
                                       size_t row_bytes, size_t rows, void* stream) {
     if (!dst_host || !src_dev || row_bytes == 0 || dst_pitch < row_bytes || src_pitch < row_bytes)
         return fail(TCFD_EINVAL, "copy_rows_to_host: bad argument");

@@ -13,8 +13,8 @@ but ``NavierStokes2DSpectral.forward`` / ``explicit_terms`` / ``residual`` run t
 hand-written gfx950 kernels of ``csrc/tcfd_ns2d.hip`` through the C ABI in
 ``include/tcfd.h`` (three launches per RK stage instead of ~40 ATen launches).
 There is no CPU or eager fallback: tensors must live on a HIP device and the grid
-must be square with n = 2^k (8..2048), n = 3 * 2^k (96..768) or n = 5 * 2^k (80..640) -- the fused kernels -- or another
-n = p * 2^k with a small odd p (48, 112, 1536, ...: power-of-two HIP transforms + tensor ops, ``mixed_radix.py``)
+must be square with n = 2^k (8..2048), n = 3 * 2^k (96..1536) or n = 5 * 2^k (80..1280) -- the fused kernels -- or another
+n = p * 2^k with a small odd p (48, 112, 224, ...: power-of-two HIP transforms + tensor ops, ``mixed_radix.py``)
 -- anything else raises.  The fused kernels are
 forward-only; when gradients are asked for (a state that requires grad, trainable
 stepper coefficients) the operator steps through ``autograd.py``: the same arithmetic
@@ -248,9 +248,9 @@ def _composite_plan(op, n: int, cdtype, device, forcing_hat=None):
 
 
 def _is_pow2(n: int) -> bool:
-    """Grids the FUSED kernels cover: n = 2^k (8..2048), n = 3 * 2^k (96..768: radix-12 first pass) and n = 5 * 2^k
-    (80..640: radix 20)."""
-    return (8 <= n <= 2048 and (n & (n - 1)) == 0) or n in (96, 192, 384, 768, 80, 160, 320, 640)
+    """Grids the FUSED kernels cover: n = 2^k (8..2048), n = 3 * 2^k (96..1536: radix-12 first pass) and n = 5 * 2^k
+    (80..1280: radix 20)."""
+    return (8 <= n <= 2048 and (n & (n - 1)) == 0) or n in (96, 192, 384, 768, 1536, 80, 160, 320, 640, 1280)
 
 
 def _plan_for_mesh(kx: torch.Tensor, ky: torch.Tensor, like: torch.Tensor):
