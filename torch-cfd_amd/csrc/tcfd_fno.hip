@@ -1826,9 +1826,17 @@ template <int ACT>
 __device__ __forceinline__ void pw_act_pair(float z, float& h, float& d) {
     if constexpr (ACT == 1) { h = z > 0.f ? z : 0.f; d = z > 0.f ? 1.f : 0.f; }
     else if constexpr (ACT == 2) {
-        const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+        // GELU and its derivative from ONE exponential: erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p x), x >= 0
+        // (Abramowitz & Stegun 7.1.26, |error| < 1.5e-7), and exp(-x^2) with x = |z| / sqrt(2) is the Gaussian of the
+        // derivative's second term.  (erff + expf per element made the GELU backward 1.6 x the ReLU one.)
+        const float ax = fabsf(z) * 0.70710678118654752f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+        const float e = __expf(-ax * ax);
+        const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+        const float erf_abs = fmaf(-poly, e, 1.f);
+        const float cdf = 0.5f * (1.f + (z < 0.f ? -erf_abs : erf_abs));
         h = z * cdf;
-        d = cdf + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+        d = fmaf(z * 0.3989422804014327f, e, cdf);
     } else if constexpr (ACT == 3) { const float sg = 1.f / (1.f + __expf(-z)); h = z * sg; d = sg * (1.f + z * (1.f - sg)); }
     else if constexpr (ACT == 4) { const float t = tanhf(z); h = t; d = 1.f - t * t; }
     else { h = z; d = 1.f; }
