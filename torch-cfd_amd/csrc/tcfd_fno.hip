@@ -1881,8 +1881,8 @@ __device__ __forceinline__ void pw_act_tiles(const V4 (&z)[N], V4 (&h)[N], V4 (&
 //                                                   g2^T = g2^T I (identity fragment), dh^T = g2^T W2,
 //                                                   dx^T = g1^T W1, ds^T = g2^T Ws           (O1 tiles as A operands)
 // and the weight gradients are  dW2 += (g2^T)^T h^T,  [dWs | db2] += (g2^T)^T [s;1]^T,  [dW1 | db1] += (g1^T)^T [x;1]^T
-// with OT tiles as both operands.  Biases ride as a constant-1 channel.  105 MFMAs per 16 points at width 10 (52 for the
-// chain, 25 for the second orientation, 28 for the weight gradients): the kernel is bound by the matrix pipe (~1.8 ms for
+// with OT tiles as both operands.  Biases ride as a constant-1 channel.  93 MFMAs per 16 points at width 10 (45 for the
+// chain, 20 for the second orientation, 28 for the weight gradients; 105 before the row map pw_tile_row): the kernel is bound by the matrix pipe (~1.8 ms for
 // the (32, 10, 256, 256, 10) activations of config 5) instead of 4.3 ms of LDS issue.  Inputs are read in the two
 // fragment layouts they are needed in ([ch 4j + q][pt c]: 64-byte rows; [ch c][pt 4q .. 4q + 3]: 16-byte lanes), the
 // second read of a line hits the vector cache; dx / ds leave as 16-byte lanes.  One row of partial sums per wave.
@@ -1890,11 +1890,33 @@ __device__ __forceinline__ void pw_act_tiles(const V4 (&z)[N], V4 (&h)[N], V4 (&
 // activation per element) -> 3.51 (one switch per tile set) -> 3.02 (buffer loads: the prefetch stays in flight) -> 2.87
 // (sched_barrier behind the prefetch) -> 2.82 (issue order).  Three waves per SIMD (weights re-read from LDS, 168 registers)
 // gain nothing (3.06): what is left is the ~40-cycle gap every time a product's D tile turns into the next product's operand.
+// Row map of a 16-row D tile that holds only N < 16 channels: D register r of lane (q, c) is row 4q + r, and a k-step of a
+// chained product contracts over the four rows {4q + r : q} of ONE register index r.  Channels are therefore dealt to the
+// rows with r < RV = ceil(N / 4) only (row 4q + r <-> channel q RV + r), so that the k-steps r >= RV of a partly filled
+// tile hold nothing and are never issued: width 10 / 40 / 10 has 3 of 4 steps over the output channels and 10 of 12 over the
+// hidden ones, 93 instead of 105 MFMAs per 16 points.  (The order of channels inside a tile is free: it only has to be the
+// same in the weight fragments, the loads and the rows of the partial sums.)
+template <int N>
+__device__ __forceinline__ int pw_tile_row(int rho) {
+    constexpr int RV = (N + 3) / 4;
+    const int i = (rho >> 2) * RV + (rho & 3);
+    return ((rho & 3) < RV && i < N) ? i : -1;
+}
+constexpr int pw_tile_steps(int n_total, int t) { return n_total - 16 * t >= 16 ? 4 : (n_total - 16 * t + 3) / 4; }
+template <int CM>
+__device__ __forceinline__ int pw_hid_row(int t, int rho) {      // hidden channel of row rho of tile t, or -1
+    if (CM - 16 * t >= 16) return 16 * t + rho;
+    constexpr int REM = CM % 16 ? CM % 16 : 16;
+    const int i = pw_tile_row<REM>(rho);
+    return i < 0 ? -1 : 16 * t + i;
+}
+
 template <int CI, int CM, int CO, int MODE>
 __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     constexpr int KI = (CI + 1 + 3) / 4;        // k-steps over [x ; 1]
     constexpr int TM = (CM + 15) / 16;          // 16-row tiles of the hidden layer
+    constexpr int RO = (CO + 3) / 4;            // k-steps over the output channels (pw_tile_row)
     static_assert(CI + 1 <= 16 && CO <= 16 && TM <= 4, "k_pointwise_bwd_mfma geometry");
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
@@ -1903,36 +1925,38 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     float W1a[TM][KI], W2a[TM][4], Wsa[KI], Idf[4], W2b[TM][4], W1b[TM][4], Wsb[4];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        const int hid = 16 * t + c;
+        const int hid = pw_hid_row<CM>(t, c);                      // hidden channel of tile row / column c (or -1)
 #pragma unroll
         for (int j = 0; j < KI; ++j) {
             const int k = 4 * j + q;
             float v = 0.f;
-            if (hid < CM) v = k < CI ? a.w1[hid * CI + k] : ((k == CI && a.b1) ? a.b1[hid] : 0.f);
+            if (hid >= 0) v = k < CI ? a.w1[hid * CI + k] : ((k == CI && a.b1) ? a.b1[hid] : 0.f);
             W1a[t][j] = v;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int hq = 16 * t + 4 * q + r, cq = 4 * q + r;
-            W2a[t][r] = (c < CO && hq < CM) ? a.w2t[hq * CO + c] : 0.f;          // W2[co c][hid 16t+4q+r]
-            W2b[t][r] = (cq < CO && hid < CM) ? a.w2t[hid * CO + cq] : 0.f;      // W2[co 4q+r][hid 16t+c]
-            W1b[t][r] = (hq < CM && c < CI) ? a.w1[hq * CI + c] : 0.f;           // W1[hid 16t+4q+r][ci c]
+            const int hq = pw_hid_row<CM>(t, 4 * q + r), cq = pw_tile_row<CO>(4 * q + r), cc = pw_tile_row<CO>(c);
+            W2a[t][r] = (cc >= 0 && hq >= 0) ? a.w2t[hq * CO + cc] : 0.f;        // W2[co of row c][hid of row 4q+r]
+            W2b[t][r] = (cq >= 0 && hid >= 0) ? a.w2t[hid * CO + cq] : 0.f;      // W2[co of row 4q+r][hid of row c]
+            W1b[t][r] = (hq >= 0 && c < CI) ? a.w1[hq * CI + c] : 0.f;           // W1[hid of row 4q+r][ci c]
         }
     }
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
         const int k = 4 * j + q;
         float v = 0.f;
-        if (c < CO) {
-            if (k < CI) v = mode == 1 ? a.wst[k * CO + c] : 0.f;
-            else if (k == CI) v = (a.b2 ? a.b2[c] : 0.f) + ((mode == 1 && a.bs) ? a.bs[c] : 0.f);
+        const int cc = pw_tile_row<CO>(c);
+        if (cc >= 0) {
+            if (k < CI) v = mode == 1 ? a.wst[k * CO + cc] : 0.f;
+            else if (k == CI) v = (a.b2 ? a.b2[cc] : 0.f) + ((mode == 1 && a.bs) ? a.bs[cc] : 0.f);
         }
         Wsa[j] = v;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        Idf[r] = c == 4 * q + r ? 1.f : 0.f;
-        Wsb[r] = (mode == 1 && 4 * q + r < CO && c < CI) ? a.wst[c * CO + 4 * q + r] : 0.f;
+        const int cq = pw_tile_row<CO>(4 * q + r);
+        Idf[r] = c == cq ? 1.f : 0.f;                                // g2^T comes out with its columns in natural order
+        Wsb[r] = (mode == 1 && cq >= 0 && c < CI) ? a.wst[c * CO + cq] : 0.f;
     }
     f4 accW2[TM], accW1[TM], accWs = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1972,8 +1996,17 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     const float cb_one = c == CI ? 1.f : 0.f;
     unsigned co_off[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) co_off[r] = 4 * q + r < CO ? (unsigned)(4 * q + r) * P4 : OOB;
+    for (int r = 0; r < 4; ++r) {
+        const int cq = pw_tile_row<CO>(4 * q + r);
+        co_off[r] = cq >= 0 ? (unsigned)cq * P4 : OOB;
+    }
     const unsigned sP4 = mode == 2 ? (unsigned)((a.P / a.T) * a.sT) * 4u : 0u;
+    unsigned cs_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cq = pw_tile_row<CO>(4 * q + r);
+        cs_off[r] = cq >= 0 ? (unsigned)cq * sP4 : OOB;
+    }
     auto load = [&](int G, In& in) {
         const int b = G / gpb;
         const unsigned p0 = (unsigned)(G - b * gpb) * 16u;
@@ -2011,7 +2044,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             const unsigned os = (unsigned)b * CO * sP4 + ((pc / (unsigned)a.T) * (unsigned)a.sT + (unsigned)(a.sT - 1)) * 4u;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                in.sl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * q + r < CO ? (unsigned)(4 * q + r) * sP4 + os : OOB, 0, 0));
+                in.sl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cs_off[r] != OOB ? cs_off[r] + os : OOB, 0, 0));
         }
     };
 #define PW_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
@@ -2052,7 +2085,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z2 = PW_MFMA(W2a[t][r], h[t][r], z2);
+                for (int r = 0; r < pw_tile_steps(CM, t); ++r) z2 = PW_MFMA(W2a[t][r], h[t][r], z2);
             pw_act_tiles<TM>(zT, hT, dT, a.act1);                      // under the z2 chain
             f4 zz[1] = {z2}, hh[1], dd[1];
             pw_act_tiles<1>(zz, hh, dd, a.act2);
@@ -2065,25 +2098,25 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             for (int t = 0; t < TM; ++t) {
                 dh[t] = dhT[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dh[t] = PW_MFMA(W2b[t][r], z2[r], dh[t]);
+                for (int r = 0; r < RO; ++r) dh[t] = PW_MFMA(W2b[t][r], z2[r], dh[t]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g2T = PW_MFMA(z2[r], Idf[r], g2T);
+            for (int r = 0; r < RO; ++r) g2T = PW_MFMA(z2[r], Idf[r], g2T);
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dhT[t] = PW_MFMA(z2[r], W2b[t][r], dhT[t]);
+                for (int r = 0; r < RO; ++r) dhT[t] = PW_MFMA(z2[r], W2b[t][r], dhT[t]);
             // ---- dx^T, ds^T from the O1 tiles as A operands
             f4 dxT = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dxT = PW_MFMA(dh[t][r] * d1[t][r], W1b[t][r], dxT);
+                for (int r = 0; r < pw_tile_steps(CM, t); ++r) dxT = PW_MFMA(dh[t][r] * d1[t][r], W1b[t][r], dxT);
             if constexpr (MODE == 1) {
                 if (a.ds) {
                     f4 dsT = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dsT = PW_MFMA(z2[r], Wsb[r], dsT);
+                    for (int r = 0; r < RO; ++r) dsT = PW_MFMA(z2[r], Wsb[r], dsT);
                     if (c < CI && live_b) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + c) * a.P + pb) = dsT;
                 }
             } else if constexpr (MODE == 2) {
@@ -2112,8 +2145,9 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (16 * t + c < CM) out[(4 * q + r) * Gm::CB + 16 * t + c] = accW2[t][r];
-            if (c <= CI) o1[(16 * t + 4 * q + r) * Gm::CIP + c] = accW1[t][r];
+            const int hc = pw_hid_row<CM>(t, c), hq = pw_hid_row<CM>(t, 4 * q + r);
+            if (hc >= 0) out[(4 * q + r) * Gm::CB + hc] = accW2[t][r];
+            if (c <= CI && hq >= 0) o1[hq * Gm::CIP + c] = accW1[t][r];
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
