@@ -202,10 +202,22 @@ int tcfd_fno_forward_trunc(const tcfd_fno_plan* plan, const void* v, void* vh, i
                            void* workspace, size_t workspace_bytes, void* stream);
 int tcfd_fno_inverse_trunc(const tcfd_fno_plan* plan, const void* vh, void* out, int batch, int c, int t_keep,
                            double inv_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* out = acc + inverse_trunc(vh): acc has the shape of out and may be out itself (NULL: plain inverse_trunc).  Training: the
+ * gradient of a layer input that also feeds the skip path is finished by the transform that produces its spectral part. */
+int tcfd_fno_inverse_trunc_acc(const tcfd_fno_plan* plan, const void* vh, void* out, const void* acc, int batch, int c,
+                               int t_keep, double inv_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* The contraction alone on truncated spectra (batch, c, 2mx, 2my, mt), dtype TCFD_C64 / TCFD_C128 (tests). */
 int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, double delta,
                       void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma, int dtype,
                       void* stream);
+/* Gradient w.r.t. the spectrum: gv (batch, cin_fwd, ..) = sum_o conj(W[i][o]) gh (batch, cout_fwd, ..), reading the FORWARD
+ * blocks (cin_fwd, cout_fwd, mx, my, mt) in place (no conjugate-transposed copy). */
+int tcfd_fno_contract_adjoint(const void* gh, const void* const* weights, void* gv, int batch, int cout_fwd, int cin_fwd,
+                              int mx, int my, int mt, int use_mfma, int dtype, void* stream);
+/* Its weight / bias gradient (training): gw[k] (cin, cout, mx, my, mt) = sum_b conj(vh) gh over corner k = ix + 2 iy,
+ * gb[k] (mx, my, mt) = delta sum_{b, o} gh; entries (or the whole array) may be NULL.  What autograd derives for the einsum of fno/sfno.py:376-389. */
+int tcfd_fno_contract_wgrad(const void* vh, const void* gh, void* const* gw, void* const* gb, double delta, int batch,
+                            int cin, int cout, int mx, int my, int mt, int dtype, void* stream);
 
 /* Fused pointwise block of an SFNO layer (fp32, channel-major (batch, C, P) tensors, P = X*Y*T):
  *     out = act2( W2.act1(W1.x + b1) + b2  [+ Ws.skip + bs  |  + skip[..., -1:]] )
@@ -249,6 +261,14 @@ int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* plan, const void* v, c
 int tcfd_row_moments(const void* x, void* stats, int rows, long L, void* stream);
 /* The same for float64 rows. */
 int tcfd_row_moments_f64(const void* x, void* stats, int rows, long L, void* stream);
+/* Small reductions of the SFNO training step (fp32 data):
+ *   sum_rows: out (cols) double = column sums of in (rows, cols); scratch = tcfd_sum_rows_slices(rows) * cols doubles.
+ *     The per-wave partial weight-gradient rows of tcfd_fno_pointwise_bwd are added with it.
+ *   sum_t_into_last: g (rows, sT) = 0 except g[r][sT-1] = sum_t d[r][t], d (rows, T): the gradient of the skip input of
+ *     skip_mode 2 (only its last time slice is used, fno/sfno.py:258-259) from the full dL/dz2. */
+int tcfd_sum_rows_slices(long rows);
+int tcfd_sum_rows(const void* in, void* out, void* scratch, long rows, long cols, void* stream);
+int tcfd_sum_t_into_last(const void* d, void* g, long rows, int T, int sT, void* stream);
 
 /* ---- per-launch event timing (measurement aid; no reference counterpart) -------
  * Between profile_begin and profile_end every kernel the plan launches is

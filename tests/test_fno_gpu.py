@@ -138,6 +138,69 @@ def test_contraction_mfma_equals_valu_and_oracle(dev):
     assert a64.dtype == torch.complex128 and rel_l2(c64, ref64) < 1e-14 and rel_l2(a64, ref64) < 1e-14
 
 
+@pytest.mark.parametrize("real,use_mfma,tol", [(torch.float32, True, 2e-6), (torch.float32, False, 2e-6), (torch.float64, True, 1e-13)])
+def test_contraction_gradients_against_the_oracle_under_autograd(real, use_mfma, tol, dev):
+    """tcfd_fno_contract_adjoint (spectrum) and tcfd_fno_contract_wgrad (weights, biases; all four corners in one launch)
+    against autograd through the oracle's contraction: asymmetric channel counts, real-view parameters, delta != 1."""
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    g = torch.Generator().manual_seed(11)
+    b, ci, co, modes = 7, 5, 12, (3, 4, 5)
+    mx, my, mt = modes
+    cplx = torch.complex64 if real == torch.float32 else torch.complex128
+    vh = torch.view_as_complex(torch.randn(b, ci, 2 * mx, 2 * my, mt, 2, generator=g, dtype=real))
+    w = [torch.randn(ci, co, *modes, 2, generator=g, dtype=real) for _ in range(4)]
+    bias = [torch.randn(*modes, 2, generator=g, dtype=real) for _ in range(4)]
+    cot = torch.view_as_complex(torch.randn(b, co, 2 * mx, 2 * my, mt, 2, generator=g, dtype=real))
+    # oracle, float64 autograd on the CPU
+    vr = vh.to(torch.complex128).clone().requires_grad_(True)
+    wr = [x.double().requires_grad_(True) for x in w]
+    br = [x.double().requires_grad_(True) for x in bias]
+    ref = OF.spectral_contract(vr, [torch.view_as_complex(x) for x in wr], modes, bias=[torch.view_as_complex(x) for x in br], delta=0.3)
+    torch.autograd.backward(ref, cot.to(torch.complex128))
+    # HIP
+    vd = vh.detach().to(dev).requires_grad_(True)
+    wd = [x.to(dev).requires_grad_(True) for x in w]
+    bd = [x.to(dev).requires_grad_(True) for x in bias]
+    out = fno._ContractFn.apply(vd, 0.3, modes, use_mfma, True, *wd, *bd)
+    assert out.dtype == cplx and rel_l2(out, ref.detach()) < tol
+    torch.autograd.backward(out, cot.to(dev))
+    assert rel_l2(vd.grad, vr.grad) < tol
+    for k in range(4):
+        assert wd[k].grad.shape == w[k].shape and rel_l2(wd[k].grad, wr[k].grad) < tol, k
+        assert bd[k].grad.shape == bias[k].shape and rel_l2(bd[k].grad, br[k].grad) < tol, k
+
+
+def test_fused_layer_node_gives_the_gradients_of_the_separate_nodes(dev, monkeypatch):
+    """hip_spectral_layer (one autograd node per layer, the skip gradient joined inside the last inverse transform,
+    tcfd_fno_inverse_trunc_acc) against the chain of separate nodes (TCFD_FUSED_LAYER_GRAD=0) on a small SFNO: same loss,
+    same gradient for every parameter and for the input."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(3)
+    model = fno.SFNO(8, 8, 4, width=10, num_spectral_layers=2).to(dev).train()
+    x = torch.randn(3, 32, 32, 10, device=dev)
+    y = torch.randn(3, 32, 32, 10, device=dev)
+    loss_fn = fno.SobolevLoss(n_grid=32, norm_order=0, relative=True).to(dev)
+
+    def grads(flag):
+        monkeypatch.setenv("TCFD_FUSED_LAYER_GRAD", flag)
+        model.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        loss = loss_fn(model(xi), y)
+        loss.backward()
+        return float(loss), xi.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l1, gx1, g1 = grads("1")
+    l0, gx0, g0 = grads("0")
+    assert l1 == l0
+    assert rel_l2(gx1, gx0) < 1e-6
+    assert set(g1) == set(g0) and len(g1) > 20
+    for name in g0:
+        assert rel_l2(g1[name], g0[name]) < 2e-5, name
+
+
 def test_linearity_and_zero_input(dev):
     from torch_cfd_amd import fno
 

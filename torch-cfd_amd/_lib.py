@@ -129,13 +129,19 @@ SIGNATURES = {
                                     _i, _i, _d, _d, _i, _vp, _sz, _vp]),
     "tcfd_fno_forward_trunc": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _sz, _vp]),
     "tcfd_fno_inverse_trunc": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _vp, _sz, _vp]),
+    "tcfd_fno_inverse_trunc_acc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _sz, _vp]),
     "tcfd_fno_contract": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _d, _vp, _i, _i, _i, _i, _i,
                                _i, _i, _i, _vp]),
+    "tcfd_fno_contract_adjoint": (_i, [_vp, ctypes.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tcfd_fno_contract_wgrad": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _d, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
                                 _l, _vp, _vp]),
     "tcfd_fno_pointwise_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l, _l,
                                     _vp]),
     "tcfd_row_moments_f64": (_i, [_vp, _vp, _i, _l, _vp]),
+    "tcfd_sum_rows_slices": (_i, [_l]),
+    "tcfd_sum_rows": (_i, [_vp, _vp, _vp, _l, _l, _vp]),
+    "tcfd_sum_t_into_last": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "tcfd_fno_spectral_conv_pointwise": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i,
                                               _i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _vp, _sz,
                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

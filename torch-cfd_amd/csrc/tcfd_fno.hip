@@ -266,7 +266,8 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>
 template <typename T, int Y, int EPT>
 __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, T* __restrict__ out,
                                                   const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_ti, int T_out,
-                                                  int t_keep, int mt, int my, T scale, int P, int NS, long slabs, int Ys) {
+                                                  int t_keep, int mt, int my, T scale, int P, int NS, long slabs, int Ys,
+                                                  const T* acc) {
     typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
@@ -347,6 +348,22 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, 
     __syncthreads();
     const int n4 = (int)((size_t)Y * t_keep * sizeof(T) / 16);
     b128* d4 = reinterpret_cast<b128*>(out + (size_t)base * Y * t_keep);
+    if (acc) {   // out = acc + transform (acc may BE out): a gradient that joins another one, e.g. the skip path's (training)
+        const b128* a4 = reinterpret_cast<const b128*>(acc + (size_t)base * Y * t_keep);
+        constexpr int NV = 16 / (int)sizeof(T);
+        for (int q = 0; q < count; ++q) {
+            const b128* s4 = reinterpret_cast<const b128*>(ex + (size_t)q * P * Y);
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+                union { b128 v; T e[NV]; } s_, a_;
+                s_.v = s4[i];
+                a_.v = __builtin_nontemporal_load(a4 + (size_t)q * n4 + i);
+#pragma unroll
+                for (int u = 0; u < NV; ++u) s_.e[u] += a_.e[u];
+                __builtin_nontemporal_store(s_.v, d4 + (size_t)q * n4 + i);
+            }
+        }
+        return;
+    }
     for (int q = 0; q < count; ++q) {   // streamed out: nothing on this GPU reads it before it has left the caches
         const b128* s4 = reinterpret_cast<const b128*>(ex + (size_t)q * P * Y);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) __builtin_nontemporal_store(s4[i], d4 + (size_t)q * n4 + i);
@@ -406,6 +423,8 @@ struct ContractArgsT {
     const cx<T>* bias[4]; // (mx, my, mt) or null
     T delta;
     int b, ci, co, mx, my, mt;
+    int adjoint;          // 1: w holds the blocks of the FORWARD contraction, (co, ci, mx, my, mt), and is applied as its
+                          // conjugate transpose (the gradient w.r.t. the spectrum): no transposed copy of the weights is made
 };
 typedef ContractArgsT<float> ContractArgs;
 
@@ -432,7 +451,8 @@ __global__ void k_contract_valu(ContractArgsT<T> a) {
         T re = 0, im = 0;
         for (int i = 0; i < a.ci; ++i) {
             const cf xv = a.vin[((long)bb * a.ci + i) * M + mode];
-            const cf wv = w[((long)i * a.co + o) * MB + wm];
+            cf wv = a.adjoint ? w[((long)o * a.ci + i) * MB + wm] : w[((long)i * a.co + o) * MB + wm];
+            if (a.adjoint) wv.y = -wv.y;
             re += xv.x * wv.x - xv.y * wv.y;
             im += xv.x * wv.y + xv.y * wv.x;
         }
@@ -493,7 +513,9 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
     for (int i = threadIdx.x; i < a.ci * a.co * NM; i += blockDim.x) {
         const int mm = i % NM, rest = i / NM;
         const int o = rest % a.co, ic = rest / a.co;
-        Bs[((size_t)mm * cip + ic) * cop + o] = w[((long)ic * a.co + o) * MB + wm0 + mm];
+        cf wv = a.adjoint ? w[((long)o * a.ci + ic) * MB + wm0 + mm] : w[((long)ic * a.co + o) * MB + wm0 + mm];
+        if (a.adjoint) wv.y = -wv.y;
+        Bs[((size_t)mm * cip + ic) * cop + o] = wv;
     }
     __syncthreads();
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -598,7 +620,7 @@ static int launch_fwd_ty2(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long sl
 
 template <typename T, int Y>
 static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T scale,
-                          hipStream_t st) {
+                          hipStream_t st, const T* acc) {
     typedef cx<T> ct;
     constexpr int EPT = TyCfg2<Y, T>::EPT, G = TyCfg2<Y, T>::G;
     const int P = (t_keep + 1) / 2;
@@ -614,7 +636,7 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long 
     auto kern = k_inv_ty2<T, Y, EPT>;
     if ((rc = set_lds_attr(kern, lds))) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const ct*)p->tw_y,
-                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys);
+                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys, acc);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -637,8 +659,9 @@ static int do_fwd_ty(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, 
     DISPATCH_POW2(p->Y, (launch_fwd_ty2<T, N_>(p, v, w1, slabs, s, st)));
 }
 template <typename T>
-static int do_inv_ty(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T s, hipStream_t st) {
-    DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st)));
+static int do_inv_ty(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T s, hipStream_t st,
+                     const T* acc = nullptr) {
+    DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st, acc)));
 }
 template <typename T>
 static int do_fwd_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
@@ -679,6 +702,7 @@ static ContractArgsT<T> contract_args(const void* vin, void* vout, const void* c
         a.bias[k] = bias ? (const cx<T>*)bias[k] : nullptr;
     }
     a.delta = (T)delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
+    a.adjoint = 0;
     return a;
 }
 
@@ -739,8 +763,9 @@ extern "C" int tcfd_fno_forward_trunc(const tcfd_fno_plan* p, const void* v, voi
     return do_fwd_x<float>(p, (const cf*)ws, (cf*)vh, (long)batch * c, st);
 }
 
-extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
-                                      double inv_scale, void* ws, size_t ws_bytes, void* stream) {
+// out = [acc +] inverse transform; acc (same shape as out, may be out itself) or NULL
+extern "C" int tcfd_fno_inverse_trunc_acc(const tcfd_fno_plan* p, const void* vh, void* out, const void* acc, int batch, int c,
+                                          int t_keep, double inv_scale, void* ws, size_t ws_bytes, void* stream) {
     if (!p || !vh || !out || batch <= 0 || c <= 0 || t_keep <= 0 || t_keep > p->T_out)
         return FAIL(TCFD_EINVAL, "fno_inverse_trunc: bad argument");
     if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
@@ -748,10 +773,15 @@ extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, vo
     int rc;
     if (p->dtype == TCFD_C128) {
         if ((rc = do_inv_x<double>(p, (const cx<double>*)vh, (cx<double>*)ws, (long)batch * c, st))) return rc;
-        return do_inv_ty<double>(p, (const cx<double>*)ws, (double*)out, (long)batch * c * p->X, t_keep, inv_scale, st);
+        return do_inv_ty<double>(p, (const cx<double>*)ws, (double*)out, (long)batch * c * p->X, t_keep, inv_scale, st,
+                                 (const double*)acc);
     }
     if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
-    return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st);
+    return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st, (const float*)acc);
+}
+extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
+                                      double inv_scale, void* ws, size_t ws_bytes, void* stream) {
+    return tcfd_fno_inverse_trunc_acc(p, vh, out, nullptr, batch, c, t_keep, inv_scale, ws, ws_bytes, stream);
 }
 
 // Contraction alone on caller-provided truncated spectra (tests, MFMA vs VALU cross-check); dtype TCFD_C64 / TCFD_C128.
@@ -765,6 +795,110 @@ extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, co
     if (dtype != TCFD_C64) return FAIL(TCFD_EINVAL, "fno_contract: bad dtype %d", dtype);
     return do_contract<float>(contract_args<float>(vin, vout, weights, bias, delta, batch, cin, cout, mx, my, mt), use_mfma,
                               (hipStream_t)stream);
+}
+
+// gv[b][i] = sum_o conj(W[i][o]) gh[b][o]: the same kernels reading the forward blocks (cin_fwd = cout here) transposed
+extern "C" int tcfd_fno_contract_adjoint(const void* gh, const void* const* weights, void* gv, int batch, int cout_fwd,
+                                         int cin_fwd, int mx, int my, int mt, int use_mfma, int dtype, void* stream) {
+    if (!gh || !weights || !gv) return FAIL(TCFD_EINVAL, "fno_contract_adjoint: null argument");
+    if (dtype == TCFD_C128) {
+        auto a = contract_args<double>(gh, gv, weights, nullptr, 0.0, batch, cout_fwd, cin_fwd, mx, my, mt);
+        a.adjoint = 1;
+        return do_contract<double>(a, use_mfma, (hipStream_t)stream);
+    }
+    if (dtype != TCFD_C64) return FAIL(TCFD_EINVAL, "fno_contract_adjoint: bad dtype %d", dtype);
+    auto a = contract_args<float>(gh, gv, weights, nullptr, 0.0, batch, cout_fwd, cin_fwd, mx, my, mt);
+    a.adjoint = 1;
+    return do_contract<float>(a, use_mfma, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ weight / bias gradient of the contraction
+//   gw_k[i][o][x'][y'][t] = sum_b conj(vh[b][i][x][y][t]) gh[b][o][x][y][t]        (k = corner of (x, y), torch's convention
+//   gb_k[x'][y'][t]       = delta sum_{b, o} gh[b][o][x][y][t]                      dL/dRe + i dL/dIm for a complex leaf)
+// One lane per (mode, input channel), OC output channels in registers, the batch as the loop: lanes run along the contiguous
+// mode axis, so spectrum reads and gradient writes are coalesced; the OC spectra of gh are shared by the ci lanes of a mode
+// through the caches.  Replaces four einsum("bixyt,boxyt->ioxyt") on strided corner views (conj + copies + bmm: ~0.44 ms per
+// layer at config 5) with one launch that reads both spectra once (2 x 29.5 MB) and writes the 9.2 MB gradient.
+template <typename T>
+struct WgradArgsT {
+    const cx<T>* vh;      // (b, ci, 2mx, 2my, mt)
+    const cx<T>* gh;      // (b, co, 2mx, 2my, mt)
+    cx<T>* gw[4];         // (ci, co, mx, my, mt) or null
+    cx<T>* gb[4];         // (mx, my, mt) or null
+    T delta;
+    int b, ci, co, mx, my, mt;
+};
+
+template <typename T, int OC>
+__global__ __launch_bounds__(256) void k_contract_wgrad(WgradArgsT<T> a) {
+    const int M = 4 * a.mx * a.my * a.mt;
+    const int mode = blockIdx.x * 256 + threadIdx.x;
+    if (mode >= M) return;
+    const int i = blockIdx.y, o0 = blockIdx.z * OC;
+    const int kt = mode % a.mt;
+    const int kyi = (mode / a.mt) % (2 * a.my);
+    const int kxi = mode / (a.mt * 2 * a.my);
+    const int ix = kxi >= a.mx, iy = kyi >= a.my;
+    const int blk = ix + 2 * iy;
+    const long MB = (long)a.mx * a.my * a.mt;
+    const long wm = ((long)(kxi - ix * a.mx) * a.my + (kyi - iy * a.my)) * a.mt + kt;
+    if (a.gw[blk]) {
+        T re[OC], im[OC];
+#pragma unroll
+        for (int u = 0; u < OC; ++u) re[u] = im[u] = 0;
+        for (int bb = 0; bb < a.b; ++bb) {
+            const cx<T> v = a.vh[((long)bb * a.ci + i) * M + mode];
+#pragma unroll
+            for (int u = 0; u < OC; ++u) {
+                if (o0 + u < a.co) {
+                    const cx<T> g = a.gh[((long)bb * a.co + o0 + u) * M + mode];
+                    re[u] += v.x * g.x + v.y * g.y;          // conj(v) g
+                    im[u] += v.x * g.y - v.y * g.x;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OC; ++u)
+            if (o0 + u < a.co) a.gw[blk][((long)i * a.co + o0 + u) * MB + wm] = mk<T>(re[u], im[u]);
+    }
+    if (a.gb[blk] && i == 0 && blockIdx.z == 0) {
+        T re = 0, im = 0;
+        for (long r = 0; r < (long)a.b * a.co; ++r) {
+            const cx<T> g = a.gh[r * M + mode];
+            re += g.x;
+            im += g.y;
+        }
+        a.gb[blk][wm] = mk<T>(a.delta * re, a.delta * im);
+    }
+}
+
+template <typename T>
+static int do_contract_wgrad(const void* vh, const void* gh, void* const* gw, void* const* gb, double delta, int batch, int cin,
+                             int cout, int mx, int my, int mt, hipStream_t st) {
+    WgradArgsT<T> a;
+    a.vh = (const cx<T>*)vh; a.gh = (const cx<T>*)gh;
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+        a.gw[k] = gw ? (cx<T>*)gw[k] : nullptr;
+        a.gb[k] = gb ? (cx<T>*)gb[k] : nullptr;
+        any = any || a.gw[k] || a.gb[k];
+    }
+    if (!any) return 0;
+    a.delta = (T)delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
+    const long M = 4L * mx * my * mt;
+    if (M <= 0 || M > (1L << 30) || cin < 1 || cout < 1 || batch < 1) return FAIL(TCFD_EINVAL, "fno_contract_wgrad: bad shape");
+    constexpr int OC = 10;
+    hipLaunchKernelGGL((k_contract_wgrad<T, OC>), dim3((unsigned)((M + 255) / 256), cin, (cout + OC - 1) / OC), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tcfd_fno_contract_wgrad(const void* vh, const void* gh, void* const* gw, void* const* gb, double delta,
+                                       int batch, int cin, int cout, int mx, int my, int mt, int dtype, void* stream) {
+    if (!vh || !gh) return FAIL(TCFD_EINVAL, "fno_contract_wgrad: null argument");
+    if (dtype == TCFD_C128) return do_contract_wgrad<double>(vh, gh, gw, gb, delta, batch, cin, cout, mx, my, mt, (hipStream_t)stream);
+    if (dtype != TCFD_C64) return FAIL(TCFD_EINVAL, "fno_contract_wgrad: bad dtype %d", dtype);
+    return do_contract_wgrad<float>(vh, gh, gw, gb, delta, batch, cin, cout, mx, my, mt, (hipStream_t)stream);
 }
 
 
@@ -2399,6 +2533,76 @@ extern "C" int tcfd_row_moments(const void* x, void* stats, int rows, long L, vo
     int chunks = (int)std::min<long>(std::max<long>(L / (256 * 4 * 8), 1), 2048 / std::max(rows, 1) + 1);
     hipLaunchKernelGGL(k_row_moments, dim3((unsigned)chunks, (unsigned)rows), dim3(256), 0, st, (const float*)x,
                        (double*)stats, L, chunks);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ small reductions of the training step
+// Column sums of a (rows, cols) fp32 matrix in double: the per-wave rows of partial weight-gradient sums of the pointwise
+// backward (2048 x ~1800 values).  torch's sum(dim=0) runs this shape at ~80 GB/s (0.19 ms per layer); here lanes run along
+// the columns, `slices` row ranges go to blockIdx.y, a second tiny launch adds the slices: deterministic, ~10 us.
+__global__ __launch_bounds__(256) void k_sum_rows_stage(const float* __restrict__ in, double* __restrict__ scratch, long rows,
+                                                        long cols, int slices) {
+    const long c = blockIdx.x * 256L + threadIdx.x;
+    if (c >= cols) return;
+    const long r0 = rows * blockIdx.y / slices, r1 = rows * (blockIdx.y + 1) / slices;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        a0 += (double)in[r * cols + c];
+        a1 += (double)in[(r + 1) * cols + c];
+        a2 += (double)in[(r + 2) * cols + c];
+        a3 += (double)in[(r + 3) * cols + c];
+    }
+    for (; r < r1; ++r) a0 += (double)in[r * cols + c];
+    scratch[(long)blockIdx.y * cols + c] = (a0 + a1) + (a2 + a3);
+}
+__global__ __launch_bounds__(256) void k_sum_rows_final(const double* __restrict__ scratch, double* __restrict__ out, long cols,
+                                                        int slices) {
+    const long c = blockIdx.x * 256L + threadIdx.x;
+    if (c >= cols) return;
+    double a = 0;
+    for (int s = 0; s < slices; ++s) a += scratch[(long)s * cols + c];
+    out[c] = a;
+}
+// out (cols) double; scratch: tcfd_sum_rows_slices(rows) * cols doubles
+extern "C" int tcfd_sum_rows_slices(long rows) { return (int)std::max<long>(1, std::min<long>(64, rows / 32)); }
+extern "C" int tcfd_sum_rows(const void* in, void* out, void* scratch, long rows, long cols, void* stream) {
+    if (!in || !out || !scratch || rows <= 0 || cols <= 0) return FAIL(TCFD_EINVAL, "sum_rows: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int slices = tcfd_sum_rows_slices(rows);
+    const unsigned bx = (unsigned)((cols + 255) / 256);
+    hipLaunchKernelGGL(k_sum_rows_stage, dim3(bx, (unsigned)slices), dim3(256), 0, st, (const float*)in, (double*)scratch, rows, cols,
+                       slices);
+    hipLaunchKernelGGL(k_sum_rows_final, dim3(bx), dim3(256), 0, st, (const double*)scratch, (double*)out, cols, slices);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// g (rows, sT) = 0 except g[r][sT - 1] = sum_t d[r][t], d (rows, T): the gradient of a skip input of which only the LAST time
+// slice was used, broadcast over the T output steps (lifting operator, fno/sfno.py:258-259), from the full dL/dz2 in one pass
+// (zeros_like + sum(dim=-1) + strided copy before: 1.1 ms at config 5).
+__global__ __launch_bounds__(256) void k_sum_t_into_last(const float* __restrict__ d, float* __restrict__ g, long rows, int T, int sT) {
+    const long r = blockIdx.x * 256L + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = d + r * T;
+    float a = 0.f;
+    if ((T & 1) == 0) {
+        for (int t = 0; t < T; t += 2) {
+            const float2 v = *reinterpret_cast<const float2*>(p + t);
+            a += v.x + v.y;
+        }
+    } else {
+        for (int t = 0; t < T; ++t) a += p[t];
+    }
+    float* q = g + r * sT;
+    for (int t = 0; t < sT - 1; ++t) q[t] = 0.f;
+    q[sT - 1] = a;
+}
+extern "C" int tcfd_sum_t_into_last(const void* d, void* g, long rows, int T, int sT, void* stream) {
+    if (!d || !g || rows <= 0 || T <= 0 || sT <= 0) return FAIL(TCFD_EINVAL, "sum_t_into_last: bad argument");
+    hipLaunchKernelGGL(k_sum_t_into_last, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)d,
+                       (float*)g, rows, T, sT);
     HIP_TRY(hipGetLastError());
     return 0;
 }

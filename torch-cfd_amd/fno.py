@@ -302,20 +302,30 @@ def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[
 
 
 def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward",
-                         scale: Optional[float] = None) -> torch.Tensor:
-    """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep)."""
+                         scale: Optional[float] = None, accumulate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep).
+    ``accumulate``: a contiguous tensor of the output's shape that the result is ADDED to, in place, by the transform's own
+    store loop (``tcfd_fno_inverse_trunc_acc``) -- it is returned."""
     X, Y, T, t_pad, t_out, mx, my, mt = plan.key
     b, c = vh.shape[:2]
     if tuple(vh.shape[2:]) != (2 * mx, 2 * my, mt) or not vh.is_complex():
         raise ValueError(f"expected a complex (b, C, {2 * mx}, {2 * my}, {mt}) truncated spectrum, got {tuple(vh.shape)} {vh.dtype}")
     vh = vh.detach().to(plan.cplx).contiguous()   # e.g. a float64 post-processing table promotes an fp32 layer's spectrum
-    out = torch.empty(b, c, X, Y, t_keep, dtype=plan.real, device=vh.device)
+    if accumulate is not None:
+        if (tuple(accumulate.shape) != (b, c, X, Y, t_keep) or accumulate.dtype != plan.real or accumulate.device != vh.device
+                or not accumulate.is_contiguous()):
+            raise ValueError("accumulate must be a contiguous tensor of the output's shape, precision and device")
+        out = accumulate
+    else:
+        out = torch.empty(b, c, X, Y, t_keep, dtype=plan.real, device=vh.device)
     ws = plan.workspace(b, c, c)
     _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     is_ = is_ if scale is None else float(scale)
     with torch.cuda.device(vh.device):
-        rc = plan.lib.tcfd_fno_inverse_trunc(plan.handle, vh.data_ptr(), out.data_ptr(), b, c, t_keep, is_, ws.data_ptr(),
-                                             ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
+        rc = plan.lib.tcfd_fno_inverse_trunc_acc(plan.handle, vh.data_ptr(), out.data_ptr(),
+                                                 out.data_ptr() if accumulate is not None else None, b, c, t_keep, is_,
+                                                 ws.data_ptr(), ws.numel(),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_inverse_trunc")
     return out
 
@@ -358,6 +368,71 @@ def _corner_slices(mx: int, my: int):
     return [(sx[k % 2], sy[k // 2]) for k in range(4)]
 
 
+def _fwd_trunc_vjp(z, cfg, accumulate=None):
+    """F^T(z) for the truncated forward transform F (cfg of ``_FwdTruncFn``); ``accumulate``: added to, in place."""
+    (b, c, X, Y, T), modes, t_pad, t_out, norm = cfg
+    Tp = T + t_pad
+    fs, _ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
+    plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device, _real_of(z.dtype))       # its inverse reconstructs Tp steps
+    zh = (z / _c2r_weights(modes[2], Tp, z.device, z.dtype)).contiguous()
+    return hip_truncated_irfftn(zh, plan, T, scale=fs, accumulate=accumulate)
+
+
+def _inv_trunc_vjp(dy, cfg):
+    """G^T(dy) for the zero-padded inverse transform G (cfg of ``_InvTruncFn``)."""
+    (X, Y, T, t_pad, t_out, mx, my, mt), t_keep, norm = cfg
+    _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
+    gh, _ = hip_truncated_rfftn(dy.contiguous(), (mx, my, mt), t_pad=t_out - t_keep, t_out=t_out, scale=is_)
+    return gh * _c2r_weights(mt, t_out, dy.device, dy.dtype)
+
+
+def _contract_vjp(gh, vh, params, cfg, need_v, need_params):
+    """(gv, parameter gradients) of the 4-corner contraction: the contraction kernels reading the weight blocks as their
+    conjugate transpose (``tcfd_fno_contract_adjoint``), ONE launch of batch-summed outer products for all the weight and
+    bias blocks (``tcfd_fno_contract_wgrad``), written in the parameters' own layout."""
+    delta, modes, use_mfma, has_bias = cfg
+    weights = params[:4]
+    mx, my, mt = modes
+    b, ci = vh.shape[:2]
+    co = weights[0].shape[1]
+    real = _real_of(vh.dtype)
+    cplx = torch.complex128 if real == torch.float64 else torch.complex64
+    code = _lib.TCFD_C128 if real == torch.float64 else _lib.TCFD_C64
+    gh = gh.to(cplx).contiguous()
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream)
+    grads = [None] * len(params)
+    want_w = [bool(need_params[k]) for k in range(4)]
+    want_b = [bool(has_bias and need_params[4 + k]) for k in range(4)]
+    if any(want_w) or any(want_b):
+        gw = [torch.empty(ci, co, mx, my, mt, dtype=cplx, device=vh.device) if w_ else None for w_ in want_w]
+        gb = [torch.empty(mx, my, mt, dtype=cplx, device=vh.device) if b_ else None for b_ in want_b]
+        arr = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() if t is not None else None for t in ts])
+        with torch.cuda.device(vh.device):
+            rc = lib.tcfd_fno_contract_wgrad(vh.data_ptr(), gh.data_ptr(), arr(gw), arr(gb), float(delta), b, ci, co, mx, my,
+                                             mt, code, stream)
+        _lib.check(rc, "tcfd_fno_contract_wgrad")
+
+        def like(g, prm):
+            g = g if prm.is_complex() else torch.view_as_real(g)
+            return g.to(prm.dtype).reshape(prm.shape)
+        for k in range(4):
+            if gw[k] is not None:
+                grads[k] = like(gw[k], params[k])
+            if gb[k] is not None:
+                grads[4 + k] = like(gb[k], params[4 + k])
+    gv = None
+    if need_v:
+        ws_ = [(torch.view_as_real(w) if w.is_complex() else w).detach().to(device=vh.device, dtype=real).contiguous()
+               for w in weights]
+        gv = torch.empty(b, ci, 2 * mx, 2 * my, mt, dtype=cplx, device=vh.device)
+        with torch.cuda.device(vh.device):
+            rc = lib.tcfd_fno_contract_adjoint(gh.data_ptr(), _ptr_array(ws_), gv.data_ptr(), b, co, ci, mx, my, mt,
+                                               1 if use_mfma else 0, code, stream)
+        _lib.check(rc, "tcfd_fno_contract_adjoint")
+    return gv, grads
+
+
 class _FwdTruncFn(torch.autograd.Function):
     """F: truncated rfftn of the left-padded input on the HIP kernels.  For a complex cotangent z (torch's convention
     dL/dRe + i dL/dIm),  F^T(z) = G'(z / c_in): the zero-padded inverse of the plan with output length T_in + t_pad
@@ -372,12 +447,7 @@ class _FwdTruncFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, z):
-        (b, c, X, Y, T), modes, t_pad, t_out, norm = ctx.cfg
-        Tp = T + t_pad
-        fs, _ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
-        plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device, _real_of(z.dtype))       # its inverse reconstructs Tp steps
-        zh = (z / _c2r_weights(modes[2], Tp, z.device, z.dtype)).contiguous()
-        return hip_truncated_irfftn(zh, plan, T, scale=fs), None, None, None, None
+        return _fwd_trunc_vjp(z, ctx.cfg), None, None, None, None
 
 
 class _InvTruncFn(torch.autograd.Function):
@@ -392,15 +462,11 @@ class _InvTruncFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        (X, Y, T, t_pad, t_out, mx, my, mt), t_keep, norm = ctx.cfg
-        _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
-        gh, _ = hip_truncated_rfftn(dy.contiguous(), (mx, my, mt), t_pad=t_out - t_keep, t_out=t_out, scale=is_)
-        return gh * _c2r_weights(mt, t_out, dy.device, dy.dtype), None, None, None
+        return _inv_trunc_vjp(dy, ctx.cfg), None, None, None
 
 
 class _ContractFn(torch.autograd.Function):
-    """The 4-corner mode contraction (+ delta * bias) on the MFMA kernel.  Backward: the same kernel with the
-    conjugate-transposed weight blocks for the spectrum, batch-summed outer products for the weights."""
+    """The 4-corner mode contraction (+ delta * bias) on the MFMA kernel; backward: ``_contract_vjp``."""
 
     @staticmethod
     def forward(ctx, vh, delta, modes, use_mfma, has_bias, *params):
@@ -412,27 +478,8 @@ class _ContractFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh):
-        delta, modes, use_mfma, has_bias = ctx.cfg
         vh, *params = ctx.saved_tensors
-        weights = params[:4]
-        mx, my, mt = modes
-        gh = gh.contiguous()
-        grads = [None] * len(params)
-        for k, (sx, sy) in enumerate(_corner_slices(mx, my)):
-            if ctx.needs_input_grad[5 + k]:
-                gw = torch.einsum("bixyt,boxyt->ioxyt", vh[:, :, sx, sy].conj(), gh[:, :, sx, sy])
-                grads[k] = gw if weights[k].is_complex() else torch.view_as_real(gw.contiguous())
-            if has_bias and ctx.needs_input_grad[9 + k]:
-                gb = delta * gh[:, :, sx, sy].sum(dim=(0, 1))
-                grads[4 + k] = gb if params[4 + k].is_complex() else torch.view_as_real(gb.contiguous())
-        gv = None
-        if ctx.needs_input_grad[0]:
-            wh = []
-            for w in weights:
-                w = w.detach()
-                w = w if w.is_complex() else torch.view_as_complex(w.contiguous())
-                wh.append(w.conj().transpose(0, 1).resolve_conj().contiguous())   # (Co, Ci, mx, my, mt)
-            gv = hip_contract(gh, wh, None, 0.0, modes, use_mfma=use_mfma)
+        gv, grads = _contract_vjp(gh, vh, params, ctx.cfg, ctx.needs_input_grad[0], ctx.needs_input_grad[5:])
         return (gv, None, None, None, None, *grads)
 
 
@@ -496,6 +543,28 @@ def _pointwise_reference(spec, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
     return act2(o) if act2 is not None else o
 
 
+def _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode):
+    """Layout query of ``tcfd_fno_pointwise_bwd`` (no data): the six geometry numbers, or None when the backward kernel is
+    not instantiated for the combination."""
+    dims = (ctypes.c_int * 6)()
+    one = ctypes.c_void_p(1) if has_l1 else None   # only null / non-null of w1 matters
+    rc = _lib.load().tcfd_fno_pointwise_bwd(None, None, None, None, None, one, None, None, None, None, None, None, 0, dims, b, ci,
+                                            cm, co, P, T, sT, c1, c2, mode, 0, None)
+    return dims if rc == 0 else None
+
+
+def _sum_rows(mat: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Column sums (float64) of the first ``rows * cols`` values of an fp32 buffer read as a (rows, cols) matrix
+    (``tcfd_sum_rows``: the per-wave rows of partial sums of the backward kernels)."""
+    lib = _lib.load()
+    out = torch.empty(cols, dtype=torch.float64, device=mat.device)
+    scratch = torch.empty(lib.tcfd_sum_rows_slices(rows) * cols, dtype=torch.float64, device=mat.device)
+    with torch.cuda.device(mat.device):
+        _lib.check(lib.tcfd_sum_rows(mat.data_ptr(), out.data_ptr(), scratch.data_ptr(), rows, cols,
+                                     ctypes.c_void_p(torch.cuda.current_stream(mat.device).cuda_stream)), "tcfd_sum_rows")
+    return out
+
+
 def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
     """Gradients of the fused block from ``tcfd_fno_pointwise_bwd`` (one pass; weight gradients accumulated on MFMA,
     per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm or a width
@@ -512,13 +581,10 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     cm = w1.shape[0] if has_l1 else ci
     P = x[0, 0].numel()
     lib = _lib.load()
-    dims = (ctypes.c_int * 6)()
-    one = ctypes.c_void_p(1) if has_l1 else None   # layout query: only null / non-null of w1 matters
     T = x.shape[-1]
     sT = skip.shape[-1] if mode == 2 else 0
-    rc = lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, one, None, None, None, None, None, None, 0, dims, b, ci, cm,
-                                    co, P, T, sT, c1, c2, mode, 0, None)
-    if rc != 0:
+    dims = _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode)
+    if dims is None:
         return None
     COP, CB, CM1, CIP, per_row, _ = list(dims)
     dev = x.device
@@ -542,7 +608,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
                                         ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1, c2, mode, 0,
                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd")
-    tot = partials[: dims[5]].sum(dim=0, dtype=torch.float64).float()
+    tot = _sum_rows(partials, dims[5], per_row).float()
     A = tot[: COP * CB].view(COP, CB)
     ch = cm if has_l1 else ci
     g_w2 = A[:co, :ch].reshape(w2.shape)
@@ -555,8 +621,10 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
         g_w1 = Bm[:cm, :ci].reshape(w1.shape)
         g_b1 = Bm[:cm, ci].contiguous() if b1 is not None else None
     if mode == 2:   # the skip's last time slice was broadcast over t: its gradient is the t-sum of dL/dz2
-        g_skip = torch.zeros_like(skip)
-        g_skip[..., -1] = ds.sum(dim=-1)
+        g_skip = torch.empty_like(skip, memory_format=torch.contiguous_format)
+        with torch.cuda.device(dev):
+            _lib.check(lib.tcfd_sum_t_into_last(ds.data_ptr(), g_skip.data_ptr(), ds.numel() // T, T, sT,
+                                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tcfd_sum_t_into_last")
     else:
         g_skip = ds.view_as(skip) if ds is not None else None
     return (dx.view_as(x), g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
@@ -597,7 +665,7 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta):
                                         None, partials.data_ptr(), max_waves, dims, b, C, C, co, P, 0, 0, 0, 0, 0, 1, stream)
     _lib.check(rc, "tcfd_fno_pointwise_bwd")
     rows = dims[5]
-    M = partials[:rows].view(rows // b, b, per_row).sum(dim=0, dtype=torch.float64)[:, : COP * CB].view(b, COP, CB)
+    M = _sum_rows(partials, rows // b, b * per_row).view(b, per_row)[:, : COP * CB].view(b, COP, CB)
     Mx, M1 = M[:, :co, :C], M[:, :co, C]                                   # (b, co, C), (b, co)
     mu = stats[:, 0] / L
     r = torch.rsqrt((stats[:, 1] / L - mu * mu).clamp_min(0) + eps)
@@ -656,6 +724,91 @@ class _PointwiseFn(torch.autograd.Function):
             got = iter(torch.autograd.grad(out, wanted, dout, allow_unused=True))
         grads = [next(got) if (l is not None and n) else None for l, n in zip(leaves, need)]
         return (None, None, *grads)
+
+
+class _SpectralLayerFn(torch.autograd.Function):
+    """One autograd node for a whole spectral layer  out = act2(FFN(conv(v)) + skip(v)):  the forward values come from the
+    HIP kernels (passed in), the backward chains the same pieces as the separate nodes (``_hip_pointwise_backward``,
+    ``_inv_trunc_vjp``, ``_contract_vjp``, ``_fwd_trunc_vjp``) -- but as one node it knows that the layer input feeds BOTH
+    the convolution and the skip path, so the last inverse transform ADDS its result to the skip gradient in its own store
+    loop (``tcfd_fno_inverse_trunc_acc``) instead of autograd adding two activation-sized tensors (0.42 ms per layer at
+    config 5)."""
+
+    @staticmethod
+    def forward(ctx, out, x1, vh, cfg, v, *params):
+        ctx.cfg = cfg
+        ctx.present = [t is not None for t in params]
+        ctx.save_for_backward(x1, vh, v, *[t for t in params if t is not None])
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        spec, n_conv, ccfg, fwd_cfg, inv_cfg = ctx.cfg
+        x1, vh, v, *rest = ctx.saved_tensors
+        it = iter(rest)
+        params = [next(it) if p else None for p in ctx.present]
+        conv_params, pw = params[:n_conv], params[n_conv:]
+        need = ctx.needs_input_grad[5:]
+        need_v = ctx.needs_input_grad[4]
+        hip = _hip_pointwise_backward(spec, dout, x1, v if spec[3] else None, *pw, None, None)
+        if hip is None:
+            raise _lib.TcfdError("pointwise backward kernel not available for a layer that was admitted to the fused path")
+        dx1, g_skip = hip[0], hip[1]
+        gh = _inv_trunc_vjp(dx1, inv_cfg)
+        gv, cgrads = _contract_vjp(gh, vh, conv_params, ccfg, need_v, list(need[:n_conv]) + [False] * 8)
+        dv = None
+        if need_v:
+            acc = g_skip if (g_skip is not None and g_skip.is_contiguous() and g_skip.shape == v.shape) else None
+            dv = _fwd_trunc_vjp(gv, fwd_cfg, accumulate=acc)
+            if acc is None and g_skip is not None:
+                dv = dv + g_skip
+        pgrads = [g if n else None for g, n in zip(hip[2:8], need[n_conv:])]
+        cgrads = [g if n else None for g, n in zip(cgrads, need[:n_conv])]
+        return (None, None, None, None, dv, *cgrads, *pgrads)
+
+
+def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, skip_last_slice: bool = False,
+                       out_steps: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Training form of one SFNO layer, ``act2(FFN(conv(v)) + skip_conv(v))`` (fno/sfno.py:607-614) or of the lifting tail
+    ``act2(v[..., -1:] + FFN(conv(v)))`` (:258-259), as ONE autograd node (``_SpectralLayerFn``).  Returns None when gradients
+    are not being recorded or the combination is not covered; the caller then composes ``conv(v)`` and ``hip_pointwise``."""
+    if (not torch.is_grad_enabled() or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5
+            or os.environ.get("TCFD_FUSED_LAYER_GRAD", "1") == "0" or not hasattr(conv, "_plain_args")):
+        return None
+    cargs = conv._plain_args(v, out_steps)
+    if cargs is None:
+        return None
+    weights, bias, delta, modes, t_pad, t_out, t_keep, norm = cargs
+    conv_params = list(weights) + (list(bias) if bias is not None else [])
+    pw = lambda m, a: getattr(m, a) if m is not None else None
+    pw_t = [pw(lin1, "weight"), pw(lin1, "bias"), lin2.weight, lin2.bias, pw(skip_conv, "weight"), pw(skip_conv, "bias")]
+    every = [v] + conv_params + [t for t in pw_t if t is not None]
+    if not any(t.requires_grad for t in every) or any(t.dtype != torch.float32 for t in every if not t.is_complex()):
+        return None
+    if any(t.is_complex() and t.dtype != torch.complex64 for t in every) or v.shape[0] == 0:
+        return None
+    c1, c2 = _act_code(act1), _act_code(act2)
+    mode = 1 if skip_conv is not None else (2 if skip_last_slice else 0)
+    b, ci, X, Y, T = v.shape
+    co_conv = weights[0].shape[1]
+    if c1 is None or c2 is None or not _is_pointwise(lin2) or (lin1 is not None and not _is_pointwise(lin1)):
+        return None
+    cm = lin1.out_channels if lin1 is not None else co_conv
+    if _pointwise_bwd_layout(lin1 is not None, b, co_conv, cm, lin2.out_channels, X * Y * t_keep, t_keep, T if mode == 2 else 0,
+                             c1, c2, mode) is None:
+        return None
+    with torch.no_grad():
+        vh, plan = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
+        oh = hip_contract(vh, weights, bias, delta, modes)
+        x1 = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
+        out = hip_pointwise(x1, lin1, act1, lin2, skip=v if mode else None, skip_conv=skip_conv, act2=act2,
+                            skip_last_slice=skip_last_slice)
+    if out is None:
+        return None
+    spec = (lin1 is not None, act1, act2, mode, None)
+    cfg = (spec, len(conv_params), (float(delta), tuple(modes), True, bias is not None),
+           (tuple(v.shape), tuple(modes), t_pad, t_out, norm), ((X, Y, T, t_pad, t_out) + tuple(modes), t_keep, norm))
+    return _SpectralLayerFn.apply(out, x1, vh, cfg, v, *conv_params, *pw_t)
 
 
 _ACT_CODES = {nn.Identity: 0, nn.ReLU: 1, nn.GELU: 2, nn.SiLU: 3, nn.Tanh: 4}
@@ -1020,6 +1173,12 @@ class SpectralConvS(SpectralConv):
     def modes(self):
         return (self.modes_x, self.modes_y, self.modes_t)
 
+    def _plain_args(self, v, out_steps=None):
+        """(weights, bias, delta, modes, t_pad, t_out, t_keep, norm) of ``forward(v)`` -- what ``hip_spectral_layer`` needs to
+        run the convolution piecewise -- or None when this call is not the plain transform / contract / inverse chain."""
+        T = v.shape[-1]
+        return list(self.weight), self._bias_list(), self.delta, self.modes, 0, T, T, self.norm
+
     def spectral_conv(self, vh, kx: int = None, ky: int = None, kt: int = None):
         """Contraction on an ALREADY TRUNCATED spectrum (b, Ci, 2mx, 2my, mt) -> (b, Co, 2mx, 2my, mt)."""
         return hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
@@ -1057,6 +1216,14 @@ class SpectralConvT(SpectralConvS):
         self.out_steps = out_steps
         self.temporal_padding = temporal_padding
         self.postprocess = postprocess
+
+    def _plain_args(self, v, out_steps=None):
+        if out_steps is None and self.out_steps is not None:
+            out_steps = self.out_steps
+        if out_steps is None or not isinstance(self.postprocess, nn.Identity):
+            return None
+        t_pad = v.size(-1) if self.temporal_padding else 0
+        return list(self.weight), self._bias_list(), self.delta, self.modes, t_pad, out_steps + t_pad, out_steps, self.norm
 
     def forward(self, v, out_steps: int = None):
         if out_steps is None and self.out_steps is not None:
@@ -1265,6 +1432,10 @@ class LiftingOperator(nn.Module):
             out = hip_conv_pointwise(self.sconv, v, self.mlp, v, act2=self.activation, skip_last_slice=True)
             if out is not None:
                 return out
+        lin = (self.mlp.linear1, self.mlp.activation, self.mlp.linear2) if isinstance(self.mlp, PointwiseFFN) else (None, None, self.mlp)
+        out = hip_spectral_layer(self.sconv, v, *lin, act2=self.activation, skip_last_slice=True)
+        if out is not None:             # training: convolution + tail as one autograd node
+            return out
         x1 = self.sconv(v)
         if isinstance(self.mlp, PointwiseFFN):
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=v,
@@ -1367,6 +1538,10 @@ class SFNO(FNOBase):
         for conv, mlp, w, act in zip(self.spectral_conv, self.mlp, self.w, self.activations):
             fused = hip_conv_pointwise(conv, v, mlp, v, skip_conv=w, act2=act) if fuse else None
             if fused is not None:
+                v = fused
+                continue
+            fused = hip_spectral_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
+            if fused is not None:       # training: the whole layer as one autograd node
                 v = fused
                 continue
             x1 = conv(v)
