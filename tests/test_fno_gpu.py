@@ -155,8 +155,8 @@ def test_contraction_gradients_against_the_oracle_under_autograd(real, use_mfma,
     cot = torch.view_as_complex(torch.randn(b, co, 2 * mx, 2 * my, mt, 2, generator=g, dtype=real))
     # oracle, float64 autograd on the CPU
     vr = vh.to(torch.complex128).clone().requires_grad_(True)
-    wr = [x.double().requires_grad_(True) for x in w]
-    br = [x.double().requires_grad_(True) for x in bias]
+    wr = [x.double().clone().requires_grad_(True) for x in w]
+    br = [x.double().clone().requires_grad_(True) for x in bias]
     ref = OF.spectral_contract(vr, [torch.view_as_complex(x) for x in wr], modes, bias=[torch.view_as_complex(x) for x in br], delta=0.3)
     torch.autograd.backward(ref, cot.to(torch.complex128))
     # HIP

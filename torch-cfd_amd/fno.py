@@ -565,7 +565,7 @@ def _sum_rows(mat: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return out
 
 
-def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
+def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta, need_dx: bool = True):
     """Gradients of the fused block from ``tcfd_fno_pointwise_bwd`` (one pass; weight gradients accumulated on MFMA,
     per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm or a width
     that is not instantiated -- the caller then recomputes the
@@ -575,7 +575,8 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     if c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
         return None
     if eps is not None:
-        return _hip_norm_proj_backward(eps, dout, x, w2, b2, gamma, beta) if (not has_l1 and mode == 0 and c2 == 0) else None
+        return (_hip_norm_proj_backward(eps, dout, x, w2, b2, gamma, beta, need_dx=need_dx)
+                if (not has_l1 and mode == 0 and c2 == 0) else None)
     b, ci = x.shape[:2]
     co = w2.shape[0]
     cm = w1.shape[0] if has_l1 else ci
@@ -596,7 +597,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     wst = mat(ws).t().contiguous() if mode == 1 else None
     vec = lambda t: t.detach().contiguous() if t is not None else None
     b1v, b2v, bsv = vec(b1), vec(b2), vec(bs)
-    dx = torch.empty_like(xs)
+    dx = torch.empty_like(xs) if need_dx else None
     ds = torch.empty_like(sk) if mode == 1 else (torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=dev)
                                                  if mode == 2 else None)
     max_waves = 2048
@@ -627,10 +628,10 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tcfd_sum_t_into_last")
     else:
         g_skip = ds.view_as(skip) if ds is not None else None
-    return (dx.view_as(x), g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
+    return (dx.view_as(x) if dx is not None else None, g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
 
 
-def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta):
+def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = True):
     """Backward of ``proj(LayerNorm(x))`` (one group over (C, X, Y, T), per-channel affine) in two passes over the data.
 
     Pass 1 (``tcfd_fno_pointwise_bwd`` with per-sample partial sums, no dx): M_b[o, c] = sum_p dy[o] x[c] and
@@ -678,6 +679,9 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta):
     G1 = torch.einsum("oc,bo->bc", Wd, M1)                                  # sum_p g[c]
     Gx = torch.einsum("oc,boc->bc", Wd, Sx)                                 # sum_p g[c] x^[c]
     g_beta, g_gamma = G1.sum(0), Gx.sum(0)
+    cast = lambda t, like: t.to(like.dtype).reshape(like.shape) if like is not None else None
+    if not need_dx:      # the block's input is data (e.g. the network input + positional encoding): pass 2 is not needed
+        return (None, None, None, None, cast(g_w, w), cast(g_b, bias), None, None, cast(g_gamma, gamma), cast(g_beta, beta))
     A = (g_[None] * G1).sum(1)
     B = (g_[None] * Gx).sum(1)
     # pass 2: dx = sum_o (r gamma_c W[o,c]) dy[o] + alpha_b + kappa_b x
@@ -693,7 +697,6 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta):
         return None
     _lib.check(rc, "tcfd_fno_pointwise")
     dx.addcmul_(xs, kappa.float().view(b, *([1] * (x.dim() - 1))))
-    cast = lambda t, like: t.to(like.dtype).reshape(like.shape) if like is not None else None
     return (dx.view_as(x), None, None, None, cast(g_w, w), cast(g_b, bias), None, None, cast(g_gamma, gamma), cast(g_beta, beta))
 
 
@@ -713,7 +716,7 @@ class _PointwiseFn(torch.autograd.Function):
         it = iter(ctx.saved_tensors)
         tensors = [next(it) if p else None for p in ctx.present]
         need = ctx.needs_input_grad[2:]
-        hip = _hip_pointwise_backward(ctx.spec, dout, *tensors)
+        hip = _hip_pointwise_backward(ctx.spec, dout, *tensors, need_dx=bool(need[0]))
         if hip is not None:
             return (None, None, *[g if n else None for g, n in zip(hip, need)])
         with torch.enable_grad():
