@@ -145,6 +145,26 @@ def test_composite_transforms_for_grids_with_an_odd_factor():
         assert (f.irfft2(z) - torch.fft.irfft2(z, s=(n, n))).abs().max() < 1e-13
 
 
+def test_dense_transforms_for_the_remaining_even_sizes():
+    """mixed_radix.DenseDft (any even n as three products with DFT matrices) against torch.fft, including torch's c2r
+    semantics on spectra that are not Hermitian (Im of the DC / Nyquist columns dropped after the transform along x)."""
+    from torch_cfd_amd.mixed_radix import DenseDft, odd_factor_split
+
+    g = torch.Generator().manual_seed(1)
+    for n, cdtype, tol in ((100, torch.complex128, 1e-13), (14, torch.complex128, 1e-13), (250, torch.complex64, 2e-5),
+                           (998, torch.complex128, 1e-12)):
+        assert odd_factor_split(n) is None
+        f = DenseDft(n, cdtype)
+        y = torch.randn(2, n, n, generator=g, dtype=f.rdtype)
+        z = torch.complex(torch.randn(2, n, n // 2 + 1, generator=g, dtype=torch.float64),
+                          torch.randn(2, n, n // 2 + 1, generator=g, dtype=torch.float64))
+        ref, refi = torch.fft.rfft2(y.double()), torch.fft.irfft2(z, s=(n, n))
+        assert f.rfft2(y).dtype == cdtype and (f.rfft2(y) - ref).abs().max() < tol * ref.abs().max()
+        assert (f.irfft2(z.to(cdtype)) - refi).abs().max() < tol * refi.abs().max()
+    with pytest.raises(ValueError):
+        DenseDft(101, torch.complex128)
+
+
 # ----------------------------------------------------------------------------- caller-facing helpers of the reference
 def test_stable_time_step_bounds():
     dx = L / 1024

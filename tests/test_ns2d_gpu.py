@@ -467,10 +467,14 @@ def test_errors_are_loud(dev):
     w = torch.zeros(1, 16, 9, dtype=torch.complex128, device=dev, requires_grad=True)
     assert op(w, 1e-3)[0].requires_grad            # round 1 raised here; gradients now go through autograd.py
     torch.set_default_dtype(torch.float64)
-    grid = tc.Grid(shape=(20, 20), domain=((0, L), (0, L)))   # 5 * 4: the power-of-two part is below 8
+    grid = tc.Grid(shape=(20, 20), domain=((0, L), (0, L)))   # 5 * 4: the power-of-two part is below 8 -> dense transforms
+    small = tc.NavierStokes2DSpectral(1e-3, grid, solver=tc.RK4CrankNicolsonStepper()).to(dev)
+    out, _ = small(torch.zeros(1, 20, 11, dtype=torch.complex128, device=dev), 1e-3)
+    assert out.shape == (1, 20, 11) and float(out.abs().max()) == 0.0
+    grid = tc.Grid(shape=(4098, 4098), domain=((0, L), (0, L)))   # beyond every transform this library has
     bad = tc.NavierStokes2DSpectral(1e-3, grid, solver=tc.RK4CrankNicolsonStepper()).to(dev)
-    with pytest.raises(tc._lib.TcfdError, match="n = 20"):
-        bad(torch.zeros(1, 20, 11, dtype=torch.complex128, device=dev), 1e-3)
+    with pytest.raises(tc._lib.TcfdError, match="n = 4098"):
+        bad(torch.zeros(1, 4098, 2050, dtype=torch.complex128, device=dev), 1e-3)
 
 
 class _DenseVorticityForcing(torch.nn.Module):
@@ -992,12 +996,15 @@ def test_trajectory_with_require_grad(dev):
     (96, "f32", None, True), (768, "f32", None, True),
     (80, "f64", "sincos", True), (160, "f32", "kolmogorov", True), (320, "f64", None, True), (640, "f64", "kolmogorov", True), (640, "f32", None, True),
     (1536, "f64", "kolmogorov", True), (1280, "f32", None, True),
-    (48, "f32", None, False), (48, "f64", "sincos", False)])
+    (48, "f32", None, False), (48, "f64", "sincos", False),
+    (100, "f64", "kolmogorov", False), (200, "f32", None, False), (250, "f64", "sincos", False), (36, "f64", None, False)])
 def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, fused, dev):
     """n = p * 2^k (the reference accepts any even n, equations.py:413-422).  n = 3 * 2^k (96 .. 768) and n = 5 * 2^k
     (80 .. 640) run the FUSED column / row kernels (radix-12 / radix-20 first pass: 4-point transforms, twiddles, 3- / 5-point
     transforms in registers); other sizes with a small odd factor (48, 112, ...) the power-of-two HIP transforms composed by
-    decimation over the odd factor + the stage loop in tensor ops (mixed_radix.py).  Transforms against torch.fft semantics (non-Hermitian c2r input
+    decimation over the odd factor + the stage loop in tensor ops (mixed_radix.py); every OTHER even n (100, 200, 250, 36:
+    odd factor 25, 125, 9 times a power of two below 8) dense device transforms (mixed_radix.DenseDft).  Transforms against
+    torch.fft semantics (non-Hermitian c2r input
     included), explicit terms / steps / residual / stream function / trajectory against the oracle."""
     import torch_cfd_amd as tc
     from oracle import ns2d as O
@@ -1014,7 +1021,9 @@ def test_grids_with_an_odd_factor_against_oracle(n, tag, forcing, fused, dev):
     assert rel_l2(plan.irfft2(z.to(dev)), torch.fft.irfft2(z, s=(n, n))) < ttol
     w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 20 + s, real)) for s in range(2)])
     info = op._plan(w0.to(dev)).info()
-    assert ("composite" in info) == (not fused) and (fused or info["composite"] in (3, 5))
+    assert ("composite" in info) == (not fused)
+    if not fused:
+        assert info["dense_dft"] == (0 if n == 48 else 1) and info["composite"] == (3 if n == 48 else 0)
     tol = 1e-10 if tag == "f64" else 4e-6
     assert rel_l2(op.explicit_terms(w0.to(dev)), O.explicit_terms(w0, t)) < (1e-10 if tag == "f64" else 2e-5)
     ref, ref_dt = O.advance(w0, 1e-3, t, steps=3)

@@ -236,15 +236,19 @@ class _MeshTables:
 
 
 def _composite_plan(op, n: int, cdtype, device, forcing_hat=None):
-    """Plan of a grid n = p * 2^k (odd p): power-of-two HIP transforms + tensor ops, see mixed_radix.py."""
-    from .mixed_radix import CompositeFft, TensorOpPlan, odd_factor_split
+    """Plan of a grid outside the fused kernels' sizes: n = p * 2^k with a small odd p on power-of-two HIP transforms, any
+    other even n on dense device transforms; the stage loop in tensor ops either way (mixed_radix.py)."""
+    from .mixed_radix import CompositeFft, DenseDft, TensorOpPlan, odd_factor_split
 
     split = odd_factor_split(n)
-    if split is None:
-        raise _lib.TcfdError(f"n = {n}: the HIP spectral path covers n = 2^k (8..2048, fused kernels) and n = p * 2^k with a "
-                             "small odd factor p (power-of-two transforms + tensor ops)")
-    p_, m_ = split
-    return TensorOpPlan(op, CompositeFft(n, p_, fft_plan(m_, cdtype, device)), device, forcing_hat)
+    if split is not None:
+        p_, m_ = split
+        return TensorOpPlan(op, CompositeFft(n, p_, fft_plan(m_, cdtype, device)), device, forcing_hat)
+    if n % 2 or n < 4 or n > 4096:
+        raise _lib.TcfdError(f"n = {n}: the HIP spectral path covers even n (the reference's irfft2 default size, "
+                             "torch_cfd/equations.py:413-422): 2^k, 3 * 2^k, 5 * 2^k on the fused kernels, the rest up to 4096 "
+                             "through composite / dense transforms")
+    return TensorOpPlan(op, DenseDft(n, cdtype), device, forcing_hat)
 
 
 def _is_pow2(n: int) -> bool:

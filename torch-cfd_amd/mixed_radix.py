@@ -1,4 +1,5 @@
-"""Grids that are not a power of two: n = p * 2^k with a small odd factor p (96, 192, 384, 768, 1536; 80, 160, ...).
+"""Grids the fused kernels do not cover: n = p * 2^k with a small odd factor p (48, 112, 224, 448, ...) on ``CompositeFft``,
+every other even n (100, 200, 1000, ...) on ``DenseDft``.
 
 The hand-written transforms are power-of-two Stockham kernels.  The reference accepts any even n
 (torch_cfd/equations.py:413-422, ``irfft2`` default size); to keep such grids usable WITHOUT leaving the device or
@@ -104,6 +105,69 @@ class CompositeFft:
         return y.reshape(*lead, n, n)
 
 
+class DenseDft:
+    """rfft2 / irfft2 of (*, n, n) fields for ANY even n as dense transforms: three matrix products with the DFT matrices
+    on the device (rocBLAS GEMMs -- the one place a library GEMM is the right tool: O(n^3) per field, but on the fp64
+    matrix pipe a 1000^2 field is ~16 GFLOP = a fraction of a millisecond, and no radix schedule exists for, say, n = 2 * 499).
+
+    Serves the even sizes that neither the fused kernels (2^k, 3 * 2^k, 5 * 2^k) nor ``CompositeFft`` (odd factor <= 15)
+    cover: 100, 200, 250, 1000, ...  The reference takes any even n (torch_cfd/equations.py:413-422).  Angles are reduced
+    with integer arithmetic (j k mod n) before the sine / cosine, so the tables are accurate to the last bit for every n.
+
+        rfft2 :  H = y Cy            (n x n real) (n x m complex)          Cy[j, k] = exp(-2 pi i j k / n), m = n/2 + 1
+                 X = Fx H            (n x n complex) (n x m complex)       Fx[a, j] = exp(-2 pi i a j / n)
+        irfft2:  G = conj(Fx) X      inverse along x
+                 y = Re(G) Ar - Im(G) Ai,   Ar[k, j] = c_k cos(2 pi j k / n) / n^2,  Ai[k, j] = c_k sin(2 pi j k / n) / n^2
+    with c = 1 on the DC and Nyquist columns, 2 elsewhere -- torch's c2r semantics: the imaginary parts of those two
+    columns are dropped after the transform along x (their sine rows are exactly zero here)."""
+
+    p = 0      # no odd-factor split: TensorOpPlan.info() reports "composite": 0
+
+    def __init__(self, n: int, cdtype: torch.dtype):
+        if n < 4 or n % 2 or n > 4096:
+            raise ValueError(f"dense transforms cover even 4 <= n <= 4096, got {n}")
+        self.n, self.m = n, n // 2 + 1
+        self.cdtype = cdtype
+        self.rdtype = torch.float64 if cdtype == torch.complex128 else torch.float32
+        self._tables = {}
+
+    def _t(self, device):
+        t = self._tables.get(device)
+        if t is None:
+            n, m = self.n, self.m
+            j = torch.arange(n, device=device)
+            ang_full = (2 * math.pi / n) * ((j[:, None] * j[None, :]) % n).to(torch.float64)           # (n, n)
+            ang_half = ang_full[:, :m]                                                                 # (j, k)
+            fx = torch.polar(torch.ones_like(ang_full), -ang_full)                                     # exp(-2 pi i a j / n)
+            c = torch.full((m,), 2.0, dtype=torch.float64, device=device)
+            c[0] = c[-1] = 1.0
+            ar = (c[:, None] * torch.cos(ang_half.t())) / float(n * n)                                 # (k, j)
+            ai = (c[:, None] * torch.sin(ang_half.t())) / float(n * n)
+            ai[0].zero_()
+            ai[-1].zero_()
+            t = {"cy_re": torch.cos(ang_half).to(self.rdtype), "cy_im": (-torch.sin(ang_half)).to(self.rdtype),
+                 "fx": fx.to(self.cdtype), "fxc": fx.conj().resolve_conj().to(self.cdtype),
+                 "ar": ar.to(self.rdtype), "ai": ai.to(self.rdtype)}
+            self._tables[device] = t
+        return t
+
+    def rfft2(self, y: torch.Tensor) -> torch.Tensor:
+        n, m = self.n, self.m
+        lead = y.shape[:-2]
+        t = self._t(y.device)
+        y3 = y.reshape(-1, n, n).to(self.rdtype)
+        h = torch.complex(y3 @ t["cy_re"], y3 @ t["cy_im"])                                            # (B, n, m)
+        return (t["fx"] @ h).reshape(*lead, n, m)
+
+    def irfft2(self, xh: torch.Tensor) -> torch.Tensor:
+        n, m = self.n, self.m
+        lead = xh.shape[:-2]
+        t = self._t(xh.device)
+        g = t["fxc"] @ xh.reshape(-1, n, m).to(self.cdtype)                                            # (B, n, m)
+        y = g.real @ t["ar"] - g.imag @ t["ai"]
+        return y.reshape(*lead, n, n)
+
+
 class TensorOpPlan:
     """The operations ``NavierStokes2DSpectral`` asks of a plan (step / explicit terms / residual sweep / velocity /
     transforms), carried out with the stage loop of ``autograd.py`` around a ``CompositeFft``."""
@@ -116,7 +180,8 @@ class TensorOpPlan:
         self.forcing = None if forcing_hat is None else forcing_hat.to(device=device, dtype=fft.cdtype)
 
     def info(self):
-        return {"separable": 0, "sparse_forcing": 0, "keep_cols": 0, "split": 0, "rows_kernel": 0, "composite": self.fft.p}
+        return {"separable": 0, "sparse_forcing": 0, "keep_cols": 0, "split": 0, "rows_kernel": 0, "composite": self.fft.p,
+                "dense_dft": int(isinstance(self.fft, DenseDft))}
 
     def _w(self, w):
         if not w.is_cuda and self.device.type == "cuda":
