@@ -190,7 +190,7 @@ def test_fused_layer_node_gives_the_gradients_of_the_separate_nodes(dev, monkeyp
         xi = x.clone().requires_grad_(True)
         loss = loss_fn(model(xi), y)
         loss.backward()
-        return float(loss), xi.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return float(loss.detach()), xi.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
     l1, gx1, g1 = grads("1")
     l0, gx0, g0 = grads("0")
@@ -199,6 +199,68 @@ def test_fused_layer_node_gives_the_gradients_of_the_separate_nodes(dev, monkeyp
     assert set(g1) == set(g0) and len(g1) > 20
     for name in g0:
         assert rel_l2(g1[name], g0[name]) < 2e-5, name
+
+
+@pytest.mark.parametrize("dim", [1, 2, 4])
+def test_layer_template_in_other_dimensions(dim, dev):
+    """The dimension-generic template (fno/base.py:114-237): a subclass that implements ``spectral_conv`` for dim = 1, 2, 4
+    runs rfftn / irfftn as dense device transforms (dense_fft.py).  Against the same layer evaluated with torch.fft in
+    float64 on the CPU: forward, another output size, and gradients of input and weights."""
+    import pickle
+    from torch_cfd_amd import fno
+
+    class LowModes(fno.SpectralConv):
+        """Keeps the block of the lowest modes of every axis and contracts it with weight[0] (dim = 1: a scaling)."""
+
+        def spectral_conv(self, vhat, *fft_mesh_size, **kwargs):
+            modes = [min(m_, n_) for m_, n_ in zip(self.modes_, fft_mesh_size)]
+            sl = (slice(None), slice(None)) + tuple(slice(0, m_) for m_ in modes)
+            out = torch.zeros(vhat.shape[0], self.out_channels, *fft_mesh_size, dtype=vhat.dtype, device=vhat.device)
+            if len(self.weight):
+                w = torch.view_as_complex(self.weight[0])[(slice(None), slice(None)) + tuple(slice(0, m_) for m_ in modes)]
+                out[sl] = self.complex_matmul(vhat[sl], w.to(vhat.dtype))
+            else:
+                out[sl] = 0.5 * vhat[sl][:, : self.out_channels]
+            return out
+
+    torch.manual_seed(dim)
+    mesh = {1: [24], 2: [12, 10], 4: [6, 5, 4, 8]}[dim]
+    modes = [3] * dim
+    layer = LowModes(3, 3, modes, dim=dim, bias=False, norm="ortho")
+    layer.modes_ = modes
+    assert len(layer.weight) == 2 * (dim - 1)
+    pickle.dumps(layer.complex_matmul)
+    x = torch.randn(2, 3, *mesh, dtype=torch.float64)
+    out_size = [n + 2 for n in mesh]
+    dims = tuple(range(-dim, 0))
+
+    def reference(xr, weights):
+        vh = torch.fft.rfftn(xr, dim=dims, norm="ortho")
+        ms = [min(m_, n_) for m_, n_ in zip(modes, vh.shape[2:])]
+        sl = (slice(None), slice(None)) + tuple(slice(0, m_) for m_ in ms)
+        oh = torch.zeros_like(vh)
+        if weights:
+            w = torch.view_as_complex(weights[0])[(slice(None), slice(None)) + tuple(slice(0, m_) for m_ in ms)]
+            oh[sl] = torch.einsum("bi...,io...->bo...", vh[sl], w)
+        else:
+            oh[sl] = 0.5 * vh[sl]
+        return torch.fft.irfftn(oh, s=out_size, dim=dims, norm="ortho")
+
+    xr = x.clone().requires_grad_(True)
+    wr = [w.detach().double().clone().requires_grad_(True) for w in layer.weight]
+    ref = reference(xr, wr)
+    cot = torch.randn_like(ref)
+    ref.backward(cot)
+    dl = layer.double().to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = dl(xd, out_mesh_size=out_size)
+    assert out.shape == ref.shape and rel_l2(out, ref.detach()) < 1e-13
+    out.backward(cot.to(dev))
+    assert rel_l2(xd.grad, xr.grad) < 1e-13
+    if wr:                                                 # only block 0 is used by this subclass
+        assert rel_l2(dl.weight[0].grad, wr[0].grad) < 1e-13 and all(w.grad is None for w in list(dl.weight)[1:])
+    with pytest.raises(NotImplementedError):
+        fno.SpectralConv(2, 2, [3, 3], dim=2).to(dev)(torch.randn(1, 2, 8, 8, device=dev))
 
 
 def test_linearity_and_zero_input(dev):

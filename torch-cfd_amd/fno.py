@@ -23,6 +23,7 @@ ordinary torch modules running on the same device.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 import math
 import weakref
@@ -1148,11 +1149,10 @@ class SpectralConv(nn.Module):
         self.bias = bias
         self.norm = norm
         assert len(modes) == dim, "modes should match the dimension"
-        if dim != 3:
-            raise NotImplementedError("the HIP spectral convolution covers the (2+1)-D layer (dim=3)")
         size = [in_channels, out_channels, *modes, 2]
         gain = 0.5 / (in_channels * out_channels)
         self._initialize_weights(size, gain)
+        self._set_complex_matmul_nd(dim)
 
     def _initialize_weights(self, size, gain=1e-4):
         n_blocks = 2 * (self.dim - 1)
@@ -1162,6 +1162,41 @@ class SpectralConv(nn.Module):
 
     def _bias_list(self):
         return list(self.bias) if isinstance(self.bias, nn.ParameterList) else None
+
+    # -- the dimension-generic template of fno/base.py:114-237: 2 (dim - 1) weight blocks, a channel contraction over any
+    #    number of mesh axes, forward = rfftn -> spectral_conv (the subclass's) -> irfftn.  The (2+1)-D subclasses below
+    #    replace ``forward`` by the fused HIP kernels; any other dimension runs the two transforms as dense matrix products
+    #    on the device (dense_fft.py) around the subclass's ``spectral_conv``.
+    @staticmethod
+    def complex_matmul(x, w, **kwargs):
+        """(b, c_i, *mesh), (c_i, c_o, *mesh) -> (b, c_o, *mesh)"""
+        return torch.einsum("bi...,io...->bo...", x, w)
+
+    def _set_complex_matmul_nd(self, dim: int = None):
+        """Bind ``complex_matmul`` to the einsum of exactly ``dim`` mesh axes ("bixy,ioxy->boxy" for dim = 2)."""
+        dim = self.dim if dim is None else dim
+        assert dim >= 1
+        mesh = "".join(chr(ord("z") - k) for k in range(dim - 1, -1, -1))
+        equation = f"bi{mesh},io{mesh}->bo{mesh}"
+        self.complex_matmul = functools.partial(torch.einsum, equation)      # picklable, unlike a closure
+
+    def spectral_conv(self, vhat, *fft_mesh_size, **kwargs):
+        raise NotImplementedError("Subclasses must implement spectral_conv() to perform spectral convolution")
+
+    def forward(self, v, out_mesh_size=None, **kwargs):
+        from .dense_fft import irfftn_dense, rfftn_dense
+
+        if not v.is_cuda:
+            raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+        mesh_size = list(v.shape[2:])
+        if len(mesh_size) != self.dim:
+            raise ValueError(f"expected (b, C) + {self.dim} mesh axes, got {tuple(v.shape)}")
+        out_mesh_size = mesh_size if out_mesh_size is None else [int(n) for n in out_mesh_size]
+        fft_mesh_size = mesh_size.copy()
+        fft_mesh_size[-1] = mesh_size[-1] // 2 + 1
+        v_hat = rfftn_dense(v, self.dim, self.norm)
+        v_hat = self.spectral_conv(v_hat, *fft_mesh_size, **kwargs)
+        return irfftn_dense(v_hat, out_mesh_size, self.norm)
 
 
 class SpectralConvS(SpectralConv):
