@@ -139,6 +139,21 @@ int tcfd_ns2d_explicit_terms(const tcfd_ns2d_plan* plan, const void* w, void* ou
 int tcfd_ns2d_explicit_terms_vjp(const tcfd_ns2d_plan* plan, const void* w, const void* gm, void* xout, long batch,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* wbar (batch, plane) = sum_f post_f (.) X_f: the closing sum of the vector-Jacobian product above (X = xout, post (4, plane)
+ * complex tables -(c / n^2) conj(a_f) built by the caller) in one pass. */
+int tcfd_ns2d_vjp_combine(const void* X, const void* post, void* out, long batch, long plane, int dtype, void* stream);
+
+/* Stage bookkeeping of the differentiable step with constant coefficients (what autograd derives for the low-storage RK /
+ * Crank-Nicolson stage of torch_cfd/equations.py:139-160, 355-357 when only the STATE requires grad), one launch each way:
+ *     h = fa f + beta h_prev ,   u = (b + gdt h + mu L b) / (1 - mud L)          coef = {fa, beta, gdt, mu, mud}
+ *     G = g_h + gdt r g_u ,   g_f = fa G ,  g_hprev = beta G ,  g_b = (1 + mu L) r g_u ,   r = 1 / (1 - mud L)
+ * f, h_prev, b, h, u and the cotangents: (batch, plane) complex of dtype (TCFD_C64 / TCFD_C128); lin: the (plane) real linear
+ * term in the matching precision.  h_prev / g_h / g_hprev may be NULL (first stage: no previous h; last stage: nothing reads h). */
+int tcfd_ns2d_stage_update(const void* f, const void* h_prev, const void* b, const void* lin, const double* coef, void* h,
+                           void* u, long batch, long plane, int dtype, void* stream);
+int tcfd_ns2d_stage_update_vjp(const void* g_u, const void* g_h, const void* lin, const double* coef, void* g_f,
+                               void* g_hprev, void* g_b, long batch, long plane, int dtype, void* stream);
+
 /* psi = -w/lap and residual = w_t - F(w) - L w in one call: the record step of
  * get_trajectory_imex (fno/data_gen/solvers.py:245-247, torch_cfd/spectral.py:113,
  * equations.py:405-411).  Either output may be NULL. */

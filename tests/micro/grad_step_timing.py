@@ -23,8 +23,9 @@ for n, B in ((512, 16), (1024, 8)):
         for _ in range(reps): fn()
         torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
     r = {"forward_only_ms": round(timed(fwd_only), 3)}
-    for flag in ("1", "0"):
-        os.environ["TCFD_FUSED_VJP"] = flag
-        r["fwd_bwd_fused_vjp_ms" if flag == "1" else "fwd_bwd_tensor_ops_ms"] = round(timed(grad_step), 3)
+    for name, vjp, stage in (("fwd_bwd_fused_nodes_ms", "1", "1"), ("fwd_bwd_fused_vjp_tensor_stage_ms", "1", "0"),
+                             ("fwd_bwd_tensor_ops_ms", "0", "0")):
+        os.environ["TCFD_FUSED_VJP"], os.environ["TCFD_FUSED_STAGE"] = vjp, stage
+        r[name] = round(timed(grad_step), 3)
     res[f"{n}x{B}_f64"] = r
 print(json.dumps(res))

@@ -116,6 +116,9 @@ SIGNATURES = {
                                  _vp]),
     "tcfd_ns2d_explicit_terms": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
     "tcfd_ns2d_explicit_terms_vjp": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_ns2d_vjp_combine": (_i, [_vp, _vp, _vp, _l, _l, _i, _vp]),
+    "tcfd_ns2d_stage_update": (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(_d), _vp, _vp, _l, _l, _i, _vp]),
+    "tcfd_ns2d_stage_update_vjp": (_i, [_vp, _vp, _vp, ctypes.POINTER(_d), _vp, _vp, _vp, _l, _l, _i, _vp]),
     "tcfd_ns2d_stream_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _sz, _vp]),
     "tcfd_ns2d_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),

@@ -11,9 +11,10 @@ hand-written transforms:
 
 with c = 1 on the DC and Nyquist columns of the half spectrum and 2 elsewhere (the c2r transform counts the interior
 columns twice, the r2c transform once).  Nothing here touches torch.fft or the CPU.  Since round 3 the explicit terms and
-their vector-Jacobian product run on the fused kernels (``FusedExplicitTerms``: 3 launches forward, ~10 backward); what is
-left in tensor ops is the Runge-Kutta / Crank-Nicolson bookkeeping of a stage (a handful of element-wise launches), which is
-also what lets trainable coefficients receive gradients.
+their vector-Jacobian product run on the fused kernels (``FusedExplicitTerms``: 3 launches forward, ~10 backward), and with
+constant coefficients the Runge-Kutta / Crank-Nicolson bookkeeping of a stage is one launch each way as well
+(``StageUpdate``); the tensor-op stage loops below remain for trainable coefficients (whose gradients they produce), for the
+composite grids and as the cross-check (``TCFD_FUSED_STAGE=0``, ``TCFD_FUSED_VJP=0``).
 """
 from __future__ import annotations
 
@@ -97,8 +98,18 @@ class FusedExplicitTerms(torch.autograd.Function):
         lead = w_hat.shape
         w3 = w_hat.reshape(-1, ctx.plan.n, ctx.plan.m)
         gm = (g.reshape(w3.shape) * pre).contiguous()
-        X = ctx.plan.explicit_terms_vjp(w3, gm)                          # (4, B, n, m)
-        wbar = (X * post[:, None]).sum(dim=0)
+        X = ctx.plan.explicit_terms_vjp(w3, gm).contiguous()             # (4, B, n, m)
+        wbar = torch.empty_like(gm)
+        import ctypes
+
+        from . import _lib
+
+        plane = ctx.plan.n * ctx.plan.m
+        with torch.cuda.device(g.device):
+            rc = _lib.load().tcfd_ns2d_vjp_combine(X.data_ptr(), post.data_ptr(), wbar.data_ptr(), wbar.numel() // plane, plane,
+                                                   _lib.TCFD_C128 if wbar.dtype == torch.complex128 else _lib.TCFD_C64,
+                                                   ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+        _lib.check(rc, "tcfd_ns2d_vjp_combine")
         return wbar.reshape(lead), None, None
 
 
@@ -145,6 +156,79 @@ def rk_crank_nicolson_steps(op, plan, w_hat, dt, steps, params, forcing_hat):
             h = f if h is None else f + be[k] * h
             mu = 0.5 * dt * (al[k + 1] - al[k])
             u = (u + ga[k] * dt * h + mu * lin * u) / (1 - mu * lin)
+    return u
+
+
+class StageUpdate(torch.autograd.Function):
+    """One stage of the low-storage RK / Crank-Nicolson schedule with CONSTANT coefficients,
+        h = fa f + beta h_prev ,   u = (b + gdt h + mu L b) / (1 - mud L)        (the fused forward kernels' own arithmetic),
+    and its vector-Jacobian product, one launch each (``tcfd_ns2d_stage_update[_vjp]``) instead of ~10 / ~20 element-wise
+    tensor launches.  Linear, so nothing is saved for the backward but the table of L and five numbers."""
+
+    @staticmethod
+    def _launch(name, ptrs_in, lin, coef, ptrs_out, like):
+        import ctypes
+
+        from . import _lib
+
+        plane = lin.numel()
+        code = _lib.TCFD_C128 if like.dtype == torch.complex128 else _lib.TCFD_C64
+        c = (ctypes.c_double * 5)(*coef)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(like.device):
+            rc = getattr(_lib.load(), name)(*[ptr(t) for t in ptrs_in], lin.data_ptr(), c, *[ptr(t) for t in ptrs_out],
+                                            like.numel() // plane, plane, code,
+                                            ctypes.c_void_p(torch.cuda.current_stream(like.device).cuda_stream))
+        _lib.check(rc, name)
+
+    @staticmethod
+    def forward(ctx, f, h_prev, b, lin, coef):
+        f, b = f.contiguous(), b.contiguous()
+        hp = h_prev.contiguous() if h_prev is not None else None
+        h, u = torch.empty_like(f), torch.empty_like(f)
+        StageUpdate._launch("tcfd_ns2d_stage_update", (f, hp, b), lin, coef, (h, u), f)
+        ctx.lin, ctx.coef, ctx.has_prev = lin, coef, h_prev is not None
+        return h, u
+
+    @staticmethod
+    def backward(ctx, g_h, g_u):
+        if g_u is None:
+            g_u = torch.zeros_like(g_h)
+        g_u = g_u.contiguous()
+        gh = g_h.contiguous() if g_h is not None else None
+        g_f, g_b = torch.empty_like(g_u), torch.empty_like(g_u)
+        g_hp = torch.empty_like(g_u) if (ctx.has_prev and ctx.needs_input_grad[1]) else None
+        StageUpdate._launch("tcfd_ns2d_stage_update_vjp", (g_u, gh), ctx.lin, ctx.coef, (g_f, g_hp, g_b), g_u)
+        return g_f, g_hp, g_b, None, None
+
+
+def _linear_term_on(op, plan, device):
+    """The real (n, m) linear term in the plan's precision on the device, cached on the plan."""
+    lin = op.linear_term
+    key = (plan.rdtype, device, lin.data_ptr(), lin._version)
+    cached = getattr(plan, "_lin_dev", None)
+    if cached is None or cached[0] != key:
+        cached = (key, lin.detach().to(device=device, dtype=plan.rdtype).contiguous())
+        plan._lin_dev = cached
+    return cached[1]
+
+
+def fused_scheduled_steps(op, plan, w_hat, steps, sched, forcing_hat):
+    """``scheduled_steps`` for a schedule of plain numbers (only the STATE requires grad) on fused nodes: the explicit
+    terms (``FusedExplicitTerms``) and the stage update (``StageUpdate``), i.e. 4 launches forward and ~11 backward per stage."""
+    n = len(sched["beta"])
+    fa = sched.get("fa") or [1.0] * n
+    mu_den = sched.get("mu_den") or sched["mu"]
+    base0 = sched.get("base0") or [0] * n
+    lin = _linear_term_on(op, plan, w_hat.device)
+    u = w_hat
+    for _ in range(steps):
+        start, h = u, None
+        for k in range(n):
+            f = explicit_terms(op, plan, u, forcing_hat)
+            b = start if base0[k] else u
+            coef = (float(fa[k]), float(sched["beta"][k]), float(sched["gdt"][k]), float(sched["mu"][k]), float(mu_den[k]))
+            h, u = StageUpdate.apply(f, h, b, lin, coef)
     return u
 
 

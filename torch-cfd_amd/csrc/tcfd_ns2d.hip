@@ -2925,3 +2925,127 @@ TCFD_API int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void
                              (hipStream_t)stream));
     return 0;
 }
+
+// ---------------------------------------------------------------- stage bookkeeping of the DIFFERENTIABLE step
+// With constant coefficients a stage of the low-storage RK / Crank-Nicolson schedule is linear in (f, h_prev, b):
+//     h = fa f + beta h_prev ,    u = (b + gdt h + mu L b) / (1 - mud L)            (L: the real (n, m) linear term)
+// -- written exactly as the fused forward kernels write it (k_cols, MODE_C), so a differentiable trajectory reproduces the
+// plain one to round-off.  autograd.py ran this as ~10 element-wise tensor launches forward and ~20 backward per stage; these
+// two kernels are the stage and its vector-Jacobian product in one launch each:
+//     G = g_h + gdt r (.) g_u ,   g_f = fa G ,   g_hprev = beta G ,   g_b = (1 + mu L) r (.) g_u ,      r = 1 / (1 - mud L).
+#if TCFD_UNIT != 1
+template <typename T>
+__global__ __launch_bounds__(256) void k_stage_update(const cx<T>* __restrict__ f, const cx<T>* __restrict__ hp,
+                                                      const cx<T>* __restrict__ b, const T* __restrict__ Lt, T fa, T beta, T gdt,
+                                                      T mu, T mud, cx<T>* __restrict__ h, cx<T>* __restrict__ u, long total,
+                                                      long plane) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+        const T L = Lt[e % plane];
+        cx<T> hn = cscale(f[e], fa);
+        if (hp) hn = hn + cscale(hp[e], beta);
+        const cx<T> bv = b[e];
+        const cx<T> rhs = bv + cscale(hn, gdt) + cscale(cscale(bv, L), mu);
+        h[e] = hn;
+        u[e] = cscale(rhs, fast_rcp((T)1 - mud * L));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_stage_update_vjp(const cx<T>* __restrict__ gu, const cx<T>* __restrict__ gh,
+                                                          const T* __restrict__ Lt, T fa, T beta, T gdt, T mu, T mud,
+                                                          cx<T>* __restrict__ gf, cx<T>* __restrict__ ghp,
+                                                          cx<T>* __restrict__ gb, long total, long plane) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+        const T L = Lt[e % plane];
+        const cx<T> g = cscale(gu[e], fast_rcp((T)1 - mud * L));     // r (.) g_u
+        cx<T> G = cscale(g, gdt);
+        if (gh) G = G + gh[e];
+        gf[e] = cscale(G, fa);
+        if (ghp) ghp[e] = cscale(G, beta);
+        gb[e] = g + cscale(cscale(g, L), mu);
+    }
+}
+template <typename T>
+static int stage_update_impl(const void* f, const void* hp, const void* b, const void* Lt, const double* c, void* h, void* u,
+                             long batch, long plane, hipStream_t st) {
+    const long total = batch * plane;
+    const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(k_stage_update<T>, dim3(blocks), dim3(256), 0, st, (const cx<T>*)f, (const cx<T>*)hp, (const cx<T>*)b,
+                       (const T*)Lt, (T)c[0], (T)c[1], (T)c[2], (T)c[3], (T)c[4], (cx<T>*)h, (cx<T>*)u, total, plane);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <typename T>
+static int stage_update_vjp_impl(const void* gu, const void* gh, const void* Lt, const double* c, void* gf, void* ghp, void* gb,
+                                 long batch, long plane, hipStream_t st) {
+    const long total = batch * plane;
+    const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(k_stage_update_vjp<T>, dim3(blocks), dim3(256), 0, st, (const cx<T>*)gu, (const cx<T>*)gh, (const T*)Lt,
+                       (T)c[0], (T)c[1], (T)c[2], (T)c[3], (T)c[4], (cx<T>*)gf, (cx<T>*)ghp, (cx<T>*)gb, total, plane);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+#endif
+// coef = {fa, beta, gdt, mu, mud}
+TCFD_API int tcfd_ns2d_stage_update(const void* f, const void* h_prev, const void* b, const void* lin, const double* coef,
+                                    void* h, void* u, long batch, long plane, int dtype, void* stream) {
+#if TCFD_UNIT != 1
+    if (!f || !b || !lin || !coef || !h || !u || batch <= 0 || plane <= 0) return fail(TCFD_EINVAL, "stage_update: bad argument");
+    if (dtype == TCFD_C128) return stage_update_impl<double>(f, h_prev, b, lin, coef, h, u, batch, plane, (hipStream_t)stream);
+    if (dtype == TCFD_C64) return stage_update_impl<float>(f, h_prev, b, lin, coef, h, u, batch, plane, (hipStream_t)stream);
+    return fail(TCFD_EINVAL, "stage_update: bad dtype %d", dtype);
+#else
+    return 0;
+#endif
+}
+TCFD_API int tcfd_ns2d_stage_update_vjp(const void* g_u, const void* g_h, const void* lin, const double* coef, void* g_f,
+                                        void* g_hprev, void* g_b, long batch, long plane, int dtype, void* stream) {
+#if TCFD_UNIT != 1
+    if (!g_u || !lin || !coef || !g_f || !g_b || batch <= 0 || plane <= 0) return fail(TCFD_EINVAL, "stage_update_vjp: bad argument");
+    if (dtype == TCFD_C128)
+        return stage_update_vjp_impl<double>(g_u, g_h, lin, coef, g_f, g_hprev, g_b, batch, plane, (hipStream_t)stream);
+    if (dtype == TCFD_C64)
+        return stage_update_vjp_impl<float>(g_u, g_h, lin, coef, g_f, g_hprev, g_b, batch, plane, (hipStream_t)stream);
+    return fail(TCFD_EINVAL, "stage_update_vjp: bad dtype %d", dtype);
+#else
+    return 0;
+#endif
+}
+
+// wbar = sum_f post_f (.) X_f : the last step of the explicit terms' vector-Jacobian product (X: (4, batch, plane) half spectra
+// from tcfd_ns2d_explicit_terms_vjp, post: (4, plane) complex tables -(c / n^2) conj(a_f)).  As tensor ops this was a broadcast
+// multiply writing 4 planes per field and a reduction reading them back (0.34 ms per stage at 1024^2 x 8); one pass here.
+#if TCFD_UNIT != 1
+template <typename T>
+__global__ __launch_bounds__(256) void k_vjp_combine(const cx<T>* __restrict__ X, const cx<T>* __restrict__ post,
+                                                     cx<T>* __restrict__ out, long total, long plane) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+        const long t = e % plane;
+        cx<T> acc = mk<T>((T)0, (T)0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const cx<T> x = X[(long)f * total + e], p = post[(long)f * plane + t];
+            acc = acc + mk<T>(x.x * p.x - x.y * p.y, x.x * p.y + x.y * p.x);
+        }
+        out[e] = acc;
+    }
+}
+#endif
+TCFD_API int tcfd_ns2d_vjp_combine(const void* X, const void* post, void* out, long batch, long plane, int dtype, void* stream) {
+#if TCFD_UNIT != 1
+    if (!X || !post || !out || batch <= 0 || plane <= 0) return fail(TCFD_EINVAL, "vjp_combine: bad argument");
+    const long total = batch * plane;
+    const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 1 << 16);
+    if (dtype == TCFD_C128)
+        hipLaunchKernelGGL(k_vjp_combine<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const cx<double>*)X,
+                           (const cx<double>*)post, (cx<double>*)out, total, plane);
+    else if (dtype == TCFD_C64)
+        hipLaunchKernelGGL(k_vjp_combine<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const cx<float>*)X,
+                           (const cx<float>*)post, (cx<float>*)out, total, plane);
+    else
+        return fail(TCFD_EINVAL, "vjp_combine: bad dtype %d", dtype);
+    HIP_TRY(hipGetLastError());
+    return 0;
+#else
+    return 0;
+#endif
+}

@@ -23,6 +23,7 @@ as device tensor ops around the HIP transforms and their hand-written adjoints.
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import Callable, Dict, Optional, Tuple, Union
 
@@ -550,7 +551,13 @@ class NavierStokes2DSpectral(ImplicitExplicitODE):
         lead = w.shape
         w = w.reshape(-1, plan.n, plan.m)
         forcing = self._forcing_on(w)
-        if isinstance(stepper, RK4CrankNicolsonStepper):
+        constant = not any(torch.is_tensor(v) and v.requires_grad for v in params.values())
+        if (constant and ad._fused_vjp_ok(plan) and _is_module_stepper(stepper) and os.environ.get("TCFD_FUSED_STAGE", "1") != "0"
+                and w.is_cuda):
+            # only the STATE asks for gradients: the schedule is plain numbers (rounded as the fused forward kernels round
+            # them), every stage is two fused nodes -- F(w) with its VJP and the stage update with its VJP
+            out = ad.fused_scheduled_steps(self, plan, w, steps, stepper.stage_schedule(params, dt), forcing)
+        elif isinstance(stepper, RK4CrankNicolsonStepper):
             out = ad.rk_crank_nicolson_steps(self, plan, w, dt, steps, params, forcing)
         else:   # alpha / beta stay tensors: a trainable IMEX scheme gets its gradients (as the reference's 0-dim arithmetic gives)
             sched = stepper.stage_schedule(params, dt, as_tensors=True)
