@@ -274,7 +274,12 @@ def sfno_config5(dev):
                                     "algo_bytes_per_launch": 5 * A_H, "avg_launch_ms": round(t_bwd, 4),
                                     "achieved": round(5 * A_H / (t_bwd * 1e-3) / 1e9, 1),
                                     "frac": round(5 * A_H / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "note": "matrix-pipe bound: 105 v_mfma_f32_16x16x4_f32 per 16 points = 1.8 ms of MFMA time per launch"}}
+                                    "mfma": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+                                             # issued: 93 v_mfma_f32_16x16x4_f32 (2048 flop each) per 16 points, tile padding included
+                                             "issued_flop_per_launch": 93 * 2048 * (A_H // 40 // 16),
+                                             "achieved": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12, 1),
+                                             "frac": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12 / 157.3, 4)},
+                                    "note": "matrix-pipe bound: 93 v_mfma_f32_16x16x4_f32 per 16 points (105 before the tile row map) = 1.6 ms of MFMA time per launch; peak = dense fp32 matrix rate, 256 flop/clk/CU x 256 CUs x 2.4 GHz"}}
     except Exception as e:
         roof = {"error": repr(e)}
     return {"roofline": roof, "workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",

@@ -138,8 +138,9 @@ def test_contraction_mfma_equals_valu_and_oracle(dev):
     assert a64.dtype == torch.complex128 and rel_l2(c64, ref64) < 1e-14 and rel_l2(a64, ref64) < 1e-14
 
 
-@pytest.mark.parametrize("real,use_mfma,tol", [(torch.float32, True, 2e-6), (torch.float32, False, 2e-6), (torch.float64, True, 1e-13)])
-def test_contraction_gradients_against_the_oracle_under_autograd(real, use_mfma, tol, dev):
+@pytest.mark.parametrize("real,use_mfma,tol,complex_params", [(torch.float32, True, 2e-6, False), (torch.float32, False, 2e-6, True),
+                                                               (torch.float64, True, 1e-13, False), (torch.float64, True, 1e-13, True)])
+def test_contraction_gradients_against_the_oracle_under_autograd(real, use_mfma, tol, complex_params, dev):
     """tcfd_fno_contract_adjoint (spectrum) and tcfd_fno_contract_wgrad (weights, biases; all four corners in one launch)
     against autograd through the oracle's contraction: asymmetric channel counts, real-view parameters, delta != 1."""
     from oracle import fno as OF
@@ -161,15 +162,18 @@ def test_contraction_gradients_against_the_oracle_under_autograd(real, use_mfma,
     torch.autograd.backward(ref, cot.to(torch.complex128))
     # HIP
     vd = vh.detach().to(dev).requires_grad_(True)
-    wd = [x.to(dev).requires_grad_(True) for x in w]
-    bd = [x.to(dev).requires_grad_(True) for x in bias]
+    as_param = (lambda x: torch.view_as_complex(x.clone()).to(dev).requires_grad_(True)) if complex_params else (
+        lambda x: x.clone().to(dev).requires_grad_(True))     # SpectralConv3d keeps complex parameters, SpectralConvS real views
+    wd = [as_param(x) for x in w]
+    bd = [as_param(x) for x in bias]
     out = fno._ContractFn.apply(vd, 0.3, modes, use_mfma, True, *wd, *bd)
     assert out.dtype == cplx and rel_l2(out, ref.detach()) < tol
     torch.autograd.backward(out, cot.to(dev))
     assert rel_l2(vd.grad, vr.grad) < tol
+    real_view = (lambda t: torch.view_as_real(t)) if complex_params else (lambda t: t)
     for k in range(4):
-        assert wd[k].grad.shape == w[k].shape and rel_l2(wd[k].grad, wr[k].grad) < tol, k
-        assert bd[k].grad.shape == bias[k].shape and rel_l2(bd[k].grad, br[k].grad) < tol, k
+        assert wd[k].grad.shape == wd[k].shape and rel_l2(real_view(wd[k].grad), wr[k].grad) < tol, k
+        assert bd[k].grad.shape == bd[k].shape and rel_l2(real_view(bd[k].grad), br[k].grad) < tol, k
 
 
 def test_fused_layer_node_gives_the_gradients_of_the_separate_nodes(dev, monkeypatch):
