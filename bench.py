@@ -293,7 +293,7 @@ def other_baseline_configs(dev):
     """Secondary lines for the other single-GPU BASELINE configs on the same kernels: C2 = 256^2, B=16,
     fp32, unforced McWilliams, dt=1e-3 (1000-step job, measured over 400 steps through forward(w, dt, steps=k)); C4 per-GPU
     shard = 512^2, B=64, fp64, unforced, dt=1e-3; plus two sizes outside BASELINE: 768^2 (n = 3 * 2^k on the fused kernels)
-    and 2048^2 (one field exceeds the Infinity Cache: the call is not chunked).  value = batch steps/s."""
+    and 2048^2 (one field nearly fills the Infinity Cache: single-field chunks).  value = batch steps/s."""
     import torch_cfd_amd as tc
     from torch_cfd_amd.initial_conditions import vorticity_field
 
@@ -301,7 +301,7 @@ def other_baseline_configs(dev):
     for name, n, B, real, steps, fused in (("C2_256x16_f32", 256, 16, torch.float32, 400, True),
                                            ("C4_shard_512x64_f64", 512, 64, torch.float64, 40, False),
                                            ("n768x64_f64", 768, 64, torch.float64, 20, False),       # n = 3 * 2^k: radix-12 first pass
-                                           ("n2048x16_f64", 2048, 16, torch.float64, 6, False)):      # a field exceeds the cache: not chunked
+                                           ("n2048x16_f64", 2048, 16, torch.float64, 6, False)):      # one field per chunk
         torch.set_default_dtype(real)
         L = 2 * math.pi
         grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))

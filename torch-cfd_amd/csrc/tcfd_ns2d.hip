@@ -2535,8 +2535,7 @@ TCFD_DISPATCHED(fill_round_fields, (tcfd_ns2d_plan * p), (p), (round_fields_impl
 // Fields per chunk of a batched call.  TCFD_CHUNK > 0 forces it, 0 disables chunking, -1 (default) sizes the chunk so
 // that its working set -- 4 planes + advection + RK accumulator + padded state, 7 workspace fields per batch element --
 // fits the 256 MB Infinity Cache (measured on MI355X, steps/s per call: 1024^2 x 64 fp64 122.7 -> 129.3 at 4 fields
-// per chunk, 114.5 at 5; 512^2 x 64 fp64 408 -> 501 at 16).  Chunks are balanced, and a chunk of fewer than 3 fields
-// (2048^2: a single field already exceeds the cache) is not worth the extra launches.
+// per chunk, 114.5 at 5; 512^2 x 64 fp64 408 -> 501 at 16).  Chunks are balanced.
 static long chunk_fields(const tcfd_ns2d_plan* p, long batch) {
     long c = p->tune.chunk;
     if (c == 0) return batch;
@@ -2544,7 +2543,11 @@ static long chunk_fields(const tcfd_ns2d_plan* p, long batch) {
         const size_t per_field = 7 * (size_t)p->n * p->ldw * (p->dtype == TCFD_C128 ? 16 : 8);
         // 61/64 of the cache (244 of 256 MB, the measured optimum on MI355X: 4 fields of 1024^2 fp64 = 239 MB fit, 5 do not)
         c = (long)((p->tune.cache_bytes / 64 * 61) / per_field);
-        if (c < 3) return batch;
+        // fewer than 3 fields per chunk: only at 2048^2, where ONE field is a whole round of workgroups (258 column tiles) and
+        // most of its working set (237 of 244 MB) still fits: 16 fields 12.8 -> 11.5 ms per step with single-field chunks; at
+        // 1536^2 / 1280^2 (1 - 2 fields would fit, 194 / 162 workgroups per field) the whole batch at once is faster
+        // (6.3 vs 7.9 ms, 9.3 vs 13.0 ms: tests/micro/n2048_chunk.py)
+        if (c < 3) return (c >= 1 && p->n >= 2048) ? 1 : batch;
         if (p->tune.round_fields > 0 && c > p->tune.round_fields) c = c / p->tune.round_fields * p->tune.round_fields;   // whole rounds
     }
     if (c >= batch) return batch;
