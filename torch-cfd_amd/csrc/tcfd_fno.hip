@@ -1176,7 +1176,9 @@ template <int CI, int CM, int CO, bool HAS_L1>
 static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
     // packed pairs need 8-byte aligned rows: even P (every channel row starts on a pair), even T for the
     // broadcast skip, 8-byte aligned base pointers
-    // (width 32 keeps one point per lane: two need > 128 VGPRs and lose more in occupancy than they gain; 20: +5 %)
+    // (width 32 keeps one point per lane: two need > 128 VGPRs and lose more in occupancy than they gain; 20: +5 %.
+    //  FOUR points per lane -- 16-byte loads / stores, two packed FMAs per weight -- at width 10: SFNO forward 5.41 -> 5.51 ms,
+    //  measured late in round 3 and not kept)
     const bool pairs = (CI <= env_int("TCFD_PW_PAIR_MAXC", 20)) && (a.P % 2 == 0) && (a.skip_mode != 2 || a.T % 2 == 0) &&
                        (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.pe | (uintptr_t)(a.skip_mode == 1 ? a.s : nullptr)) % 8 == 0);
     if constexpr (CI <= 20) {      // (the packed form is not even compiled for wider layers)
