@@ -267,6 +267,51 @@ def test_layer_template_in_other_dimensions(dim, dev):
         fno.SpectralConv(2, 2, [3, 3], dim=2).to(dev)(torch.randn(1, 2, 8, 8, device=dev))
 
 
+@pytest.mark.parametrize("act,bias,frozen", [("GELU", True, False), ("ReLU", False, True), ("SiLU", True, True)])
+def test_fused_layer_node_with_bias_other_activations_and_frozen_parameters(act, bias, frozen, dev):
+    """hip_spectral_layer on ONE layer (width 10, expansion 4) against the composition conv -> hip_pointwise (separate autograd
+    nodes): spectral bias blocks, GELU / SiLU, and a mix of frozen parameters (their gradients must stay None, the others'
+    must not change)."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(7)
+    conv = fno.SpectralConvS(10, 10, 6, 6, 4, bias=bias, delta=0.7).to(dev)
+    mlp = fno.PointwiseFFN(10, 10, 40, act).to(dev)
+    w = torch.nn.Conv3d(10, 10, 1).to(dev)
+    a2 = getattr(torch.nn, act)()
+    if bias:
+        for p_ in conv.bias:
+            p_.data.normal_()
+    if frozen:
+        conv.weight[1].requires_grad_(False)
+        mlp.linear1.bias.requires_grad_(False)
+        w.weight.requires_grad_(False)
+    x = torch.randn(2, 10, 32, 32, 8, device=dev)
+    cot = torch.randn(2, 10, 32, 32, 8, device=dev)
+    params = [p_ for m in (conv, mlp, w) for p_ in m.parameters()]
+
+    def run(fused):
+        for p_ in params:
+            p_.grad = None
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            out = fno.hip_spectral_layer(conv, xi, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=a2)
+            assert out is not None and type(out.grad_fn).__name__ == "_SpectralLayerFnBackward"
+        else:
+            out = fno.hip_pointwise(conv(xi), mlp.linear1, mlp.activation, mlp.linear2, skip=xi, skip_conv=w, act2=a2)
+            assert out is not None and type(out.grad_fn).__name__ == "_PointwiseFnBackward"
+        out.backward(cot)
+        return out.detach(), xi.grad, [None if p_.grad is None else p_.grad.clone() for p_ in params]
+
+    o1, gx1, g1 = run(True)
+    o0, gx0, g0 = run(False)
+    assert torch.equal(o1, o0) and rel_l2(gx1, gx0) < 1e-6
+    for p_, a, b in zip(params, g1, g0):
+        assert (a is None) == (b is None) == (not p_.requires_grad)
+        if a is not None:
+            assert rel_l2(a, b) < 1e-5
+
+
 def test_linearity_and_zero_input(dev):
     from torch_cfd_amd import fno
 
