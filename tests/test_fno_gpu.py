@@ -312,6 +312,33 @@ def test_fused_layer_node_with_bias_other_activations_and_frozen_parameters(act,
             assert rel_l2(a, b) < 1e-5
 
 
+def test_lifting_projection_in_training_matches_the_materialised_form(dev, monkeypatch):
+    """hip_lift_project under autograd (``_LiftProjectFn``: v + positional encoding never formed in the forward, moments
+    reused in the backward) against the path that materialises it (TCFD_LIFT_PROJECT_GRAD=0): output and the gradients of the
+    LayerNorm / projection parameters of a lifting operator."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(5)
+    model = fno.SFNO(8, 8, 4, width=10, num_spectral_layers=2).to(dev).train()
+    x = torch.randn(3, 32, 32, 10, device=dev)
+    y = torch.randn(3, 32, 32, 10, device=dev)
+
+    def grads(flag):
+        monkeypatch.setenv("TCFD_LIFT_PROJECT_GRAD", flag)
+        model.zero_grad(set_to_none=True)
+        out = model(x)
+        ((out - y) ** 2).mean().backward()
+        return out.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    o1, g1 = grads("1")
+    o0, g0 = grads("0")
+    assert rel_l2(o1, o0) < 1e-6 and set(g1) == set(g0)
+    names = [n for n in g0 if "lifting" in n or "lift" in n]
+    assert any("norm" in n for n in names) and any("proj" in n for n in names), sorted(g0)
+    for n in g0:
+        assert rel_l2(g1[n], g0[n]) < 2e-5, n
+
+
 def test_linearity_and_zero_input(dev):
     from torch_cfd_amd import fno
 

@@ -632,7 +632,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     return (dx.view_as(x) if dx is not None else None, g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
 
 
-def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = True):
+def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = True, moments=None):
     """Backward of ``proj(LayerNorm(x))`` (one group over (C, X, Y, T), per-channel affine) in two passes over the data.
 
     Pass 1 (``tcfd_fno_pointwise_bwd`` with per-sample partial sums, no dx): M_b[o, c] = sum_p dy[o] x[c] and
@@ -656,13 +656,14 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = 
         return None
     COP, CB, _, _, per_row, _ = list(dims)
     xs, dz = x.detach().contiguous(), dout.detach().contiguous()
-    stats = torch.empty(b, 2, dtype=torch.float64, device=dev)
+    stats = moments if moments is not None else torch.empty(b, 2, dtype=torch.float64, device=dev)   # (sum, sum of squares) per sample
     W = w.detach().reshape(co, C)
     w2t = W.t().contiguous()
     max_waves = 2048 + b
     partials = torch.empty(max_waves, per_row, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.tcfd_row_moments(xs.data_ptr(), stats.data_ptr(), b, L, stream), "tcfd_row_moments")
+        if moments is None:
+            _lib.check(lib.tcfd_row_moments(xs.data_ptr(), stats.data_ptr(), b, L, stream), "tcfd_row_moments")
         rc = lib.tcfd_fno_pointwise_bwd(xs.data_ptr(), None, dz.data_ptr(), None, None, None, None, w2t.data_ptr(), None, None,
                                         None, partials.data_ptr(), max_waves, dims, b, C, C, co, P, 0, 0, 0, 0, 0, 1, stream)
     _lib.check(rc, "tcfd_fno_pointwise_bwd")
@@ -1089,10 +1090,16 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
         sum = C sum(v) + sum(q),   sum of squares = C sum(v^2) + 2 sum_p v_p (sum_c q_cp) + sum(q^2),
     and the projection kernel rebuilds v + q[c] in registers (``pe`` mode of ``tcfd_fno_pointwise``): 84 MB + a 26 MB
     L2-resident table are read instead of writing and re-reading an 839 MB tensor twice (config 5).  ``consts`` are the
-    table's constants when the caller has them cached (``SpaceTimePositionalEncoding.table_constants``).  Forward only;
-    returns None when the combination is not covered."""
-    if (not v1.is_cuda or v1.dtype != torch.float32 or v1.shape[1] != 1 or not _is_pointwise(proj) or norm.num_groups != 1
-            or torch.is_grad_enabled() and (v1.requires_grad or any(p.requires_grad for m in (norm, proj) for p in m.parameters()))):
+    table's constants when the caller has them cached (``SpaceTimePositionalEncoding.table_constants``).  Training (the
+    parameters of ``norm`` / ``proj`` require grad, the input is data): the same forward behind ``_LiftProjectFn``, whose
+    backward forms ``v1 + q`` once and reuses the forward's moments.  Returns None when the combination is not covered
+    (an input that itself requires grad included)."""
+    if not v1.is_cuda or v1.dtype != torch.float32 or v1.shape[1] != 1 or not _is_pointwise(proj) or norm.num_groups != 1:
+        return None
+    training = torch.is_grad_enabled() and any(p.requires_grad for m in (norm, proj) for p in m.parameters())
+    if torch.is_grad_enabled() and (v1.requires_grad or q.requires_grad):
+        return None
+    if training and os.environ.get("TCFD_LIFT_PROJECT_GRAD", "1") == "0":
         return None
     for prm in list(norm.parameters()) + list(proj.parameters()):
         if prm.dtype != torch.float32 or prm.device != v1.device:
@@ -1135,7 +1142,42 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
     if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
         return None
     _lib.check(rc, "tcfd_fno_pointwise")
+    if training:
+        dims = (ctypes.c_int * 6)()      # layout query of the per-sample weight-gradient pass (no data)
+        if lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, None, None, None, None, None, None, None, 0, dims, b, C, C, co,
+                                      P, 0, 0, 0, 0, 0, 1, None) != 0:
+            return None
+        moments = torch.stack([s1, s2], dim=1).contiguous()                  # of the (C, X, Y, T) block of every sample
+        return _LiftProjectFn.apply(out, vf, qf, moments, float(norm.eps), tuple(v1.shape[2:]), proj.weight, proj.bias,
+                                    norm.weight, norm.bias)
     return out
+
+
+class _LiftProjectFn(torch.autograd.Function):
+    """``proj(norm(v1 + q))`` under autograd with the forward of ``hip_lift_project`` (v1 + q never formed): the backward
+    forms it once (the weight-gradient kernel reads it), takes the LayerNorm moments from the forward and skips the input
+    gradient (v1 and the table are data)."""
+
+    @staticmethod
+    def forward(ctx, out, vf, qf, moments, eps, mesh, w, bias, gamma, beta):
+        ctx.eps, ctx.mesh = eps, mesh
+        ctx.present = [t is not None for t in (w, bias, gamma, beta)]
+        ctx.save_for_backward(vf, qf, moments, *[t for t in (w, bias, gamma, beta) if t is not None])
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        vf, qf, moments, *rest = ctx.saved_tensors
+        it = iter(rest)
+        w, bias, gamma, beta = [next(it) if p else None for p in ctx.present]
+        b, C = vf.shape[0], qf.shape[0]
+        vp = (vf[:, None, :] + qf[None]).reshape(b, C, *ctx.mesh)
+        res = _hip_norm_proj_backward(ctx.eps, dout, vp, w, bias, gamma, beta, need_dx=False, moments=moments)
+        if res is None:
+            raise _lib.TcfdError("LayerNorm-projection backward kernel not available for a block admitted to the fused path")
+        need = ctx.needs_input_grad[6:]
+        g_w, g_b, g_gamma, g_beta = res[4], res[5], res[8], res[9]
+        return (None, None, None, None, None, None, *[g if n else None for g, n in zip((g_w, g_b, g_gamma, g_beta), need)])
 
 
 # ----------------------------------------------------------------------------- spectral convolutions
