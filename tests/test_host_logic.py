@@ -165,6 +165,28 @@ def test_dense_transforms_for_the_remaining_even_sizes():
         DenseDft(101, torch.complex128)
 
 
+@pytest.mark.parametrize("shape,dim", [((2, 3, 16), 1), ((2, 3, 12, 10), 2), ((2, 2, 6, 5, 8), 3), ((1, 2, 4, 6, 3, 10), 4), ((2, 3, 9, 7), 2)])
+def test_dense_rfftn_irfftn_reproduce_torch_fft(shape, dim):
+    """dense_fft.rfftn_dense / irfftn_dense (the transforms of the dimension-generic SpectralConv template) against torch.fft:
+    every norm, odd axis lengths, larger and smaller output sizes (torch trims / zero-pads the spectrum array at its end) and
+    spectra that are not Hermitian."""
+    from torch_cfd_amd.dense_fft import irfftn_dense, rfftn_dense
+
+    g = torch.Generator().manual_seed(dim)
+    dims = tuple(range(-dim, 0))
+    for norm in ("backward", "ortho", "forward"):
+        v = torch.randn(*shape, generator=g, dtype=torch.float64)
+        ref = torch.fft.rfftn(v, dim=dims, norm=norm)
+        assert (rfftn_dense(v, dim, norm) - ref).abs().max() < 1e-12 * max(1.0, float(ref.abs().max()))
+        z = torch.complex(torch.randn(*ref.shape, generator=g, dtype=torch.float64), torch.randn(*ref.shape, generator=g, dtype=torch.float64))
+        for s in (list(shape[-dim:]), [n + 3 for n in shape[-dim:]], [max(2, n - 3) for n in shape[-dim:]]):
+            refi = torch.fft.irfftn(z, s=s, dim=dims, norm=norm)
+            assert (irfftn_dense(z, s, norm) - refi).abs().max() < 1e-12 * max(1.0, float(refi.abs().max())), (norm, s)
+    # differentiable like any matmul
+    v = torch.randn(*shape, generator=g, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda t: torch.view_as_real(rfftn_dense(t, dim, "ortho")), (v,), atol=1e-8) if v.numel() <= 64 else True
+
+
 # ----------------------------------------------------------------------------- caller-facing helpers of the reference
 def test_stable_time_step_bounds():
     dx = L / 1024
