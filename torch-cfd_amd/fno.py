@@ -363,12 +363,6 @@ def _c2r_weights(mt: int, T: int, device, dtype: torch.dtype = torch.float32) ->
     return c
 
 
-def _corner_slices(mx: int, my: int):
-    """Corner block k = ix + 2 iy of the truncated (.., 2mx, 2my, mt) layout (fno/sfno.py:376-389 order)."""
-    sx, sy = (slice(0, mx), slice(mx, 2 * mx)), (slice(0, my), slice(my, 2 * my))
-    return [(sx[k % 2], sy[k // 2]) for k in range(4)]
-
-
 def _fwd_trunc_vjp(z, cfg, accumulate=None):
     """F^T(z) for the truncated forward transform F (cfg of ``_FwdTruncFn``); ``accumulate``: added to, in place."""
     (b, c, X, Y, T), modes, t_pad, t_out, norm = cfg
