@@ -308,6 +308,11 @@ int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, vo
                            const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
                            void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
                            int skip_T, int act1, int act2, int skip_mode, int per_sample, void* stream);
+/* The single-layer form (w1 NULL, no skip, no activations) whose input is x1 (batch, 1, P) + pe (ci, P) -- the `pe` mode of
+ * tcfd_fno_pointwise -- so the weight gradients of the lifting operator's projection need no materialised (batch, ci, P) input. */
+int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const void* dout, void* dx, const void* w2t, const void* b2,
+                              void* partials, int max_waves, int* dims, int batch, int ci, int co, long P, int per_sample,
+                              void* stream);
 /* per_sample = 1: the rows written (dims[5], a multiple of batch) are per-SAMPLE partial sums, row r belongs to batch
  * element r % batch -- what the backward of a LayerNorm folded into the convolution needs (its statistics differ per
  * sample); dx may then be NULL (only the sums are wanted). */

@@ -1452,6 +1452,8 @@ extern "C" int tcfd_fno_pointwise_f64(const void* x, const void* skip, void* out
 // (28 registers at width 10) live across the wave's whole grid-stride loop; every wave writes its partial sums
 // once, the caller adds the partials (deterministic, no atomics).
 struct PwBwdArgs {
+    const float* pe;     // (CI, P) or null.  Not null (k_pointwise_bwd only): x is ONE channel (b, 1, P) and the block input is
+                         // x + pe[c] -- the lifting operator's input + positional encoding, never materialised
     const float* x;      // (b, CI, P)
     const float* s;      // (b, CI, P) skip input (skip_mode 1) or null
     const float* dout;   // (b, CO, P)
@@ -1557,10 +1559,16 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
         const bool live = p < a.P;
         const long pc = live ? p : a.P - 1;
         float x[CI], g2[CO], z2[CO], dx[CI];
-        const float* xb = a.x + (size_t)b * CI * a.P + pc;
         const float* db = a.dout + (size_t)b * CO * a.P + pc;
+        if (a.pe) {
+            const float v1 = a.x[(size_t)b * a.P + pc];
 #pragma unroll
-        for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+            for (int i = 0; i < CI; ++i) x[i] = v1 + a.pe[(size_t)i * a.P + pc];
+        } else {
+            const float* xb = a.x + (size_t)b * CI * a.P + pc;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) x[i] = xb[(size_t)i * a.P];
+        }
 #pragma unroll
         for (int c = 0; c < CO; ++c) g2[c] = live ? db[(size_t)c * a.P] : 0.f;
 #pragma unroll
@@ -2400,11 +2408,33 @@ static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipSt
 //   A (COP x CB):  A[o][0:ch] = dW2[o][.] (ch = cm, single layer: ci),  A[o][ch] = db2[o] (= dbs),  A[o][ch+1 : ch+1+ci] = dWs[o][.]
 //   B (CM1 x CIP): B[m][0:ci] = dW1[m][.],  B[m][ci] = db1[m]            (two-layer form only)
 // The caller sums the rows.  Passing x == NULL only fills dims (layout query).
+static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, const void* dout, void* dx, void* dskip,
+                              const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
+                              const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
+                              int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
+                              int per_sample, void* stream);
 extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, void* dx, void* dskip,
                                       const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
                                       const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
                                       int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
                                       int per_sample, void* stream) {
+    return pointwise_bwd_impl(nullptr, x, skip, dout, dx, dskip, w1, b1, w2t, b2, wst, bs, partials, max_waves, dims, batch, ci, cm,
+                              co, P, T, skip_T, act1, act2, skip_mode, per_sample, stream);
+}
+// The single-layer form whose input is x1 (batch, 1, P) + pe (ci, P) (the `pe` mode of tcfd_fno_pointwise): weight-gradient
+// partial sums (and dx, if asked for) without the (batch, ci, P) input ever being materialised.
+extern "C" int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const void* dout, void* dx, const void* w2t,
+                                         const void* b2, void* partials, int max_waves, int* dims, int batch, int ci, int co,
+                                         long P, int per_sample, void* stream) {
+    if (x1 && !pe) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd_pe: null table");
+    return pointwise_bwd_impl(pe, x1, nullptr, dout, dx, nullptr, nullptr, nullptr, w2t, b2, nullptr, nullptr, partials, max_waves,
+                              dims, batch, ci, ci, co, P, 0, 0, 0, 0, 0, per_sample, stream);
+}
+static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, const void* dout, void* dx, void* dskip,
+                              const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
+                              const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
+                              int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
+                              int per_sample, void* stream) {
     if (!dims) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: null dims");
     if (x && (!dout || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
         return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad argument");
@@ -2412,6 +2442,7 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
     if (x && skip_mode == 1 && (!skip || !wst)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip input missing");
     if (x && skip_mode == 2 && (!skip || T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad T");
     PwBwdArgs a;
+    a.pe = (const float*)pe;
     a.x = (const float*)x; a.s = (const float*)skip; a.dout = (const float*)dout; a.dx = (float*)dx; a.ds = (float*)dskip;
     a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
     a.wst = (const float*)wst; a.bs = (const float*)bs; a.partials = (float*)partials;

@@ -626,7 +626,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     return (dx.view_as(x) if dx is not None else None, g_skip, g_w1, g_b1, g_w2, g_b2, g_ws, g_bs, None, None)
 
 
-def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = True, moments=None):
+def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = True, moments=None, table=None):
     """Backward of ``proj(LayerNorm(x))`` (one group over (C, X, Y, T), per-channel affine) in two passes over the data.
 
     Pass 1 (``tcfd_fno_pointwise_bwd`` with per-sample partial sums, no dx): M_b[o, c] = sum_p dy[o] x[c] and
@@ -637,13 +637,18 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = 
         A_b = sum_{c,p} gamma_c g,   B_b = sum_{c,p} gamma_c g x^.
     Pass 2: dx = r (gamma g - A/L - x^ B/L) = (per-sample 1x1x1 convolution of dy) + alpha_b + kappa_b x  -- the
     convolution on ``tcfd_fno_pointwise`` with per-sample weights, the rank-one correction as one fused multiply-add."""
-    b, C = x.shape[:2]
+    # ``table`` (C, P): x is the ONE-channel input (b, P) and the block input is x + table[c] (the lifting operator): the
+    # weight-gradient pass reads them through the kernel's ``pe`` mode; needs ``moments`` and ``need_dx=False``
+    b = x.shape[0]
+    C = table.shape[0] if table is not None else x.shape[1]
     co = w.shape[0]
-    P = x[0, 0].numel()
+    P = table.shape[1] if table is not None else x[0, 0].numel()
     L = C * P
     dev = x.device
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if table is not None and (moments is None or need_dx):
+        raise ValueError("the table form needs the forward's moments and does not produce an input gradient")
     dims = (ctypes.c_int * 6)()
     if lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, None, None, None, None, None, None, None, 0, dims, b, C, C, co,
                                   P, 0, 0, 0, 0, 0, 1, None) != 0:
@@ -658,8 +663,12 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = 
     with torch.cuda.device(dev):
         if moments is None:
             _lib.check(lib.tcfd_row_moments(xs.data_ptr(), stats.data_ptr(), b, L, stream), "tcfd_row_moments")
-        rc = lib.tcfd_fno_pointwise_bwd(xs.data_ptr(), None, dz.data_ptr(), None, None, None, None, w2t.data_ptr(), None, None,
-                                        None, partials.data_ptr(), max_waves, dims, b, C, C, co, P, 0, 0, 0, 0, 0, 1, stream)
+        if table is not None:
+            rc = lib.tcfd_fno_pointwise_bwd_pe(xs.data_ptr(), table.data_ptr(), dz.data_ptr(), None, w2t.data_ptr(), None,
+                                               partials.data_ptr(), max_waves, dims, b, C, co, P, 1, stream)
+        else:
+            rc = lib.tcfd_fno_pointwise_bwd(xs.data_ptr(), None, dz.data_ptr(), None, None, None, None, w2t.data_ptr(), None, None,
+                                            None, partials.data_ptr(), max_waves, dims, b, C, C, co, P, 0, 0, 0, 0, 0, 1, stream)
     _lib.check(rc, "tcfd_fno_pointwise_bwd")
     rows = dims[5]
     M = _sum_rows(partials, rows // b, b * per_row).view(b, per_row)[:, : COP * CB].view(b, COP, CB)
@@ -1148,9 +1157,9 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
 
 
 class _LiftProjectFn(torch.autograd.Function):
-    """``proj(norm(v1 + q))`` under autograd with the forward of ``hip_lift_project`` (v1 + q never formed): the backward
-    forms it once (the weight-gradient kernel reads it), takes the LayerNorm moments from the forward and skips the input
-    gradient (v1 and the table are data)."""
+    """``proj(norm(v1 + q))`` under autograd with the forward of ``hip_lift_project``: v1 + q is never formed, neither in the
+    forward nor in the backward (the weight-gradient kernel rebuilds it in registers, ``tcfd_fno_pointwise_bwd_pe``); the
+    LayerNorm moments come from the forward and the input gradient is skipped (v1 and the table are data)."""
 
     @staticmethod
     def forward(ctx, out, vf, qf, moments, eps, mesh, w, bias, gamma, beta):
@@ -1164,9 +1173,7 @@ class _LiftProjectFn(torch.autograd.Function):
         vf, qf, moments, *rest = ctx.saved_tensors
         it = iter(rest)
         w, bias, gamma, beta = [next(it) if p else None for p in ctx.present]
-        b, C = vf.shape[0], qf.shape[0]
-        vp = (vf[:, None, :] + qf[None]).reshape(b, C, *ctx.mesh)
-        res = _hip_norm_proj_backward(ctx.eps, dout, vp, w, bias, gamma, beta, need_dx=False, moments=moments)
+        res = _hip_norm_proj_backward(ctx.eps, dout, vf, w, bias, gamma, beta, need_dx=False, moments=moments, table=qf)
         if res is None:
             raise _lib.TcfdError("LayerNorm-projection backward kernel not available for a block admitted to the fused path")
         need = ctx.needs_input_grad[6:]
