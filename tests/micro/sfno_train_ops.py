@@ -22,14 +22,15 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=rows, max_name_column_width=60))
 
+THR = float(os.environ.get("THR", 100))
 if os.environ.get("BIG", "0") == "1":
     # every operator call with more than 100 us of device time, with its shapes and the chain of enclosing operators
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         step(); torch.cuda.synchronize()
     for ev in prof.events():
-        if ev.device_time_total > 100 and ev.cpu_parent is not None or (ev.device_time_total > 100 and ev.name.startswith("aten::")):
+        if ev.device_time_total > THR and ev.cpu_parent is not None or (ev.device_time_total > THR and ev.name.startswith("aten::")):
             chain, p = [], ev.cpu_parent
             while p is not None:
                 chain.append(p.name[:40]); p = p.cpu_parent
-            if ev.self_device_time_total > 100:
+            if ev.self_device_time_total > THR:
                 print(f"{ev.name[:40]:40s} {ev.self_device_time_total:8.0f} us  {str(ev.input_shapes)[:90]:90s} <- {' <- '.join(chain[:4])}")
