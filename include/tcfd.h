@@ -313,6 +313,12 @@ int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, vo
 int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const void* dout, void* dx, const void* w2t, const void* b2,
                               void* partials, int max_waves, int* dims, int batch, int ci, int co, long P, int per_sample,
                               void* stream);
+/* Per-sample sums of outer products over the points, on MFMA: partials (waves_per_sample, batch, 16 x 16) with, after adding
+ * the waves (tcfd_sum_rows), tile[o][c] = sum_p dy[b][o][p] xin[b][c][p] for c < C and tile[o][C] = sum_p dy[b][o][p]; xin = x
+ * (batch, C, P), or x (batch, P) + pe (C, P) when pe is given.  What the backward of proj(LayerNormnd(xin)) (fno/sfno.py:252-254,
+ * fno/base.py:61-83) needs from the data.  C <= 15, co <= 16, P % 16 == 0, waves_per_sample a multiple of 4. */
+int tcfd_fno_sample_outer_sums(const void* dy, const void* x, const void* pe, void* partials, int batch, int c, int co, long P,
+                               int waves_per_sample, void* stream);
 /* per_sample = 1: the rows written (dims[5], a multiple of batch) are per-SAMPLE partial sums, row r belongs to batch
  * element r % batch -- what the backward of a LayerNorm folded into the convolution needs (its statistics differ per
  * sample); dx may then be NULL (only the sums are wanted). */

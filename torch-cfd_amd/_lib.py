@@ -151,6 +151,7 @@ SIGNATURES = {
     "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_fno_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "tcfd_fno_sample_outer_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _i, _vp]),
     "tcfd_fno_pointwise_bwd_pe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i), _i, _i, _i, _l, _i, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),

@@ -2648,3 +2648,48 @@ extern "C" int tcfd_sum_t_into_last(const void* d, void* g, long rows, int T, in
     HIP_TRY(hipGetLastError());
     return 0;
 }
+
+// M_b[o][c] = sum_p dy[b][o][p] xin[b][c][p]  for c < C,  M_b[o][C] = sum_p dy[b][o][p]      (per sample b)
+// -- everything the backward of proj(LayerNorm(xin)) needs from the data (fno.py::_hip_norm_proj_backward), with
+// xin = x (b, C, P) or x1 (b, P) + pe (C, P).  One wave takes 16 points at a time: lane (q, c) loads the 16-byte run
+// dy[c][4q .. 4q+3] and xin[c][4q .. 4q+3]; register r of the two runs IS the A resp. B fragment of the k-step over the points
+// {4q + r}, so the 16 x 16 tile of sums grows by four v_mfma_f32_16x16x4_f32 per group and nothing else: the kernel runs at
+// the rate its two loads arrive (the LDS-staged k_pointwise_bwd<10,10,10,false> spent 0.59 ms on the same sums at config 5).
+// partials: (waves_per_sample, batch, 256) floats, row-major 16 x 16 tiles [o][c]; added up by tcfd_sum_rows.
+__global__ __launch_bounds__(256) void k_sample_outer_mfma(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ pe, float* __restrict__ partials, long P,
+                                                           int C, int CO, int waves_per_sample, int batch) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const long groups = P / 16;
+    const float* dyr = dy + ((size_t)b * CO + (c < CO ? c : 0)) * P + 4 * q;
+    const float* xr = pe ? x + (size_t)b * P + 4 * q : x + ((size_t)b * C + (c < C ? c : 0)) * P + 4 * q;
+    const float* per = pe ? pe + (size_t)(c < C ? c : 0) * P + 4 * q : nullptr;
+    const float ones = c == C ? 1.f : 0.f;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (long g = w; g < groups; g += waves_per_sample) {
+        f4 a = *reinterpret_cast<const f4*>(dyr + g * 16);
+        f4 v = *reinterpret_cast<const f4*>(xr + g * 16);
+        if (per) v += *reinterpret_cast<const f4*>(per + g * 16);
+        if (c >= CO) a = f4{0.f, 0.f, 0.f, 0.f};
+        if (c >= C) v = f4{ones, ones, ones, ones};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], v[r], acc, 0, 0, 0);
+    }
+    float* out = partials + ((size_t)w * batch + b) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * q + r) * 16 + c] = acc[r];
+}
+extern "C" int tcfd_fno_sample_outer_sums(const void* dy, const void* x, const void* pe, void* partials, int batch, int c, int co,
+                                          long P, int waves_per_sample, void* stream) {
+    if (!dy || !x || !partials || batch <= 0 || c < 1 || c > 15 || co < 1 || co > 16 || P <= 0 || P % 16 != 0 ||
+        waves_per_sample < 4 || waves_per_sample % 4 != 0)
+        return FAIL(TCFD_EINVAL, "fno_sample_outer_sums: bad argument (needs c <= 15, co <= 16, P %% 16 == 0, whole workgroups)");
+    hipLaunchKernelGGL(k_sample_outer_mfma, dim3((unsigned)(waves_per_sample / 4), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)dy, (const float*)x, (const float*)pe, (float*)partials, P, c, co,
+                       waves_per_sample, batch);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
