@@ -21,6 +21,37 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     for (int j = 0; j < 8; ++j) s += v[j];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// the same with v_mfma_f32_16x16x16_bf16 (the matrix engine proper: 4 passes for 4 x the K of the fp32 instruction)
+typedef short s4 __attribute__((ext_vector_type(4)));
+template <int M, int V>
+__global__ __launch_bounds__(256) void kb(float* out, int iters) {
+    f4 acc[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    const s4 av = s4{(short)0x3f80, (short)0x3f00, (short)0x3e80, (short)0x3f80}, bv = s4{(short)0x3f80, (short)0x3f80, (short)0x3f00, (short)0x3e80};
+    float v[8] = {a, b, a + 1, b + 1, a + 2, b + 2, a + 3, b + 3};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[m & 3], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j & 7] = __builtin_fmaf(v[j & 7], 1.0001f, 0.5f);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0;
+    for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+    for (int j = 0; j < 8; ++j) s += v[j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int M, int V>
+static void runb(int wgs_per_cu, float* d) {
+    const int iters = 20000, blocks = 256 * wgs_per_cu;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kb<M, V>), dim3(blocks), dim3(256), 0, 0, d, 100);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kb<M, V>), dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("bf16 16x16x16: M=%d V=%2d waves/SIMD=%d : %8.3f ms  -> %6.1f ns per iteration\n", M, V, wgs_per_cu, ms, ms * 1e6 / iters);
+}
 template <int M, int V>
 static void run(int wgs_per_cu, float* d) {
     const int iters = 20000, blocks = 256 * wgs_per_cu;
@@ -38,6 +69,9 @@ int main() {
     float* d; hipMalloc(&d, 256 * 8 * 256 * sizeof(float));
     for (int w = 1; w <= 2; ++w) {
         run<4, 0>(w, d); run<4, 8>(w, d); run<4, 16>(w, d); run<4, 32>(w, d); run<0, 32>(w, d);
+    }
+    for (int w = 1; w <= 2; ++w) {
+        runb<4, 0>(w, d); runb<4, 8>(w, d); runb<4, 16>(w, d); runb<4, 32>(w, d);
     }
     return 0;
 }
