@@ -2064,7 +2064,16 @@ __device__ __forceinline__ int pw_hid_row(int t, int rho) {      // hidden chann
     return i < 0 ? -1 : 16 * t + i;
 }
 
-template <int CI, int CM, int CO, int MODE>
+// ACT = 1: both activations are ReLU, known at compile time.  Vector instructions do not hide behind the matrix instructions
+// on this part (profiles/r03_mfma_f32_vs_valu_overlap.txt), so every one of them counts: the generic path spends 5 per
+// hidden element (compare, two v_max -- hipcc canonicalises the operand of the select first --, the 0 / 1 derivative, and the
+// product with it later); here h = v_max_i32(0, z) is ONE instruction and the derivative is never formed -- z itself is kept and
+// the cotangent passes through a compare + select: 3 per element, 56 + 28 instructions less per group of 16 points.
+__device__ __forceinline__ float pw_relu(float z) {      // max(0, z) on the bit pattern: positive floats are positive integers
+    const int zi = __float_as_int(z);                     // (an inline-asm v_max_f32 is invisible to hipcc's MFMA hazard handling:
+    return __int_as_float(zi > 0 ? zi : 0);               //  it read the accumulators before they were written)
+}
+template <int CI, int CM, int CO, int MODE, int ACT = -1>
 __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     constexpr int KI = (CI + 1 + 3) / 4;        // k-steps over [x ; 1]
@@ -2226,7 +2235,16 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             for (int t = 0; t < TM; ++t)
 #pragma unroll
                 for (int j = 0; j < KI; ++j) zT[t] = PW_MFMA(cur.xa[j], W1a[t][j], zT[t]);
-            pw_act_tiles<TM>(z, h, d1, a.act1);
+            if constexpr (ACT == 1) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    d1[t] = z[t];                                       // the pre-activation stands in for the derivative
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[t][r] = pw_relu(z[t][r]);
+                }
+            } else {
+                pw_act_tiles<TM>(z, h, d1, a.act1);
+            }
             // ---- O1: z2 = [Ws | b] [s ; 1] + W2 h  (the skip part first: it does not wait for the activation)
             f4 z2 = f4{cur.sl[0], cur.sl[1], cur.sl[2], cur.sl[3]};
             if constexpr (MODE == 1) {
@@ -2239,11 +2257,25 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             for (int t = 0; t < TM; ++t)
 #pragma unroll
                 for (int r = 0; r < pw_tile_steps(CM, t); ++r) z2 = PW_MFMA(W2a[t][r], h[t][r], z2);
-            pw_act_tiles<TM>(zT, hT, dT, a.act1);                      // under the z2 chain
-            f4 zz[1] = {z2}, hh[1], dd[1];
-            pw_act_tiles<1>(zz, hh, dd, a.act2);
+            if constexpr (ACT == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z2[r] = cur.dz[r] * dd[0][r];
+                for (int t = 0; t < TM; ++t) {
+                    dT[t] = zT[t];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hT[t][r] = pw_relu(zT[t][r]);
+                }
+            } else {
+                pw_act_tiles<TM>(zT, hT, dT, a.act1);                  // under the z2 chain
+            }
+            if constexpr (ACT == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z2[r] = z2[r] > 0.f ? cur.dz[r] : 0.f;
+            } else {
+                f4 zz[1] = {z2}, hh[1], dd[1];
+                pw_act_tiles<1>(zz, hh, dd, a.act2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z2[r] = cur.dz[r] * dd[0][r];
+            }
             // g2 now lives in z2's registers
             // ---- everything that needs only g2: dh (O1), dh^T and g2^T (OT)
             f4 dh[TM], dhT[TM], g2T = f4{0.f, 0.f, 0.f, 0.f};
@@ -2264,7 +2296,8 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < pw_tile_steps(CM, t); ++r) dxT = PW_MFMA(dh[t][r] * d1[t][r], W1b[t][r], dxT);
+                for (int r = 0; r < pw_tile_steps(CM, t); ++r)
+                    dxT = PW_MFMA(ACT == 1 ? (d1[t][r] > 0.f ? dh[t][r] : 0.f) : dh[t][r] * d1[t][r], W1b[t][r], dxT);
             if constexpr (MODE == 1) {
                 if (a.ds) {
                     f4 dsT = f4{0.f, 0.f, 0.f, 0.f};
@@ -2283,7 +2316,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     accW2[t] = PW_MFMA(g2T[r], hT[t][r], accW2[t]);
-                    accW1[t] = PW_MFMA(dhT[t][r] * dT[t][r], cur.xb[r], accW1[t]);
+                    accW1[t] = PW_MFMA(ACT == 1 ? (dT[t][r] > 0.f ? dhT[t][r] : 0.f) : dhT[t][r] * dT[t][r], cur.xb[r], accW1[t]);
                 }
             if (a.dx && c < CI && live_b)
                 *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + c) * a.P + pb) = dxT;
@@ -2307,13 +2340,13 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         if (c <= CI) out[(4 * q + r) * Gm::CB + CM + (c == CI ? 0 : 1 + c)] = accWs[r];
 }
 
-template <int CI, int CM, int CO, int MODE>
+template <int CI, int CM, int CO, int MODE, int ACT = -1>
 static int launch_pw_bwd_mfma_m(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
     if (!a.x) return 0;
     a.batch = batch;
-    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE>;
+    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE, ACT>;
     int per_cu = 0, dev = 0, cus = 256;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
     HIP_TRY(hipGetDevice(&dev));
@@ -2333,6 +2366,12 @@ static int launch_pw_bwd_mfma_m(PwBwdArgs a, int batch, int max_rows, int* dims,
 
 template <int CI, int CM, int CO>
 static int launch_pw_bwd_mfma(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
+    if constexpr (CI == 10 && CM == 40 && CO == 10) {      // the reference's default width with its default activation (ReLU)
+        if (a.x && a.act1 == 1 && a.act2 == 1 && env_int("TCFD_PW_BWD_RELU", 1)) {
+            if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1>(a, batch, max_rows, dims, st);
+            if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1>(a, batch, max_rows, dims, st);
+        }
+    }
     if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1>(a, batch, max_rows, dims, st);
     if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2>(a, batch, max_rows, dims, st);
     return launch_pw_bwd_mfma_m<CI, CM, CO, 0>(a, batch, max_rows, dims, st);
