@@ -2126,7 +2126,10 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 
     const int gpb = (int)((a.P + 15) / 16);                 // groups of 16 points per batch element (the launcher checks
     const int total = gpb * a.batch;                        // that the group count fits 31 bits)
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), wstride = gridDim.x * 4;
+    // the wave index through readfirstlane: hipcc then KNOWS that the group index and everything derived from it (batch element,
+    // first point, base offsets: an integer division and several 32 / 64-bit multiplies per group) is wave uniform and puts it on
+    // the scalar unit -- as vector code those were ~40 instructions, a quarter of them quarter rate, that the matrix pipe waits for
+    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wstride = gridDim.x * 4;
 
     struct In {
         float xa[KI], sa[KI], dz[4], sl[4];
