@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(128) void k_pointwise_bwd(PwBwdArgs a) {
     constexpr int RI = Wm::RI, RO = Wm::RO;
     typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave uniform, and hipcc knows it
     float* Wl = reinterpret_cast<float*>(smem_raw);
     float* L0 = Wl + ((Wm::TOTAL + 3) & ~3) + (size_t)wave * Gm::ROWS * PITCH;   // g2, later [x, 1]
     float* L1 = L0 + Gm::R0 * PITCH;                                              // [h, 1, s], later g1 over h
@@ -2703,7 +2703,7 @@ __global__ __launch_bounds__(256) void k_sample_outer_mfma(const float* __restri
                                                            int C, int CO, int waves_per_sample, int batch) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), b = blockIdx.y;
     const long groups = P / 16;
     const float* dyr = dy + ((size_t)b * CO + (c < CO ? c : 0)) * P + 4 * q;
     const float* xr = pe ? x + (size_t)b * P + 4 * q : x + ((size_t)b * C + (c < C ? c : 0)) * P + 4 * q;
