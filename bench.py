@@ -204,7 +204,82 @@ def cpu_baseline(n, real, dt, seconds):
     }
 
 
-def sfno_config5(dev):
+def _cpu_time(fn, budget_s, cands=(8, 16, 32), max_reps=50):
+    """Seconds per call of `fn` on the host cores: the thread count that is fastest on this host out of `cands` (one warm-up +
+    one timed call each; all 256 logical cpus are ~100x slower than 16-32 for these sizes), then as many calls as fit
+    `budget_s` (at least one).  Returns (seconds per call, threads, calls timed)."""
+    cands = sorted({c for c in cands if c <= (os.cpu_count() or 1)} or {1})
+    best = None
+    t_begin = time.perf_counter()
+    for c in cands:
+        torch.set_num_threads(c)
+        fn()                                      # warm-up: MKL plans, thread team
+        t0 = time.perf_counter()
+        fn()
+        el = time.perf_counter() - t0
+        if best is None or el < best[1]:
+            best = (c, el)
+        if time.perf_counter() - t_begin > budget_s * 0.6:
+            break
+    torch.set_num_threads(best[0])
+    left = budget_s - (time.perf_counter() - t_begin)
+    reps = int(max(1, min(max_reps, left / max(best[1], 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    per = (time.perf_counter() - t0) / reps
+    return min(per, best[1]), best[0], reps
+
+
+def cpu_baseline_solver_config(n, B_timed, B_config, real, dt, forced, drag, budget_s, steps_per_call=1):
+    """`cpu_baseline` object for one solver config: oracle/ns2d.py on the host cores at
+    `B_timed` fields, extrapolated linearly to the config's `B_config` when they differ (stated in `sample`)."""
+    from oracle import ns2d as O
+
+    L = 2 * math.pi
+    t = O.make_tables(n, L, 1e-3, drag, True, None, real)
+    if forced:
+        t.forcing_hat = O.kolmogorov_forcing_hat(n, L, t.kx, t.ky, 1.0, 4, real=real)
+    w = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, real)) for s in range(B_timed)])
+    model, physical, logical = host_cpu()
+    with torch.no_grad():
+        per, threads, reps = _cpu_time(lambda: O.advance(w, dt, t, steps=steps_per_call), budget_s)
+    per_step = per / steps_per_call * (B_config / B_timed)
+    return {"value": 1.0 / per_step, "unit": f"steps/s (batch {B_config})", "cores": physical, "threads": threads,
+            "logical_cpus": logical, "cpu_model": model, "kind": "port",
+            "sample": f"oracle/ns2d.py, {n}^2 {str(real)[6:]}, {'Kolmogorov-forced' if forced else 'unforced'}, B={B_timed}, "
+                      f"{reps} x {steps_per_call} step(s) at {per / steps_per_call * 1e3:.1f} ms/step with {threads} threads"
+                      + (f", extrapolated linearly to B={B_config} (x{B_config // B_timed})" if B_config != B_timed else "")}
+
+
+def cpu_baseline_sfno(budget_s):
+    """`cpu_baseline` for config 5: oracle/sfno.py forward + oracle/fno.py sobolev_loss at b = 4 (the config's b = 32 is 8 x
+    that: samples do not interact), same model / input construction as `sfno_config5`."""
+    from oracle import fno as OF
+    from oracle import sfno as OS
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4).state_dict().items()}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(4, 256, 256, 10, generator=g)
+    y = torch.randn(4, 256, 256, 10, generator=g)
+
+    def fwd_loss():
+        out = OS.sfno_forward(sd, x, (24, 24, 5), width=10, num_hidden=3, out_steps=10)
+        return OF.sobolev_loss(out, y, 256, norm_order=0, relative=True)
+
+    model, physical, logical = host_cpu()
+    with torch.no_grad():
+        per, threads, reps = _cpu_time(fwd_loss, budget_s, cands=(16, 32), max_reps=3)
+    return {"value": 4 / per, "unit": "samples/s (forward + loss)", "cores": physical, "threads": threads, "logical_cpus": logical,
+            "cpu_model": model, "kind": "port",
+            "sample": f"oracle/sfno.py + oracle/fno.py sobolev_loss, b=4 of the config's 32 (samples are independent: x8 stated, "
+                      f"samples/s unchanged), {reps} call(s) at {per * 1e3:.0f} ms with {threads} threads"}
+
+
+def sfno_config5(dev, with_cpu=True):
     """Secondary measurement (BASELINE configs[4], SURVEY 8d "C5"): SFNO(24,24,5, width 10, 4 layers) forward +
     SobolevLoss on x = randn(32,256,256,10) fp32, random-init weights (seed 0); plus one training step
     (forward + loss + backward).  Algorithmic bytes: 21.5 A_H = 18.0 GB per forward+loss."""
@@ -278,18 +353,35 @@ def sfno_config5(dev):
                                              # issued: 93 v_mfma_f32_16x16x4_f32 (2048 flop each) per 16 points, tile padding included
                                              "issued_flop_per_launch": 93 * 2048 * (A_H // 40 // 16),
                                              "achieved": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12, 1),
-                                             "frac": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12 / 157.3, 4)},
+                                             "frac": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
+                                             # useful: the block's own multiply-adds per point -- forward recompute W1 (10x40) +
+                                             # W2 (40x10) + Ws (10x10), input gradients W2^T, W1^T, Ws^T (the same three shapes) and
+                                             # the three weight-gradient outer products (again the same shapes): 3 x 900 = 2700 MAC,
+                                             # biases as a constant-1 channel +60 -> 2 x 2760 flop per point.  The rest of the issued
+                                             # work is the zero padding of width 10 / 40 into 16 x 16 x 4 tiles.
+                                             "useful_flop_per_launch": 2 * 2760 * (A_H // 40),
+                                             "useful_achieved": round(2 * 2760 * (A_H // 40) / (t_bwd * 1e-3) / 1e12, 1),
+                                             "useful_frac": round(2 * 2760 * (A_H // 40) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
+                                             "useful_over_issued": round(2 * 2760 * 16 / (93 * 2048), 3)},
                                     "note": "matrix-pipe bound: 93 v_mfma_f32_16x16x4_f32 per 16 points (105 before the tile row map) = 1.6 ms of MFMA time per launch; peak = dense fp32 matrix rate, 256 flop/clk/CU x 256 CUs x 2.4 GHz"}}
     except Exception as e:
         roof = {"error": repr(e)}
-    return {"roofline": roof, "workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
+    base = None
+    if with_cpu:
+        try:
+            base = cpu_baseline_sfno(14.0)
+        except Exception as e:
+            base = {"value": None, "error": repr(e)}
+    return {"roofline": roof, "cpu_baseline": base,
+            "gpu_over_cpu": round(32 / (t_all * 1e-3) / base["value"], 1) if base and base.get("value") else None,
+            "workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
             "forward_ms": round(t_fwd, 3), "forward_plus_loss_ms": round(t_all, 3), "train_step_ms": round(t_train, 2),
             "train_step_ms_each": [round(t, 2) for t in per_step],
             "samples_per_s": round(32 / (t_all * 1e-3), 1), "algo_GB": round(algo_gb, 2),
             "algo_GBps": round(algo_gb / (t_all * 1e-3), 1), "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4)}
 
 
-def other_baseline_configs(dev):
+def other_baseline_configs(dev, with_cpu=True):
     """Secondary lines for the other single-GPU BASELINE configs on the same kernels: C2 = 256^2, B=16,
     fp32, unforced McWilliams, dt=1e-3 (1000-step job, measured over 400 steps through forward(w, dt, steps=k)); C4 per-GPU
     shard = 512^2, B=64, fp64, unforced, dt=1e-3; plus two sizes outside BASELINE: 768^2 (n = 3 * 2^k on the fused kernels)
@@ -298,14 +390,18 @@ def other_baseline_configs(dev):
     from torch_cfd_amd.initial_conditions import vorticity_field
 
     out = {}
-    for name, n, B, real, steps, fused in (("C2_256x16_f32", 256, 16, torch.float32, 400, True),
-                                           ("C4_shard_512x64_f64", 512, 64, torch.float64, 40, False),
-                                           ("n768x64_f64", 768, 64, torch.float64, 20, False),       # n = 3 * 2^k: radix-12 first pass
-                                           ("n2048x16_f64", 2048, 16, torch.float64, 6, False)):      # one field per chunk
+    # (name, n, B, dtype, steps, one forward(steps=k) call?, Kolmogorov forcing + drag 0.1?)
+    for name, n, B, real, steps, fused, forced in (("C1_128x1_f64", 128, 1, torch.float64, 200, True, True),
+                                                   ("C2_256x16_f32", 256, 16, torch.float32, 400, True, False),
+                                                   ("C4_shard_512x64_f64", 512, 64, torch.float64, 40, False, False),
+                                                   ("n768x64_f64", 768, 64, torch.float64, 20, False, False),   # n = 3 * 2^k: radix-12 first pass
+                                                   ("n2048x16_f64", 2048, 16, torch.float64, 6, False, False)):  # one field per chunk
         torch.set_default_dtype(real)
         L = 2 * math.pi
         grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
-        op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.0, smooth=True, solver=tc.RK4CrankNicolsonStepper()).to(dev)
+        forcing = tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4) if forced else None
+        op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1 if forced else 0.0, smooth=True, forcing_fn=forcing,
+                                       solver=tc.RK4CrankNicolsonStepper()).to(dev)
         cdt = torch.complex64 if real == torch.float32 else torch.complex128
         with torch.no_grad():
             w = tc.fft_plan(n, cdt, dev).rfft2(torch.cat([vorticity_field(grid, 4, batch_seeds=list(range(i, min(i + 8, B))),
@@ -323,6 +419,17 @@ def other_baseline_configs(dev):
         out[name] = {"steps_per_s": round(steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
                      "step_algo_GBps": round(70.0 * S * steps / el / 1e9, 1),
                      "api": "forward(w,dt,steps=k)" if fused else "k x forward(w,dt)"}
+    if with_cpu:
+        # the CPU restatement beside every BASELINE config line, bounded: ~8 s per config
+        for name, args_ in (("C1_128x1_f64", (128, 1, 1, torch.float64, 1e-3, True, 0.1, 6.0, 20)),
+                            ("C2_256x16_f32", (256, 16, 16, torch.float32, 1e-3, False, 0.0, 8.0, 1)),
+                            ("C4_shard_512x64_f64", (512, 8, 64, torch.float64, 1e-3, False, 0.0, 8.0, 1))):
+            try:
+                base = cpu_baseline_solver_config(*args_)
+                out[name]["cpu_baseline"] = base
+                out[name]["gpu_over_cpu"] = round(out[name]["steps_per_s"] / base["value"], 1)
+            except Exception as e:
+                out[name]["cpu_baseline"] = {"value": None, "error": repr(e)}
     return out
 
 
@@ -368,7 +475,7 @@ def host_only_run(args, world, rank, real_stdout):
         dist.destroy_process_group()
 
 
-def c4_ensemble(dev, world, rank, total):
+def c4_ensemble(dev, world, rank, total, as_rank0_of=None):
     """BASELINE configs[3] as ONE job cut across the ranks (strong scaling of the data-generation loop of
     fno/data_gen/data_gen_McWilliams2d.py:126-152): `total` McWilliams samples of 512^2 in batches of 64, fp64, 100 warm-up
     + 550 recorded steps, a record every 55 (10 records x 4 fields), c2r + 2x subsample + fp32 cast on the device, records
@@ -384,7 +491,8 @@ def c4_ensemble(dev, world, rank, total):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     data = generate_mcwilliams_dataset(512, total, 64, 1e-3, 100, 550, 55, viscosity=1e-3, peak_wavenumber=4, random_state=0,
-                                       subsample=2, dtype=torch.float32, cdtype=torch.complex64, device=dev, stats=stats)
+                                       subsample=2, dtype=torch.float32, cdtype=torch.complex64, device=dev, stats=stats,
+                                       as_rank0_of=as_rank0_of)
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     phases = torch.tensor([el, stats["setup_s"], stats["stepping_s"], stats["handover_tail_s"]], dtype=torch.float64, device=dev)
@@ -393,6 +501,9 @@ def c4_ensemble(dev, world, rank, total):
     el, setup, stepping, tail = phases.tolist()
     if rank != 0:
         return None
+    if as_rank0_of is not None:      # the proxy: only rank 0's rows of the result exist
+        return {"seconds": round(el, 3), "setup_s": round(setup, 3), "stepping_s": round(stepping, 3),
+                "handover_tail_s": round(tail, 3), "samples": stats["samples"]}
     ok = all(bool(torch.isfinite(v).all()) for v in data.values() if v.is_floating_point())
     gb = sum(v.numel() * v.element_size() for v in data.values()) / 1e9
     return {"workload": f"McWilliams ensemble, {total} samples of 512^2 in batches of 64 over {world} GPU(s), fp64, 100 + 550 "
@@ -625,6 +736,32 @@ def main():
         del w
     torch.cuda.empty_cache()
 
+    # ---- strong-scaling PROXY on one GPU: what one rank of an N-GPU strong-scaling run does is advance
+    # batch/N fields with the same per-call API -- there is no communication inside a step (torch_cfd/equations.py:413-447 is
+    # per sample), so t(batch) / t(batch/N) on ONE device IS the N-GPU speed-up up to box-to-box spread and the timing barrier.
+    proxy = None
+    if world == 1 and args.scaling == "weak" and args.batch >= 8:
+        try:
+            per_n = {}
+            for N in (1, 2, 4, 8):
+                if args.batch % N:
+                    continue
+                wp = initial_state(list(range(args.batch // N)))
+                best = None
+                for _ in range(3):      # best of three K-step regions: a region at N = 8 is only ~25 ms long
+                    wp, el_p = timed(wp, args.warmup, args.steps)
+                    best = el_p if best is None else min(best, el_p)
+                per_n[N] = best / args.steps * 1e3
+                del wp
+            torch.cuda.empty_cache()
+            proxy = {"fields_per_gpu": {str(N): args.batch // N for N in per_n},
+                     "ms_per_step": {str(N): round(t, 4) for N, t in per_n.items()},
+                     "predicted_speedup": {str(N): round(per_n[1] / t, 3) for N, t in per_n.items()},
+                     "method": f"K x forward(w, dt) on batch/N fields of this ONE GPU, same timed region as `value` (best of 3); "
+                               f"speed-up = t({args.batch}) / t({args.batch}/N); exact for this path: no collective inside a step"}
+        except Exception as e:
+            proxy = {"error": repr(e)}
+
     # STREAM-style probe of this box: what a plain 16-B/lane copy / read / fill reaches next to the 8 TB/s spec
     probe = {}
     try:
@@ -743,6 +880,7 @@ def main():
         "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 3),
         "fused_steps_api": fused_api,
         "strong_scaling": strong,
+        "strong_scaling_proxy": proxy,
         "hbm_probe": probe,
     }
     if not args.no_c4:
@@ -756,17 +894,31 @@ def main():
         else:
             try:
                 out["c4_ensemble"] = c4_ensemble(dev, world, rank, args.c4_samples)
+                if world == 1 and args.c4_samples % 8 == 0 and args.c4_samples >= 64:
+                    # one-GPU proxy of the 8-GPU job: what rank 0 of 8 runs (full-size page-locked result, its 1/8 of the
+                    # samples); the other ranks do strictly less (no result, no D2H)
+                    torch.cuda.empty_cache()
+                    if hasattr(torch._C, "_host_emptyCache"):
+                        torch._C._host_emptyCache()      # rank 0 of a fresh job page-locks its result anew: no cached blocks
+                    one = out["c4_ensemble"]
+                    px = c4_ensemble(dev, 1, 0, args.c4_samples, as_rank0_of=8)
+                    px["predicted_speedup_whole_job"] = round(one["seconds"] / px["seconds"], 2)
+                    px["predicted_speedup_stepping"] = round(one["stepping_s"] / px["stepping_s"], 2)
+                    px["method"] = ("this GPU runs what rank 0 of an 8-rank job runs (full-size page-locked result allocated on a "
+                                    "helper thread, its 64 of the 512 samples); left out: receiving the 7 peers' records over "
+                                    "xGMI and their D2H (7 x 67 MB per record interval on side streams)")
+                    out["c4_ensemble"]["strong_scaling_proxy_8gpu"] = px
             except Exception as e:
                 out["c4_ensemble"] = {"error": repr(e)}
         torch.set_default_dtype(real)
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_sfno:
         try:
-            out["other_configs"] = other_baseline_configs(dev)
+            out["other_configs"] = other_baseline_configs(dev, with_cpu=not args.no_cpu_baseline)
         except Exception as e:
             out["other_configs"] = {"error": repr(e)}
         try:
-            out["sfno_config5"] = sfno_config5(dev)
+            out["sfno_config5"] = sfno_config5(dev, with_cpu=not args.no_cpu_baseline)
         except Exception as e:  # secondary measurement: never takes the headline line down
             out["sfno_config5"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -52,9 +52,16 @@ typedef enum { TCFD_C64 = 0, TCFD_C128 = 1 } tcfd_dtype;
 typedef struct tcfd_ns2d_plan tcfd_ns2d_plan;
 typedef struct tcfd_fno_plan tcfd_fno_plan;
 
+#define TCFD_ABI_VERSION 4   /* what tcfd_version() of a library built from THIS header returns */
+
 #ifndef TCFD_H_TYPES_ONLY   /* (the library's second compilation unit wants the types without the prototypes) */
 
 const char* tcfd_last_error(void);
+/* ABI revision of the library that was loaded.  It changes whenever an entry point changes its argument list or the
+ * meaning of an argument (round 3 turned the float scalars of the tcfd_fno_* calls into doubles and gave tcfd_fno_contract
+ * a dtype: revision 1 -> 4, the build round).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
+ * first call: a stale prebuilt library would otherwise be called with the wrong argument layout and return garbage
+ * (torch-cfd_amd/_lib.py::load does). */
 int tcfd_version(void);
 
 /* ---- plan: constant tables of one NavierStokes2DSpectral instance -----------

@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol():
     lib = tc._lib.load()
     for name in header_symbols():
         assert hasattr(lib, name), f"{name} declared in include/tcfd.h but not exported"
-    assert lib.tcfd_version() >= 1
+    assert lib.tcfd_version() == tc._lib.ABI_VERSION
 
 
 def test_ctypes_table_matches_header():

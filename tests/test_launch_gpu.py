@@ -152,3 +152,60 @@ def test_two_threads_share_one_plan(n, steps):
     assert not errors, errors
     for i in range(2):
         assert torch.equal(results[i], serial[i])
+
+
+def _two_ranks(mode, out, timeout):
+    """Two ranks of tests/two_rank_one_gpu_worker.py, both on cuda:0; returns [(returncode, output)] per rank."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_one_gpu_worker.py"), mode, out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    res = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()              # exactly the child started above
+            o, _ = p.communicate()
+            o += "\n[timeout]"
+        res.append((p.returncode, o))
+    return res
+
+
+def test_two_ranks_share_the_one_device(tmp_path):
+    """the record hand-over with a REAL peer on a one-GPU box.  (a) RCCL with two ranks on one device:
+    expected to be refused at communicator creation ("Duplicate GPU detected", librccl) -- the test records which of the
+    two outcomes happened and fails only on a third (a hang, a wrong answer).  (b) the staged form that does run here: a
+    gloo group, DEVICE tensors, a peer's records staged through page-locked memory -- side stream, events, the pitched
+    copies into the (sample, record) slots of the page-locked result all execute on the GPU; the two-rank dataset must equal
+    the one-process dataset bit for bit (batch elements are independent trajectories)."""
+    res = _two_ranks("rccl", str(tmp_path / "unused.pt"), 180)
+    text = "\n".join(o for _, o in res)
+    if all(rc == 0 for rc, _ in res):
+        assert text.count("RCCL_TWO_RANKS_ONE_DEVICE_OK") == 2
+        rccl = "ran"
+    else:
+        assert "[timeout]" not in text, text[-2000:]
+        assert "uplicate GPU" in text or "invalid usage" in text.lower() or "ncclInvalidUsage" in text, text[-2000:]
+        rccl = "refused (duplicate GPU)"
+    print("RCCL, two ranks on one device:", rccl)
+    out = str(tmp_path / "two_rank.pt")
+    res = _two_ranks("staged", out, 600)
+    for rc, o in res:
+        assert rc == 0 and "STAGED_OK" in o, o[-3000:]
+    two = torch.load(out)
+    from torch_cfd_amd.data_gen import generate_mcwilliams_dataset
+
+    torch.set_default_dtype(torch.float64)
+    try:
+        one = generate_mcwilliams_dataset(64, 6, 2, 1e-3, 4, 12, 4, random_state=3, subsample=2, device="cuda:0")
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert sorted(one) == sorted(two)
+    for k in one:
+        assert one[k].shape == two[k].shape and torch.equal(one[k], two[k]), k

@@ -881,6 +881,35 @@ def test_fused_vjp_of_the_explicit_terms_matches_the_tensor_op_path(n, tag, B, f
     assert rel_l2(grads["1"], grads["0"]) < tol
 
 
+def test_second_order_gradients_through_the_fused_nodes(dev, monkeypatch):
+    """create_graph=True through the fused autograd nodes: a Hessian-vector product of a scalar of one RK4-CN
+    step, d/dw <grad_w loss(w), v>, must equal the one of the tensor-op path (TCFD_FUSED_STAGE=0 / TCFD_FUSED_VJP=0), whose
+    transforms differentiate through each other; the fused nodes' raw-pointer backward would silently return the gradient of a
+    constant."""
+    from oracle import ns2d as O
+
+    n, B = 32, 2
+    grid, op = build_op(n, "f64", "kolmogorov", dev)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 7 + s, torch.float64)) for s in range(B)]).to(dev)
+    g = torch.Generator().manual_seed(3)
+    v = torch.complex(torch.randn(B, n, n // 2 + 1, generator=g, dtype=torch.float64),
+                      torch.randn(B, n, n // 2 + 1, generator=g, dtype=torch.float64)).to(dev)
+    hvp, first = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_FUSED_VJP", flag)
+        monkeypatch.setenv("TCFD_FUSED_STAGE", flag)
+        w = w0.clone().requires_grad_(True)
+        out, _ = op(w, 2e-3, steps=1)
+        loss = out.abs().pow(4).sum()                    # a non-quadratic scalar: its Hessian sees the state
+        (gw,) = torch.autograd.grad(loss, w, create_graph=True)
+        assert gw.requires_grad
+        first[flag] = gw.detach()
+        (hv,) = torch.autograd.grad((gw * v.conj()).real.sum(), w)
+        hvp[flag] = hv
+    assert rel_l2(first["1"], first["0"]) < 1e-10
+    assert torch.linalg.norm(hvp["0"]) > 0 and rel_l2(hvp["1"], hvp["0"]) < 1e-9
+
+
 def test_trainable_rk_coefficients_receive_gradients(dev):
     """RK4CrankNicolsonStepper(requires_grad=True): d loss / d gammas from the differentiable path against central
     differences of the FUSED forward step (two different code paths must agree)."""

@@ -27,6 +27,7 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip")
 
 TCFD_C64, TCFD_C128 = 0, 1
+ABI_VERSION = 4   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -171,6 +172,14 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). torch-cfd_amd has no CPU / eager fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.tcfd_version.restype, lib.tcfd_version.argtypes = _i, []
+    have = lib.tcfd_version()
+    if have != ABI_VERSION:
+        # a stale prebuilt library (newer mtime than the sources, older argument lists): calling it would pass doubles where
+        # it reads floats.  Never guess -- say so; build_library(force=True) replaces it.
+        raise TcfdError(f"{LIB_PATH} has ABI revision {have}, this package expects {ABI_VERSION} (include/tcfd.h TCFD_ABI_VERSION): "
+                        "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'` after deleting the stale file, or "
+                        "torch_cfd_amd._lib.build_library(force=True)")
     for name, (res, args) in SIGNATURES.items():
         if not hasattr(lib, name):
             continue  # optional symbol groups are checked by tests/test_abi.py against the header

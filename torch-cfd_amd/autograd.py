@@ -94,6 +94,15 @@ class FusedExplicitTerms(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (w_hat,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True (gradient penalties, Hessian-vector products): the raw-pointer launches below would cut
+            # the VJP's own dependence on w and g out of the graph.  Form it from the differentiable tensor-op restatement
+            # (Rfft2 / Irfft2 differentiate through each other any number of times), as the reference's pure-torch graph allows.
+            with torch.enable_grad():
+                w = w_hat if w_hat.requires_grad else w_hat.detach().requires_grad_(True)
+                f = _explicit_terms_tensor_ops(ctx.op, ctx.plan, w, None)
+                (wbar,) = torch.autograd.grad(f, w, g.reshape(f.shape), create_graph=True)
+            return wbar, None, None
         pre, post = FusedExplicitTerms._tables(ctx.op, ctx.plan, g.device)
         lead = w_hat.shape
         w3 = w_hat.reshape(-1, ctx.plan.n, ctx.plan.m)
@@ -127,6 +136,11 @@ def explicit_terms(op, plan, w_hat: torch.Tensor, forcing_hat) -> torch.Tensor:
         if torch.is_grad_enabled() and w_hat.requires_grad:
             return FusedExplicitTerms.apply(w_hat, op, plan)
         return plan.explicit_terms(w_hat).reshape(w_hat.shape)     # nothing to differentiate: the plain fused sweep
+    return _explicit_terms_tensor_ops(op, plan, w_hat, forcing_hat)
+
+
+def _explicit_terms_tensor_ops(op, plan, w_hat: torch.Tensor, forcing_hat) -> torch.Tensor:
+    """The same F(w) as device tensor operations around the two differentiable transforms (any order of derivative)."""
     kx, ky = op.kx.to(w_hat.device), op.ky.to(w_hat.device)
     two_pi_i = 2j * torch.pi
     lap = -4 * torch.pi**2 * (kx**2 + ky**2)
@@ -194,6 +208,14 @@ class StageUpdate(torch.autograd.Function):
     def backward(ctx, g_h, g_u):
         if g_u is None:
             g_u = torch.zeros_like(g_h)
+        if torch.is_grad_enabled():
+            # create_graph=True: the stage is linear, its VJP as differentiable tensor ops (see FusedExplicitTerms.backward)
+            fa, beta, gdt, mu, mud = ctx.coef
+            lin = ctx.lin
+            den = 1 / (1 - mud * lin)
+            gh_total = gdt * den * g_u if g_h is None else g_h + gdt * den * g_u
+            g_hp = beta * gh_total if (ctx.has_prev and ctx.needs_input_grad[1]) else None
+            return fa * gh_total, g_hp, (1 + mu * lin) * den * g_u, None, None
         g_u = g_u.contiguous()
         gh = g_h.contiguous() if g_h is not None else None
         g_f, g_b = torch.empty_like(g_u), torch.empty_like(g_u)

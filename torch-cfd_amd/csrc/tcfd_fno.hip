@@ -264,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>
 }
 
 template <typename T, int Y, int EPT>
-__global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, T* __restrict__ out,
+__global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, T* out /* may be == acc: no restrict */,
                                                   const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_ti, int T_out,
                                                   int t_keep, int mt, int my, T scale, int P, int NS, long slabs, int Ys,
                                                   const T* acc) {

@@ -63,7 +63,7 @@ int tcfd_set_error(int code, const char* fmt, ...) {  // shared with tcfd_fno.hi
 
 #if TCFD_UNIT != 1
 extern "C" const char* tcfd_last_error(void) { return g_err; }
-extern "C" int tcfd_version(void) { return 1; }
+extern "C" int tcfd_version(void) { return TCFD_ABI_VERSION; }
 #endif
 
 // ------------------------------------------------------------------ per-size configuration

@@ -47,8 +47,8 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
                                 diam: float = 2 * torch.pi, peak_wavenumber: float = 4, random_state: int = 0,
                                 subsample: int = 1, dtype: torch.dtype = torch.float32,
                                 cdtype: torch.dtype = torch.complex64, device="cuda", dst: int = 0,
-                                path: Optional[str] = None, stats: Optional[dict] = None
-                                ) -> Optional[Dict[str, torch.Tensor]]:
+                                path: Optional[str] = None, stats: Optional[dict] = None,
+                                as_rank0_of: Optional[int] = None) -> Optional[Dict[str, torch.Tensor]]:
     """Decaying-turbulence ensemble (McWilliams IC).  Computes in the torch default dtype (the reference driver
     sets float64), stores ``dtype`` / ``cdtype``.  Returns the dataset dict on rank ``dst`` (saved with
     ``torch.save`` when ``path`` is given), ``None`` on the other ranks.
@@ -58,7 +58,12 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     ``dst`` -> its page-locked result over PCIe.  ``stats`` (optional dict) receives the wall-clock split: ``setup_s``
     (operator, plans, page-locked result), ``stepping_s`` (until this rank's last step has finished on the device,
     hand-over of all earlier records running underneath) and ``handover_tail_s`` (what is left of the hand-over
-    after that: the un-hidden part of gather + D2H)."""
+    after that: the un-hidden part of gather + D2H).
+
+    ``as_rank0_of=N`` (single process only) runs what rank 0 of an N-rank job runs -- the full-size page-locked result, rank
+    0's batches -- with nobody to receive from: the one-GPU PROXY of the N-GPU job's wall time that ``bench.py`` reports
+    (the rows of the other ranks stay uninitialised; what the proxy leaves out is the receive + D2H of their records on the
+    side streams)."""
     import time
 
     import torch.distributed as dist
@@ -71,6 +76,10 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     world = dist.get_world_size() if distributed else 1
     rank = dist.get_rank() if distributed else 0
     layout = batch_layout(total_samples, world, batch_size)
+    if as_rank0_of is not None:
+        if distributed and world > 1:
+            raise ValueError("as_rank0_of is the single-process proxy of a multi-rank job")
+        layout = [batch_layout(total_samples, as_rank0_of, batch_size)[0]]
     grid = Grid(shape=(n, n), domain=((0, diam), (0, diam)), device=device)
     op = NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=0, smooth=True, forcing_fn=None,
                                 solver=RK4CrankNicolsonStepper()).to(device)

@@ -139,10 +139,14 @@ class RecordHandover:
     ``finish`` posts the receives still outstanding, waits, and returns ``{field: (total, n_rec, *trailing)}`` host
     tensors on ``dst`` (``None`` elsewhere).  What a job pays at the end is the hand-over of the LAST record only.
     No process group: the same pipeline with the device -> host stage alone.  CPU tensors (gloo, the tests): plain
-    blocking copies."""
+    blocking copies.  Device tensors over a gloo group (``staged``): gloo moves host memory only, so a peer's record goes
+    device -> page-locked staging buffer (side stream, event) -> gloo -> ``dst``'s host result, while ``dst``'s own records
+    keep the side-stream pitched copies -- the form a one-GPU box can run with two ranks (RCCL refuses two ranks on one
+    device: "Duplicate GPU detected"), exercising the stream / event ordering and the slicing of the page-locked result."""
 
     def __init__(self, fields: Sequence[str], total: int, n_rec: int, trailing: Tuple[int, ...], dtype: torch.dtype,
-                 layout: List[List[Tuple[int, int]]], device, dst: int = 0, group: Optional[dist.ProcessGroup] = None):
+                 layout: List[List[Tuple[int, int]]], device, dst: int = 0, group: Optional[dist.ProcessGroup] = None,
+                 lazy_host: bool = True):
         self.fields, self.total, self.n_rec = tuple(fields), total, n_rec
         self.trailing, self.dtype = tuple(trailing), dtype
         self.device = torch.device(device)
@@ -160,10 +164,39 @@ class RecordHandover:
             self.row_bytes *= d
         self._keep: list = []          # device buffers a copy or a send still reads
         self._sends: list = []
+        self.staged = bool(self.distributed and self.on_gpu and dist.get_backend(group) == "gloo")
+        self._outbox: list = []        # staged peers: (event, page-locked copy) of records not yet handed to gloo
+        self._inbox: list = []         # staged dst: (work, staging tensor, start, count, record) of receives in flight
         self.host: Optional[Dict[str, torch.Tensor]] = None
+        self._host_ready: Dict[str, object] = {}
+        self._alloc_thread = None
+        self._alloc_error: Optional[BaseException] = None
         if self.rank == dst:
-            self.host = {f: torch.empty((total, n_rec) + self.trailing, dtype=dtype, pin_memory=self.on_gpu)
-                         for f in self.fields}
+            shape = (total, n_rec) + self.trailing
+            if self.on_gpu and lazy_host:
+                # Page-locking the result is host work proportional to the WHOLE data set (5.4 GB at BASELINE config 4:
+                # ~0.5 s) that only rank dst does -- serial time no number of GPUs shrinks.  It runs on a helper thread,
+                # field by field, while the first record_every steps are computed; a copy into a field waits for that
+                # field only (the first record exists ~100 steps into the job).
+                import threading
+
+                self.host = {}
+                self._host_ready = {f: threading.Event() for f in self.fields}
+
+                def allocate():
+                    try:
+                        for f in self.fields:
+                            self.host[f] = torch.empty(shape, dtype=dtype, pin_memory=True)
+                            self._host_ready[f].set()
+                    except BaseException as e:   # surfaced by the next _land / finish on the caller's thread
+                        self._alloc_error = e
+                        for ev in self._host_ready.values():
+                            ev.set()
+
+                self._alloc_thread = threading.Thread(target=allocate, name="tcfd-pinned-result", daemon=True)
+                self._alloc_thread.start()
+            else:
+                self.host = {f: torch.empty(shape, dtype=dtype, pin_memory=self.on_gpu) for f in self.fields}
         if self.on_gpu:
             from . import _lib
 
@@ -190,12 +223,53 @@ class RecordHandover:
             import ctypes
 
             for f, name in enumerate(self.fields):
-                h = self.host[name]
+                h = self._host_field(name)
                 rc = self._clib.tcfd_copy_rows_to_host(
                     h[start, rec].data_ptr(), self.n_rec * self.row_bytes, buf[:, f].data_ptr(), F * self.row_bytes,
                     self.row_bytes, count, ctypes.c_void_p(self.side.cuda_stream))
                 self._lib.check(rc, "tcfd_copy_rows_to_host")
-        self._keep.append(buf)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._keep.append((done, buf))
+
+    def _host_field(self, name: str) -> torch.Tensor:
+        ev = self._host_ready.get(name)
+        if ev is not None:
+            ev.wait()
+            if self._alloc_error is not None:
+                raise self._alloc_error
+        return self.host[name]
+
+    def _release_finished(self):
+        """Drop the device buffers whose copy (dst) or send (peers) has completed: the footprint stays at the records in
+        flight instead of growing with the whole data set (a reference-scale job is thousands of samples x 100 records)."""
+        self._keep = [(ev, buf) for ev, buf in self._keep if not ev.query()]
+        self._sends = [(works, buf) for works, buf in self._sends if not all(w.is_completed() for w in works)]
+
+    # -- staged form (device tensors, gloo group)
+    def _flush_outbox(self, block: bool):
+        """Hand the staged copies whose device -> host copy has finished to gloo, in push order."""
+        while self._outbox:
+            ev, host = self._outbox[0]
+            if not ev.query():
+                if not block:
+                    return
+                ev.synchronize()
+            self._outbox.pop(0)
+            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, host, _global_rank(self.group, self.dst), group=self.group)])
+            self._sends.append((works, host))
+
+    def _drain_inbox(self, block: bool):
+        """Copy the received staging tensors into their (sample, record) slots of the host result."""
+        left = []
+        for work, stage, s, c, j in self._inbox:
+            if not block and not work.is_completed():
+                left.append((work, stage, s, c, j))
+                continue
+            work.wait()
+            for f, name in enumerate(self.fields):
+                self._host_field(name)[s:s + c, j].copy_(stage[:, f])
+        self._inbox = left
 
     def _post_receives(self):
         """One receive per peer that still has a record to send (its next one), all in one group call."""
@@ -205,12 +279,19 @@ class RecordHandover:
                 continue
             s, c, j = self.items[r][self.cursor[r]]
             self.cursor[r] += 1
-            stage = torch.empty((c, len(self.fields)) + self.trailing, dtype=self.dtype, device=self.device)
+            shape = (c, len(self.fields)) + self.trailing
+            stage = (torch.empty(shape, dtype=self.dtype, pin_memory=True) if self.staged
+                     else torch.empty(shape, dtype=self.dtype, device=self.device))
             ops.append(dist.P2POp(dist.irecv, stage, _global_rank(self.group, r), group=self.group))
             meta.append((stage, s, c, j))
         if not ops:
             return False
         works = dist.batch_isend_irecv(ops)
+        if self.staged:
+            works = list(works) if len(works) == len(meta) else [works[0]] + [_Done()] * (len(meta) - 1)
+            self._inbox.extend((w, stage, s, c, j) for w, (stage, s, c, j) in zip(works, meta))
+            self._drain_inbox(block=False)
+            return True
         if len(works) == len(meta):
             for w, (stage, s, c, j) in zip(works, meta):
                 self._land(stage, s, c, j, work=w)
@@ -232,10 +313,23 @@ class RecordHandover:
             raise ValueError(f"record must be a contiguous {self.dtype} tensor of shape {want}, got "
                              f"{tuple(packed.shape)} {packed.dtype}")
         self.cursor[self.rank] += 1
+        if self.on_gpu:
+            self._release_finished()
         if self.rank == self.dst:
             self._land(packed, start, count, rec)
             if self.world > 1:
                 self._post_receives()
+        elif self.staged:
+            main = torch.cuda.current_stream(self.device)
+            host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            with torch.cuda.stream(self.side):
+                self.side.wait_stream(main)          # the record was produced on the caller's stream
+                host.copy_(packed, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.side)
+            self._keep.append((done, packed))
+            self._outbox.append((done, host))
+            self._flush_outbox(block=False)
         else:
             # through batch_isend_irecv like the receiving side: ProcessGroupNCCL runs batched point-to-point operations on
             # the group's communicator and unbatched ones on a separate two-rank communicator -- a batched receive and an
@@ -250,10 +344,16 @@ class RecordHandover:
         if self.rank == self.dst:
             while self.world > 1 and self._post_receives():
                 pass
+            self._drain_inbox(block=True)
+            if self._alloc_thread is not None:
+                self._alloc_thread.join()
+                if self._alloc_error is not None:
+                    raise self._alloc_error
             if self.on_gpu:
                 self.side.synchronize()
             self._keep.clear()
             return self.host
+        self._flush_outbox(block=True)
         for works, _ in self._sends:
             for work in works:
                 work.wait()
@@ -267,4 +367,7 @@ class _Done:
     """Stand-in for the members of a coalesced group whose single work object was already waited on."""
 
     def wait(self):
+        return True
+
+    def is_completed(self):
         return True

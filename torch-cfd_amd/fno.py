@@ -802,6 +802,12 @@ def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, ski
     if (not torch.is_grad_enabled() or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5
             or os.environ.get("TCFD_FUSED_LAYER_GRAD", "1") == "0" or not hasattr(conv, "_plain_args")):
         return None
+    # a user subclass that overrides forward() / spectral_conv() is a different convolution: it must run under grad exactly
+    # as it runs under no_grad (through conv(v)), never be rebuilt from the parent's parameters
+    cls = type(conv)
+    if cls.forward not in (SpectralConvS.forward, SpectralConvT.forward) or cls.spectral_conv is not SpectralConvS.spectral_conv \
+            or cls._plain_args not in (SpectralConvS._plain_args, SpectralConvT._plain_args):
+        return None
     cargs = conv._plain_args(v, out_steps)
     if cargs is None:
         return None
