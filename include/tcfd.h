@@ -337,6 +337,28 @@ int tcfd_fno_sample_outer_sums(const void* dy, const void* x, const void* pe, vo
 int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks, int dtype,
                          void* stream);
 
+/* ---- SobolevLoss in three launches (fno/losses.py:263-315; BASELINE config 5 "forward + loss") -------------------------
+ * x, y: (batch, n, n, nt) real, TIME-LAST and contiguous, read in place (no permuted copies, no x - y tensor).
+ *   pass 1  per (b, row) slab: d = x - y while staging, one complex n-point FFT per time step of d_t + i y_t, Hermitian
+ *           separation -> half-spectrum planes (field, b, t, row, ky) in the workspace
+ *   pass 2  n-point FFT down 128-byte column tiles, |.|^2 * w2 accumulated in double (no spectrum written)
+ *   pass 3  the scalar (relative / mesh-weighted / time-averaged / batch mean or sum, losses.py:297-314)
+ * The plan holds the twiddle table of one (n, precision): n a power of two in [16, 1024]; dtype TCFD_C64 = float data,
+ * TCFD_C128 = double data.  w2: (n, n/2+1) real table of the data's precision = weight^2 of the half spectrum with the
+ * Hermitian multiplicity (1 on the DC / Nyquist columns, else 2) and the fft-norm scale folded in -- the caller builds it
+ * once per (n, order, alpha, cutoff, norm).  nfields = 2: both ||w (x - y)^|| and ||w y^|| (relative loss); 1: the first only
+ * (y may be NULL: the norm of x).  out: ONE scalar of the data's precision (device memory); sums (optional, device):
+ * (nfields, batch, nt) doubles = the per-time squared norms.  tcfd_sobolev_loss_supported: 0 when nt time steps of an
+ * n-point row do not fit one workgroup (the caller then composes the loss from tcfd_rfft2 + tcfd_weighted_sqnorm). */
+typedef struct tcfd_loss_plan tcfd_loss_plan;
+int tcfd_loss_plan_create(tcfd_loss_plan** out, int n, int dtype);
+void tcfd_loss_plan_destroy(tcfd_loss_plan* p);
+size_t tcfd_loss_workspace_bytes(const tcfd_loss_plan* p, long batch, int nt, int nfields);
+int tcfd_sobolev_loss_supported(const tcfd_loss_plan* p, int nt, int nfields);
+int tcfd_sobolev_loss(const tcfd_loss_plan* p, const void* x, const void* y, const void* w2, long batch, int nt, int nfields,
+                      int relative, int mesh_weighted, int time_average, int reduction, void* out, void* sums, void* ws,
+                      size_t ws_bytes, void* stream);
+
 /* STREAM-style device probe (measurement aid, SURVEY 8d "verify with a device STREAM-style probe"): `iters`
  * launches of a 16-byte-per-lane grid-stride kernel over `bytes` (a multiple of 16) of caller-owned device memory,
  * timed with HIP events on `stream`.  mode 0: copy src -> dst (2*bytes of traffic per launch); 1: read-only
@@ -351,6 +373,14 @@ int tcfd_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int iters
  * blocking `.cpu()` calls per record, fno/data_gen/solvers.py:246-250). */
 int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t row_bytes,
                            size_t rows, void* stream);
+
+/* Page-lock / release a range of ordinary (pageable) host memory, so that tcfd_copy_rows_to_host into it is a true
+ * asynchronous DMA.  The ensemble driver locks its result region by region from a helper thread while the steps run: one
+ * page-locked allocation of the whole result would hold the runtime's memory lock for its whole duration and stall every
+ * device allocation of the stepping thread behind it (measured: 0.14 - 0.28 s stalls at 5.4 GB).  The caller keeps the
+ * memory alive until it has been unregistered. */
+int tcfd_host_register(void* ptr, size_t bytes);
+int tcfd_host_unregister(void* ptr);
 
 #endif /* TCFD_H_TYPES_ONLY */
 

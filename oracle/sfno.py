@@ -57,7 +57,8 @@ def _ffn(v, sd, prefix, act):
 
 def sfno_forward(sd: Dict[str, torch.Tensor], v: torch.Tensor, modes: Sequence[int], width: int, num_hidden: int,
                  out_steps: int, latent_steps: int = 10, beta: float = -1e-2, delta: float = 1e-1,
-                 activation: str = "ReLU", norm: str = "backward", lift_activation: bool = True) -> torch.Tensor:
+                 activation: str = "ReLU", norm: str = "backward", lift_activation: bool = True,
+                 spatial_padding: int = 0) -> torch.Tensor:
     """(b, x, y, t_in) -> (b, x, y, out_steps); ``sd`` = the model's ``state_dict`` on the CPU,
     ``num_hidden`` = num_spectral_layers - 1."""
     act = _ACT[activation]
@@ -81,7 +82,12 @@ def sfno_forward(sd: Dict[str, torch.Tensor], v: torch.Tensor, modes: Sequence[i
     v = _conv1(v, sd, "reduction")
     # ---- output operator (out_dim = 1: no Helmholtz projection)
     frames = torch.cat([v_res.unsqueeze(1)[..., -1:], v], dim=-1)
+    sp = spatial_padding
+    if sp > 0:      # fno/sfno.py:313-321: zero frame of sp points around the spatial grid, cropped again after the convolution
+        frames = F.pad(frames, (0, 0, sp, sp, sp, sp))
     out = spectral_conv_t(frames, _complex_blocks(sd, "output_operator.conv", "weight"), modes,
                           _complex_blocks(sd, "output_operator.conv", "bias"), delta, out_steps=out_steps + 1,
                           temporal_padding=True, norm=norm)
+    if sp > 0:
+        out = out[..., sp:-sp, sp:-sp, :]
     return (v_res.unsqueeze(1)[..., -1:] + out[..., -out_steps:]).squeeze(1)

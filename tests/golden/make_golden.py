@@ -285,6 +285,54 @@ def gen_sfno():
     save("fno_sfno_tiny.npz", **out)
 
 
+def gen_sfno_padding():
+    """Round 4: what the round-3 build raised on.  ``SFNO(spatial_padding=8)`` on 16^2 (the output convolution then runs on
+    32^2) and on 24^2 (-> 40^2: no power of two anywhere), a 96^2 ``SpectralConvS`` layer, and the reference GRADIENTS of a
+    spatially + temporally resampled ``SpectralConvS`` (fno/base.py:229-237 with ``out_mesh_size``)."""
+    torch.set_default_dtype(torch.float32)
+    from fno.sfno import SFNO, SpectralConvS
+
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    for n in (16, 24):
+        torch.manual_seed(0)
+        model = SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10, spatial_padding=8).eval()
+        with torch.no_grad():
+            for b_ in model.output_operator.conv.bias:
+                b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+            x = torch.randn(2, n, n, 10, generator=g)
+            out[f"pad{n}_x"] = npy(x)
+            for k, v in model.state_dict().items():
+                out[f"pad{n}_sd_" + k] = npy(v)
+            out[f"pad{n}_y10"] = npy(model(x))
+            out[f"pad{n}_y20"] = npy(model(x, out_steps=20))
+    with torch.no_grad():
+        x96 = torch.randn(1, 3, 96, 96, 10, generator=g)
+        torch.manual_seed(4)
+        m = SpectralConvS(3, 4, 12, 12, 5, bias=True, delta=0.5)
+        for b_ in m.bias:
+            b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+        out["c96_x"] = npy(x96)
+        for k, v in m.state_dict().items():
+            out["c96_sd_" + k] = npy(v)
+        out["c96_y"] = npy(m(x96))
+    # gradients of a resampled layer: (16, 16, 10) -> (24, 20, 12) and -> (12, 16, 8)
+    for tag, size in (("up", [24, 20, 12]), ("down", [12, 16, 8])):
+        torch.manual_seed(5)
+        m = SpectralConvS(3, 4, 4, 3, 3)
+        x = torch.randn(2, 3, 16, 16, 10, generator=g).requires_grad_(True)
+        y = m(x, out_mesh_size=size)
+        cot = torch.randn(y.shape, generator=g)
+        (y * cot).sum().backward()
+        out[f"rs_{tag}_x"], out[f"rs_{tag}_cot"], out[f"rs_{tag}_y"] = npy(x), npy(cot), npy(y)
+        out[f"rs_{tag}_gx"] = npy(x.grad)
+        for k, v in m.state_dict().items():
+            out[f"rs_{tag}_sd_" + k] = npy(v)
+        for k, prm in m.named_parameters():
+            out[f"rs_{tag}_g_" + k] = npy(prm.grad)
+    save("fno_sfno_padding.npz", **out)
+
+
 def gen_grads():
     """Reference gradients (torch autograd through torch.fft on the CPU, fp32): SpectralConvS, SpectralConvT with
     temporal padding / resampling, and the tiny SFNO of gen_sfno under a SobolevLoss -- parameter and input grads."""
@@ -416,7 +464,7 @@ def gen_legacy_cn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "grads", "imex",
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "sfno_padding", "grads", "imex",
                              "helmholtz", "legacy_cn"]
     for w in which:
         globals()["gen_" + w]()

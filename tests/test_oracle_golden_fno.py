@@ -101,3 +101,32 @@ def test_oracle_sfno_matches_reference_golden(steps):
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
     y = OS.sfno_forward(sd, torch.from_numpy(g["x"]), (4, 4, 3), width=4, num_hidden=2, out_steps=steps)
     assert rel_l2(y, g[f"y{steps}"]) < 2e-6
+
+
+@pytest.mark.parametrize("n", [16, 24])
+@pytest.mark.parametrize("steps", [10, 20])
+def test_oracle_sfno_with_spatial_padding_matches_reference_golden(n, steps):
+    """``SFNO(spatial_padding=8)`` (fno/sfno.py:313-328): the output convolution runs on the zero-framed (n + 16)^2 grid."""
+    from oracle import sfno as OS
+
+    g = load_golden("fno_sfno_padding.npz")
+    sd = {k[len(f"pad{n}_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"pad{n}_sd_")}
+    y = OS.sfno_forward(sd, torch.from_numpy(g[f"pad{n}_x"]), (4, 4, 3), width=4, num_hidden=2, out_steps=steps, spatial_padding=8)
+    assert rel_l2(y, g[f"pad{n}_y{steps}"]) < 2e-6
+
+
+def test_oracle_96_layer_and_resampled_gradients_match_reference_golden():
+    """A 96^2 layer, and output + gradients of a layer resampled in space and time (``out_mesh_size``, fno/base.py:229-237)."""
+    g = load_golden("fno_sfno_padding.npz")
+    w, b = weights_from_sd(g, "c96")
+    y = OF.spectral_conv(torch.from_numpy(g["c96_x"]), w, (12, 12, 5), b, delta=0.5)
+    assert rel_l2(y, g["c96_y"]) < 1e-6
+    for tag in ("up", "down"):
+        x = torch.from_numpy(g[f"rs_{tag}_x"]).requires_grad_(True)
+        wr = [torch.from_numpy(g[f"rs_{tag}_sd_weight.{k}"]).requires_grad_(True) for k in range(4)]
+        y = OF.spectral_conv(x, [torch.view_as_complex(a) for a in wr], (4, 3, 3), out_size=g[f"rs_{tag}_y"].shape[-3:])
+        assert rel_l2(y, g[f"rs_{tag}_y"]) < 1e-6
+        (y * torch.from_numpy(g[f"rs_{tag}_cot"])).sum().backward()
+        assert rel_l2(x.grad, g[f"rs_{tag}_gx"]) < 1e-6
+        for k in range(4):
+            assert rel_l2(wr[k].grad, g[f"rs_{tag}_g_weight.{k}"]) < 1e-6

@@ -24,7 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_NAME = "libtcfd_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip")
+SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_loss.hip")
 
 TCFD_C64, TCFD_C128 = 0, 1
 ABI_VERSION = 4   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
@@ -72,7 +72,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 # float32 kernels -- so that the three hipcc processes take ~3 minutes side by side instead of 7 for the solver file alone.
 JOBS = (("tcfd_ns2d.hip", ("-DTCFD_UNIT=0",), "tcfd_ns2d.o"),
         ("tcfd_ns2d.hip", ("-DTCFD_UNIT=1",), "tcfd_ns2d_f32.o"),
-        ("tcfd_fno.hip", (), "tcfd_fno.o"))
+        ("tcfd_fno.hip", (), "tcfd_fno.o"),
+        ("tcfd_loss.hip", (), "tcfd_loss.o"))
 
 
 def _build_locked(srcs, verbose):
@@ -157,8 +158,15 @@ SIGNATURES = {
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     "tcfd_weighted_sqnorm": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp]),
+    "tcfd_loss_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i]),
+    "tcfd_loss_plan_destroy": (None, [_vp]),
+    "tcfd_loss_workspace_bytes": (_sz, [_vp, _l, _i, _i]),
+    "tcfd_sobolev_loss_supported": (_i, [_vp, _i, _i]),
+    "tcfd_sobolev_loss": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "tcfd_hbm_probe": (_i, [_vp, _vp, ctypes.c_size_t, _i, _i, ctypes.POINTER(ctypes.c_float), _vp]),
     "tcfd_copy_rows_to_host": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
+    "tcfd_host_register": (_i, [_vp, _sz]),
+    "tcfd_host_unregister": (_i, [_vp]),
 }
 
 

@@ -202,11 +202,34 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>
     const int count = (int)(slabs - base < NS ? slabs - base : NS);
     const size_t slab_elems = (size_t)Y * T_in;
     {
+        // Stage the workgroup's slabs (one contiguous range of global memory).  EIGHT 16-byte loads per lane are issued before
+        // the first one is used: written as a plain load -> LDS-store loop, hipcc waits for every load before it issues the
+        // next (`global_load_dwordx4; s_waitcnt vmcnt(0); ds_write_b128` per trip: one KB in flight per wave, eight memory round
+        // trips per workgroup -- the kernel read at 3.9 TB/s where the box's read probe reaches 6.3).
         const b128* s4 = reinterpret_cast<const b128*>(v + (size_t)base * slab_elems);
         const int n4 = (int)(slab_elems * sizeof(T) / 16);
-        for (int q = 0; q < count; ++q) {
-            b128* d4 = reinterpret_cast<b128*>(slabs_b + (size_t)q * per);
-            for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[(size_t)q * n4 + i];
+        const int total4 = count * n4;
+        const bool contig = per == (size_t)n4 * 16;      // the exchange buffers are no larger than the slab: LDS is one range too
+        constexpr int UN = 8;
+        for (int i0 = threadIdx.x; i0 < total4; i0 += UN * blockDim.x) {
+            b128 r[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int idx = i0 + u * blockDim.x;
+                if (idx < total4) r[u] = __builtin_nontemporal_load(s4 + idx);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int idx = i0 + u * blockDim.x;
+                if (idx < total4) {
+                    if (contig) {
+                        reinterpret_cast<b128*>(slabs_b)[idx] = r[u];
+                    } else {
+                        const int q = idx / n4;
+                        reinterpret_cast<b128*>(slabs_b + (size_t)q * per)[idx - q * n4] = r[u];
+                    }
+                }
+            }
         }
         for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
     }

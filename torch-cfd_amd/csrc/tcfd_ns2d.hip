@@ -2929,6 +2929,20 @@ TCFD_API int tcfd_copy_rows_to_host(void* dst_host, size_t dst_pitch, const void
     return 0;
 }
 
+// Page-lock / release a range of ordinary host memory (hipHostRegister): the record hand-over locks the result of an
+// ensemble job region by region on a helper thread -- ONE page-locked allocation of the whole result holds the runtime's
+// memory lock for its full duration (0.36 s at 5.4 GB) and stalls every hipMalloc of the stepping thread behind it.
+TCFD_API int tcfd_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(TCFD_EINVAL, "host_register: bad argument");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+TCFD_API int tcfd_host_unregister(void* ptr) {
+    if (!ptr) return fail(TCFD_EINVAL, "host_unregister: null pointer");
+    HIP_TRY(hipHostUnregister(ptr));
+    return 0;
+}
+
 // ---------------------------------------------------------------- stage bookkeeping of the DIFFERENTIABLE step
 // With constant coefficients a stage of the low-storage RK / Crank-Nicolson schedule is linear in (f, h_prev, b):
 //     h = fa f + beta h_prev ,    u = (b + gdt h + mu L b) / (1 - mud L)            (L: the real (n, m) linear term)

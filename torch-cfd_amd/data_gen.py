@@ -89,12 +89,20 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     n_rec = len(range(0, total_steps, record_every_steps))
     handover = RecordHandover(TRAJECTORY_FIELDS, total_samples, n_rec, (ns, ns), dtype, layout, device, dst=dst)
     on_gpu = device.type == "cuda"
+    if on_gpu and layout[rank]:
+        # every plan the loop will ask for, NOW: plan creation is host work on fresh memory (tables in float64 on the CPU,
+        # their upload), and it must not run beside the page-locking of the result -- that holds the process's memory-map
+        # lock and makes every page fault of this thread wait (measured: the first record of the C4 job 0.14 s late)
+        cplx = torch.complex128 if real == torch.float64 else torch.complex64
+        op._plan(torch.empty(0, n, n // 2 + 1, dtype=cplx, device=device))
+        fft_plan(n, torch.promote_types(cdtype, torch.complex64), device)
     if on_gpu:
         torch.cuda.synchronize(device)
     t_setup = time.perf_counter()
     for start, count in layout[rank]:
         seeds = [random_state + start + k for k in range(count)]
         w = plan.rfft2(vorticity_field(grid, peak_wavenumber, batch_seeds=seeds, device=device))
+        handover.start_allocation()     # page-lock the result now: under the warm-up steps, not under the CPU noise above
         if warmup_steps > 0:
             w, _ = op._fused_steps(w, dt, warmup_steps, want_dwdt=False)
 
@@ -111,6 +119,8 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     t_stepped = time.perf_counter()
     full = handover.finish()
     t_end = time.perf_counter()
+    if stats is not None and handover.trace is not None:
+        stats["trace"] = list(handover.trace)
     if stats is not None:
         stats.update(setup_s=t_setup - t_begin, stepping_s=t_stepped - t_setup, handover_tail_s=t_end - t_stepped,
                      batches=len(layout[rank]), samples=sum(c for _, c in layout[rank]))

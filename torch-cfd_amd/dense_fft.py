@@ -100,3 +100,79 @@ def irfftn_dense(vh: torch.Tensor, s: Sequence[int], norm="backward") -> torch.T
     y = g.real @ _table("c2r_re", n, keep, real, vh.device) - g.imag @ _table("c2r_im", n, keep, real, vh.device)
     f = _norm_factor(norm, math.prod(s), inverse=True)
     return y * f if f != 1.0 else y
+
+
+# ----------------------------------------------------------------------------- truncated (2+1)-D transforms, any X / Y
+# The fused FNO kernels (csrc/tcfd_fno.hip) transform power-of-two X and Y.  Every other spatial size -- a 96^2 / 192^2
+# data set, the X + 2p grid of ``SFNO(spatial_padding=p)`` (fno/sfno.py:313-328) -- runs the SAME pruned transforms as
+# matrix products with the kept rows of the DFT matrices: only 2mx x 2my x mt modes are ever formed
+# (fno/sfno.py:379-381), so the matrices are (X, 2mx), (Y, 2my), (T, mt) -- three thin GEMMs per direction (rocBLAS),
+# differentiable through autograd.  torch's semantics as above: the left zero padding in t is skipped arithmetically, an
+# output grid other than the input's keeps the high-frequency block at the ARRAY indices it had on the source grid.
+def _kept_indices(n: int, m: int, device) -> torch.Tensor:
+    """Array indices of the rows [:m] + [-m:] of a length-n spectrum axis, in truncated order."""
+    return torch.cat([torch.arange(m, device=device), torch.arange(n - m, n, device=device)])
+
+
+def _trunc_table(kind: str, key: Tuple, real: torch.dtype, device) -> torch.Tensor:
+    full = ("trunc", kind) + key + (real, str(device))
+    t = _TABLES.get(full)
+    if t is not None:
+        return t
+    cdt = torch.complex128 if real == torch.float64 else torch.complex64
+    if kind == "fwd_xy":            # (n, 2m): e^{-2 pi i j k / n} at the kept k
+        n, m = key
+        ang = (2 * math.pi / n) * ((torch.arange(n, device=device)[:, None] * _kept_indices(n, m, device)[None, :]) % n).to(torch.float64)
+        t = torch.polar(torch.ones_like(ang), -ang).to(cdt)
+    elif kind == "fwd_t":           # (T, mt) complex: e^{-2 pi i kt (t + t_pad) / Tp}
+        T, t_pad, mt = key
+        Tp = T + t_pad
+        tt = torch.arange(T, device=device) + t_pad
+        ang = (2 * math.pi / Tp) * ((tt[:, None] * torch.arange(mt, device=device)[None, :]) % Tp).to(torch.float64)
+        t = torch.polar(torch.ones_like(ang), -ang).to(cdt)
+    elif kind == "inv_xy":          # (2m, n_out): e^{+2 pi i j a / n_out}, a = array index on the SOURCE grid; rows beyond n_out vanish
+        n_out, n_src, m = key
+        a = _kept_indices(n_src, m, device)
+        ang = (2 * math.pi / n_out) * ((a[:, None] * torch.arange(n_out, device=device)[None, :]) % n_out).to(torch.float64)
+        t = torch.polar(torch.ones_like(ang), ang)
+        t = torch.where((a < n_out)[:, None], t, torch.zeros_like(t)).to(cdt)
+    else:                           # "inv_t_re" / "inv_t_im": (mt, t_keep) real c2r rows of the LAST t_keep output steps
+        T_out, t_keep, mt = key
+        k = torch.arange(mt, device=device)
+        tt = torch.arange(T_out - t_keep, T_out, device=device)
+        ang = (2 * math.pi / T_out) * ((k[:, None] * tt[None, :]) % T_out).to(torch.float64)
+        c = torch.full((mt,), 2.0, dtype=torch.float64, device=device)
+        c[0] = 1.0
+        if T_out % 2 == 0 and mt > T_out // 2:
+            c[T_out // 2] = 1.0
+        c = torch.where(k <= T_out // 2, c, torch.zeros_like(c))        # torch trims the spectrum to T_out // 2 + 1 columns
+        t = (c[:, None] * (torch.cos(ang) if kind == "inv_t_re" else torch.sin(ang))).to(real)
+    _TABLES[full] = t
+    return t
+
+
+def truncated_rfftn_dense(v: torch.Tensor, modes: Sequence[int], t_pad: int = 0) -> torch.Tensor:
+    """Kept modes of ``rfftn(left_pad_t(v, t_pad))`` (unnormalised): (b, C, X, Y, T) real -> (b, C, 2mx, 2my, mt) complex."""
+    b, c, X, Y, T = v.shape
+    mx, my, mt = modes
+    if 2 * mx > X or 2 * my > Y or mt > (T + t_pad) // 2 + 1:
+        raise ValueError(f"modes {tuple(modes)} exceed the spectrum of a ({X}, {Y}, {T + t_pad}) grid")
+    real, dev = v.dtype, v.device
+    at = _trunc_table("fwd_t", (T, t_pad, mt), real, dev)
+    h = torch.complex(v @ at.real.contiguous(), v @ at.imag.contiguous())          # (b, C, X, Y, mt)
+    h = torch.einsum("bcxyt,yk->bcxkt", h, _trunc_table("fwd_xy", (Y, my), real, dev))
+    return torch.einsum("bcxkt,xj->bcjkt", h, _trunc_table("fwd_xy", (X, mx), real, dev))
+
+
+def truncated_irfftn_dense(oh: torch.Tensor, out_size: Sequence[int], src_xy: Sequence[int], t_keep: int) -> torch.Tensor:
+    """``irfftn(spectrum that is zero outside the kept modes, s=out_size)[..., -t_keep:]`` (unnormalised):
+    (b, C, 2mx, 2my, mt) -> (b, C, Xo, Yo, t_keep).  ``src_xy`` = the grid the modes were taken from."""
+    Xo, Yo, To = (int(n) for n in out_size)
+    Xs, Ys = (int(n) for n in src_xy)
+    mx, my, mt = oh.shape[2] // 2, oh.shape[3] // 2, oh.shape[4]
+    real = torch.float64 if oh.dtype == torch.complex128 else torch.float32
+    dev = oh.device
+    g = torch.einsum("bcjkt,jx->bcxkt", oh, _trunc_table("inv_xy", (Xo, Xs, mx), real, dev))
+    g = torch.einsum("bcxkt,ky->bcxyt", g, _trunc_table("inv_xy", (Yo, Ys, my), real, dev))
+    return (g.real @ _trunc_table("inv_t_re", (To, t_keep, mt), real, dev)
+            - g.imag @ _trunc_table("inv_t_im", (To, t_keep, mt), real, dev))

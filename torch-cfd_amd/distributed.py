@@ -168,33 +168,62 @@ class RecordHandover:
         self._outbox: list = []        # staged peers: (event, page-locked copy) of records not yet handed to gloo
         self._inbox: list = []         # staged dst: (work, staging tensor, start, count, record) of receives in flight
         self.host: Optional[Dict[str, torch.Tensor]] = None
+        import os
+        import time
+
+        self.trace = [] if os.environ.get("TCFD_HANDOVER_TRACE") == "1" else None
+        self._t0 = time.perf_counter()
         self._host_ready: Dict[str, object] = {}
         self._alloc_thread = None
+        self._alloc_pending = None
+        self._deferred: list = []      # (buffer, field, ...) copies waiting for their page-locked host field
         self._alloc_error: Optional[BaseException] = None
         if self.rank == dst:
             shape = (total, n_rec) + self.trailing
             if self.on_gpu and lazy_host:
                 # Page-locking the result is host work proportional to the WHOLE data set (5.4 GB at BASELINE config 4:
-                # ~0.5 s) that only rank dst does -- serial time no number of GPUs shrinks.  It runs on a helper thread,
-                # field by field, while the first record_every steps are computed; a copy into a field waits for that
-                # field only (the first record exists ~100 steps into the job).
+                # ~0.4 s) that only rank dst does -- serial time no number of GPUs shrinks -- so it runs on a helper thread
+                # under the steps.  Not as one page-locked allocation: that holds the runtime's memory lock for its whole
+                # duration, and every hipMalloc of the stepping thread (the caching allocator asking for a block) waits behind
+                # it (measured: stalls of 0.14 - 0.28 s, the 8-GPU job's rank 0 at 1.4 s instead of 1.05).  The result is
+                # ordinary memory (allocated at once); the helper page-locks it REGION BY REGION -- the rows of one batch in
+                # one field, the unit a record's pitched copy writes into -- in the order the records will arrive, with a
+                # pause between regions that lets other threads at the lock; a copy waits (deferred, never blocking the
+                # caller) only for its own region.
                 import threading
 
-                self.host = {}
-                self._host_ready = {f: threading.Event() for f in self.fields}
+                self.host = {f: torch.empty(shape, dtype=dtype) for f in self.fields}
+                order = []          # (field, start, count): dst's own batches first, then batch k of every peer
+                ranks = [dst] + [r for r in range(self.world) if r != dst]
+                for k in range(max((len(bt) for bt in layout), default=0)):
+                    for r in ranks:
+                        if k < len(layout[r]) and layout[r][k][1] > 0:
+                            order.extend((f, layout[r][k][0], layout[r][k][1]) for f in self.fields)
+                self._host_ready = {(f, s0): threading.Event() for f, s0, _ in order}
+                self._registered: list = []
 
                 def allocate():
+                    import time as _time
+
+                    from . import _lib as L
+
+                    lib = L.load()
                     try:
-                        for f in self.fields:
-                            self.host[f] = torch.empty(shape, dtype=dtype, pin_memory=True)
-                            self._host_ready[f].set()
+                        self._trace("page-lock begin")
+                        for f, s0, c in order:
+                            view = self.host[f][s0:s0 + c]
+                            ptr = view.data_ptr()
+                            L.check(lib.tcfd_host_register(ptr, view.numel() * view.element_size()), "tcfd_host_register")
+                            self._registered.append(ptr)
+                            self._host_ready[(f, s0)].set()
+                            _time.sleep(0.0005)
+                        self._trace("page-lock end")
                     except BaseException as e:   # surfaced by the next _land / finish on the caller's thread
                         self._alloc_error = e
                         for ev in self._host_ready.values():
                             ev.set()
 
-                self._alloc_thread = threading.Thread(target=allocate, name="tcfd-pinned-result", daemon=True)
-                self._alloc_thread.start()
+                self._alloc_pending = allocate       # started by start_allocation()
             else:
                 self.host = {f: torch.empty(shape, dtype=dtype, pin_memory=self.on_gpu) for f in self.fields}
         if self.on_gpu:
@@ -219,23 +248,83 @@ class RecordHandover:
                 work.wait()                      # orders the side stream behind the receive, the host does not block
             else:
                 self.side.wait_stream(main)      # own record: produced on the caller's stream
-            F = len(self.fields)
-            import ctypes
-
             for f, name in enumerate(self.fields):
-                h = self._host_field(name)
-                rc = self._clib.tcfd_copy_rows_to_host(
-                    h[start, rec].data_ptr(), self.n_rec * self.row_bytes, buf[:, f].data_ptr(), F * self.row_bytes,
-                    self.row_bytes, count, ctypes.c_void_p(self.side.cuda_stream))
-                self._lib.check(rc, "tcfd_copy_rows_to_host")
+                if self._field_ready(name, start):
+                    self._copy_field(buf, f, name, start, count, rec)
+                else:                            # its page-locked field is still being allocated: the copy follows later,
+                    self._deferred.append((buf, f, name, start, count, rec))   # the caller's thread never waits for it
             done = torch.cuda.Event()
             done.record(self.side)
         self._keep.append((done, buf))
 
-    def _host_field(self, name: str) -> torch.Tensor:
-        ev = self._host_ready.get(name)
+    def _copy_field(self, buf, f: int, name: str, start: int, count: int, rec: int):
+        """Pitched device -> host copy of field f of a record into host[name][start:start+count, rec] (current stream = side)."""
+        import ctypes
+
+        h = self.host[name]
+        rc = self._clib.tcfd_copy_rows_to_host(
+            h[start, rec].data_ptr(), self.n_rec * self.row_bytes, buf[:, f].data_ptr(), len(self.fields) * self.row_bytes,
+            self.row_bytes, count, ctypes.c_void_p(self.side.cuda_stream))
+        self._lib.check(rc, "tcfd_copy_rows_to_host")
+
+    def _field_ready(self, name: str, start: int) -> bool:
+        ev = self._host_ready.get((name, start))
+        if ev is None:
+            return True
+        if self._alloc_thread is None:
+            self.start_allocation()
+        if ev.is_set() and self._alloc_error is not None:
+            raise self._alloc_error
+        return ev.is_set()
+
+    def _flush_deferred(self, block: bool):
+        """Issue the copies that waited for their page-locked field (all of them when ``block``)."""
+        if not self._deferred:
+            return
+        left, touched = [], []
+        with torch.cuda.stream(self.side):
+            for item in self._deferred:
+                buf, f, name, start, count, rec = item
+                if block:
+                    self._host_field(name, start)
+                if self._field_ready(name, start):
+                    self._copy_field(buf, f, name, start, count, rec)
+                    touched.append(buf)
+                else:
+                    left.append(item)
+            if touched:
+                done = torch.cuda.Event()
+                done.record(self.side)
+                self._keep.extend((done, b) for b in touched)
+        self._deferred = left
+
+    def start_allocation(self):
+        """Start page-locking the result on the helper thread (idempotent).  The caller picks the moment: page-locking holds
+        the process's memory-map lock for long stretches, so a thread that is first-touching fresh host memory at the same
+        time (the seeded CPU noise of the initial conditions) crawls -- measured: the first record of the C4 job 0.27 s late.
+        ``generate_mcwilliams_dataset`` starts it once the first batch's initial conditions are on the device; without the
+        call the first record's hand-over starts it."""
+        if self._alloc_pending is not None and self._alloc_thread is None:
+            import threading
+
+            self._alloc_thread = threading.Thread(target=self._alloc_pending, name="tcfd-pinned-result", daemon=True)
+            self._alloc_thread.start()
+
+    def _trace(self, what: str):
+        """(label, seconds since construction) pairs when TCFD_HANDOVER_TRACE=1 (tests/micro/c4_pinned_overlap.py)."""
+        if self.trace is not None:
+            import time
+
+            self.trace.append((what, round(time.perf_counter() - self._t0, 4)))
+
+    def _host_field(self, name: str, start: int = 0) -> torch.Tensor:
+        ev = self._host_ready.get((name, start))
         if ev is not None:
-            ev.wait()
+            self.start_allocation()
+            if not ev.is_set():
+                self._trace(f"wait {name} begin")
+                ev.wait()
+                self._trace(f"wait {name} end")
             if self._alloc_error is not None:
                 raise self._alloc_error
         return self.host[name]
@@ -268,7 +357,7 @@ class RecordHandover:
                 continue
             work.wait()
             for f, name in enumerate(self.fields):
-                self._host_field(name)[s:s + c, j].copy_(stage[:, f])
+                self.host[name][s:s + c, j].copy_(stage[:, f])
         self._inbox = left
 
     def _post_receives(self):
@@ -313,7 +402,9 @@ class RecordHandover:
             raise ValueError(f"record must be a contiguous {self.dtype} tensor of shape {want}, got "
                              f"{tuple(packed.shape)} {packed.dtype}")
         self.cursor[self.rank] += 1
+        self._trace(f"push {start} {rec}")
         if self.on_gpu:
+            self._flush_deferred(block=False)
             self._release_finished()
         if self.rank == self.dst:
             self._land(packed, start, count, rec)
@@ -345,13 +436,29 @@ class RecordHandover:
             while self.world > 1 and self._post_receives():
                 pass
             self._drain_inbox(block=True)
-            if self._alloc_thread is not None:
+            if self._alloc_pending is not None:
+                self.start_allocation()
                 self._alloc_thread.join()
                 if self._alloc_error is not None:
                     raise self._alloc_error
+                self._flush_deferred(block=True)
             if self.on_gpu:
                 self.side.synchronize()
             self._keep.clear()
+            registered = getattr(self, "_registered", None)
+            if registered:
+                # release the page locks behind the caller's back: the thread keeps the result alive until every region is
+                # unregistered (unlocking 5 GB is tens of milliseconds nobody has to wait for)
+                import threading
+
+                host, ptrs, lib = self.host, list(registered), self._clib
+                self._registered = []
+
+                def release(alive=host):        # the default argument holds the tensors until the last region is unlocked
+                    for ptr in ptrs:
+                        lib.tcfd_host_unregister(ptr)
+
+                threading.Thread(target=release, name="tcfd-unlock-result").start()
             return self.host
         self._flush_outbox(block=True)
         for works, _ in self._sends:

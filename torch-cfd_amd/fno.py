@@ -118,6 +118,45 @@ def _norm_scales(norm: str, n_in: int, n_out: int) -> Tuple[float, float]:
     raise ValueError(f"unknown fft norm {norm!r}")
 
 
+def _fused_xy(X: int, Y: int) -> bool:
+    """Spatial sizes the fused transform kernels cover (tcfd_fno_plan_create): powers of two in [8, 1024]."""
+    return all(8 <= n <= 1024 and (n & (n - 1)) == 0 for n in (X, Y))
+
+
+def dense_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad: int = 0, t_out: Optional[int] = None,
+                        t_keep: Optional[int] = None, norm: str = "backward", out_xy=None, post=None,
+                        use_mfma: bool = True) -> torch.Tensor:
+    """The spectral convolution for ANY spatial size (the reference's rfftn / irfftn take any mesh, fno/base.py:229-237): the
+    pruned transforms as thin matrix products with the kept rows of the DFT matrices (``dense_fft.truncated_*``: three GEMMs
+    per direction, rocBLAS), the 4-corner contraction on the same MFMA kernel as the fused path.  Differentiable (matmuls +
+    ``_ContractFn``), so it is also the gradient path of a spatially resampled layer.  ``out_xy``: output grid when the layer
+    resamples in space (the high-frequency block keeps its array indices, as torch's ``irfftn(s=...)`` does)."""
+    from .dense_fft import truncated_irfftn_dense, truncated_rfftn_dense
+
+    if not v.is_cuda:
+        raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
+    if v.dtype not in (torch.float32, torch.float64) or v.dim() != 5:
+        raise TypeError(f"expected a real fp32 / fp64 (b, C, X, Y, T) tensor, got {v.dtype} {tuple(v.shape)}")
+    b, ci, X, Y, T = v.shape
+    Xo, Yo = (X, Y) if out_xy is None else (int(out_xy[0]), int(out_xy[1]))
+    t_out = T + t_pad if t_out is None else t_out
+    t_keep = t_out if t_keep is None else t_keep
+    fs, is_ = _norm_scales(norm, X * Y * (T + t_pad), Xo * Yo * t_out)
+    params = list(weights) + (list(bias) if bias is not None else [])
+    if b == 0:
+        return torch.empty(0, weights[0].shape[1], Xo, Yo, t_keep, dtype=v.dtype, device=v.device)
+    vh = truncated_rfftn_dense(v, modes, t_pad)
+    vh = (vh * fs if fs != 1.0 else vh).contiguous()
+    if torch.is_grad_enabled() and (vh.requires_grad or any(p.requires_grad for p in params)):
+        oh = _ContractFn.apply(vh, float(delta), tuple(modes), use_mfma, bias is not None, *params)
+    else:
+        oh = hip_contract(vh, weights, bias, delta, modes, use_mfma=use_mfma)
+    if post is not None:
+        oh = post(oh).to(vh.dtype)
+    out = truncated_irfftn_dense(oh, (Xo, Yo, t_out), (X, Y), t_keep)
+    return out * is_ if is_ != 1.0 else out
+
+
 def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad: int = 0,
                       t_out: Optional[int] = None, t_keep: Optional[int] = None, norm: str = "backward",
                       use_mfma: bool = True) -> torch.Tensor:
@@ -142,6 +181,8 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     co = weights[0].shape[1]
     t_out = T + t_pad if t_out is None else t_out
     t_keep = t_out if t_keep is None else t_keep
+    if not _fused_xy(X, Y):      # 96^2, 272^2 (= 256 + 2 * 8 of spatial_padding), ...: the same pruned transforms as thin GEMMs
+        return dense_spectral_conv(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma=use_mfma)
     params = list(weights) + (list(bias) if bias is not None else [])
     if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params)):
         return hip_spectral_conv_autograd(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma)
@@ -800,7 +841,8 @@ def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, ski
     ``act2(v[..., -1:] + FFN(conv(v)))`` (:258-259), as ONE autograd node (``_SpectralLayerFn``).  Returns None when gradients
     are not being recorded or the combination is not covered; the caller then composes ``conv(v)`` and ``hip_pointwise``."""
     if (not torch.is_grad_enabled() or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5
-            or os.environ.get("TCFD_FUSED_LAYER_GRAD", "1") == "0" or not hasattr(conv, "_plain_args")):
+            or os.environ.get("TCFD_FUSED_LAYER_GRAD", "1") == "0" or not hasattr(conv, "_plain_args")
+            or not _fused_xy(v.shape[2], v.shape[3])):
         return None
     # a user subclass that overrides forward() / spectral_conv() is a different convolution: it must run under grad exactly
     # as it runs under no_grad (through conv(v)), never be rebuilt from the parent's parameters
@@ -1034,7 +1076,8 @@ def hip_conv_pointwise(conv, v: torch.Tensor, mlp, skip: torch.Tensor, skip_conv
     post-processed or resampled convolutions, widths other than 8 / 10, rows that do not fit a workgroup) and the caller
     makes the two calls.  NOT the default: at config 5 it is slower than the two kernels (7.5 vs 5.9 ms per forward --
     one row-sized workgroup per CU cannot hide what 4-8 small ones do); ``TCFD_FNO_FUSE_TAIL=1`` switches the models to it."""
-    if not isinstance(mlp, PointwiseFFN) or not isinstance(conv, SpectralConvS) or not v.is_cuda or v.dtype != torch.float32:
+    if (not isinstance(mlp, PointwiseFFN) or not isinstance(conv, SpectralConvS) or not v.is_cuda or v.dtype != torch.float32
+            or v.dim() != 5 or not _fused_xy(v.shape[2], v.shape[3])):
         return None
     if isinstance(conv, SpectralConvT) and not isinstance(conv.postprocess, nn.Identity):
         return None
@@ -1301,12 +1344,16 @@ class SpectralConvS(SpectralConv):
     def _resampled(self, v, out_size):
         """``irfftn(spectrum, s=out_size)`` with a spatial size other than the input's (fno/base.py:229-237): torch pads /
         trims the spectrum array at its END, so the high-frequency block stays at the array indices it had on the input
-        grid; the inverse plan reproduces exactly that placement (``tcfd_fno_plan_create_resample``).  Forward only."""
-        if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("spatial resampling of SpectralConv is forward-only on the HIP path")
+        grid; the inverse plan reproduces exactly that placement (``tcfd_fno_plan_create_resample``)."""
         b, c, X, Y, T = v.shape
         Xo, Yo, To = out_size
         mx, my, mt = self.modes
+        wants_grad = torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if wants_grad or not (_fused_xy(X, Y) and _fused_xy(Xo, Yo)):
+            # gradients of a resampled layer (super-resolution fine-tuning differentiates it, fno/base.py:229-237) and grids
+            # off the fused kernels: the dense pruned transforms (differentiable)
+            return dense_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, 0, To, To, self.norm,
+                                       out_xy=(Xo, Yo))
         vh, _ = hip_truncated_rfftn(v, self.modes, norm=self.norm)
         oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
         inv = _plan((Xo, Yo, T, 0, To, mx, my, mt, X, Y), v.device, _real_of(v.dtype))
@@ -1340,6 +1387,11 @@ class SpectralConvT(SpectralConvS):
             # so it acts on the kept modes only -- transform, contract, project, inverse-transform
             if not v.is_cuda or v.dtype not in (torch.float32, torch.float64):
                 raise _lib.TcfdError("expected an fp32 / fp64 HIP device tensor (torch-cfd_amd has no CPU fallback)")
+            if not _fused_xy(v.shape[2], v.shape[3]):
+                post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
+                    self.postprocess, "forward_truncated") else self.postprocess
+                return dense_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad,
+                                           out_steps + t_pad, out_steps, self.norm, post=post)
             if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters())):
                 post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
                     self.postprocess, "forward_truncated") else self.postprocess
@@ -1662,6 +1714,9 @@ class SFNO(FNOBase):
 from .autograd import Rfft2 as _Rfft2Fn  # noqa: E402  (rfft2 on the HIP kernels with its hand-written adjoint)
 
 
+_LOSS_PLANS: Dict[tuple, ctypes.c_void_p] = {}   # (n, precision, device) -> tcfd_loss_plan (a twiddle table; lives with the process)
+
+
 def hip_weighted_sqnorm(zh: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     """``(|zh|^2 * w2).sum(dim=(-2, -1))`` for half spectra ``zh`` (*, n, m) and real weights ``w2`` (n, m) in one pass
     over the spectrum (``tcfd_weighted_sqnorm``; double accumulation, the result comes back in ``w2.dtype``)."""
@@ -1720,13 +1775,64 @@ class SobolevLoss(nn.Module):
         self.register_buffer("weight", weight[None, :, :, None])
 
     def _half_spectrum_weights(self, device, dtype):
+        """(n, n/2+1) table: multiplier^2 x Hermitian multiplicity x fft-norm scale.  Built once per (device, dtype) and
+        state of the ``weight`` buffer -- it took ~20 small launches per call, more than the loss kernels themselves."""
+        key = (torch.device(device), dtype, self.weight.data_ptr(), self.weight._version, self.norm_order, self._sq_scale)
+        cached = getattr(self, "_w2_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         n = self.n_grid
-        w = torch.sqrt(self.weight[0, :, : n // 2 + 1, 0].to(device=device, dtype=dtype))
-        w = w ** (self.norm_order / 2) if self.norm_order != 0 else w
+        # sqrt and power in the BUFFER's precision, as the reference forms its multiplier (losses.py:279-289) before the
+        # product with the spectrum promotes it: a float32 module on float64 data uses float32-rounded weights there too
+        # (and on the CPU, once: a device pow differs from the CPU's in the last float32 bit, 5e-10 on an order -1 loss)
+        w = torch.sqrt(self.weight[0, :, : n // 2 + 1, 0].detach().cpu())
+        w = (w ** (self.norm_order / 2) if self.norm_order != 0 else w).to(device=device, dtype=dtype)
         herm = torch.full((n // 2 + 1,), 2.0, dtype=dtype, device=device)  # |X[k]|^2 counted twice except DC/Nyquist
         herm[0] = 1.0
         herm[-1] = 1.0
-        return w**2 * herm * self._sq_scale
+        w2 = (w**2 * herm * self._sq_scale).contiguous()
+        self._w2_cache = (key, w2)
+        return w2
+
+    def _fused(self, x, y):
+        """The loss in three launches on the time-last tensors in place (``tcfd_sobolev_loss``, csrc/tcfd_loss.hip), or None
+        when this call is outside its cover (gradients wanted, a grid that is not a power of two in [16, 1024], more time
+        steps than one workgroup transforms)."""
+        if os.environ.get("TCFD_LOSS_FUSED", "1") == "0" or not x.is_cuda or x.dtype not in (torch.float32, torch.float64):
+            return None
+        if torch.is_grad_enabled() and (x.requires_grad or (y is not None and y.requires_grad)):
+            return None
+        bsz, n, n2, nt = x.shape
+        if n != n2 or n < 16 or n > 1024 or (n & (n - 1)) or bsz == 0 or (y is not None and (y.shape != x.shape or y.dtype != x.dtype)):
+            return None
+        lib = _lib.load()
+        code = _lib.TCFD_C128 if x.dtype == torch.float64 else _lib.TCFD_C64
+        pkey = (n, code, x.device)
+        plan = _LOSS_PLANS.get(pkey)
+        if plan is None:
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(x.device):
+                _lib.check(lib.tcfd_loss_plan_create(ctypes.byref(handle), n, code), "tcfd_loss_plan_create")
+            plan = _LOSS_PLANS[pkey] = handle
+        nf = 2 if (self.relative and y is not None) else 1
+        if not lib.tcfd_sobolev_loss_supported(plan, nt, nf):
+            return None
+        xc = x.contiguous()
+        yc = y.contiguous() if y is not None else None
+        w2 = self._half_spectrum_weights(x.device, x.dtype)
+        need = lib.tcfd_loss_workspace_bytes(plan, bsz, nt, nf)
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need or ws.device != x.device:
+            self._ws = None
+            ws = self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        out = torch.empty((), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.tcfd_sobolev_loss(plan, xc.data_ptr(), yc.data_ptr() if yc is not None else None, w2.data_ptr(), bsz,
+                                             nt, nf, int(bool(self.relative and y is not None)), int(bool(self.mesh_weighted)),
+                                             int(bool(self.time_average)), int(bool(self.reduction)), out.data_ptr(), None,
+                                             ws.data_ptr(), ws.numel(),
+                                             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "tcfd_sobolev_loss")
+        return out
 
     def forward(self, x, y=None):
         from .equations import fft_plan
@@ -1737,6 +1843,9 @@ class SobolevLoss(nn.Module):
         bsz, n, _, nt = x.shape
         if n != self.n_grid:
             raise ValueError(f"grid {n} != n_grid {self.n_grid}")
+        fused = self._fused(x, y)
+        if fused is not None:
+            return fused
         plan = fft_plan(n, torch.complex64 if x.dtype == torch.float32 else torch.complex128, x.device, self.diam)
         w2 = self._half_spectrum_weights(x.device, x.dtype)
 
