@@ -341,10 +341,26 @@ def sfno_config5(dev, with_cpu=True):
             t_bwd = timeit(bwd, 10)
         del x1, v
         ach = 3 * A_H / (t_blk * 1e-3) / 1e9
+        # L2 <-> memory bytes per launch from the rocprofv3 PMC passes of tests/prof_sfno.sh (profiles/sfno_traffic.json ships with
+        # the repo, it is not re-measured by this run): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the guide's gfx950 correction
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "sfno_traffic.json")))
+        except Exception:
+            tj = {}
+        pw_key = next((k for k in tj if k.startswith("k_pointwise<10, 40, 10")), None)
+        kern_table = {k: {kk: vv for kk, vv in v.items() if kk in ("launches_in_profile", "avg_us", "algo_bytes", "algo_TBps", "traffic_bytes",
+                                                                    "l2_hit", "lds_conflict_share", "what")}
+                      for k, v in tj.items() if isinstance(v, dict)}
         roof = {"kernel": "k_pointwise<10,40,10> (FFN + skip conv + activation of one hidden layer)", "bound": "hbm",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "algo_bytes_per_launch": 3 * A_H, "avg_launch_ms": round(t_blk, 4), "launches_per_forward": 4,
-                "traffic": None,
+                "traffic": tj.get(pw_key, {}).get("traffic_bytes") if pw_key else None,
+                "traffic_source": ("profiles/sfno_traffic.json (rocprofv3 --pmc passes of tests/bench_sfno.py, tests/prof_sfno.sh): "
+                                   "bytes between L2 and the memory side per launch; the 839 MB activations exceed the Infinity Cache"
+                                   ) if pw_key else None,
+                "also_compute_bound": "900 FMAs per point as v_pk_fma_f32: 0.48 ms of packed-fp32 issue per launch at the 157 TFLOP/s "
+                                      "vector peak, beside 0.31 ms of HBM time at 8 TB/s -- the kernel sits at ~0.8 of BOTH",
+                "kernels_from_profile": kern_table or None,
                 "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
                                     "algo_bytes_per_launch": 5 * A_H, "avg_launch_ms": round(t_bwd, 4),
                                     "achieved": round(5 * A_H / (t_bwd * 1e-3) / 1e9, 1),

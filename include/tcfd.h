@@ -337,6 +337,27 @@ int tcfd_fno_sample_outer_sums(const void* dy, const void* x, const void* pe, vo
 int tcfd_weighted_sqnorm(const void* z, const void* w2, void* partial, long batch, long elems, int blocks, int dtype,
                          void* stream);
 
+/* Output operator glue (fno/sfno.py:313-328) without its two extra passes over the data:
+ *   tcfd_fno_reduce_frames: the 1x1x1 channel reduction (ci -> 1) writes its T latent steps BEHIND the last frame of the
+ *     network input, out (b, 1, P / T * (T + 1)) = cat([frame[..., -1:], conv1x1(x)], dim=t) -- the reference's torch.cat.
+ *     x (b, ci, P), w2t (ci, 1), b2 (1) or NULL, frame (b, P / T, frame_T), fp32; T even.
+ *   tcfd_fno_inverse_trunc_residual: tcfd_fno_inverse_trunc whose store loop adds res[..., -1:] (res (batch * c, X, Y, res_T))
+ *     to every kept step -- the reference's `v_res[..., -1:] + conv(...)[..., -out_steps:]`. */
+int tcfd_fno_reduce_frames(const void* x, void* out, const void* w2t, const void* b2, const void* frame, int frame_T, int batch,
+                           int ci, long P, int T, void* stream);
+int tcfd_fno_inverse_trunc_residual(const tcfd_fno_plan* p, const void* vh, void* out, const void* res, int res_T, int batch, int c,
+                                    int t_keep, double inv_scale, void* ws, size_t ws_bytes, void* stream);
+
+/* Lifting operator, proj(LayerNormnd(v + q)) with v ONE channel (fno/sfno.py:252-254, fno/base.py:61-83): the three
+ * per-sample sums over v (sum, sum of squares, dot product with the table's channel sum qs) and, from them and the table's
+ * constants sq = sum q, sq2 = sum q^2 (one double each, on the device), the per-sample folded weights for the `pe` form of
+ * tcfd_fno_pointwise:  w2t (b, C, co) = W[o][c] gamma[c] rstd_b,  fb (b, co) = sum_c (beta[c] - gamma[c] mu_b rstd_b) W[o][c] +
+ * bias[o].  Two launches.  v (b, P), qs (P), W (co, C), bias (co) / gamma (C) / beta (C) fp32 or NULL; moments (b, 2) double
+ * or NULL receives (sum, sum of squares) of every sample's (C, P) block; scratch: (b, 3) doubles. */
+int tcfd_fno_lift_fold(const void* v, const void* qs, const void* sq, const void* sq2, const void* W, const void* bias,
+                       const void* gamma, const void* beta, double eps, void* w2t, void* fb, void* moments, void* scratch,
+                       int batch, int C, int co, long P, void* stream);
+
 /* ---- SobolevLoss in three launches (fno/losses.py:263-315; BASELINE config 5 "forward + loss") -------------------------
  * x, y: (batch, n, n, nt) real, TIME-LAST and contiguous, read in place (no permuted copies, no x - y tensor).
  *   pass 1  per (b, row) slab: d = x - y while staging, one complex n-point FFT per time step of d_t + i y_t, Hermitian

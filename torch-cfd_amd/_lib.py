@@ -158,6 +158,9 @@ SIGNATURES = {
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     "tcfd_weighted_sqnorm": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp]),
+    "tcfd_fno_reduce_frames": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _i, _vp]),
+    "tcfd_fno_inverse_trunc_residual": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _sz, _vp]),
+    "tcfd_fno_lift_fold": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "tcfd_loss_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i]),
     "tcfd_loss_plan_destroy": (None, [_vp]),
     "tcfd_loss_workspace_bytes": (_sz, [_vp, _l, _i, _i]),

@@ -290,7 +290,7 @@ template <typename T, int Y, int EPT>
 __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, T* out /* may be == acc: no restrict */,
                                                   const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_ti, int T_out,
                                                   int t_keep, int mt, int my, T scale, int P, int NS, long slabs, int Ys,
-                                                  const T* acc) {
+                                                  const T* acc, const T* __restrict__ accb, int accT) {
     typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
@@ -382,6 +382,22 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, 
                 a_.v = __builtin_nontemporal_load(a4 + (size_t)q * n4 + i);
 #pragma unroll
                 for (int u = 0; u < NV; ++u) s_.e[u] += a_.e[u];
+                __builtin_nontemporal_store(s_.v, d4 + (size_t)q * n4 + i);
+            }
+        }
+        return;
+    }
+    if (accb) {   // out[slab][y][t] = transform + accb[slab][y][accT - 1]: the residual frame of the output operator
+                  // (v_res[..., -1:] + conv(...), fno/sfno.py:327) added by the store loop instead of a pass of its own
+        constexpr int NV = 16 / (int)sizeof(T);
+        for (int q = 0; q < count; ++q) {
+            const b128* s4 = reinterpret_cast<const b128*>(ex + (size_t)q * P * Y);
+            const T* rb = accb + (size_t)(base + q) * Y * accT + (accT - 1);
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+                union { b128 v; T e[NV]; } s_;
+                s_.v = s4[i];
+#pragma unroll
+                for (int u = 0; u < NV; ++u) s_.e[u] += rb[(size_t)((i * NV + u) / t_keep) * accT];
                 __builtin_nontemporal_store(s_.v, d4 + (size_t)q * n4 + i);
             }
         }
@@ -643,7 +659,7 @@ static int launch_fwd_ty2(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long sl
 
 template <typename T, int Y>
 static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T scale,
-                          hipStream_t st, const T* acc) {
+                          hipStream_t st, const T* acc, const T* accb = nullptr, int accT = 0) {
     typedef cx<T> ct;
     constexpr int EPT = TyCfg2<Y, T>::EPT, G = TyCfg2<Y, T>::G;
     const int P = (t_keep + 1) / 2;
@@ -659,7 +675,7 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long 
     auto kern = k_inv_ty2<T, Y, EPT>;
     if ((rc = set_lds_attr(kern, lds))) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const ct*)p->tw_y,
-                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys, acc);
+                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys, acc, accb, accT);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -683,8 +699,8 @@ static int do_fwd_ty(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, 
 }
 template <typename T>
 static int do_inv_ty(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T s, hipStream_t st,
-                     const T* acc = nullptr) {
-    DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st, acc)));
+                     const T* acc = nullptr, const T* accb = nullptr, int accT = 0) {
+    DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT)));
 }
 template <typename T>
 static int do_fwd_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
@@ -801,6 +817,25 @@ extern "C" int tcfd_fno_inverse_trunc_acc(const tcfd_fno_plan* p, const void* vh
     }
     if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
     return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st, (const float*)acc);
+}
+// out = transform + res[..., -1:] broadcast over the kept steps: res (batch * c, X, Y, res_T) real, its LAST time slice is the
+// residual frame the output operator adds to the convolution (fno/sfno.py:327)
+extern "C" int tcfd_fno_inverse_trunc_residual(const tcfd_fno_plan* p, const void* vh, void* out, const void* res, int res_T,
+                                               int batch, int c, int t_keep, double inv_scale, void* ws, size_t ws_bytes,
+                                               void* stream) {
+    if (!p || !vh || !out || !res || res_T <= 0 || batch <= 0 || c <= 0 || t_keep <= 0 || t_keep > p->T_out)
+        return FAIL(TCFD_EINVAL, "fno_inverse_trunc_residual: bad argument");
+    if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (p->dtype == TCFD_C128) {
+        if ((rc = do_inv_x<double>(p, (const cx<double>*)vh, (cx<double>*)ws, (long)batch * c, st))) return rc;
+        return do_inv_ty<double>(p, (const cx<double>*)ws, (double*)out, (long)batch * c * p->X, t_keep, inv_scale, st, nullptr,
+                                 (const double*)res, res_T);
+    }
+    if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
+    return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st, nullptr,
+                            (const float*)res, res_T);
 }
 extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
                                       double inv_scale, void* ws, size_t ws_bytes, void* stream) {
@@ -958,6 +993,9 @@ struct PwArgs {
                                   // affine map (e.g. a folded LayerNorm) ride in the single-layer form
     int T, sT, act1, act2, skip_mode;
     int cm;             // hidden width when the kernel is instantiated with CM = 0 (any channel expansion)
+    const float* frame; // not null: the output is (b, CO, P / T * (T + 1)) -- every (x, y) row of T steps is written behind ONE
+    int fT;             // extra leading step that holds frame[b][xy][fT - 1] (frame (b, P / T, fT): the last input frame the output
+                        // operator prepends to the latent steps, fno/sfno.py:314-315) -- its torch.cat never runs
 };
 
 __device__ __forceinline__ float pw_act(float v, int act) {
@@ -1053,6 +1091,21 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
         const float* sb = a.s + (size_t)b * CO * sP + xy * a.sT + (a.sT - 1);
 #pragma unroll
         for (int c = 0; c < CO; ++c) o[c] += (vf)sb[(size_t)c * sP];
+    }
+    if constexpr (!HAS_L1 && CO == 1) if (a.frame) {     // (the channel reduction in front of the output operator only)
+        const long xy = p / a.T;             // V = 2 needs an even T (checked by the host): both points of a lane share (x, y)
+        const int t = (int)(p - xy * a.T);
+        const long oP = (a.P / a.T) * (a.T + 1);
+        float* ob = a.out + (size_t)b * CO * oP + xy * (a.T + 1) + t + 1;
+        const float fr = a.frame[((size_t)b * (a.P / a.T) + xy) * a.fT + (a.fT - 1)];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const vf r = pw_act(o[c], a.act2);
+            float* oc = ob + (size_t)c * oP;
+            if constexpr (V == 2) { oc[0] = r.x; oc[1] = r.y; } else { oc[0] = r; }
+            if (t == 0) oc[-1] = fr;
+        }
+        return;
     }
     float* ob = a.out + (size_t)b * CO * a.P + p;
 #pragma unroll
@@ -1306,6 +1359,7 @@ extern "C" int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* p, const vo
 
 // Returns TCFD_EINVAL (with a message) for channel combinations that are not instantiated; the caller then
 // uses its own pointwise modules.
+static int pw_dispatch(PwArgs a, int batch, int ci, int cm, int co, hipStream_t st);
 extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w1, const void* b1,
                                   const void* w2t, const void* b2, const void* wst, const void* bs, int batch, int ci,
                                   int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
@@ -1320,8 +1374,27 @@ extern "C" int tcfd_fno_pointwise(const void* x, const void* skip, void* out, co
     a.P = P; a.T = T; a.sT = skip_T; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode;
     a.w2_bstride = w2_bstride; a.b2_bstride = b2_bstride;
     a.cm = cm;
-    hipStream_t st = (hipStream_t)stream;
-    const bool l1 = w1 != nullptr;
+    a.frame = nullptr; a.fT = 0;
+    return pw_dispatch(a, batch, ci, cm, co, (hipStream_t)stream);
+}
+
+// The channel reduction in front of the output operator (fno/sfno.py:618 `reduction`, then :314-315): out (b, 1, P / T * (T + 1))
+// = [last frame of `frame` (b, P / T, frame_T) | conv1x1(x) (b, ci, P) -> 1 channel] along t -- the reference's torch.cat of
+// the last input frame and the T latent steps, written by the reduction itself.  T even (two points per lane share a row).
+extern "C" int tcfd_fno_reduce_frames(const void* x, void* out, const void* w2t, const void* b2, const void* frame, int frame_T,
+                                      int batch, int ci, long P, int T, void* stream) {
+    if (!x || !out || !w2t || !frame || batch <= 0 || P <= 0 || T <= 0 || frame_T <= 0 || P % T != 0 || (T & 1))
+        return FAIL(TCFD_EINVAL, "fno_reduce_frames: bad argument (T must be even)");
+    PwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const float*)x; a.out = (float*)out; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
+    a.P = P; a.T = T; a.cm = ci;
+    a.frame = (const float*)frame; a.fT = frame_T;
+    return pw_dispatch(a, batch, ci, ci, 1, (hipStream_t)stream);
+}
+
+static int pw_dispatch(PwArgs a, int batch, int ci, int cm, int co, hipStream_t st) {
+    const bool l1 = a.w1 != nullptr;
 #define PW_CASE(CI_, CM_, CO_)                                                             \
     if (ci == CI_ && cm == CM_ && co == CO_)                                                \
         return l1 ? launch_pw<CI_, CM_, CO_, true>(a, batch, st) : launch_pw<CI_, CM_, CO_, false>(a, batch, st);
@@ -2640,6 +2713,105 @@ extern "C" int tcfd_row_moments(const void* x, void* stats, int rows, long L, vo
     int chunks = (int)std::min<long>(std::max<long>(L / (256 * 4 * 8), 1), 2048 / std::max(rows, 1) + 1);
     hipLaunchKernelGGL(k_row_moments, dim3((unsigned)chunks, (unsigned)rows), dim3(256), 0, st, (const float*)x,
                        (double*)stats, L, chunks);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ lifting operator: LayerNorm folded into the projection
+// proj(LayerNormnd(v + q)) of the lifting operator (fno/sfno.py:252-254, fno/base.py:61-83) with v ONE channel (b, P) and q the
+// (C, P) positional table: the statistics of a sample's (C, P) block follow from three sums over v -- sum, sum of squares and
+// the dot product with qs[p] = sum_c q[c][p] -- and two constants of the table (sq = sum q, sq2 = sum q^2):
+//     s1 = C sum(v) + sq ,   s2 = C sum(v^2) + 2 <v, qs> + sq2 ,   mu = s1 / (C P) ,   rstd = 1 / sqrt(s2 / (C P) - mu^2 + eps)
+// and normalisation + affine + projection collapse into per-sample weights for the pointwise kernel (its `pe` mode):
+//     w2t[b][c][o] = W[o][c] gamma[c] rstd_b ,   fb[b][o] = sum_c (beta[c] - gamma[c] mu_b rstd_b) W[o][c] + bias[o].
+// Two launches replace ~25 tensor-op launches (a GEMV, a dozen 0-dim double ops, broadcasts) per forward.
+__global__ __launch_bounds__(256) void k_row_moments_dot(const float* __restrict__ x, const float* __restrict__ qs,
+                                                         double* __restrict__ stats, long L, int chunks) {
+    __shared__ double sh[3][4];
+    const int row = blockIdx.y, chunk = blockIdx.x;
+    const long per = ((L + chunks - 1) / chunks + 3) & ~3L;
+    const long lo = (long)chunk * per, hi = lo + per < L ? lo + per : L;
+    const float* r = x + (size_t)row * L;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int cnt = 0;
+    if ((L & 3) == 0) {
+        for (long i = lo + (long)threadIdx.x * 4; i < hi; i += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(r + i);
+            const float4 q = *reinterpret_cast<const float4*>(qs + i);
+            a1 += (v.x + v.y) + (v.z + v.w);
+            a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            a3 += (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
+            if (++cnt == 16) { s1 += a1; s2 += a2; s3 += a3; a1 = a2 = a3 = 0.f; cnt = 0; }  // short fp32 runs, double totals
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = r[i];
+            a1 += v; a2 += v * v; a3 += v * qs[i];
+            if (++cnt == 64) { s1 += a1; s2 += a2; s3 += a3; a1 = a2 = a3 = 0.f; cnt = 0; }
+        }
+    }
+    s1 += a1; s2 += a2; s3 += a3;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+        s3 += __shfl_down(s3, off);
+    }
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; sh[2][wave] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        atomicAdd(&stats[3 * row + k], sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lift_fold(const double* __restrict__ stats, const double* __restrict__ sq,
+                                                   const double* __restrict__ sq2, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, double eps, float* __restrict__ w2t,
+                                                   float* __restrict__ fb, double* __restrict__ moments, int C, int co, long P) {
+    const int b = blockIdx.x;
+    const double L = (double)C * (double)P;
+    const double s1 = C * stats[3 * b] + sq[0];
+    const double s2 = C * stats[3 * b + 1] + 2.0 * stats[3 * b + 2] + sq2[0];
+    const double mu = s1 / L;
+    double var = s2 / L - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    if (threadIdx.x == 0 && moments) { moments[2 * b] = s1; moments[2 * b + 1] = s2; }
+    for (int i = threadIdx.x; i < C * co; i += 256) {
+        const int c = i / co, o = i - c * co;
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        w2t[((size_t)b * C + c) * co + o] = (float)((double)W[(size_t)o * C + c] * (g * rstd));
+    }
+    for (int o = threadIdx.x; o < co; o += 256) {
+        double acc = bias ? (double)bias[o] : 0.0;
+        double dot = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+            dot += (be - g * (mu * rstd)) * (double)W[(size_t)o * C + c];
+        }
+        fb[(size_t)b * co + o] = (float)(dot + acc);
+    }
+}
+
+// v (b, P) fp32; qs (P) fp32; sq, sq2: ONE double each on the device (constants of the table); W (co, C), bias (co) / gamma (C) /
+// beta (C) fp32 or NULL; outputs w2t (b, C, co), fb (b, co) fp32, moments (b, 2) double or NULL; scratch (b, 3) double.
+extern "C" int tcfd_fno_lift_fold(const void* v, const void* qs, const void* sq, const void* sq2, const void* W, const void* bias,
+                                  const void* gamma, const void* beta, double eps, void* w2t, void* fb, void* moments,
+                                  void* scratch, int batch, int C, int co, long P, void* stream) {
+    if (!v || !qs || !sq || !sq2 || !W || !w2t || !fb || !scratch || batch <= 0 || C <= 0 || co <= 0 || P <= 0)
+        return FAIL(TCFD_EINVAL, "lift_fold: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)batch * 3 * sizeof(double), st));
+    int chunks = (int)std::min<long>(std::max<long>(P / (256 * 4 * 8), 1), 2048 / std::max(batch, 1) + 1);
+    hipLaunchKernelGGL(k_row_moments_dot, dim3((unsigned)chunks, (unsigned)batch), dim3(256), 0, st, (const float*)v,
+                       (const float*)qs, (double*)scratch, P, chunks);
+    hipLaunchKernelGGL(k_lift_fold, dim3((unsigned)batch), dim3(256), 0, st, (const double*)scratch, (const double*)sq,
+                       (const double*)sq2, (const float*)W, (const float*)bias, (const float*)gamma, (const float*)beta, eps,
+                       (float*)w2t, (float*)fb, (double*)moments, C, co, P);
     HIP_TRY(hipGetLastError());
     return 0;
 }

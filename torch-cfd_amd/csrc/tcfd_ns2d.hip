@@ -711,13 +711,18 @@ __device__ __forceinline__ void load_raw(RawPair<T, EPT>& r, const cx<T>* __rest
 // Z[e] = A~[e] + i B~[e] (Hermitian completions, Im of DC / Nyquist dropped) in the j + t*G
 // distribution.  The upper half is the mirror image of data owned by OTHER lanes: it goes through
 // the group's LDS buffer (half an exchange) instead of being loaded from HBM a second time.
-template <typename T, int N, int EPT, bool WG, int NYQ = 0>
+// SWZ: the XOR swizzle of the Stockham exchanges (lds_addr<.., true>).  The cross-lane row kernel (v7) has no stride-EPT
+// stores -- its transform exchanges through xl_slot -- and passes SWZ = false: with the swizzle the MIRRORED accesses
+// (lanes j -> slots N - j, descending) straddle two 8-element blocks with different XOR constants and collide pairwise
+// (rocprofv3: SQ_LDS_BANK_CONFLICT 0.84 M of 4.03 M LDS-array cycles per chunk launch); unswizzled, descending consecutive
+// 16-byte slots are conflict free for both the 8-lane store groups and the 16-lane load groups of the b128 instructions.
+template <typename T, int N, int EPT, bool WG, int NYQ = 0, bool SWZ = true>
 __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>& r, cx<T>* lds, int j) {
     constexpr int G = N / EPT;
     // G % EPT^2 == 0: the swizzle term of lds_addr is the same for every t, so the mirrored slots N - j - t G and
     // the read slots j + t G are ONE address each plus compile-time offsets
-    constexpr bool AFFINE = (G % (EPT * EPT) == 0);
-    cx<T>* mir = lds + lds_addr<EPT, 1, true>(N - j, 0);   // j = 0: slot N is never touched (k >= 1 below)
+    constexpr bool AFFINE = !SWZ || (G % (EPT * EPT) == 0);
+    cx<T>* mir = lds + lds_addr<EPT, 1, SWZ>(N - j, 0);   // j = 0: slot N is never touched (k >= 1 below)
 #pragma unroll
     for (int t = 0; t < EPT / 2; ++t) {
         const int k = j + t * G;
@@ -727,17 +732,17 @@ __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>
         if (k >= 1) {
             const cx<T> m = mk<T>(pa.x + pb.y, pb.x - pa.y);
             if constexpr (AFFINE) mir[-t * G] = m;
-            else lds[lds_addr<EPT, 1, true>(N - k, 0)] = m;
+            else lds[lds_addr<EPT, 1, SWZ>(N - k, 0)] = m;
         }
     }
     if (j == 0)   // lane 0 holds element 0 in a[0] / b[0]
-        lds[lds_addr<EPT, 1, true>(N / 2, 0)] = NYQ ? mk<T>(r.a[0].y, r.b[0].y) : mk<T>(r.an.x, r.bn.x);
+        lds[lds_addr<EPT, 1, SWZ>(N / 2, 0)] = NYQ ? mk<T>(r.a[0].y, r.b[0].y) : mk<T>(r.an.x, r.bn.x);
     group_sync<WG>();
-    const cx<T>* src = lds + lds_addr<EPT, 1, true>(j, 0);
+    const cx<T>* src = lds + lds_addr<EPT, 1, SWZ>(j, 0);
 #pragma unroll
     for (int t = EPT / 2; t < EPT; ++t) {
         if constexpr (AFFINE) x[t] = src[t * G];
-        else x[t] = lds[lds_addr<EPT, 1, true>(j + t * G, 0)];
+        else x[t] = lds[lds_addr<EPT, 1, SWZ>(j + t * G, 0)];
     }
     group_sync<WG>();
 }
@@ -1125,6 +1130,7 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int N = 1024, EPT = 8, G = 128, N2 = N / 2;
     constexpr bool WG = true;
+    constexpr bool SWZ7 = false;     // mirror accesses without the Stockham swizzle: no bank conflicts (see pack_herm)
     const int j = threadIdx.x;
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
     const long stride = (long)gridDim.x;
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
                     H.an = H.an + o;
                 }
             }
-            pack_herm<T, N, EPT, WG, NYQ>(out, H, lds, j);
+            pack_herm<T, N, EPT, WG, NYQ, SWZ7>(out, H, lds, j);
             if constexpr (PF) load_raw<T, N, EPT, NYQ>(H, nextA, nextA + second, j);
             xl_fft1024<T, +1, 1>(out, lds, xtw, j, nohook);
         };
@@ -1187,9 +1193,9 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
 
         xl_fft1024<T, -1, 1>(p, lds, xtw, j, nohook);   // pi -> natural order
         // unpack the two real-row spectra (mirror through the exchange buffer)
-        const cx<T>* mir = lds + lds_addr<EPT, 1, true>(N - j, 0);
+        const cx<T>* mir = lds + lds_addr<EPT, 1, SWZ7>(N - j, 0);
 #pragma unroll
-        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(j + t * G, 0)] = p[t];
+        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, SWZ7>(j + t * G, 0)] = p[t];
         group_sync<WG>();
         const T half = (T)0.5;
         cx<T>* out0 = adv + off;

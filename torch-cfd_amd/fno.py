@@ -1186,26 +1186,21 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
     vf = v1.detach().reshape(b, P).contiguous()
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    stats = torch.empty(b, 2, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.tcfd_row_moments(vf.data_ptr(), stats.data_ptr(), b, P, stream), "tcfd_row_moments")
     if consts is None:   # constants of the table: channel sum per point, total sum, total sum of squares
         consts = _lift_table_constants(qf)
     qs, sq, sq2 = consts
-    cross = torch.mv(vf.double() if P < 4096 else vf, qs.double() if P < 4096 else qs).double()
-    L = C * P
-    s1 = C * stats[:, 0] + sq
-    s2 = C * stats[:, 1] + 2 * cross + sq2
-    mu = s1 / L
-    rstd = torch.rsqrt((s2 / L - mu * mu).clamp_min(0) + norm.eps)
-    gamma = norm.weight.detach().double() if norm.weight is not None else torch.ones(C, dtype=torch.float64, device=dev)
-    beta = norm.bias.detach().double() if norm.bias is not None else torch.zeros(C, dtype=torch.float64, device=dev)
-    W = proj.weight.detach().reshape(co, C).double()
-    w2t = (W.t()[None] * (gamma[None, :, None] * rstd[:, None, None])).float().contiguous()      # (b, C, co)
-    fb = (beta[None, :] - gamma[None, :] * (mu * rstd)[:, None]) @ W.t()
-    if proj.bias is not None:
-        fb = fb + proj.bias.detach().double()[None]
-    fb = fb.float().contiguous()
+    # the three per-sample sums over v and the per-sample folded weights in two launches (tcfd_fno_lift_fold; this was a GEMV
+    # and ~25 small tensor-op launches per forward: 0.1 ms of a 5 ms forward at config 5)
+    w2t = torch.empty(b, C, co, dtype=torch.float32, device=dev)
+    fb = torch.empty(b, co, dtype=torch.float32, device=dev)
+    moments = torch.empty(b, 2, dtype=torch.float64, device=dev)
+    scratch = torch.empty(b, 3, dtype=torch.float64, device=dev)
+    ptr = lambda t: t.detach().contiguous().data_ptr() if t is not None else None
+    Wc = proj.weight.detach().reshape(co, C).contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(lib.tcfd_fno_lift_fold(vf.data_ptr(), qs.data_ptr(), sq.data_ptr(), sq2.data_ptr(), Wc.data_ptr(), ptr(proj.bias),
+                                          ptr(norm.weight), ptr(norm.bias), float(norm.eps), w2t.data_ptr(), fb.data_ptr(),
+                                          moments.data_ptr(), scratch.data_ptr(), b, C, co, P, stream), "tcfd_fno_lift_fold")
     out = torch.empty(b, co, *v1.shape[2:], dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise(vf.data_ptr(), None, out.data_ptr(), None, None, w2t.data_ptr(), fb.data_ptr(), None, None,
@@ -1218,7 +1213,7 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
         if lib.tcfd_fno_pointwise_bwd(None, None, None, None, None, None, None, None, None, None, None, None, 0, dims, b, C, C, co,
                                       P, 0, 0, 0, 0, 0, 1, None) != 0:
             return None
-        moments = torch.stack([s1, s2], dim=1).contiguous()                  # of the (C, X, Y, T) block of every sample
+        # (moments: sum and sum of squares of the (C, X, Y, T) block of every sample, from the fold kernel)
         return _LiftProjectFn.apply(out, vf, qf, moments, float(norm.eps), tuple(v1.shape[2:]), proj.weight, proj.bias,
                                     norm.weight, norm.bias)
     return out
@@ -1378,10 +1373,20 @@ class SpectralConvT(SpectralConvS):
         t_pad = v.size(-1) if self.temporal_padding else 0
         return list(self.weight), self._bias_list(), self.delta, self.modes, t_pad, out_steps + t_pad, out_steps, self.norm
 
-    def forward(self, v, out_steps: int = None):
+    def forward(self, v, out_steps: int = None, keep_steps: int = None):
+        """``keep_steps`` (an extension; the reference's signature ends at ``out_steps``): return only the LAST ``keep_steps`` of
+        the ``out_steps`` steps -- the inverse transform then never produces the others (the output operator drops the first
+        one, fno/sfno.py:326: a strided slice + copy of the whole output otherwise)."""
         if out_steps is None and self.out_steps is not None:
             out_steps = self.out_steps
         t_pad = v.size(-1) if self.temporal_padding else 0
+        if keep_steps is not None:
+            if not 0 < keep_steps <= out_steps:
+                raise ValueError(f"keep_steps = {keep_steps} outside (0, {out_steps}]")
+            if isinstance(self.postprocess, nn.Identity):
+                return hip_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad=t_pad,
+                                         t_out=out_steps + t_pad, t_keep=keep_steps, norm=self.norm)
+            return self.forward(v, out_steps)[..., -keep_steps:]
         if not isinstance(self.postprocess, nn.Identity):
             # spectrum post-processing (Helmholtz projection for out_dim = 2): the projection is diagonal in k,
             # so it acts on the kept modes only -- transform, contract, project, inverse-transform
@@ -1617,16 +1622,66 @@ class OutConv(nn.Module):
         self.n_grid, self.norm, self.delta = n_grid, norm, delta
         self.spatial_padding, self.temporal_padding = spatial_padding, temporal_padding
 
+    def fused_forward(self, v, v_res, reduction, out_steps: int):
+        """``self(reduction(v), v_res, out_steps)`` for the forward-only fp32 single-output-channel case without the glue
+        passes of fno/sfno.py:313-328: the channel reduction writes its latent steps behind the last input frame
+        (``tcfd_fno_reduce_frames``: no ``torch.cat``), the inverse transform produces only the kept steps and adds the residual
+        frame in its store loop (``tcfd_fno_inverse_trunc_residual``: no slice copy, no ``add``).  None when not covered."""
+        conv = self.conv
+        if (torch.is_grad_enabled() and (v.requires_grad or v_res.requires_grad or any(p.requires_grad for p in self.parameters())
+                                         or any(p.requires_grad for p in reduction.parameters()))):
+            return None
+        if (not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5 or v_res.dim() != 4 or v_res.dtype != torch.float32
+                or self.spatial_padding > 0 or self.size[0] != 1 or not _is_pointwise(reduction) or reduction.out_channels != 1
+                or type(conv).forward is not SpectralConvT.forward or not isinstance(conv.postprocess, nn.Identity)
+                or os.environ.get("TCFD_FNO_FUSED_OUT", "1") == "0"):
+            return None
+        b, C, X, Y, T = v.shape
+        if (T % 2) or not _fused_xy(X, Y) or b == 0 or tuple(v_res.shape[:3]) != (b, X, Y) or any(
+                p.dtype != torch.float32 for p in reduction.parameters()):
+            return None
+        lib = _lib.load()
+        dev = v.device
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        vc, rc_ = v.detach().contiguous(), v_res.detach().contiguous()
+        frames = torch.empty(b, 1, X, Y, T + 1, dtype=torch.float32, device=dev)
+        w2t = reduction.weight.detach().reshape(1, C).t().contiguous()
+        b2 = reduction.bias.detach().contiguous() if reduction.bias is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.tcfd_fno_reduce_frames(vc.data_ptr(), frames.data_ptr(), w2t.data_ptr(), b2.data_ptr() if b2 is not None else None,
+                                            rc_.data_ptr(), rc_.shape[-1], b, C, X * Y * T, T, stream)
+        if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+            return None
+        _lib.check(rc, "tcfd_fno_reduce_frames")
+        steps = out_steps + 1
+        t_pad = (T + 1) if conv.temporal_padding else 0
+        vh, plan = hip_truncated_rfftn(frames, conv.modes, t_pad=t_pad, t_out=steps + t_pad, norm=conv.norm)
+        oh = hip_contract(vh, list(conv.weight), conv._bias_list(), conv.delta, conv.modes)
+        out = torch.empty(b, 1, X, Y, out_steps, dtype=torch.float32, device=dev)
+        ws = plan.workspace(b, 1, 1)
+        _, inv_scale = _norm_scales(conv.norm, X * Y * (T + 1 + t_pad), X * Y * (steps + t_pad))
+        with torch.cuda.device(dev):
+            _lib.check(lib.tcfd_fno_inverse_trunc_residual(plan.handle, oh.data_ptr(), out.data_ptr(), rc_.data_ptr(), rc_.shape[-1], b, 1,
+                                                           out_steps, inv_scale, ws.data_ptr(), ws.numel(), stream),
+                       "tcfd_fno_inverse_trunc_residual")
+        return out.squeeze(1)
+
     def forward(self, v, v_res, out_steps: int, **kwargs):
         v_res = v_res.unsqueeze(1).expand(-1, v.size(1), -1, -1, -1)
         v = torch.cat([v_res[..., -1:], v], dim=-1)
         sp = self.spatial_padding
         if sp > 0:
             v = F.pad(v, pad=(0, 0, sp, sp, sp, sp), mode="constant")
-        v = self.conv(v, out_steps=out_steps + 1)
+        if type(self.conv).forward is SpectralConvT.forward:
+            v = self.conv(v, out_steps=out_steps + 1, keep_steps=out_steps)       # the first output step is never formed
+        else:
+            v = self.conv(v, out_steps=out_steps + 1)[..., -out_steps:]
         if sp > 0:
             v = v[..., sp:-sp, sp:-sp, :]
-        v = v_res[..., -1:] + v[..., -out_steps:]
+        if v.is_contiguous() and not (torch.is_grad_enabled() and (v.requires_grad or v_res.requires_grad)):
+            v.add_(v_res[..., -1:])         # the convolution's own output buffer: one pass, no second tensor
+        else:
+            v = v_res[..., -1:] + v
         return v.squeeze(1)
 
 
@@ -1705,6 +1760,9 @@ class SFNO(FNOBase):
             x1 = conv(v)
             fused = hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
             v = fused if fused is not None else act(mlp(x1) + w(v))
+        out = self.output_operator.fused_forward(v, v_res, self.reduction, out_steps) if type(self.output_operator) is OutConv else None
+        if out is not None:
+            return out
         red = hip_pointwise(v, None, None, self.reduction)
         v = red if red is not None else self.reduction(v)
         return self.output_operator(v, v_res, out_steps=out_steps)
