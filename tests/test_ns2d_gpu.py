@@ -619,6 +619,40 @@ def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
         assert rel_l2(a, b) < tol
 
 
+@pytest.mark.parametrize("n,tag,B,forcing", [(64, "f64", 1, "kolmogorov"), (128, "f64", 1, "kolmogorov"), (256, "f32", 16, None),
+                                            (256, "f64", 3, "sincos"), (128, "f32", 5, "kolmogorov_vort")])
+def test_plane_split_column_passes_agree_with_the_fused_ones(n, tag, B, forcing, dev, monkeypatch):
+    """The round-4 experiment for the small-grid regime (BASELINE configs 1 and 2), kept opt-in because it measured SLOWER
+    (TCFD_PSPLIT=1; 256^2 x 16 fp32: 8457 -> 7182 steps/s): column passes split by PLANE -- four workgroups per tile, each
+    emits one of the four planes, one of them stores the state / accumulator into the buffers that are not being read.
+    Same arithmetic, other transform factorisation (wide tiles): multi-step calls (the ping-pong of both buffers over
+    5 stages x k steps), per-call steps and dw/dt must agree with the default pass to round-off, and with the oracle."""
+    from oracle import ns2d as O
+
+    real = REAL[tag]
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 11 + s, real)) for s in range(min(B, 4))])
+    w0 = w0.repeat((B + w0.shape[0] - 1) // w0.shape[0], 1, 1)[:B].contiguous().to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TCFD_PSPLIT", flag)      # read at plan creation
+        _, op = build_op(n, tag, forcing, dev)
+        a7, d7 = op(w0, 1e-3, steps=7)
+        b = w0
+        for _ in range(3):
+            b, db = op(b, 1e-3)
+        res[flag] = (a7, d7, b, db)
+    monkeypatch.delenv("TCFD_PSPLIT")
+    tols = (1e-13, 1e-10, 1e-13, 1e-10) if tag == "f64" else (1e-6, 5e-4, 1e-6, 5e-4)   # dw/dt amplifies round-off by |w| / |dw|
+    for x, y, tol in zip(res["0"], res["1"], tols):
+        assert rel_l2(x, y) < tol
+    # and the plane-split pass itself against the oracle
+    monkeypatch.setenv("TCFD_PSPLIT", "1")
+    _, op = build_op(n, tag, forcing, dev)
+    t = oracle_tables(n, tag, forcing)
+    ref, _ = O.advance(w0[:2].cpu(), 1e-3, t, steps=7)
+    assert rel_l2(op(w0[:2], 1e-3, steps=7)[0], ref) < (1e-10 if tag == "f64" else 1e-5)
+
+
 @pytest.mark.parametrize("n", [512, 1024])
 def test_cross_lane_column_transforms_agree_with_stockham(n, dev, monkeypatch):
     """512-point column tiles (512^2 and the split 1024^2 plans, fp64) run their transforms with one LDS exchange +

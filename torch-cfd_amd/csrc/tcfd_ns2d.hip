@@ -181,6 +181,13 @@ struct ColArgs {
     int nyq;       // 1: packed Nyquist column (see emit_planes): no lone tile for column m - 1, the lanes of column 0 own it too
     int nt_planes; // plane stores with the non-temporal hint (small cache-resident problems, see launch_cols)
     int pair_xcd;  // block->tile map: 0 = batch fastest; LG = 2 / 4: the LG tiles that share a 128-byte line on one XCD
+    int psplit;    // 1 (MODE_A / MODE_CA, grid.y = 4): workgroup blockIdx.y emits plane blockIdx.y only.  A small problem's launch
+                   // is ONE round of workgroups whose run time is the dependency chain of one workgroup -- forward transform,
+                   // update, FOUR inverse transforms one after the other, 16 plane stores per lane.  Split by plane the chain
+                   // is one forward + one inverse transform; the forward part is recomputed by the four workgroups of a tile
+                   // (from the caches: the machine is idle otherwise), only y = 0 stores the accumulator and the state -- to
+                   // OTHER buffers than the ones read (h_out, u_out: the host alternates them), the siblings still read those.
+    cx<T>* h_out;  // RK accumulator write (== h unless psplit)
 };
 
 // SP = 1 ("split"): the workgroup owns the rows of ONE parity q of the column (i = 2 s + q) and runs N/2-point
@@ -256,8 +263,9 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
     const T ky = valid ? a.ky[jc] : (T)0;
     const bool nyq_lane = nyq_tile && c == 0;
     const T ky_n = nyq_tile ? a.ky[a.m - 1] : (T)0;
+    const int f_first = a.psplit ? (int)blockIdx.y : 0, f_end = a.psplit ? f_first + 1 : 4;
 #pragma unroll 1
-    for (int f = 0; f < 4; ++f) {
+    for (int f = f_first; f < f_end; ++f) {
         cx<T> x[EPT];
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
             }
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
+            const bool writer = !a.psplit || blockIdx.y == 0;   // plane-split launches: ONE of the four sibling workgroups stores h / u
             // packed Nyquist column (tile 0, a row per thread): its reads go out first, in the shadow of the tile's own
             constexpr int NYQ_PER = (NT + C * G - 1) / (C * G);
             [[maybe_unused]] cx<T> nyq_u[NYQ_PER], nyq_w0[NYQ_PER];
@@ -553,14 +562,14 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                         const int i = TCFD_IROW(sl);
                         const size_t gw = wbase + (wq + (size_t)sl) * a.ldw;  // h is stored parity-major when split
                         const cx<T> hn = cscale(x[t], a.fa) + cscale(hv[tt], a.beta);   // hv = 0: nothing to add
-                        if (h_live[tt] && a.store_h) a.h[gw] = hn;
+                        if (h_live[tt] && a.store_h && writer) a.h_out[gw] = hn;
                         const T L = Lv[tt];
                         const cx<T> u = uv[tt];
                         // u + gamma dt h + mu L u, then / (1 - mu L)     (equations.py:355-357)
                         cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
                         const T den = fast_rcp((T)1 - a.mud * L);
                         x[t] = cscale(rhs, den);
-                        a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
+                        if (writer) a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                         if constexpr (MODE == MODE_C) {
                             if (a.dwdt) {   // (w_new - w_old) / (steps dt), equations.py:461-462, fused into the last stage
                                 const size_t gi = (size_t)b * N * a.m + jc + (size_t)i * a.m;
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                         const T L = (a.ablate & 4) ? (T)-0.5 : (a.sep ? rt_lin[sl] + lcn : a.lin[(size_t)i * a.m + jn]);
                         const cx<T> rhs = uo + cscale(cscale(uo, L), a.mu);
                         unew[r] = cscale(rhs, fast_rcp((T)1 - a.mud * L));
-                        a.u_out[(size_t)b * N * a.u_out_ld + jn + (size_t)i * a.u_out_ld] = unew[r];
+                        if (writer) a.u_out[(size_t)b * N * a.u_out_ld + jn + (size_t)i * a.u_out_ld] = unew[r];
                         if constexpr (MODE == MODE_C) {
                             if (a.dwdt) {
                                 const size_t gi = (size_t)b * N * a.m + jn + (size_t)i * a.m;
@@ -1522,8 +1531,10 @@ struct Tuning {
     int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
     int nyq_pack;            // TCFD_NYQ_PACK: packed Nyquist column in the step (1 = default where the plan allows it)
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
-    int graph;               // TCFD_GRAPH: hipGraph replay of interior steps (-1 = when the state is <= 16 MB)
+    int graph;               // TCFD_GRAPH: hipGraph replay of interior steps (1 = on; off by default since round 4: plain stream
+                             // launches measured 3-13 % faster than replay for every small problem, tests/micro/graph_crossover.py)
     int overlap;             // TCFD_OVERLAP: two half batches on two streams (opt-in experiment)
+    int psplit;              // TCFD_PSPLIT=1: the four planes of a column pass on four workgroups (opt-in: measured slower)
     int round_fields;        // n = 3 * 2^k: fields whose column tiles fill the resident workgroup slots exactly once (0: not used)
     size_t cache_bytes;      // last-level (Infinity Cache / MALL) size of the plan's device: what a chunk is sized for
     int cache_source;        // 0 = built-in 256 MB, 1 = KFD topology of this device, 2 = TCFD_CACHE_MB
@@ -1774,6 +1785,7 @@ TCFD_API int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const
     p->tune.nyq_pack = env_int("TCFD_NYQ_PACK", 1);
     p->tune.graph = env_int("TCFD_GRAPH", -1);
     p->tune.overlap = env_int("TCFD_OVERLAP", 0);
+    p->tune.psplit = env_int("TCFD_PSPLIT", 0);
     p->tune.cache_bytes = last_level_cache_bytes(&p->tune.cache_source);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
@@ -1810,13 +1822,26 @@ static size_t field_bytes(const tcfd_ns2d_plan* p, long batch) {
 }
 
 static long chunk_fields(const tcfd_ns2d_plan* p, long batch);
+// plane-split column passes (ColArgs::psplit) exist for the small power-of-two grids; they alternate two RK accumulators
+static bool psplit_capable(const tcfd_ns2d_plan* p) {
+    return p->tune.psplit == 1 && p->n >= 64 && p->n <= 256 && (p->n & (p->n - 1)) == 0 && p->tune.split != 1;
+}
+// MEASURED SLOWER and therefore opt-in (TCFD_PSPLIT=1): 256^2 x 16 fp32 8457 -> 7182 steps/s with the wide tiles, 7507 with
+// the narrow ones.  The premise -- a one-round launch lasts as long as ONE workgroup's chain of five transforms -- is
+// wrong at this size: what the four sibling workgroups re-read (advection, accumulator, state: 3 x 4.2 MB x 4 per launch)
+// comes through the fabric from the Infinity Cache, not from an idle L2 (the XCDs' L2s are not coherent: every kernel
+// boundary writes back and invalidates), and that traffic is what a 12 us kernel is made of.
+static bool psplit_now(const tcfd_ns2d_plan* p, long batch, int wide_cols) {
+    (void)batch; (void)wide_cols;
+    return psplit_capable(p) && p->tune.psplit == 1;
+}
 
 // Scratch of the batched calls.  They run chunk by chunk through ONE chunk-sized set of 8 fields (h, adv, 4 planes,
 // line-aligned state, second state), so the need does not grow with the batch beyond one chunk -- except for irfft2,
 // which stages ONE field of the whole batch.  (1024^2 x 64 fp64: 0.55 GB instead of the 4.4 GB of an unchunked step.)
 TCFD_API size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
     if (!p || batch <= 0) return 0;
-    return std::max(8 * field_bytes(p, chunk_fields(p, batch)), field_bytes(p, batch));
+    return std::max((size_t)(psplit_capable(p) ? 9 : 8) * field_bytes(p, chunk_fields(p, batch)), field_bytes(p, batch));
 }
 
 // ------------------------------------------------------------------ optional per-launch event timing
@@ -1898,7 +1923,9 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.ablate = p->tune.ablate;
     long blocks = batch * a.ntiles;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
-    const dim3 grid((unsigned)(blocks * (SP ? 2 : 1))), block(C * G);
+    if constexpr (MODE != MODE_A && MODE != MODE_CA) a.psplit = 0;
+    if (!a.h_out) a.h_out = a.h;
+    const dim3 grid((unsigned)(blocks * (SP ? 2 : 1)), a.psplit ? 4u : 1u), block(C * G);
     const int kind = MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5;
     auto launch = [&](auto kern, DevOnce& once) -> int {
         if (int rc_ = set_lds(once, kern, lds)) return rc_;
@@ -1970,7 +1997,9 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
     if constexpr ((N == 128 || N == 256) && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
         const int force = p->tune.small_tiles;
         const long tiles = batch * ((p->m + Cfg<T, N>::COLS - 1) / Cfg<T, N>::COLS);
-        if (force == 1 || (force != 0 && tiles < 2 * 256)) return launch_cols_v<T, N, MODE, 4, 4>(p, a, batch, st);
+        // (plane-split launches have four times the workgroups already: they keep the wide tiles -- whole 128-byte lines per
+        //  row, ONE exchange per 256-point transform at 16 elements per lane -- unless TCFD_SMALL_TILES=1 forces the narrow ones)
+        if (force == 1 || (force != 0 && tiles < 2 * 256 && !a.psplit)) return launch_cols_v<T, N, MODE, 4, 4>(p, a, batch, st);
     }
     // 512-point fp64 tiles are 64 KB: capping the update kernels at 128 VGPRs lets TWO workgroups share a CU,
     // so one tile's memory phases overlap the other's transforms (measured at 512^2 x 256: CA 1.05 -> 0.87 ms)
@@ -2137,6 +2166,7 @@ struct Ws {
     cx<T>* planes;
     cx<T>* upad;          // state in the line-aligned internal pitch (stages 1.. of a call)
     cx<T>* upad2;         // intermediate state of schedules whose later stages restart from the step's initial state
+    cx<T>* h2;
     size_t plane_stride;  // elements
 };
 template <typename T>
@@ -2149,6 +2179,7 @@ static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
     w.planes = (cx<T>*)(base + 2 * fb);
     w.upad = (cx<T>*)(base + 6 * fb);
     w.upad2 = (cx<T>*)(base + 7 * fb);
+    w.h2 = (cx<T>*)(base + 8 * fb);     // second RK accumulator of the plane-split passes (only plans that are psplit_capable)
     w.plane_stride = fb / sizeof(cx<T>);
     return w;
 }
@@ -2276,8 +2307,16 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     a.u_in = (const cx<T>*)w_in;
     a.u_in_ld = p->m;
     a.nyq = p->nyq_a;
+    // plane-split column passes (small one-round launches): four workgroups per tile, each emits one plane; state and
+    // accumulator are then written to the buffer that is NOT being read (upad <-> upad2, h <-> h2)
+    // (not under graph replay: a step is an odd number of buffer swaps, the captured step would read the wrong copy every
+    //  other replay)
+    const bool graph_wanted = steps >= 3 && !(p->prof && p->prof->on) && p->tune.graph == 1;
+    const bool ps = !base0 && !graph_wanted && psplit_now(p, batch, Cfg<T, N>::COLS);
+    a.psplit = ps ? 1 : 0;
     if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
     int planes_packed = p->nyq_a;   // how the planes in the workspace were written: the row pass reads them that way
+    cx<T>* h_cur = W.h;
     a.nyq = p->nyq_ca;
     // the caller's (n, m) rows are not 128-byte aligned (m is odd): only the first read and the last
     // write of a call touch that layout, every stage in between uses the aligned copy `upad`
@@ -2302,6 +2341,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.u_in_ld = from_u0 ? u0_ld : u_src_ld;
             cx<T>* dst = W.upad;
             if (u0_needed_later && (const cx<T>*)dst == u0) dst = W.upad2;
+            if (ps && (const cx<T>*)dst == u_src) dst = W.upad2;      // never the buffer the sibling workgroups still read
             a.u_out = last ? (cx<T>*)w_out : dst;
             a.u_out_ld = last ? p->m : p->ldw;
             a.beta = (T)beta[k];
@@ -2311,6 +2351,9 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.mud = mud ? (T)mud[k] : (T)mu[k];
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
             a.store_h = (k != nstages - 1);
+            a.h = h_cur;
+            a.h_out = (ps && !last) ? (h_cur == W.h ? W.h2 : W.h) : h_cur;
+            a.psplit = (ps && !last) ? 1 : 0;
             a.dwdt = last ? (cx<T>*)dwdt : nullptr;
             a.w0 = (const cx<T>*)w_in;
             a.dwdt_scale = (T)inv_total_dt;
@@ -2318,6 +2361,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             if (r) return r;
             u_src = a.u_out;
             u_src_ld = a.u_out_ld;
+            h_cur = a.h_out;
         }
         return 0;
     };
@@ -2325,7 +2369,8 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     const int graph_env = p->tune.graph;
     const bool profiling = p->prof && p->prof->on;
     const bool use_graph = steps >= 3 && !profiling &&
-                           (graph_env == 1 || (graph_env != 0 && state_bytes <= (long)16 << 20));  // launch-bound regime
+                           graph_env == 1;   // opt-in since round 4 (plain launches are faster at every size measured)
+    (void)state_bytes;
     int s0 = 0;
     if (use_graph) {
         tcfd_ns2d_plan* mp = const_cast<tcfd_ns2d_plan*>(p);
