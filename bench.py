@@ -397,6 +397,44 @@ def sfno_config5(dev, with_cpu=True):
             "algo_GBps": round(algo_gb / (t_all * 1e-3), 1), "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4)}
 
 
+def sfno_notebook_training(dev):
+    """The one training-loop figure the reference prints for this path (not the headline metric):
+    examples/ex2_SFNO_train.ipynb -- SFNO(32, 32, 5, width 10), batch 4, 64 x 64 x 10 -> 10 steps, Adam, SobolevLoss(order 0,
+    relative) -- 33-39 it/s on an unnamed GPU.  Same model / optimiser / loss on synthetic data of that shape: it/s of
+    zero_grad + forward + loss + backward + optimiser step."""
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = fno.SFNO(32, 32, 5, 10, beta=-1e-2).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss_fn = fno.SobolevLoss(n_grid=64, norm_order=0, time_average=True, relative=True).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(4, 64, 64, 10, generator=g).to(dev)
+    y = torch.randn(4, 64, 64, 10, generator=g).to(dev)
+
+    def it():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(model(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(5):
+        it()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n_it = 50
+    for _ in range(n_it):
+        last = it()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    return {"workload": "SFNO(32,32,5,width=10) training loop of examples/ex2_SFNO_train.ipynb: batch 4, 64x64x10, Adam, SobolevLoss "
+                        "(order 0, relative); synthetic data",
+            "iterations_per_s": round(n_it / el, 1), "ms_per_iteration": round(el / n_it * 1e3, 3), "finite": bool(torch.isfinite(last)),
+            "reference_printed": "33-39 it/s on an unnamed GPU (examples/ex2_SFNO_train.ipynb:147-371; other hardware, not comparable)"}
+
+
 def other_baseline_configs(dev, with_cpu=True):
     """Secondary lines for the other single-GPU BASELINE configs on the same kernels: C2 = 256^2, B=16,
     fp32, unforced McWilliams, dt=1e-3 (1000-step job, measured over 400 steps through forward(w, dt, steps=k)); C4 per-GPU
@@ -937,6 +975,10 @@ def main():
             out["sfno_config5"] = sfno_config5(dev, with_cpu=not args.no_cpu_baseline)
         except Exception as e:  # secondary measurement: never takes the headline line down
             out["sfno_config5"] = {"error": repr(e)}
+        try:
+            out["sfno_notebook_training"] = sfno_notebook_training(dev)
+        except Exception as e:
+            out["sfno_notebook_training"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(n, real, dt, args.cpu_seconds)
