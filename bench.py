@@ -429,9 +429,27 @@ def sfno_notebook_training(dev):
         last = it()
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
+    graphed = None
+    try:     # the same iteration captured once and replayed (fno.make_graphed_training_step): the eager loop is host-bound
+        torch.manual_seed(0)
+        model_g = fno.SFNO(32, 32, 5, 10, beta=-1e-2).to(dev).train()
+        opt_g = torch.optim.Adam(model_g.parameters(), lr=1e-3, capturable=True)
+        step = fno.make_graphed_training_step(model_g, loss_fn, opt_g, x, y)
+        for _ in range(3):
+            step(x, y)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(n_it):
+            lg = step(x, y)
+        torch.cuda.synchronize(dev)
+        elg = time.perf_counter() - t1
+        graphed = {"iterations_per_s": round(n_it / elg, 1), "ms_per_iteration": round(elg / n_it * 1e3, 3), "finite": bool(torch.isfinite(lg))}
+    except Exception as e:
+        graphed = {"error": repr(e)}
     return {"workload": "SFNO(32,32,5,width=10) training loop of examples/ex2_SFNO_train.ipynb: batch 4, 64x64x10, Adam, SobolevLoss "
                         "(order 0, relative); synthetic data",
             "iterations_per_s": round(n_it / el, 1), "ms_per_iteration": round(el / n_it * 1e3, 3), "finite": bool(torch.isfinite(last)),
+            "graph_replay": graphed,
             "reference_printed": "33-39 it/s on an unnamed GPU (examples/ex2_SFNO_train.ipynb:147-371; other hardware, not comparable)"}
 
 

@@ -22,9 +22,14 @@ import torch
 
 
 def _column_weights(plan, like: torch.Tensor) -> torch.Tensor:
-    c = torch.full((plan.m,), 2.0, dtype=plan.rdtype, device=like.device)
-    c[0] = c[-1] = 1.0
-    return c
+    """1 on the DC / Nyquist columns of the half spectrum, 2 elsewhere; built once per (plan, device) -- writing the two ones in
+    place cost a blocking host-to-device copy per call (and cannot be captured in a graph)."""
+    cached = getattr(plan, "_col_weights", None)
+    if cached is None or cached.device != like.device:
+        host = [2.0] * plan.m
+        host[0] = host[-1] = 1.0
+        cached = plan._col_weights = torch.tensor(host, dtype=plan.rdtype).to(like.device)
+    return cached
 
 
 class Rfft2(torch.autograd.Function):

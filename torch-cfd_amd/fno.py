@@ -395,12 +395,21 @@ def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -
     return out
 
 
+_C2R_WEIGHTS: Dict[tuple, torch.Tensor] = {}
+
+
 def _c2r_weights(mt: int, T: int, device, dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """Multiplicity of the kept time modes in a length-T c2r transform: 1 for kt = 0 and the Nyquist mode, else 2."""
-    c = torch.full((mt,), 2.0, dtype=_real_of(dtype), device=device)
-    c[0] = 1.0
-    if T % 2 == 0 and T // 2 < mt:
-        c[T // 2] = 1.0
+    """Multiplicity of the kept time modes in a length-T c2r transform: 1 for kt = 0 and the Nyquist mode, else 2.  Cached:
+    built in place (``c[0] = 1.0``) it cost a host-to-device copy of a scalar per call -- ten blocking copies per training
+    iteration, and a capture-breaking one under a graph."""
+    key = (mt, T, torch.device(device), _real_of(dtype))
+    c = _C2R_WEIGHTS.get(key)
+    if c is None:
+        host = [2.0] * mt
+        host[0] = 1.0
+        if T % 2 == 0 and T // 2 < mt:
+            host[T // 2] = 1.0
+        c = _C2R_WEIGHTS[key] = torch.tensor(host, dtype=_real_of(dtype)).to(device)
     return c
 
 
@@ -1766,6 +1775,57 @@ class SFNO(FNOBase):
         red = hip_pointwise(v, None, None, self.reduction)
         v = red if red is not None else self.reduction(v)
         return self.output_operator(v, v_res, out_steps=out_steps)
+
+
+# ----------------------------------------------------------------------------- one training iteration as a replayed graph
+def make_graphed_training_step(model: nn.Module, loss_fn, optimizer: torch.optim.Optimizer, x: torch.Tensor, y: torch.Tensor,
+                               warmup: int = 3):
+    """``step(x, y) -> loss`` = zero_grad + forward + loss + backward + optimizer step, captured ONCE in a
+    ``torch.cuda.CUDAGraph`` and replayed.  The training loops the reference ships work on small problems (examples/
+    ex2_SFNO_train.ipynb: batch 4, 64 x 64 x 10): one iteration is ~240 kernel launches and ~900 tensor-op dispatches, 1.8 ms of
+    device time behind 4-5 ms of host time; replayed as a graph it runs at the device's pace.  Every kernel of this package
+    is launched on the current stream with caller-owned buffers and never synchronises, so the whole iteration captures.
+
+    ``x`` / ``y`` fix shape and dtype; each call copies its batch into the captured input buffers.  The optimizer must be
+    capturable (``torch.optim.Adam(..., capturable=True)``: step counters on the device).  Gradients live in static buffers
+    (``zero_grad(set_to_none=False)`` semantics); learning-rate schedulers that write ``param_group["lr"]`` as a Python float
+    are frozen at capture time -- keep ``lr`` in a tensor for them."""
+    if not x.is_cuda:
+        raise _lib.TcfdError("expected HIP device tensors (torch-cfd_amd has no CPU fallback)")
+    for group in optimizer.param_groups:
+        if "capturable" in group and not group["capturable"]:
+            raise ValueError("the optimizer must be created with capturable=True to be replayed in a graph")
+    sx, sy = x.detach().clone(), y.detach().clone()
+
+    def iteration():
+        optimizer.zero_grad(set_to_none=False)
+        loss = loss_fn(model(sx), sy)
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    side = torch.cuda.Stream(device=x.device)
+    side.wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(side):          # plans, workspaces, lazily built tables, optimizer state: everything exists before capture
+        for p_ in model.parameters():
+            if p_.grad is None and p_.requires_grad:
+                p_.grad = torch.zeros_like(p_)
+        for _ in range(max(1, warmup)):
+            iteration()
+    torch.cuda.current_stream(x.device).wait_stream(side)
+    torch.cuda.synchronize(x.device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = iteration()
+
+    def step(xb: torch.Tensor, yb: torch.Tensor) -> torch.Tensor:
+        sx.copy_(xb, non_blocking=True)
+        sy.copy_(yb, non_blocking=True)
+        graph.replay()
+        return static_loss
+
+    step.graph = graph
+    return step
 
 
 # ----------------------------------------------------------------------------- loss (config 5 "forward + loss")
