@@ -364,7 +364,7 @@ def test_errors_are_loud(dev):
     with torch.no_grad():
         # a grid that is not a power of two used to raise here; since round 4 it runs (dense pruned transforms) ...
         assert m(torch.randn(1, 2, 24, 16, 10, device=dev)).shape == (1, 2, 24, 16, 10)
-        with pytest.raises(ValueError, match="exceed"):       # ... and modes that do not fit the grid are still an error
+        with pytest.raises((ValueError, _lib.TcfdError), match="exceed"):   # ... and modes that do not fit the grid are still an error
             m(torch.randn(1, 2, 6, 12, 10, device=dev))
         with pytest.raises(TypeError):
             m(torch.randn(1, 2, 16, 16, 10, device=dev, dtype=torch.float64))
@@ -512,6 +512,60 @@ def test_spectral_conv_on_a_96_grid_and_resampled_gradients_golden(dev):
         assert rel_l2(x.grad, g[f"rs_{tag}_gx"]) < 2e-5
         for k in range(4):
             assert rel_l2(layer.weight[k].grad, g[f"rs_{tag}_g_weight.{k}"]) < 2e-5
+
+
+@pytest.mark.parametrize("X,Y,T", [(32, 64, 10), (64, 32, 7), (16, 16, 11)])
+def test_any_size_kernels_agree_with_the_fft_kernels(X, Y, T, dev, monkeypatch):
+    """The pruned direct-DFT kernels that serve sizes off the FFT kernels (k_fwd_ty_dft / k_x_dft / k_inv_ty_dft) forced onto
+    power-of-two grids (TCFD_FNO_DFT=1): same layer outputs as the FFT kernels -- plain, temporally padded with resampled
+    steps, spatially resampled -- and the same gradients through the one-node training path (the adjoint transforms are the
+    same kernels with other plans)."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(X + Y)
+    s_layer = fno.SpectralConvS(3, 4, 5, 4, 3, bias=True, delta=0.3).to(dev)
+    t_layer = fno.SpectralConvT(3, 4, 5, 4, 3, delta=0.1, bias=True, temporal_padding=True).to(dev)
+    with torch.no_grad():
+        for lay in (s_layer, t_layer):
+            for p_ in lay.parameters():
+                p_.copy_(torch.randn(p_.shape) * 0.2)
+    x = torch.randn(2, 3, X, Y, T, device=dev)
+    cot = torch.randn(2, 4, X, Y, T, device=dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TCFD_FNO_DFT", flag)
+        with torch.no_grad():
+            outs = [s_layer(x), t_layer(x, out_steps=T + 3), s_layer(x, out_mesh_size=(X + 8, Y - 4, T))]
+        xg = x.clone().requires_grad_(True)
+        s_layer.zero_grad()
+        (s_layer(xg) * cot).sum().backward()
+        outs += [xg.grad, s_layer.weight[1].grad.clone(), s_layer.bias[2].grad.clone()]
+        res[flag] = outs
+    monkeypatch.delenv("TCFD_FNO_DFT")
+    for a, b in zip(res["0"], res["1"]):
+        assert a.shape == b.shape and rel_l2(a, b) < 5e-6
+
+
+@pytest.mark.parametrize("X,Y", [(96, 96), (48, 80)])
+def test_any_size_kernels_agree_with_the_dense_transforms(X, Y, dev, monkeypatch):
+    """Grids that are not powers of two: the library's direct-DFT kernels (default) against the dense GEMM transforms of
+    dense_fft.py (TCFD_FNO_DENSE=1, round 4's first route): outputs and gradients."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(X)
+    layer = fno.SpectralConvT(2, 3, 6, 5, 4, delta=0.1, bias=True, temporal_padding=True).to(dev)
+    x = torch.randn(2, 2, X, Y, 10, device=dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TCFD_FNO_DENSE", flag)
+        xg = x.clone().requires_grad_(True)
+        layer.zero_grad()
+        y = layer(xg, out_steps=12)
+        y.square().sum().backward()
+        res[flag] = (y.detach(), xg.grad, layer.weight[0].grad.clone())
+    monkeypatch.delenv("TCFD_FNO_DENSE")
+    for a, b in zip(res["0"], res["1"]):
+        assert rel_l2(a, b) < 5e-6
 
 
 @pytest.mark.parametrize("X,Y", [(96, 96), (48, 80), (272, 272)])

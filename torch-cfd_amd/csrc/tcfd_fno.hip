@@ -127,7 +127,7 @@ extern "C" int tcfd_fno_plan_create_dtype(tcfd_fno_plan** out, int X, int Y, int
                                           int my, int mt, int Xs, int Ys, int dtype) {
     if (!out) return FAIL(TCFD_EINVAL, "fno_plan_create: null argument");
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return FAIL(TCFD_EINVAL, "fno_plan_create: bad dtype %d", dtype);
-    if (!pow2(X) || !pow2(Y)) return FAIL(TCFD_EINVAL, "fno_plan_create: X=%d, Y=%d must be powers of two in [8, 1024]", X, Y);
+    if (X < 4 || Y < 4 || X > 1024 || Y > 1024) return FAIL(TCFD_EINVAL, "fno_plan_create: X=%d, Y=%d must lie in [4, 1024]", X, Y);
     if (T_in < 1 || t_pad < 0 || T_out < 1 || mx < 1 || my < 1 || mt < 1)
         return FAIL(TCFD_EINVAL, "fno_plan_create: bad sizes");
     const int Tp = T_in + t_pad;
@@ -453,6 +453,8 @@ __global__ __launch_bounds__(C*(X / EPT)) void k_x(const cx<T>* __restrict__ in,
     }
 }
 
+#include "tcfd_fno_dft.hpp"   // k_fwd_ty_dft / k_x_dft / k_inv_ty_dft: the same pipeline for sizes off the FFT kernels
+
 // ------------------------------------------------------------------ contraction
 template <typename T>
 struct ContractArgsT {
@@ -601,6 +603,74 @@ static int set_lds_attr(K kernel, size_t bytes) {
     return 0;
 }
 
+// ---- launchers of the any-size kernels
+template <typename T>
+static int launch_fwd_ty_dft(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, T scale, hipStream_t st) {
+    typedef cx<T> ct;
+    if (p->mt > 16) return FAIL(TCFD_EINVAL, "fno: modes_t = %d > 16", p->mt);
+    const size_t fixed = ((size_t)p->Y + (size_t)p->mt * p->Tp) * sizeof(ct), per = (size_t)p->Y * p->mt * sizeof(ct);
+    int NS = (int)std::max<long>(1, std::min<long>(256 / (p->my + 1), (long)((64 * 1024 - (long)fixed) / (long)per)));
+    if (fixed + per > 150 * 1024) return FAIL(TCFD_EINVAL, "fno: a slab of Y = %d does not fit LDS", p->Y);
+    const size_t lds = fixed + (size_t)NS * per;
+    const unsigned blocks = (unsigned)((slabs + NS - 1) / NS);
+#define TCFD_MT_CASE(MT_)                                                                                                       \
+    if (p->mt <= MT_) {                                                                                                         \
+        auto kern = k_fwd_ty_dft<T, MT_>;                                                                                       \
+        if (int rc = set_lds_attr(kern, lds)) return rc;                                                                        \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, v, w1, (const ct*)p->tw_y, (const ct*)p->tw_tf, p->Y, p->T_in, \
+                           p->t_pad, p->mt, p->my, scale, NS, slabs);                                                          \
+        HIP_TRY(hipGetLastError());                                                                                             \
+        return 0;                                                                                                               \
+    }
+    TCFD_MT_CASE(1) TCFD_MT_CASE(2) TCFD_MT_CASE(3) TCFD_MT_CASE(4) TCFD_MT_CASE(5) TCFD_MT_CASE(6) TCFD_MT_CASE(8) TCFD_MT_CASE(12)
+    TCFD_MT_CASE(16)
+#undef TCFD_MT_CASE
+    return FAIL(TCFD_EINVAL, "fno: modes_t = %d > 16", p->mt);
+}
+template <typename T, bool FWD>
+static int launch_x_dft(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
+    typedef cx<T> ct;
+    const int Q = 2 * p->my * p->mt;
+    const int n_out = FWD ? 2 * p->mx : p->X;
+    const size_t lds = (size_t)p->X * sizeof(ct);
+    auto kern = k_x_dft<T, FWD>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    if (bc > 65535) return FAIL(TCFD_EINVAL, "fno: batch x channels = %ld exceeds the grid's z range", bc);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Q + 255) / 256), (unsigned)((n_out + 15) / 16), (unsigned)bc), dim3(256), lds, st, in,
+                       out, (const ct*)p->tw_x, p->X, FWD ? p->X : p->Xs, p->mx, Q);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <typename T>
+static int launch_inv_ty_dft(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T scale, hipStream_t st,
+                             const T* acc, const T* accb, int accT) {
+    typedef cx<T> ct;
+    if (p->mt > 16) return FAIL(TCFD_EINVAL, "fno: modes_t = %d > 16", p->mt);
+    const size_t Q = (size_t)2 * p->my * p->mt;
+    const size_t fixed = ((size_t)p->Y + (size_t)t_keep * p->mt) * sizeof(ct);
+    const size_t per = (Q + 2 * p->mt + 2 * (size_t)(p->my + 1) * p->mt) * sizeof(ct) + (size_t)p->Y * t_keep * sizeof(T);
+    if (fixed + per > 150 * 1024) return FAIL(TCFD_EINVAL, "fno: a slab of Y = %d x %d steps does not fit LDS", p->Y, t_keep);
+    // one lane per (slab, y) row: NS slabs per workgroup so that the rows fill ~256 lanes, the block a whole number of waves
+    int NS = (int)std::max<long>(1, std::min<long>(std::max(1, 256 / p->Y), (long)((64 * 1024 - (long)fixed) / (long)per)));
+    const size_t lds = fixed + (size_t)NS * per;
+    const unsigned threads = (unsigned)std::min(1024, ((NS * p->Y + 63) / 64) * 64);
+    const unsigned blocks = (unsigned)((slabs + NS - 1) / NS);
+#define TCFD_MT_CASE(MT_)                                                                                                        \
+    if (p->mt <= MT_) {                                                                                                          \
+        auto kern = k_inv_ty_dft<T, MT_>;                                                                                        \
+        if (int rc = set_lds_attr(kern, lds)) return rc;                                                                         \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, w2, out, (const ct*)p->tw_y, (const ct*)p->tw_ti, p->Y,   \
+                           p->Ys, p->T_out, t_keep, p->mt, p->my, scale, NS, slabs, acc, accb, accT);                            \
+        HIP_TRY(hipGetLastError());                                                                                              \
+        return 0;                                                                                                                \
+    }
+    TCFD_MT_CASE(1) TCFD_MT_CASE(2) TCFD_MT_CASE(3) TCFD_MT_CASE(4) TCFD_MT_CASE(5) TCFD_MT_CASE(6) TCFD_MT_CASE(8) TCFD_MT_CASE(12)
+    TCFD_MT_CASE(16)
+#undef TCFD_MT_CASE
+    return FAIL(TCFD_EINVAL, "fno: modes_t = %d > 16", p->mt);
+}
+
 template <typename T, int X, bool FWD>
 static int launch_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
     typedef cx<T> ct;
@@ -693,21 +763,26 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long 
         default: return FAIL(TCFD_EINVAL, "unsupported transform length %d", n); \
     }
 
+static int force_dft() { return env_int("TCFD_FNO_DFT", 0); }   // 1: any-size kernels for every size (cross-check; read per call)
 template <typename T>
 static int do_fwd_ty(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, T s, hipStream_t st) {
+    if (!pow2(p->Y) || force_dft()) return launch_fwd_ty_dft<T>(p, v, w1, slabs, s, st);
     DISPATCH_POW2(p->Y, (launch_fwd_ty2<T, N_>(p, v, w1, slabs, s, st)));
 }
 template <typename T>
 static int do_inv_ty(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T s, hipStream_t st,
                      const T* acc = nullptr, const T* accb = nullptr, int accT = 0) {
+    if (!pow2(p->Y) || force_dft()) return launch_inv_ty_dft<T>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT);
     DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT)));
 }
 template <typename T>
 static int do_fwd_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
+    if (!pow2(p->X) || force_dft()) return launch_x_dft<T, true>(p, in, out, bc, st);
     DISPATCH_POW2(p->X, (launch_x<T, N_, true>(p, in, out, bc, st)));
 }
 template <typename T>
 static int do_inv_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
+    if (!pow2(p->X) || force_dft()) return launch_x_dft<T, false>(p, in, out, bc, st);
     DISPATCH_POW2(p->X, (launch_x<T, N_, false>(p, in, out, bc, st)));
 }
 

@@ -118,9 +118,18 @@ def _norm_scales(norm: str, n_in: int, n_out: int) -> Tuple[float, float]:
     raise ValueError(f"unknown fft norm {norm!r}")
 
 
-def _fused_xy(X: int, Y: int) -> bool:
-    """Spatial sizes the fused transform kernels cover (tcfd_fno_plan_create): powers of two in [8, 1024]."""
+def _pow2_xy(X: int, Y: int) -> bool:
+    """Spatial sizes of the FFT kernels (k_fwd_ty2 / k_x / k_inv_ty2): powers of two in [8, 1024]."""
     return all(8 <= n <= 1024 and (n & (n - 1)) == 0 for n in (X, Y))
+
+
+def _fused_xy(X: int, Y: int) -> bool:
+    """Spatial sizes the library's transform kernels cover (tcfd_fno_plan_create): powers of two on the FFT kernels, every
+    other size in [4, 1024] on the pruned direct-DFT kernels (k_fwd_ty_dft / k_x_dft / k_inv_ty_dft).  ``TCFD_FNO_DENSE=1``
+    sends the non-power-of-two sizes through the dense GEMM transforms of dense_fft.py instead (cross-check)."""
+    if os.environ.get("TCFD_FNO_DENSE", "0") == "1":
+        return _pow2_xy(X, Y)
+    return all(4 <= n <= 1024 for n in (X, Y))
 
 
 def dense_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad: int = 0, t_out: Optional[int] = None,
@@ -1086,7 +1095,7 @@ def hip_conv_pointwise(conv, v: torch.Tensor, mlp, skip: torch.Tensor, skip_conv
     makes the two calls.  NOT the default: at config 5 it is slower than the two kernels (7.5 vs 5.9 ms per forward --
     one row-sized workgroup per CU cannot hide what 4-8 small ones do); ``TCFD_FNO_FUSE_TAIL=1`` switches the models to it."""
     if (not isinstance(mlp, PointwiseFFN) or not isinstance(conv, SpectralConvS) or not v.is_cuda or v.dtype != torch.float32
-            or v.dim() != 5 or not _fused_xy(v.shape[2], v.shape[3])):
+            or v.dim() != 5 or not _pow2_xy(v.shape[2], v.shape[3])):
         return None
     if isinstance(conv, SpectralConvT) and not isinstance(conv.postprocess, nn.Identity):
         return None
