@@ -201,6 +201,7 @@ class RecordHandover:
                             order.extend((f, layout[r][k][0], layout[r][k][1]) for f in self.fields)
                 self._host_ready = {(f, s0): threading.Event() for f, s0, _ in order}
                 self._registered: list = []
+                self._lock_warned = False
 
                 def allocate():
                     import time as _time
@@ -213,8 +214,16 @@ class RecordHandover:
                         for f, s0, c in order:
                             view = self.host[f][s0:s0 + c]
                             ptr = view.data_ptr()
-                            L.check(lib.tcfd_host_register(ptr, view.numel() * view.element_size()), "tcfd_host_register")
-                            self._registered.append(ptr)
+                            if lib.tcfd_host_register(ptr, view.numel() * view.element_size()) == 0:
+                                self._registered.append(ptr)
+                            elif not self._lock_warned:
+                                # (a locked-memory limit, say): the copies into this region still work -- through the
+                                # runtime's own staging buffers, blocking the side stream's host thread instead of overlapping
+                                import warnings
+
+                                self._lock_warned = True
+                                warnings.warn("torch-cfd_amd: could not page-lock the ensemble result ("
+                                              + lib.tcfd_last_error().decode() + "); records are copied without overlap")
                             self._host_ready[(f, s0)].set()
                             _time.sleep(0.0005)
                         self._trace("page-lock end")
