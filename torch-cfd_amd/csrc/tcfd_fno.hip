@@ -1073,10 +1073,29 @@ struct PwArgs {
                         // operator prepends to the latent steps, fno/sfno.py:314-315) -- its torch.cat never runs
 };
 
+// max(v, 0) as ONE v_max_f32 (fmaxf / a select add a canonicalising v_max_f32 v, v, v in front of it)
+__device__ __forceinline__ float relu_f(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// GELU (exact form, torch default) of one value: the branch-free evaluation of gelu_pk below, see there.
+__device__ __forceinline__ float gelu_f(float v) {
+    const float u = fabsf(v);
+    float p = fmaf(-1.690403337e-06f, u, 2.508333091e-05f);
+    p = fmaf(p, u, -1.144628186e-04f);
+    p = fmaf(p, u, -3.233417228e-04f);
+    p = fmaf(p, u, 7.333383430e-03f);
+    p = fmaf(p, u, -5.271419883e-02f);
+    p = fmaf(p, u, -4.591154456e-01f);
+    p = fmaf(p, u, -1.151123285e+00f);
+    p = fmaf(p, u, -9.999988675e-01f);
+    return fmaf(-u, __builtin_amdgcn_exp2f(p), relu_f(v));
+}
 __device__ __forceinline__ float pw_act(float v, int act) {
     switch (act) {
-        case 1: return v > 0.f ? v : 0.f;                                  // ReLU
-        case 2: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // GELU (exact, torch default)
+        case 1: return relu_f(v);                                          // ReLU
+        case 2: return gelu_f(v);                                          // GELU (exact, torch default)
         case 3: return v / (1.f + __expf(-v));                             // SiLU
         case 4: return tanhf(v);
         default: return v;
@@ -1089,13 +1108,56 @@ __device__ __forceinline__ float pw_act(float v, int act) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 template <int V> struct PwVec { typedef float type; };
 template <> struct PwVec<2> { typedef v2f type; };
-__device__ __forceinline__ v2f pw_act(v2f v, int act) { return v2f{pw_act(v.x, act), pw_act(v.y, act)}; }
+// GELU of a packed pair without erff.  The library erff is ~40 instructions per element (two data-dependent branches and
+// a full-range expf), four times the 2 x 10 packed FMAs of the hidden unit it follows -- the block was bound by it, not by its
+// 900 FMAs per point.  Here  gelu(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|)  with  Phi(-u) = 2^-s(u):  s(u) = -log2 Phi(-u)
+// is smooth (~ u^2 / 2 ln 2), one degree-8 polynomial covers every u (fitted with weight u Phi(-u), the sensitivity of the
+// result; its leading coefficient is positive, so 2^-s underflows to 0 beyond the fitted range [0, 9]), and the hardware's
+// v_exp_f32 IS 2^x.  Eight v_pk_fma_f32 + two v_exp_f32 per pair, no branch; error <= 8.4e-8 max(|gelu|, 1) for every
+// finite v, i.e. tighter than the float32 formula 0.5 v (1 + erf(v / sqrt 2)) itself (its 1 + erf cancels for v < 0).
+// When every lane of the wave has |v| < 2 the exponential is skipped too:  gelu(v) = v (1/2 + v P(v^2))  with a degree-6
+// P (absolute error <= 2.7e-7); the test is wave uniform, so no lane diverges.  TCFD_GELU_SMALL 0 compiles that path out.
+#ifndef TCFD_GELU_SMALL
+#define TCFD_GELU_SMALL 1
+#endif
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f gelu_pk(v2f v) {
+#if TCFD_GELU_SMALL
+    const bool big = !(fabsf(v.x) < 2.f) || !(fabsf(v.y) < 2.f);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+        const v2f s = v * v;
+        v2f p = pk_fma(v2f{2.765524414e-07f, 2.765524414e-07f}, s, v2f{-7.518318853e-06f, -7.518318853e-06f});
+        p = pk_fma(p, s, v2f{1.101917369e-04f, 1.101917369e-04f});
+        p = pk_fma(p, s, v2f{-1.179484301e-03f, -1.179484301e-03f});
+        p = pk_fma(p, s, v2f{9.967512451e-03f, 9.967512451e-03f});
+        p = pk_fma(p, s, v2f{-6.648835540e-02f, -6.648835540e-02f});
+        p = pk_fma(p, s, v2f{3.989420831e-01f, 3.989420831e-01f});
+        return v * pk_fma(v, p, v2f{0.5f, 0.5f});
+    }
+#endif
+    const v2f u = v2f{fabsf(v.x), fabsf(v.y)};
+    v2f p = pk_fma(v2f{-1.690403337e-06f, -1.690403337e-06f}, u, v2f{2.508333091e-05f, 2.508333091e-05f});
+    p = pk_fma(p, u, v2f{-1.144628186e-04f, -1.144628186e-04f});
+    p = pk_fma(p, u, v2f{-3.233417228e-04f, -3.233417228e-04f});
+    p = pk_fma(p, u, v2f{7.333383430e-03f, 7.333383430e-03f});
+    p = pk_fma(p, u, v2f{-5.271419883e-02f, -5.271419883e-02f});
+    p = pk_fma(p, u, v2f{-4.591154456e-01f, -4.591154456e-01f});
+    p = pk_fma(p, u, v2f{-1.151123285e+00f, -1.151123285e+00f});
+    p = pk_fma(p, u, v2f{-9.999988675e-01f, -9.999988675e-01f});
+    const v2f e = v2f{__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+    return pk_fma(-u, e, v2f{relu_f(v.x), relu_f(v.y)});
+}
+__device__ __forceinline__ v2f pw_act(v2f v, int act) {
+    if (act == 2) return gelu_pk(v);
+    return v2f{pw_act(v.x, act), pw_act(v.y, act)};
+}
 __device__ __forceinline__ float pw_fma(float w, float x, float acc) { return fmaf(w, x, acc); }
 __device__ __forceinline__ v2f pw_fma(float w, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{w, w}, x, acc); }
 
 // o = b2 + W2 . act1(W1 . x + b1)   (HAS_L1)   |   o = b2 + W2 . x   -- the block without its skip term and final activation
-template <int CI, int CM, int CO, bool HAS_L1, typename vf>
+template <int CI, int CM, int CO, bool HAS_L1, typename vf, int ACT = -1>
 __device__ __forceinline__ void pw_core(const PwArgs& a, int b, const vf (&x)[CI], vf (&o)[CO]) {
+    const int act1 = ACT >= 0 ? ACT : a.act1;
     const float* w2t_b = a.w2t + (size_t)b * a.w2_bstride;
     const float* b2_b = a.b2 ? a.b2 + (size_t)b * a.b2_bstride : nullptr;
 #pragma unroll
@@ -1108,7 +1170,7 @@ __device__ __forceinline__ void pw_core(const PwArgs& a, int b, const vf (&x)[CI
             const float* w1 = a.w1 + m * CI;
 #pragma unroll
             for (int i = 0; i < CI; ++i) h = pw_fma(w1[i], x[i], h);
-            h = pw_act(h, a.act1);
+            h = pw_act(h, act1);
             const float* w2 = w2t_b + m * CO;
 #pragma unroll
             for (int c = 0; c < CO; ++c) o[c] = pw_fma(w2[c], h, o[c]);
@@ -1137,9 +1199,12 @@ __device__ __forceinline__ void pw_skip_conv(const PwArgs& a, const vf (&sv)[CI]
     }
 }
 
-template <int CI, int CM, int CO, bool HAS_L1, int V>
+// ACT >= 0: both activations are that code at compile time (the reference's ReLU / ReLU and GELU / GELU layers): the
+// run-time switch inside the hidden-unit loop costs ~25 scalar instructions and several taken branches per unit.
+template <int CI, int CM, int CO, bool HAS_L1, int V, int ACT = -1>
 __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     typedef typename PwVec<V>::type vf;
+    const int act2 = ACT >= 0 ? ACT : a.act2;
     const long p = ((long)blockIdx.x * 256 + threadIdx.x) * V;
     const int b = blockIdx.y;
     if (p >= a.P) return;
@@ -1153,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
 #pragma unroll
         for (int i = 0; i < CI; ++i) x[i] = *reinterpret_cast<const vf*>(xb + (size_t)i * a.P);
     }
-    pw_core<CI, CM, CO, HAS_L1, vf>(a, b, x, o);
+    pw_core<CI, CM, CO, HAS_L1, vf, ACT>(a, b, x, o);
     if (a.skip_mode == 1) {
         const float* sb = a.s + (size_t)b * CI * a.P + p;
         vf sv[CI];
@@ -1175,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
         const float fr = a.frame[((size_t)b * (a.P / a.T) + xy) * a.fT + (a.fT - 1)];
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
-            const vf r = pw_act(o[c], a.act2);
+            const vf r = pw_act(o[c], act2);
             float* oc = ob + (size_t)c * oP;
             if constexpr (V == 2) { oc[0] = r.x; oc[1] = r.y; } else { oc[0] = r; }
             if (t == 0) oc[-1] = fr;
@@ -1185,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     float* ob = a.out + (size_t)b * CO * a.P + p;
 #pragma unroll
     for (int c = 0; c < CO; ++c)   // streamed out (non-temporal): an 0.8 GB activation tensor outlives every cache; SFNO forward 5.77 -> 5.42 ms
-        __builtin_nontemporal_store(pw_act(o[c], a.act2), reinterpret_cast<vf*>(ob + (size_t)c * a.P));
+        __builtin_nontemporal_store(pw_act(o[c], act2), reinterpret_cast<vf*>(ob + (size_t)c * a.P));
 }
 
 // ------------------------------------------------------------------ inverse t/y transform + pointwise block in ONE kernel
@@ -1344,6 +1409,14 @@ static int launch_pw(const PwArgs& a, int batch, hipStream_t st) {
     if constexpr (CI <= 20) {      // (the packed form is not even compiled for wider layers)
         if (pairs) {
             dim3 grid((unsigned)((a.P / 2 + 255) / 256), (unsigned)batch);
+            if constexpr (HAS_L1 && CM > 0) {      // the 4 x width layers: activations known at compile time
+                if (a.act1 == a.act2 && (a.act1 == 1 || a.act1 == 2) && env_int("TCFD_PW_ACT_T", 1)) {
+                    if (a.act1 == 1) hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 2, 1>), grid, dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 2, 2>), grid, dim3(256), 0, st, a);
+                    HIP_TRY(hipGetLastError());
+                    return 0;
+                }
+            }
             hipLaunchKernelGGL((k_pointwise<CI, CM, CO, HAS_L1, 2>), grid, dim3(256), 0, st, a);
             HIP_TRY(hipGetLastError());
             return 0;
