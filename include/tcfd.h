@@ -182,6 +182,16 @@ int tcfd_rfft2(const tcfd_ns2d_plan* plan, const void* x_real, void* out_hat, lo
 int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* irfft2 followed by F.interpolate(size = (n / factor, n / factor), mode = "bilinear") of the data-generation
+ * drivers (fno/data_gen/data_gen_McWilliams2d.py:158-163) in one pass over the spectrum: complex (batch, n, m) ->
+ * real (batch, n / factor, n / factor); bit-identical to the two calls at factor 2, equal to rounding beyond (the two
+ * rows a pixel needs share one complex transform here and ride through two different ones in tcfd_irfft2; the rows the
+ * subsample never looks at are not transformed).  factor: a power of two >= 2 that divides n
+ * (at most the lanes of one row transform, 64 at most; TCFD_EINVAL otherwise -- the caller then runs the two calls).
+ * Same workspace as tcfd_irfft2. */
+int tcfd_irfft2_subsample(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, int factor,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- FNO / SFNO spectral convolution (fp32 and fp64) -------------------------------
  * Replaces SpectralConv.forward (fno/base.py:229-237) with SpectralConvS.spectral_conv
  * (fno/sfno.py:364-391), SpectralConvT.forward (fno/sfno.py:433-457) and

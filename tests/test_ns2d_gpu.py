@@ -436,6 +436,39 @@ def test_config4_dataset_generation_512(dev, tmp_path):
     assert scaled_err(data["residual"][:4], phys["residual"], phys["vort_t"]) < 1e-3
 
 
+@pytest.mark.parametrize("n,factor", [(64, 2), (256, 2), (256, 4), (512, 2), (512, 4), (512, 8), (1024, 2)])
+@pytest.mark.parametrize("cdtype", [torch.complex64, torch.complex128])
+def test_fused_c2r_subsample_is_bit_identical_to_the_two_steps(dev, n, factor, cdtype):
+    """Output side of the data-generation drivers (fno/data_gen/data_gen_McWilliams2d.py:158-163): irfft2 and the bilinear
+    subsample as ONE pass (tcfd_irfft2_subsample) against the HIP irfft2 followed by F.interpolate -- equal bit for bit at factor 2, to rounding beyond --
+    and against torch.fft + F.interpolate on the CPU in the same precision."""
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.data_gen import spectral_to_physical
+    from torch_cfd_amd.equations import fft_plan
+
+    g = torch.Generator().manual_seed(n + factor)
+    rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
+    x = torch.randn(3, 2, n, n, generator=g, dtype=rdtype)
+    xh = torch.fft.rfft2(x).to(dev)
+    plan = fft_plan(n, cdtype, dev)
+    assert plan.subsample_factor(n // factor) == factor
+    assert plan.subsample_factor(n // 2 - 8) == 0 and plan.subsample_factor(n) == 0 and plan.subsample_factor(None) == 0
+    fused = plan.irfft2_subsample(xh, factor)
+    two = torch.nn.functional.interpolate(plan.irfft2(xh).reshape(-1, 1, n, n), size=(n // factor, n // factor),
+                                          mode="bilinear").reshape(3, 2, n // factor, n // factor)
+    assert fused.shape == two.shape and fused.dtype == rdtype
+    if factor == 2:
+        assert torch.equal(fused, two)       # same row pairs share a complex transform in both paths, same arithmetic after it
+    else:                                    # rows S r + S/2 - 1 and S r + S/2 ride through ONE transform here, through two
+        assert rel_l2(fused, two) < (3e-7 if rdtype == torch.float32 else 5e-16)     # different ones there: rounding only
+    assert torch.equal(spectral_to_physical(xh, n // factor, rdtype), fused)        # the driver-side helper takes the fused pass
+    cpu = torch.nn.functional.interpolate(x.reshape(-1, 1, n, n), size=(n // factor, n // factor), mode="bilinear")
+    tol = 2e-6 if rdtype == torch.float32 else 1e-14
+    assert rel_l2(fused.cpu().reshape(cpu.shape), cpu) < tol
+    with pytest.raises(tc._lib.TcfdError):
+        plan.irfft2_subsample(xh, 3)
+
+
 def test_linearity_of_transforms_and_roundtrip(dev):
     import torch_cfd_amd as tc
 

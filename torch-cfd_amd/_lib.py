@@ -125,6 +125,7 @@ SIGNATURES = {
     "tcfd_ns2d_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),
     "tcfd_irfft2": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
+    "tcfd_irfft2_subsample": (_i, [_vp, _vp, _vp, _l, _i, _vp, _sz, _vp]),
     "tcfd_fno_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i]),
     "tcfd_fno_plan_create_resample": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tcfd_fno_plan_create_dtype": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -1464,6 +1464,53 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_c2r(cons
     }
 }
 
+// Second half of irfft2 + the data-generation drivers' bilinear subsample in ONE pass (fno/data_gen/data_gen_McWilliams2d.py:
+// 158-163: irfft2 -> F.interpolate(size = (N / S, N / S), mode = "bilinear")).  For an even integer factor S the sample point
+// of output pixel (r, c) is (S r + (S - 1) / 2, S c + (S - 1) / 2): exactly between rows S r + S / 2 - 1 and S r + S / 2 and
+// between the two columns of the same numbers, every weight 1 / 2.  A group transforms those two rows as ONE complex sequence
+// (any two rows pack, they need not be neighbours in the pair index) -- so the rows the subsample never looks at are not
+// transformed at all --, the horizontal neighbour is one lane away (element j + t G of lane j: S <= G keeps both in a wave),
+// the vertical one is the other component of the same register.  Arithmetic in ATen's order, 0.5 (0.5 a + 0.5 b) + 0.5 (0.5 c +
+// 0.5 d) with a, b on the upper row: at S = 2 (same row pairs as k_rows_c2r) the result is bit-identical to irfft2 followed by
+// F.interpolate, beyond it agrees to rounding (which two rows share a transform shows in the last bit); the full-size field
+// -- written and read again by the two-step path, 2.25 x the bytes of this one at S = 2 -- never exists.
+template <typename T, int N, int EPT>
+__global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_c2r_sub(const cx<T>* __restrict__ in,
+                                                                                 T* __restrict__ out,
+                                                                                 const cx<T>* __restrict__ tw, long nrows,
+                                                                                 int m /* pitch of in */, int S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = RowGeom<T, N, EPT>;
+    constexpr int G = Gm::G;
+    constexpr bool WG = (G > 64);
+    const int grp = threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
+    long orow = (long)blockIdx.x * Gm::GROUPS + grp;          // output row over all fields
+    const bool valid = orow < nrows;
+    if (!valid) orow = nrows - 1;
+    const int NS = N / S;
+    const long f = orow / NS;
+    const int r = (int)(orow - f * NS);
+    const size_t row0 = (size_t)f * N + (size_t)r * S + (S / 2 - 1);
+    cx<T> z[EPT];
+    load_herm_pair<T, N, EPT>(z, in + row0 * (size_t)m, in + (row0 + 1) * (size_t)m, j);
+    tile_fft<T, N, EPT, +1, 1, true, WG>(z, lds, tw, j, 0);
+    T* orow_p = out + (size_t)orow * NS;
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) asm volatile("" : "+v"(z[t].x), "+v"(z[t].y));   // the transform ends here: nothing below
+                                                                                  // may be contracted into its last stage
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int e = j + t * G;
+        const T bx = __shfl_down(z[t].x, 1), by = __shfl_down(z[t].y, 1);
+        if (valid && (e & (S - 1)) == S / 2 - 1) {
+            const T up = (T)0.5 * z[t].x + (T)0.5 * bx, lo = (T)0.5 * z[t].y + (T)0.5 * by;
+            orow_p[e / S] = (T)0.5 * up + (T)0.5 * lo;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ small elementwise kernels
 template <typename T>
 __global__ void k_velocity(const cx<T>* __restrict__ w, cx<T>* __restrict__ uh, cx<T>* __restrict__ vh,
@@ -2493,6 +2540,33 @@ static int irfft2_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long 
     return 0;
 }
 
+template <typename T, int N>
+static int irfft2_sub_impl(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, int S, void* ws, hipStream_t st) {
+    using Gm = RowGeom<T, N, Cfg<T, N>::ROW_EPT>;
+    if (S < 2 || (S & (S - 1)) || S > Gm::G || S > 64)
+        return fail(TCFD_EINVAL, "irfft2_subsample: factor %d is not a power of two in [2, %d] (n = %d)", S, Gm::G < 64 ? Gm::G : 64, N);
+    ColArgs<T> a{};
+    a.in = (const cx<T>*)xh;
+    a.out = (cx<T>*)ws;
+    a.in_ld = p->m;
+    a.out_ld = p->ldw;
+    a.scale = (T)1 / ((T)N * (T)N);
+    int rc;
+    if ((rc = launch_cols<T, N, MODE_INV>(p, a, batch, st))) return rc;
+    auto kern = k_rows_c2r_sub<T, N, Cfg<T, N>::ROW_EPT>;
+    static DevOnce lds_once;
+    {
+        rc = set_lds(lds_once, kern, Gm::LDS_BYTES);
+        if (rc) return rc;
+    }
+    const long nrows = batch * (N / S);
+    const long blocks = (nrows + Gm::GROUPS - 1) / Gm::GROUPS;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, (const cx<T>*)ws, (T*)out,
+                       (const cx<T>*)p->tw, nrows, p->ldw, S);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ (dtype, n) dispatch
 #define TCFD_DISPATCH_N(T, n, CALL)                                       \
     switch (n) {                                                          \
@@ -2824,6 +2898,18 @@ TCFD_DISPATCHED(rfft2_dispatch, (const tcfd_ns2d_plan* p, const void* x, void* o
                 (rfft2_impl<T_, N_>(p, x, out, batch, st)))
 TCFD_DISPATCHED(irfft2_dispatch, (const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, hipStream_t st),
                 (p, xh, out, batch, ws, st), (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)))
+
+TCFD_DISPATCHED(irfft2_sub_dispatch, (const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, int S, void* ws, hipStream_t st),
+                (p, xh, out, batch, S, ws, st), (irfft2_sub_impl<T_, N_>(p, xh, out, batch, S, ws, st)))
+
+TCFD_API int tcfd_irfft2_subsample(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, int factor, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    if (!p || !xh || !out || batch <= 0) return fail(TCFD_EINVAL, "irfft2_subsample: bad argument");
+    if (factor < 2 || p->n % factor) return fail(TCFD_EINVAL, "irfft2_subsample: factor %d does not divide n = %d", factor, p->n);
+    int rc = check_ws(p, batch, ws, ws_bytes, field_bytes(p, batch));
+    if (rc) return rc;
+    return irfft2_sub_dispatch(p, xh, out, batch, factor, ws, (hipStream_t)stream);
+}
 
 TCFD_API int tcfd_rfft2(const tcfd_ns2d_plan* p, const void* x, void* out, long batch, void* stream) {
     if (!p || !x || !out || batch <= 0) return fail(TCFD_EINVAL, "rfft2: bad argument");

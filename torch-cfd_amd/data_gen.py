@@ -8,11 +8,12 @@ The argparse / logging / dill-append plumbing of the drivers is out of scope (SU
 
 Everything between the seeded CPU noise and the final ``.cpu()`` runs on the GPU: IC generation, the fused
 RK4-CN steps (the warm-up is ONE multi-step library call), the record sweeps and the c2r of the records (HIP
-irfft2); the bilinear subsample is a torch device op.  With a process group initialised every rank generates a
+irfft2) with the bilinear subsample inside its row pass for power-of-two factors (a torch device op otherwise).  With a process group initialised every rank generates a
 contiguous slice of the samples and rank ``dst`` receives the concatenated dict (``distributed.gather_trajectory``).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -31,9 +32,15 @@ DATASET_FIELDS = TRAJECTORY_FIELDS + ("random_states",)
 def spectral_to_physical(value_hat: torch.Tensor, out_size: Optional[int] = None,
                          dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """(..., n, m) half spectra -> (..., ns, ns) real fields: HIP irfft2, then (if ns != n) bilinear
-    interpolation exactly as ``F.interpolate(value, size=(ns, ns), mode='bilinear')`` in the drivers."""
+    interpolation exactly as ``F.interpolate(value, size=(ns, ns), mode='bilinear')`` in the drivers
+    (fno/data_gen/data_gen_McWilliams2d.py:158-163) -- one fused pass when n / ns is a power of two."""
     n = value_hat.shape[-2]
     plan = fft_plan(n, torch.promote_types(value_hat.dtype, torch.complex64), value_hat.device)
+    factor = plan.subsample_factor(out_size) if hasattr(plan, "subsample_factor") else 0
+    if factor and plan.rdtype == dtype and os.environ.get("TCFD_FUSED_SUBSAMPLE", "1") != "0":
+        # power-of-two factor: c2r + subsample as one pass (tcfd_irfft2_subsample); same result as the two steps below
+        # (bit for bit at factor 2, to rounding beyond)
+        return plan.irfft2_subsample(value_hat, factor)
     phys = plan.irfft2(value_hat).to(dtype)
     if out_size is not None and out_size != n:
         lead = phys.shape[:-2]

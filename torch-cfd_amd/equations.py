@@ -221,6 +221,27 @@ class _HipPlan:
         _lib.check(rc, "tcfd_irfft2")
         return out
 
+    def subsample_factor(self, out_size) -> int:
+        """The factor ``irfft2_subsample`` runs ``n -> out_size`` with, or 0 when only the two-step path covers it."""
+        if not out_size or out_size >= self.n or self.n % out_size:
+            return 0
+        f = self.n // out_size
+        return f if (f & (f - 1)) == 0 and f <= 64 else 0
+
+    def irfft2_subsample(self, xh, factor: int):
+        """``F.interpolate(irfft2(xh), size=(n / factor,) * 2, mode="bilinear")`` as one pass (tcfd_irfft2_subsample)."""
+        xh, batch = self._prep(xh)
+        ns = self.n // factor
+        out = torch.empty(*xh.shape[:-2], ns, ns, dtype=self.rdtype, device=xh.device)
+        if batch == 0:
+            return out
+        ws = self.workspace(batch)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tcfd_irfft2_subsample(self.handle, xh.data_ptr(), out.data_ptr(), batch, factor, ws.data_ptr(),
+                                                ws.numel(), self._stream())
+        _lib.check(rc, "tcfd_irfft2_subsample")
+        return out
+
 
 _MESH_PLANS: Dict[tuple, object] = {}
 
