@@ -198,8 +198,9 @@ int tcfd_irfft2_subsample(const tcfd_ns2d_plan* plan, const void* x_hat, void* o
  * SpectralConv3d.forward (fno/fno3d.py:86-116):
  *     out = irfftn( contract( rfftn(pad_t(v)) ), s = (X, Y, T_out) )[..., -t_keep:]
  * with pruned transforms (only the 2mx x 2my x mt kept modes are produced / consumed).
- *   plan: grid (X, Y), each in [4, 1024]: powers of two run the FFT kernels, every other size pruned direct DFTs on the kept
- *         rows (same results, 4-5 x the time per grid point; csrc/tcfd_fno_dft.hpp); T_in input steps, t_pad zeros prepended
+ *   plan: grid (X, Y), each in [4, 1024]: 2^k (8 ... 1024), 3 * 2^k (96 ... 768) and 5 * 2^k (80 ... 640) run the FFT
+ *         kernels, every other size pruned direct DFTs on the kept rows (same results, 3-5 x the time per grid point;
+ *         csrc/tcfd_fno_dft.hpp); T_in input steps, t_pad zeros prepended
  *         (SpectralConvT temporal_padding), T_out = irfftn length in t, modes (mx, my, mt).
  *   precision: a plan is fp32 (TCFD_C64: real data fp32, spectra / weights complex64 -- tcfd_fno_plan_create and
  *         _resample) or fp64 (TCFD_C128, tcfd_fno_plan_create_dtype: FNOBase.double(), fno/base.py:342-349); every

@@ -18,5 +18,13 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 with torch.no_grad():
     timeit(lambda: model(x), 3)
-    print(json.dumps({"activation": "GELU", "xscale": scale, "act_template": os.environ.get("TCFD_PW_ACT_T", "1"),
-                      "forward_ms": round(timeit(lambda: model(x)), 3)}))
+    t_fwd = timeit(lambda: model(x))
+y = torch.randn(32, 256, 256, 10, generator=torch.Generator().manual_seed(1)).to(dev)
+loss_fn = fno.SobolevLoss(n_grid=256, norm_order=0, relative=True).to(dev)
+model.train()
+def train_step():
+    model.zero_grad(set_to_none=True)
+    loss_fn(model(x), y).backward()
+t_train = timeit(train_step, 3) if os.environ.get("TRAIN", "1") == "1" else None
+print(json.dumps({"activation": "GELU", "xscale": scale, "act_template": os.environ.get("TCFD_PW_ACT_T", "1"),
+                  "forward_ms": round(t_fwd, 3), "train_step_ms": t_train and round(t_train, 2)}))

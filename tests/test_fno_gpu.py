@@ -514,23 +514,27 @@ def test_spectral_conv_on_a_96_grid_and_resampled_gradients_golden(dev):
             assert rel_l2(layer.weight[k].grad, g[f"rs_{tag}_g_weight.{k}"]) < 2e-5
 
 
-@pytest.mark.parametrize("X,Y,T", [(32, 64, 10), (64, 32, 7), (16, 16, 11)])
-def test_any_size_kernels_agree_with_the_fft_kernels(X, Y, T, dev, monkeypatch):
+@pytest.mark.parametrize("X,Y,T,dtype", [(32, 64, 10, torch.float32), (64, 32, 7, torch.float32), (16, 16, 11, torch.float32),
+                                         (96, 80, 10, torch.float32), (160, 192, 6, torch.float32), (384, 320, 4, torch.float32),
+                                         (768, 640, 4, torch.float32), (80, 96, 5, torch.float64), (640, 384, 4, torch.float64)])
+def test_any_size_kernels_agree_with_the_fft_kernels(X, Y, T, dtype, dev, monkeypatch):
     """The pruned direct-DFT kernels that serve sizes off the FFT kernels (k_fwd_ty_dft / k_x_dft / k_inv_ty_dft) forced onto
-    power-of-two grids (TCFD_FNO_DFT=1): same layer outputs as the FFT kernels -- plain, temporally padded with resampled
-    steps, spatially resampled -- and the same gradients through the one-node training path (the adjoint transforms are the
-    same kernels with other plans)."""
+    the grids of the FFT kernels (TCFD_FNO_DFT=1) -- powers of two, 3 * 2^k (radix-12 first pass) and 5 * 2^k (radix 20):
+    same layer outputs -- plain, temporally padded with resampled steps, spatially resampled -- and the same gradients through
+    the one-node training path (the adjoint transforms are the same kernels with other plans)."""
     from torch_cfd_amd import fno
 
     torch.manual_seed(X + Y)
     s_layer = fno.SpectralConvS(3, 4, 5, 4, 3, bias=True, delta=0.3).to(dev)
     t_layer = fno.SpectralConvT(3, 4, 5, 4, 3, delta=0.1, bias=True, temporal_padding=True).to(dev)
+    if dtype == torch.float64:
+        s_layer, t_layer = s_layer.double(), t_layer.double()
     with torch.no_grad():
         for lay in (s_layer, t_layer):
             for p_ in lay.parameters():
                 p_.copy_(torch.randn(p_.shape) * 0.2)
-    x = torch.randn(2, 3, X, Y, T, device=dev)
-    cot = torch.randn(2, 4, X, Y, T, device=dev)
+    x = torch.randn(2, 3, X, Y, T, device=dev, dtype=dtype)
+    cot = torch.randn(2, 4, X, Y, T, device=dev, dtype=dtype)
     res = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("TCFD_FNO_DFT", flag)
@@ -543,7 +547,7 @@ def test_any_size_kernels_agree_with_the_fft_kernels(X, Y, T, dev, monkeypatch):
         res[flag] = outs
     monkeypatch.delenv("TCFD_FNO_DFT")
     for a, b in zip(res["0"], res["1"]):
-        assert a.shape == b.shape and rel_l2(a, b) < 5e-6
+        assert a.shape == b.shape and rel_l2(a, b) < (5e-6 if dtype == torch.float32 else 1e-13)
 
 
 @pytest.mark.parametrize("X,Y", [(96, 96), (48, 80)])

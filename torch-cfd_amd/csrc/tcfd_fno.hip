@@ -58,7 +58,12 @@ struct tcfd_fno_plan {
 };
 static size_t csize(const tcfd_fno_plan* p) { return p->dtype == TCFD_C128 ? 16 : 8; }
 
-static bool pow2(int n) { return n >= 8 && n <= 1024 && (n & (n - 1)) == 0; }
+// lengths of the FFT kernels: 2^k in [8, 1024], 3 * 2^k in [96, 768], 5 * 2^k in [80, 640]; every other length in [4, 1024] runs the
+// pruned direct-DFT kernels (tcfd_fno_dft.hpp)
+static bool fft_len(int n) {
+    if (n >= 8 && n <= 1024 && (n & (n - 1)) == 0) return true;
+    return n == 96 || n == 192 || n == 384 || n == 768 || n == 80 || n == 160 || n == 320 || n == 640;
+}
 
 template <typename V>
 static int upload_vec(void** dst, const std::vector<V>& h) {
@@ -179,7 +184,9 @@ extern "C" size_t tcfd_fno_workspace_bytes(const tcfd_fno_plan* p, int batch, in
 template <int Y, typename T = float>
 struct TyCfg2 {
     static constexpr int EPT0 = Y >= 256 ? 16 : (Y >= 64 ? 8 : (Y >= 16 ? 4 : 2));
-    static constexpr int EPT = (sizeof(T) == 8 && EPT0 > 8) ? 8 : EPT0;      // fp64: 16 complex doubles per lane are 64 VGPRs of data alone
+    // Y = 3 * 2^k / 5 * 2^k (96 ... 768, 80 ... 640): the solver's radix-12 / radix-20 first pass (tcfd_fft.hpp), 8 ... 64 lanes
+    static constexpr int EPT = Y % 3 == 0 ? 12 : (Y % 5 == 0 ? 20 :
+                               ((sizeof(T) == 8 && EPT0 > 8) ? 8 : EPT0));   // fp64: 16 complex doubles per lane are 64 VGPRs of data alone
     static constexpr int G = Y / EPT;
 };
 typedef unsigned int b128 __attribute__((ext_vector_type(4)));     // 16 bytes of anything (slab copies)
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>
         for (int task = p * G + j; task < ntask; task += P * G) {
             const int ky = mt == 1 ? task : (int)__umulhi((unsigned)task, mt_magic);
             const int kt = task - ky * mt;
-            const int kyn = (Y - ky) & (Y - 1);
+            const int kyn = ky ? Y - ky : 0;
             const cf* w = twt + (size_t)kt * Tp + t_pad;
             T sce = 0, sdf = 0, scf = 0, sde = 0;
             for (int pp = 0; pp < P; ++pp) {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, 
         auto slot = [&](int k) { return k < my ? k : ((k >= Ys - my && k < Ys) ? k - (Ys - 2 * my) : -1); };
         const int kmax = (Ys == Y) ? my : Y / 2;
         for (int ky = j; ky <= kmax; ky += G) {
-            const int kyn = (Y - ky) & (Y - 1);
+            const int kyn = ky ? Y - ky : 0;
             const int sa = slot(ky), sb = slot(kyn);
             const bool ha = sa >= 0, hb = sb >= 0;
             if (!ha && !hb) continue;      // the buffer is pre-zeroed
@@ -674,7 +681,7 @@ static int launch_inv_ty_dft(const tcfd_fno_plan* p, const cx<T>* w2, T* out, lo
 template <typename T, int X, bool FWD>
 static int launch_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
     typedef cx<T> ct;
-    constexpr int EPT = X >= 512 ? 16 : (X >= 64 ? 8 : 4);
+    constexpr int EPT = X % 3 == 0 ? 12 : (X % 5 == 0 ? 20 : (X >= 512 ? 16 : (X >= 64 ? 8 : 4)));
     constexpr int C = 128 / (int)sizeof(ct);  // 16 complex64 / 8 complex128 = one 128-byte line
     const int Q = 2 * p->my * p->mt;
     const int ntiles = (Q + C - 1) / C;
@@ -750,7 +757,7 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long 
     return 0;
 }
 
-#define DISPATCH_POW2(n, CALL)                                              \
+#define DISPATCH_FFT(n, CALL)                                              \
     switch (n) {                                                            \
         case 8: { constexpr int N_ = 8; return CALL; }                      \
         case 16: { constexpr int N_ = 16; return CALL; }                    \
@@ -760,30 +767,38 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long 
         case 256: { constexpr int N_ = 256; return CALL; }                  \
         case 512: { constexpr int N_ = 512; return CALL; }                  \
         case 1024: { constexpr int N_ = 1024; return CALL; }                \
+        case 96: { constexpr int N_ = 96; return CALL; }                    \
+        case 192: { constexpr int N_ = 192; return CALL; }                  \
+        case 384: { constexpr int N_ = 384; return CALL; }                  \
+        case 768: { constexpr int N_ = 768; return CALL; }                  \
+        case 80: { constexpr int N_ = 80; return CALL; }                    \
+        case 160: { constexpr int N_ = 160; return CALL; }                  \
+        case 320: { constexpr int N_ = 320; return CALL; }                  \
+        case 640: { constexpr int N_ = 640; return CALL; }                  \
         default: return FAIL(TCFD_EINVAL, "unsupported transform length %d", n); \
     }
 
 static int force_dft() { return env_int("TCFD_FNO_DFT", 0); }   // 1: any-size kernels for every size (cross-check; read per call)
 template <typename T>
 static int do_fwd_ty(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, T s, hipStream_t st) {
-    if (!pow2(p->Y) || force_dft()) return launch_fwd_ty_dft<T>(p, v, w1, slabs, s, st);
-    DISPATCH_POW2(p->Y, (launch_fwd_ty2<T, N_>(p, v, w1, slabs, s, st)));
+    if (!fft_len(p->Y) || force_dft()) return launch_fwd_ty_dft<T>(p, v, w1, slabs, s, st);
+    DISPATCH_FFT(p->Y, (launch_fwd_ty2<T, N_>(p, v, w1, slabs, s, st)));
 }
 template <typename T>
 static int do_inv_ty(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long slabs, int t_keep, T s, hipStream_t st,
                      const T* acc = nullptr, const T* accb = nullptr, int accT = 0) {
-    if (!pow2(p->Y) || force_dft()) return launch_inv_ty_dft<T>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT);
-    DISPATCH_POW2(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT)));
+    if (!fft_len(p->Y) || force_dft()) return launch_inv_ty_dft<T>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT);
+    DISPATCH_FFT(p->Y, (launch_inv_ty2<T, N_>(p, w2, out, slabs, t_keep, s, st, acc, accb, accT)));
 }
 template <typename T>
 static int do_fwd_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
-    if (!pow2(p->X) || force_dft()) return launch_x_dft<T, true>(p, in, out, bc, st);
-    DISPATCH_POW2(p->X, (launch_x<T, N_, true>(p, in, out, bc, st)));
+    if (!fft_len(p->X) || force_dft()) return launch_x_dft<T, true>(p, in, out, bc, st);
+    DISPATCH_FFT(p->X, (launch_x<T, N_, true>(p, in, out, bc, st)));
 }
 template <typename T>
 static int do_inv_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc, hipStream_t st) {
-    if (!pow2(p->X) || force_dft()) return launch_x_dft<T, false>(p, in, out, bc, st);
-    DISPATCH_POW2(p->X, (launch_x<T, N_, false>(p, in, out, bc, st)));
+    if (!fft_len(p->X) || force_dft()) return launch_x_dft<T, false>(p, in, out, bc, st);
+    DISPATCH_FFT(p->X, (launch_x<T, N_, false>(p, in, out, bc, st)));
 }
 
 template <typename T>
@@ -1316,7 +1331,7 @@ __global__ __launch_bounds__(1024) void k_inv_ty_pw(const cf* __restrict__ w2, P
         auto slot = [&](int k) { return k < my ? k : ((k >= Ys - my && k < Ys) ? k - (Ys - 2 * my) : -1); };
         const int kmax = (Ys == Y) ? my : Y / 2;
         for (int ky = j; ky <= kmax; ky += G) {
-            const int kyn = (Y - ky) & (Y - 1);
+            const int kyn = ky ? Y - ky : 0;
             const int sa = slot(ky), sb = slot(kyn);
             const bool ha = sa >= 0, hb = sb >= 0;
             if (!ha && !hb) continue;      // the buffer is pre-zeroed
