@@ -376,12 +376,15 @@ int tcfd_fno_lift_fold(const void* v, const void* qs, const void* sq, const void
  *           separation -> half-spectrum planes (field, b, t, row, ky) in the workspace
  *   pass 2  n-point FFT down 128-byte column tiles, |.|^2 * w2 accumulated in double (no spectrum written)
  *   pass 3  the scalar (relative / mesh-weighted / time-averaged / batch mean or sum, losses.py:297-314)
- * The plan holds the twiddle table of one (n, precision): n a power of two in [16, 1024]; dtype TCFD_C64 = float data,
+ * The plan holds the twiddle table of one (n, precision): n = 2^k in [16, 1024], 3 * 2^k in [96, 768] or 5 * 2^k in
+ * [80, 640]; dtype TCFD_C64 = float data,
  * TCFD_C128 = double data.  w2: (n, n/2+1) real table of the data's precision = weight^2 of the half spectrum with the
  * Hermitian multiplicity (1 on the DC / Nyquist columns, else 2) and the fft-norm scale folded in -- the caller builds it
  * once per (n, order, alpha, cutoff, norm).  nfields = 2: both ||w (x - y)^|| and ||w y^|| (relative loss); 1: the first only
  * (y may be NULL: the norm of x).  out: ONE scalar of the data's precision (device memory); sums (optional, device):
- * (nfields, batch, nt) doubles = the per-time squared norms.  tcfd_sobolev_loss_supported: 0 when nt time steps of an
+ * (nfields, batch, nt) doubles = the per-time squared norms.  mesh_weighted: 0 off, 1 on, 2 on with the unit norm of a
+ * non-relative loss divided by n in float32 (the reference's torch.ones(bsz) / n under a float32 default dtype,
+ * losses.py:297-308: differs from 1 by 1.5e-8 at n = 80, not at all when n is a power of two).  tcfd_sobolev_loss_supported: 0 when nt time steps of an
  * n-point row do not fit one workgroup (the caller then composes the loss from tcfd_rfft2 + tcfd_weighted_sqnorm). */
 typedef struct tcfd_loss_plan tcfd_loss_plan;
 int tcfd_loss_plan_create(tcfd_loss_plan** out, int n, int dtype);

@@ -707,11 +707,14 @@ def test_sobolev_loss_fft_norms_and_cutoff(norm, dev):
 
 
 @pytest.mark.parametrize("n,b,nt,tag", [(16, 2, 10, "f32"), (32, 3, 7, "f32"), (64, 2, 1, "f32"), (256, 3, 10, "f32"), (128, 2, 10, "f64"),
-                                        (512, 1, 4, "f32"), (1024, 1, 2, "f32"), (256, 2, 20, "f32"), (64, 5, 3, "f64")])
+                                        (512, 1, 4, "f32"), (1024, 1, 2, "f32"), (256, 2, 20, "f32"), (64, 5, 3, "f64"),
+                                        (96, 2, 10, "f32"), (80, 3, 4, "f64"), (192, 2, 5, "f32"), (160, 2, 10, "f32"), (768, 1, 2, "f32"),
+                                        (640, 1, 2, "f64"), (384, 1, 4, "f32"), (320, 1, 3, "f32")])
 def test_fused_sobolev_loss_against_oracle_and_composed_path(n, b, nt, tag, dev, monkeypatch):
     """tcfd_sobolev_loss (three launches, time-last tensors read in place) against oracle/fno.py's torch.fft evaluation
     (fno/losses.py:263-315) and against the composed path it replaces (rfft2 kernels + weighted norm, TCFD_LOSS_FUSED=0):
-    every flag combination that changes the arithmetic, odd / single time steps, no target, fp64, the largest grid."""
+    every flag combination that changes the arithmetic, odd / single time steps, no target, fp64, the largest grid, the
+    3 * 2^k and 5 * 2^k grids (radix-12 / radix-20 first passes)."""
     from oracle import fno as OF
     from torch_cfd_amd import fno
 

@@ -40,7 +40,7 @@ int tcfd_set_error(int code, const char* fmt, ...);  // defined in tcfd_ns2d.hip
     } while (0)
 
 struct tcfd_loss_plan {
-    int n;       // square grid, power of two in [16, 1024]
+    int n;       // square grid: 2^k in [16, 1024], 3 * 2^k in [96, 768] or 5 * 2^k in [80, 640]
     int dtype;   // TCFD_C64: float data, TCFD_C128: double data
     void* tw;    // [n] exp(-2 pi i k / n) in the plan's precision
 };
@@ -51,11 +51,12 @@ typedef unsigned int b128 __attribute__((ext_vector_type(4)));
 template <typename T, int N>
 struct LossCfg {
     static constexpr int BASE = sizeof(T) == 8 ? 8 : 16;
+    static constexpr int MIX = N % 3 == 0 ? 12 : (N % 5 == 0 ? 20 : 0);    // 3 * 2^k / 5 * 2^k: radix-12 / radix-20 first pass (tcfd_fft.hpp)
     static constexpr int ROW_EPT0 = N >= 256 ? BASE : (N >= 64 ? 8 : 4);
-    static constexpr int ROW_EPT = N / ROW_EPT0 > 64 ? N / 64 : ROW_EPT0;
+    static constexpr int ROW_EPT = MIX ? MIX : (N / ROW_EPT0 > 64 ? N / 64 : ROW_EPT0);
     static constexpr int COLS = sizeof(T) == 8 ? 8 : 16;                    // 128-byte tile rows
     static constexpr int COL_EPT0 = N >= 256 ? BASE : (N >= 64 ? 8 : 4);
-    static constexpr int COL_EPT = COLS * (N / COL_EPT0) > 1024 ? COLS * N / 1024 : COL_EPT0;
+    static constexpr int COL_EPT = MIX ? MIX : (COLS * (N / COL_EPT0) > 1024 ? COLS * N / 1024 : COL_EPT0);
 };
 
 // ------------------------------------------------------------------ pass 1: rows
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(1024) void k_loss_rows(const T* __restrict__ x, con
     cf* o1 = out + ((((size_t)f1 * batch + b) * nt + t1) * X + i) * ldk;
     const T h = (T)0.5;
     for (int k = j; k <= Y / 2; k += G) {
-        const cf za = lds[k], zb = lds[(Y - k) & (Y - 1)];
+        const cf za = lds[k], zb = lds[k ? Y - k : 0];
         o0[k] = mk<T>((za.x + zb.x) * h, (za.y - zb.y) * h);
         if (two) o1[k] = mk<T>((za.y + zb.y) * h, (zb.x - za.x) * h);
     }
@@ -218,7 +219,12 @@ __global__ __launch_bounds__(256) void k_loss_finish(const double* __restrict__ 
             for (int t = 0; t < nt; ++t) t1 += s1[t];
         double loss = sqrt(t0);
         double yn = (relative && F == 2) ? sqrt(t1) : 1.0;
-        if (mesh_weighted) yn /= (double)n;
+        if (mesh_weighted) {
+            // mesh_weighted == 2: the unit norm of a non-relative loss is float32 in the reference (torch.ones under a float32
+            // default dtype, fno/losses.py:297), so 1 / n is rounded to float32 before it divides the loss
+            if (mesh_weighted == 2 && !(relative && F == 2)) yn = (double)(1.0f / (float)n);
+            else yn /= (double)n;
+        }
         loss /= yn;
         if (time_average) loss /= sqrt((double)nt);
         mine += loss;
@@ -238,7 +244,10 @@ __global__ __launch_bounds__(256) void k_loss_finish(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------ host side
-static bool loss_n_ok(int n) { return n >= 16 && n <= 1024 && (n & (n - 1)) == 0; }
+static bool loss_n_ok(int n) {
+    if (n >= 16 && n <= 1024 && (n & (n - 1)) == 0) return true;
+    return n == 96 || n == 192 || n == 384 || n == 768 || n == 80 || n == 160 || n == 320 || n == 640;
+}
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int loss_ldk(const tcfd_loss_plan* p) {   // row pitch of the half-spectrum planes: n/2 + 1 rounded up to 128 bytes
     const int per_line = p->dtype == TCFD_C128 ? 8 : 16;
@@ -252,7 +261,7 @@ static int loss_ntiles(const tcfd_loss_plan* p) {
 extern "C" int tcfd_loss_plan_create(tcfd_loss_plan** out, int n, int dtype) {
     if (!out) return FAIL(TCFD_EINVAL, "loss_plan_create: null argument");
     if (dtype != TCFD_C64 && dtype != TCFD_C128) return FAIL(TCFD_EINVAL, "loss_plan_create: bad dtype %d", dtype);
-    if (!loss_n_ok(n)) return FAIL(TCFD_EINVAL, "loss_plan_create: n = %d must be a power of two in [16, 1024]", n);
+    if (!loss_n_ok(n)) return FAIL(TCFD_EINVAL, "loss_plan_create: n = %d is not a grid of the fused kernels (2^k in [16, 1024], 3 * 2^k in [96, 768], 5 * 2^k in [80, 640])", n);
     tcfd_loss_plan* p = new tcfd_loss_plan();
     p->n = n; p->dtype = dtype; p->tw = nullptr;
     const long double PI2 = 2.0L * 3.141592653589793238462643383279502884L;
@@ -370,7 +379,8 @@ static int loss_dispatch(const tcfd_loss_plan* p, const void* x, const void* y, 
         return loss_impl<T, N_>(p, x, y, w2, batch, nt, F, relative, mesh_weighted, time_average, reduction, out, sums, ws, st);
     switch (p->n) {
         TCFD_LOSS_CASE(16) TCFD_LOSS_CASE(32) TCFD_LOSS_CASE(64) TCFD_LOSS_CASE(128) TCFD_LOSS_CASE(256) TCFD_LOSS_CASE(512)
-        TCFD_LOSS_CASE(1024)
+        TCFD_LOSS_CASE(1024) TCFD_LOSS_CASE(96) TCFD_LOSS_CASE(192) TCFD_LOSS_CASE(384) TCFD_LOSS_CASE(768) TCFD_LOSS_CASE(80)
+        TCFD_LOSS_CASE(160) TCFD_LOSS_CASE(320) TCFD_LOSS_CASE(640)
     }
 #undef TCFD_LOSS_CASE
     return FAIL(TCFD_EINVAL, "sobolev_loss: unsupported n = %d", p->n);
@@ -390,7 +400,8 @@ extern "C" int tcfd_sobolev_loss_supported(const tcfd_loss_plan* p, int nt, int 
         break;
     switch (n) {
         TCFD_LOSS_GEO(16) TCFD_LOSS_GEO(32) TCFD_LOSS_GEO(64) TCFD_LOSS_GEO(128) TCFD_LOSS_GEO(256) TCFD_LOSS_GEO(512)
-        TCFD_LOSS_GEO(1024)
+        TCFD_LOSS_GEO(1024) TCFD_LOSS_GEO(96) TCFD_LOSS_GEO(192) TCFD_LOSS_GEO(384) TCFD_LOSS_GEO(768) TCFD_LOSS_GEO(80)
+        TCFD_LOSS_GEO(160) TCFD_LOSS_GEO(320) TCFD_LOSS_GEO(640)
     }
 #undef TCFD_LOSS_GEO
     return ok ? 1 : 0;

@@ -1923,14 +1923,16 @@ class SobolevLoss(nn.Module):
 
     def _fused(self, x, y):
         """The loss in three launches on the time-last tensors in place (``tcfd_sobolev_loss``, csrc/tcfd_loss.hip), or None
-        when this call is outside its cover (gradients wanted, a grid that is not a power of two in [16, 1024], more time
+        when this call is outside its cover (gradients wanted, a grid off the FFT kernels -- 2^k in [16, 1024], 3 * 2^k in [96, 768],
+        5 * 2^k in [80, 640] --, more time
         steps than one workgroup transforms)."""
         if os.environ.get("TCFD_LOSS_FUSED", "1") == "0" or not x.is_cuda or x.dtype not in (torch.float32, torch.float64):
             return None
         if torch.is_grad_enabled() and (x.requires_grad or (y is not None and y.requires_grad)):
             return None
         bsz, n, n2, nt = x.shape
-        if n != n2 or n < 16 or n > 1024 or (n & (n - 1)) or bsz == 0 or (y is not None and (y.shape != x.shape or y.dtype != x.dtype)):
+        if (n != n2 or not ((16 <= n <= 1024 and (n & (n - 1)) == 0) or n in (96, 192, 384, 768, 80, 160, 320, 640)) or bsz == 0
+                or (y is not None and (y.shape != x.shape or y.dtype != x.dtype))):
             return None
         lib = _lib.load()
         code = _lib.TCFD_C128 if x.dtype == torch.float64 else _lib.TCFD_C64
@@ -1955,7 +1957,8 @@ class SobolevLoss(nn.Module):
         out = torch.empty((), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.tcfd_sobolev_loss(plan, xc.data_ptr(), yc.data_ptr() if yc is not None else None, w2.data_ptr(), bsz,
-                                             nt, nf, int(bool(self.relative and y is not None)), int(bool(self.mesh_weighted)),
+                                             nt, nf, int(bool(self.relative and y is not None)),
+                                             (2 if torch.get_default_dtype() == torch.float32 else 1) if self.mesh_weighted else 0,
                                              int(bool(self.time_average)), int(bool(self.reduction)), out.data_ptr(), None,
                                              ws.data_ptr(), ws.numel(),
                                              ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "tcfd_sobolev_loss")
@@ -1989,8 +1992,10 @@ class SobolevLoss(nn.Module):
         if self.relative and y is not None:
             yn = sq_norms(y).sum(dim=-1).sqrt()
         else:
-            yn = torch.ones(bsz, device=x.device, dtype=x.dtype)
-        yn = yn / n if self.mesh_weighted else yn
+            # the reference's unit norms are torch.ones(bsz) in the DEFAULT dtype (losses.py:297): under a float32 default, 1 / n
+            # is rounded to float32 before it divides a float64 loss (1.5e-8 at n = 80; exact when n is a power of two)
+            yn = torch.ones(bsz, device=x.device, dtype=torch.get_default_dtype())
+        yn = (yn / n if self.mesh_weighted else yn).to(x.dtype)
         loss = loss / yn
         loss = loss / math.sqrt(nt) if self.time_average else loss
         loss = loss.mean(0) if self.reduction else loss.sum(0)
