@@ -305,6 +305,11 @@ def sfno_config5(dev, with_cpu=True):
     with torch.no_grad():
         t_fwd = timeit(lambda: model(x), 10)
         t_all = timeit(lambda: loss_fn(model(x), y), 10)
+        # the same model with the activation of the reference's training script (fno/train.py:303 --activation GELU; the class
+        # default, which BASELINE configs[4] is quoted on, is ReLU): exact GELU as a packed branch-free 2^-s(|v|) evaluation
+        gelu_model = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4, activation="GELU").to(dev).eval()
+        t_gelu = timeit(lambda: gelu_model(x), 10)
+        del gelu_model
     model.train()
 
     def train_step():
@@ -358,8 +363,11 @@ def sfno_config5(dev, with_cpu=True):
                 "traffic_source": ("profiles/sfno_traffic.json (rocprofv3 --pmc passes of tests/bench_sfno.py, tests/prof_sfno.sh): "
                                    "bytes between L2 and the memory side per launch; the 839 MB activations exceed the Infinity Cache"
                                    ) if pw_key else None,
-                "also_compute_bound": "900 FMAs per point as v_pk_fma_f32: 0.48 ms of packed-fp32 issue per launch at the 157 TFLOP/s "
-                                      "vector peak, beside 0.31 ms of HBM time at 8 TB/s -- the kernel sits at ~0.8 of BOTH",
+                "vector_work": "900 FMAs per point as v_pk_fma_f32 = 0.24 ms per launch at the 157 TFLOP/s packed-fp32 peak (~0.3 ms of "
+                               "VALU issue with the ReLUs and address arithmetic), beside 0.31 ms of HBM time at 8 TB/s.  Until round 4 the "
+                               "run-time activation switch inside the hidden-unit loop added 1,224 scalar instructions and ~10 taken "
+                               "branches per wave (SQ_INSTS_SALU ~ SQ_INSTS_VALU in profiles/r04_sfno_pmc.txt): 571 us; with the "
+                               "activations as template parameters 475 us",
                 "kernels_from_profile": kern_table or None,
                 "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
                                     "algo_bytes_per_launch": 5 * A_H, "avg_launch_ms": round(t_bwd, 4),
@@ -392,6 +400,7 @@ def sfno_config5(dev, with_cpu=True):
             "gpu_over_cpu": round(32 / (t_all * 1e-3) / base["value"], 1) if base and base.get("value") else None,
             "workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
             "forward_ms": round(t_fwd, 3), "forward_plus_loss_ms": round(t_all, 3), "train_step_ms": round(t_train, 2),
+            "forward_ms_with_gelu": round(t_gelu, 3),
             "train_step_ms_each": [round(t, 2) for t in per_step],
             "samples_per_s": round(32 / (t_all * 1e-3), 1), "algo_GB": round(algo_gb, 2),
             "algo_GBps": round(algo_gb / (t_all * 1e-3), 1), "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4)}

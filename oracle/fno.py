@@ -78,7 +78,7 @@ def sobolev_loss(x: torch.Tensor, y: torch.Tensor, n_grid: int, norm_order: floa
     w = weight ** (norm_order / 2) if norm_order != 0 else weight
     bsz, nt = x.shape[0], x.shape[-1]
     xh = torch.fft.fftn(x, dim=(1, 2), norm=fft_norm) * w
-    yh = torch.fft.fftn(y, dim=(1, 2), norm=fft_norm) * w
+    yh = (torch.fft.fftn(y, dim=(1, 2), norm=fft_norm) if y is not None else torch.zeros_like(xh)) * w   # losses.py:283-286
     diff = torch.linalg.norm(xh - yh, dim=(1, 2))
     if relative:
         yn = (torch.linalg.norm(yh, dim=(1, 2)) ** 2).sum(dim=-1).sqrt()

@@ -11,3 +11,6 @@ cd $GRAFT_REPO_ROOT
 python tests/micro/strong_proxy.py > gpurun_out/r04_strong_proxy.json 2>/dev/null
 TRAIN=1 ONLY_TRAIN=1 ROWS=30 bash tests/micro/sfno_profile.sh > gpurun_out/r04_final_sfno_train.txt 2>&1
 cd $GRAFT_REPO_ROOT; cat gpurun_out/r04_final_tests.log; tail -2 gpurun_out/r04_final_bench.err; cat gpurun_out/r04_final_traffic.log
+python tests/micro/gelu_bench.py > gpurun_out/r04_gelu.json 2>/dev/null
+python tests/micro/subsample_bench.py > gpurun_out/r04_subsample.json 2>/dev/null
+python tests/micro/dense_vs_fused_layer.py > gpurun_out/r04_layer_by_grid.json 2>/dev/null

@@ -50,9 +50,9 @@ def test_gather_trajectory_world2(total, dst):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q, dst)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     status = sorted(r[0] for r in res)
     assert status == ["none", "ok"], res
@@ -121,9 +121,9 @@ def test_record_handover_world2(total, batch, dst):
     procs = [ctx.Process(target=_handover_worker, args=(r, 2, port, total, batch, 3, q, dst)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == ["none", "ok"], res
     assert [r[1] for r in res if r[1]][0] == (total, 3, 4, 4)
@@ -172,9 +172,9 @@ def test_gather_shard_size_mismatch_raises_on_every_rank():
     procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert res == ["raised", "raised"], res
 
@@ -208,9 +208,9 @@ def test_gather_in_a_subgroup_addresses_peers_by_global_rank():
     procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=400) for _ in procs)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert res == ["none", "ok", "outside"], res
 

@@ -743,6 +743,9 @@ def test_fused_sobolev_loss_against_oracle_and_composed_path(n, b, nt, tag, dev,
     composed = loss(x.to(dev))
     monkeypatch.delenv("TCFD_LOSS_FUSED")
     assert float(loss(x.to(dev))) == pytest.approx(float(composed), rel=tol)
+    # a relative loss without a target divides by the norm of the reference's all-zero y (fno/losses.py:283-299): inf
+    rel = fno.SobolevLoss(n_grid=n, norm_order=0, relative=True).to(dev)
+    assert float(rel(x.to(dev))) == float(OF.sobolev_loss(x, None, n, norm_order=0, relative=True)) == float("inf")
     # gradients still go through the differentiable composition
     xg = x.to(dev).requires_grad_(True)
     assert loss._fused(xg, y.to(dev)) is None

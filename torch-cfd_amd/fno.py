@@ -1973,9 +1973,12 @@ class SobolevLoss(nn.Module):
         bsz, n, _, nt = x.shape
         if n != self.n_grid:
             raise ValueError(f"grid {n} != n_grid {self.n_grid}")
+        # relative loss without a target: the reference divides by the norm of its all-zero y (losses.py:283-299) -- inf (nan
+        # for x = 0), reproduced by dividing the plain norm by zero
+        no_target = 0.0 if (self.relative and y is None) else None
         fused = self._fused(x, y)
         if fused is not None:
-            return fused
+            return fused if no_target is None else fused / no_target
         plan = fft_plan(n, torch.complex64 if x.dtype == torch.float32 else torch.complex128, x.device, self.diam)
         w2 = self._half_spectrum_weights(x.device, x.dtype)
 
@@ -1999,4 +2002,5 @@ class SobolevLoss(nn.Module):
         loss = loss / yn
         loss = loss / math.sqrt(nt) if self.time_average else loss
         loss = loss.mean(0) if self.reduction else loss.sum(0)
-        return loss / n if self.mesh_weighted else loss
+        loss = loss / n if self.mesh_weighted else loss
+        return loss if no_target is None else loss / no_target
