@@ -138,6 +138,30 @@ def test_contraction_mfma_equals_valu_and_oracle(dev):
     assert a64.dtype == torch.complex128 and rel_l2(c64, ref64) < 1e-14 and rel_l2(a64, ref64) < 1e-14
 
 
+@pytest.mark.parametrize("nm", [8, 16])
+@pytest.mark.parametrize("b,ci,co,modes", [(32, 10, 10, (4, 4, 5)), (70, 5, 40, (2, 4, 2)), (3, 1, 1, (2, 2, 4)), (17, 33, 20, (4, 2, 2))])
+def test_contraction_staging_variants(nm, b, ci, co, modes, dev, monkeypatch):
+    """k_contract_mfma with 8 and 16 modes per workgroup (TCFD_CONTRACT_NM), results handed back through LDS: one round of
+    tiles (the result buffer aliases the operands) and several (b x co large: it lies behind them), bias, both precisions;
+    bit-identical between the two staging widths (same MFMA chains), and equal to the VALU kernel to rounding."""
+    from torch_cfd_amd import fno
+
+    monkeypatch.setenv("TCFD_CONTRACT_NM", str(nm))
+    g = torch.Generator().manual_seed(b + ci)
+    mx, my, mt = modes
+    for real, tol in ((torch.float32, 2e-6), (torch.float64, 1e-14)):
+        vh = torch.view_as_complex(torch.randn(b, ci, 2 * mx, 2 * my, mt, 2, generator=g, dtype=real)).to(dev)
+        w = [torch.view_as_complex(torch.randn(ci, co, *modes, 2, generator=g, dtype=real)).to(dev) for _ in range(4)]
+        bias = [torch.view_as_complex(torch.randn(*modes, 2, generator=g, dtype=real)).to(dev) for _ in range(4)]
+        a = fno.hip_contract(vh, w, bias, 0.7, modes, use_mfma=True)
+        c = fno.hip_contract(vh, w, bias, 0.7, modes, use_mfma=False)
+        assert torch.isfinite(torch.view_as_real(a)).all() and rel_l2(a, c) < tol
+        monkeypatch.setenv("TCFD_CONTRACT_NM", str(24 - nm))
+        other = fno.hip_contract(vh, w, bias, 0.7, modes, use_mfma=True)
+        monkeypatch.setenv("TCFD_CONTRACT_NM", str(nm))
+        assert torch.equal(torch.view_as_real(a), torch.view_as_real(other))
+
+
 @pytest.mark.parametrize("real,use_mfma,tol,complex_params", [(torch.float32, True, 2e-6, False), (torch.float32, False, 2e-6, True),
                                                                (torch.float64, True, 1e-13, False), (torch.float64, True, 1e-13, True)])
 def test_contraction_gradients_against_the_oracle_under_autograd(real, use_mfma, tol, complex_params, dev):

@@ -527,6 +527,13 @@ __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) { return __b
 template <typename T> struct Acc4 { typedef f32x4 type; };
 template <> struct Acc4<double> { typedef f64x4 type; };
 
+// mode stride of a staged slice: lanes of the staging loops run along the NM modes first, so the stride (in complex
+// elements) is padded to 64 / NM modulo 32 -- the NM x (64 / NM) elements a wave stores at once then fall on distinct
+// 8-byte slots of the 64 banks (unpadded, 32 x 12 and 12 x 16 are multiples of 32: NM-way conflicts on every store)
+#define CONTRACT_MAXW 8
+template <int NM>
+__host__ __device__ inline int contract_stride(int elems) { return elems + ((64 / NM) - elems % 32 + 32) % 32; }
+
 template <typename T, int NM>
 __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
     typedef cx<T> cf;
@@ -537,9 +544,11 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
     const int cip = (a.ci + 3) & ~3;        // K padded to a multiple of 4
     const int bp = (a.b + 15) & ~15;        // M padded to a multiple of 16
     const int cop = (a.co + 15) & ~15;      // N padded to a multiple of 16
-    // LDS: A[mode][bp][cip] complex, B[mode][cip][cop] complex (zero padded)
+    // LDS: A[mode][bp][cip] complex, B[mode][cip][cop] complex (zero padded), padded mode strides SA / SB; the results
+    // go back through the same memory as O[b][co][NM + 1] so that the stores to the spectrum run along the modes too
+    const int SA = contract_stride<NM>(bp * cip), SB = contract_stride<NM>(cip * cop);
     cf* As = reinterpret_cast<cf*>(smem_raw);
-    cf* Bs = As + (size_t)NM * bp * cip;
+    cf* Bs = As + (size_t)NM * SA;
     // this block's run of NM modes: runs never straddle a corner block (MB % NM == 0 is checked by the host)
     const int run = blockIdx.x;
     const int runs_per_blk = MB / NM;
@@ -547,57 +556,96 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
     const int wm0 = (run % runs_per_blk) * NM;               // first mode inside the weight block
     const int ix = blk & 1, iy = blk >> 1;
     const cf* w = a.w[blk];
-    // zero fill (padding) then stage
-    for (int i = threadIdx.x; i < NM * (bp * cip + cip * cop); i += blockDim.x) As[i] = mk<T>((T)0, (T)0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < a.b * a.ci * NM; i += blockDim.x) {
-        const int mm = i % NM, rest = i / NM;
-        const int wm = wm0 + mm;
+    // the mode this lane stages and stores: blockDim.x is a multiple of NM, so it is the same in every trip
+    const int mm_l = threadIdx.x % NM, rest_l = threadIdx.x / NM, rest_step = blockDim.x / NM;
+    long mode_l;
+    {
+        const int wm = wm0 + mm_l;
         const int kt = wm % a.mt, ky = (wm / a.mt) % a.my, kx = wm / (a.mt * a.my);
-        const int mode = ((kx + ix * a.mx) * 2 * a.my + (ky + iy * a.my)) * a.mt + kt;
-        const int ic = rest % a.ci, bb = rest / a.ci;
-        As[((size_t)mm * bp + bb) * cip + ic] = a.vin[((long)bb * a.ci + ic) * M + mode];
+        mode_l = ((long)(kx + ix * a.mx) * 2 * a.my + (ky + iy * a.my)) * a.mt + kt;
     }
-    for (int i = threadIdx.x; i < a.ci * a.co * NM; i += blockDim.x) {
-        const int mm = i % NM, rest = i / NM;
+    // zero fill (padding) then stage
+    for (int i = threadIdx.x; i < NM * (SA + SB); i += blockDim.x) As[i] = mk<T>((T)0, (T)0);
+    __syncthreads();
+    for (int rest = rest_l; rest < a.b * a.ci; rest += rest_step) {
+        const int ic = rest % a.ci, bb = rest / a.ci;
+        As[(size_t)mm_l * SA + bb * cip + ic] = a.vin[(long)rest * M + mode_l];
+    }
+    for (int rest = rest_l; rest < a.ci * a.co; rest += rest_step) {
         const int o = rest % a.co, ic = rest / a.co;
-        cf wv = a.adjoint ? w[((long)o * a.ci + ic) * MB + wm0 + mm] : w[((long)ic * a.co + o) * MB + wm0 + mm];
+        cf wv = a.adjoint ? w[((long)o * a.ci + ic) * MB + wm0 + mm_l] : w[(long)rest * MB + wm0 + mm_l];
         if (a.adjoint) wv.y = -wv.y;
-        Bs[((size_t)mm * cip + ic) * cop + o] = wv;
+        Bs[(size_t)mm_l * SB + ic * cop + o] = wv;
     }
     __syncthreads();
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     const int nwaves = blockDim.x / 64;
     const int mt_tiles = bp / 16, nt_tiles = cop / 16;
-    for (int work = wave; work < NM * mt_tiles * nt_tiles; work += nwaves) {
-        const int mm = work / (mt_tiles * nt_tiles);
-        const int mtile = (work / nt_tiles) % mt_tiles, ntile = work % nt_tiles;
-        acc4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0}, ir = {0, 0, 0, 0};
-        const cf* Am = As + (size_t)mm * bp * cip;
-        const cf* Bm = Bs + (size_t)mm * cip * cop;
-        for (int k0 = 0; k0 < cip; k0 += 4) {
-            // A operand: lane l holds A[m = l & 15][k = l >> 4];  B operand: B[k = l >> 4][n = l & 15]
-            const cf av = Am[(size_t)(mtile * 16 + (lane & 15)) * cip + k0 + (lane >> 4)];
-            const cf bv = Bm[(size_t)(k0 + (lane >> 4)) * cop + ntile * 16 + (lane & 15)];
-            rr = mfma4(av.x, bv.x, rr);
-            ii = mfma4(av.y, bv.y, ii);
-            ri = mfma4(av.x, bv.y, ri);
-            ir = mfma4(av.y, bv.x, ir);
-        }
-        // C/D layout: col n = lane & 15, row m = (lane >> 4) * 4 + r
-        const int wm = wm0 + mm;
-        const int kt = wm % a.mt, ky = (wm / a.mt) % a.my, kx = wm / (a.mt * a.my);
-        const int mode = ((kx + ix * a.mx) * 2 * a.my + (ky + iy * a.my)) * a.mt + kt;
-        const int o = ntile * 16 + (lane & 15);
-        cf bias = mk<T>((T)0, (T)0);
-        if (a.bias[blk]) bias = cscale(a.bias[blk][wm], a.delta);
+    const int nwork = NM * mt_tiles * nt_tiles;
+    // every wave keeps the results of its tiles in registers until the operands are no longer needed: O aliases A / B
+    // when one round covers the work (the host sizes the allocation by the same rule), else it lies behind them
+    constexpr int MAXW = CONTRACT_MAXW;   // tiles per wave held at once; more (large b x co) go round the outer loop again
+    cf* Os = nwork <= nwaves * MAXW ? As : Bs + (size_t)NM * SB;
+    for (int base = 0; base < nwork; base += nwaves * MAXW) {
+        acc4 re[MAXW], im[MAXW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // result rows: f32 16x16x4 keeps rows 4 (l >> 4) + r in register r, f64 16x16x4 rows 4 r + (l >> 4)
-            const int bb = mtile * 16 + (sizeof(T) == 8 ? 4 * r + (lane >> 4) : (lane >> 4) * 4 + r);
-            if (bb < a.b && o < a.co)
-                a.vout[((long)bb * a.co + o) * M + mode] = mk<T>(rr[r] - ii[r] + bias.x, ri[r] + ir[r] + bias.y);
+        for (int u = 0; u < MAXW; ++u) {
+            const int work = base + u * nwaves + wave;
+            acc4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0}, ir = {0, 0, 0, 0};
+            if (work < nwork) {
+                const int mm = work / (mt_tiles * nt_tiles);
+                const int mtile = (work / nt_tiles) % mt_tiles, ntile = work % nt_tiles;
+                const cf* Am = As + (size_t)mm * SA;
+                const cf* Bm = Bs + (size_t)mm * SB;
+                for (int k0 = 0; k0 < cip; k0 += 4) {
+                    // A operand: lane l holds A[m = l & 15][k = l >> 4];  B operand: B[k = l >> 4][n = l & 15]
+                    const cf av = Am[(size_t)(mtile * 16 + (lane & 15)) * cip + k0 + (lane >> 4)];
+                    const cf bv = Bm[(size_t)(k0 + (lane >> 4)) * cop + ntile * 16 + (lane & 15)];
+                    rr = mfma4(av.x, bv.x, rr);
+                    ii = mfma4(av.y, bv.y, ii);
+                    ri = mfma4(av.x, bv.y, ri);
+                    ir = mfma4(av.y, bv.x, ir);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                re[u][r] = rr[r] - ii[r];
+                im[u][r] = ri[r] + ir[r];
+            }
         }
+        __syncthreads();   // all operands of this round consumed: O may overwrite them
+#pragma unroll
+        for (int u = 0; u < MAXW; ++u) {
+            const int work = base + u * nwaves + wave;
+            if (work >= nwork) continue;
+            const int mm = work / (mt_tiles * nt_tiles);
+            const int mtile = (work / nt_tiles) % mt_tiles, ntile = work % nt_tiles;
+            // C/D layout: col n = lane & 15, row m = (lane >> 4) * 4 + r
+            const int o = ntile * 16 + (lane & 15);
+            cf bias = mk<T>((T)0, (T)0);
+            if (a.bias[blk]) bias = cscale(a.bias[blk][wm0 + mm], a.delta);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // result rows: f32 16x16x4 keeps rows 4 (l >> 4) + r in register r, f64 16x16x4 rows 4 r + (l >> 4)
+                const int bb = mtile * 16 + (sizeof(T) == 8 ? 4 * r + (lane >> 4) : (lane >> 4) * 4 + r);
+                if (bb < a.b && o < a.co) Os[((size_t)bb * a.co + o) * (NM + 1) + mm] = mk<T>(re[u][r] + bias.x, im[u][r] + bias.y);
+            }
+        }
+        __syncthreads();
+        // which (b, o) rows this round produced: all of them when one round covers the work (the usual case); otherwise
+        // the tiles of this round only -- rows are complete per round because a round covers whole modes x tiles in order
+        if (nwork <= nwaves * MAXW) {
+            for (int rest = rest_l; rest < a.b * a.co; rest += rest_step)
+                a.vout[(long)rest * M + mode_l] = Os[(size_t)rest * (NM + 1) + mm_l];
+        } else {
+            const int w_lo = base, w_hi = min(nwork, base + nwaves * MAXW);
+            for (int rest = rest_l; rest < a.b * a.co; rest += rest_step) {
+                const int bb = rest / a.co, o = rest % a.co;
+                const int work = (mm_l * mt_tiles + bb / 16) * nt_tiles + o / 16;
+                if (work >= w_lo && work < w_hi) a.vout[(long)rest * M + mode_l] = Os[(size_t)rest * (NM + 1) + mm_l];
+            }
+        }
+        if (base + nwaves * MAXW < nwork) __syncthreads();
     }
 }
 
@@ -801,22 +849,43 @@ static int do_inv_x(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, long bc
     DISPATCH_FFT(p->X, (launch_x<T, N_, false>(p, in, out, bc, st)));
 }
 
+template <typename T, int NM>
+static size_t contract_lds(const ContractArgsT<T>& a) {
+    const int cip = (a.ci + 3) & ~3, bp = (a.b + 15) & ~15, cop = (a.co + 15) & ~15;
+    const size_t stage = (size_t)NM * (contract_stride<NM>(bp * cip) + contract_stride<NM>(cip * cop));
+    const size_t outs = (size_t)a.b * a.co * (NM + 1);
+    const bool alias = NM * (bp / 16) * (cop / 16) <= 4 * CONTRACT_MAXW;   // 256 lanes = 4 waves
+    return (alias ? std::max(stage, outs) : stage + outs) * sizeof(cx<T>);
+}
+template <typename T, int NM>
+static int launch_contract_mfma(const ContractArgsT<T>& a, size_t lds, hipStream_t st) {
+    auto kern = k_contract_mfma<T, NM>;
+    int rc = set_lds_attr(kern, lds);
+    if (rc) return rc;
+    const int MB = a.mx * a.my * a.mt;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(4 * MB / NM)), dim3(256), lds, st, a);
+    return 0;
+}
 template <typename T>
 static int do_contract(ContractArgsT<T> a, int use_mfma, hipStream_t st) {
     const int MB = a.mx * a.my * a.mt;
-    constexpr int NM = 8;
-    const int cip = (a.ci + 3) & ~3, bp = (a.b + 15) & ~15, cop = (a.co + 15) & ~15;
-    const size_t lds = (size_t)NM * ((size_t)bp * cip + (size_t)cip * cop) * sizeof(cx<T>);
-    if (use_mfma && MB % NM == 0 && lds <= 150 * 1024) {
-        auto kern = k_contract_mfma<T, NM>;
-        int rc = set_lds_attr(kern, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(4 * MB / NM)), dim3(256), lds, st, a);
-    } else {
+    // 8 modes per workgroup (64-byte runs of fp32 spectrum and weights); TCFD_CONTRACT_NM=16 (read per call) selects
+    // whole 128-byte lines with half the workgroups: measured 40.5 against 39.2 us at the config-5 shape -- the launch is
+    // ~1.4 rounds of workgroups moving in step (load burst, MFMAs, store burst), not a bandwidth or LDS problem
+    const int force = env_int("TCFD_CONTRACT_NM", 0);
+    const size_t lds16 = contract_lds<T, 16>(a), lds8 = contract_lds<T, 8>(a);
+    int rc = -1;
+    if (use_mfma && force == 16 && MB % 16 == 0 && lds16 <= 150 * 1024)
+        rc = launch_contract_mfma<T, 16>(a, lds16, st);
+    else if (use_mfma && MB % 8 == 0 && lds8 <= 150 * 1024)
+        rc = launch_contract_mfma<T, 8>(a, lds8, st);
+    else {
         const long total = (long)a.b * a.co * 4 * MB;
         const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(k_contract_valu<T>, dim3(blocks), dim3(256), 0, st, a);
+        rc = 0;
     }
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
