@@ -241,6 +241,11 @@ class RecordHandover:
             self._lib = _lib
             self._clib = _lib.load()
             self.side = torch.cuda.Stream(device=self.device)
+        if self.distributed and self.world > 1 and self.on_gpu and not self.staged:
+            # ProcessGroupNCCL: batched point-to-point calls among a SUBSET of a group's ranks (a peer and dst) are only
+            # defined once the group has run a collective with every rank in it (torch.distributed.batch_isend_irecv) --
+            # every rank constructs its hand-over, so this is that collective if the caller has not made one yet
+            dist.all_reduce(torch.zeros(1, device=self.device), group=group)
 
     # -- dst side
     def _land(self, buf: torch.Tensor, start: int, count: int, rec: int, work=None):
