@@ -52,7 +52,7 @@ typedef enum { TCFD_C64 = 0, TCFD_C128 = 1 } tcfd_dtype;
 typedef struct tcfd_ns2d_plan tcfd_ns2d_plan;
 typedef struct tcfd_fno_plan tcfd_fno_plan;
 
-#define TCFD_ABI_VERSION 4   /* what tcfd_version() of a library built from THIS header returns */
+#define TCFD_ABI_VERSION 5   /* what tcfd_version() of a library built from THIS header returns */
 
 #ifndef TCFD_H_TYPES_ONLY   /* (the library's second compilation unit wants the types without the prototypes) */
 
@@ -327,6 +327,14 @@ int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, vo
                            const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
                            void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
                            int skip_T, int act1, int act2, int skip_mode, int per_sample, void* stream);
+/* The same with the block's forward OUTPUT `out` (batch, co, P) handed over (NULL: exactly the call above).  With ReLU as the
+ * output activation its mask is read from `out` (y > 0 <=> z2 > 0: the mask the forward kernel applied) instead of recomputing the
+ * pre-activation z2 -- 80 instead of 93 matrix instructions per 16 points at the reference's default width.  Other activation
+ * pairs ignore `out`.  (torch's own ReLU backward reads the saved result the same way.) */
+int tcfd_fno_pointwise_bwd_out(const void* x, const void* skip, const void* dout, const void* out, void* dx, void* dskip,
+                               const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
+                               void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
+                               int skip_T, int act1, int act2, int skip_mode, int per_sample, void* stream);
 /* The single-layer form (w1 NULL, no skip, no activations) whose input is x1 (batch, 1, P) + pe (ci, P) -- the `pe` mode of
  * tcfd_fno_pointwise -- so the weight gradients of the lifting operator's projection need no materialised (batch, ci, P) input. */
 int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const void* dout, void* dx, const void* w2t, const void* b2,

@@ -938,7 +938,7 @@ def test_sfno_training_step_gradients_golden(dev):
 @pytest.mark.parametrize("ci,cm,co,two,mode,act", [
     (10, 40, 10, True, 1, "ReLU"), (10, 40, 10, True, 1, "GELU"), (10, 40, 10, True, 0, "SiLU"), (8, 32, 8, True, 1, "Tanh"),
     (10, 10, 1, False, 0, None), (10, 10, 10, False, 1, "ReLU"), (4, 16, 4, True, 1, "ReLU"),
-    (10, 40, 10, True, 2, "GELU"), (4, 16, 4, True, 2, "ReLU"),
+    (10, 40, 10, True, 2, "GELU"), (4, 16, 4, True, 2, "ReLU"), (10, 40, 10, True, 2, "ReLU"),
     (6, 24, 6, True, 1, "ReLU"), (12, 48, 12, True, 0, "GELU"), (14, 56, 14, True, 1, "SiLU"), (10, 40, 10, True, 0, None),
 ])
 @pytest.mark.parametrize("X", [7, 6])   # P = 630 (not a multiple of 4: the LDS-staged kernels) / 540 (P % 16 = 12: the all-MFMA kernel, ragged last group)
@@ -981,6 +981,41 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
     for k, v in ref.items():
         if v is not None:
             assert got[k] is not None and rel_l2(got[k], v) < 2e-5, k
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(mode, dev, monkeypatch):
+    """tcfd_fno_pointwise_bwd_out: the ReLU mask of the output activation read from the block's forward output (80 MFMAs per 16
+    points) against the kernel that recomputes the pre-activation (93): same gradients to rounding -- the only elements that
+    may differ are those whose pre-activation is within rounding of zero -- and through the C ABI directly with out = NULL."""
+    import torch.nn as nn
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(17 + mode)
+    ci = co = 10
+    cm = 40
+    shape = (3, ci, 12, 16, 10)
+    lin1, lin2 = nn.Conv3d(ci, cm, 1).to(dev), nn.Conv3d(cm, co, 1).to(dev)
+    skc = nn.Conv3d(ci, co, 1).to(dev) if mode == 1 else None
+    x = torch.randn(*shape, device=dev)
+    s = torch.randn(*shape, device=dev) if mode == 1 else torch.randn(3, co, 12, 16, 6, device=dev)
+    act = nn.ReLU()
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_PW_BWD_YMASK", flag)
+        xs, ss = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        for m in (lin1, lin2, skc):
+            if m is not None:
+                m.zero_grad(set_to_none=True)
+        out = fno.hip_pointwise(xs, lin1, act, lin2, skip=ss, skip_conv=skc, act2=act, skip_last_slice=(mode == 2))
+        assert out is not None and type(out.grad_fn).__name__.startswith("_PointwiseFn")
+        assert fno._keeps_output((True, act, act, mode, None)) == (flag == "1")
+        torch.manual_seed(5)
+        (out * torch.randn_like(out)).sum().backward()
+        res[flag] = [xs.grad, ss.grad, lin1.weight.grad.clone(), lin1.bias.grad.clone(), lin2.weight.grad.clone(),
+                     lin2.bias.grad.clone()] + ([skc.weight.grad.clone(), skc.bias.grad.clone()] if skc is not None else [])
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.isfinite(a).all() and rel_l2(a, b) < 2e-6
 
 
 @pytest.mark.parametrize("random_feats", [False, True])

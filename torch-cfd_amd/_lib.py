@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_loss.hip")
 
 TCFD_C64, TCFD_C128 = 0, 1
-ABI_VERSION = 4   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
+ABI_VERSION = 5   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -154,6 +154,8 @@ SIGNATURES = {
     "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_fno_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "tcfd_fno_pointwise_bwd_out": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
+                                        _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_fno_sample_outer_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _i, _vp]),
     "tcfd_fno_pointwise_bwd_pe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i), _i, _i, _i, _l, _i, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),

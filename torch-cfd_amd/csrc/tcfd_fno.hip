@@ -1785,6 +1785,8 @@ struct PwBwdArgs {
     const float* x;      // (b, CI, P)
     const float* s;      // (b, CI, P) skip input (skip_mode 1) or null
     const float* dout;   // (b, CO, P)
+    const float* out;    // (b, CO, P) the block's forward OUTPUT, or null (k_pointwise_bwd_mfma with both activations ReLU: the
+                         // mask of the output activation is read from it instead of recomputing z2 -- 13 of 93 MFMAs per 16 points)
     float* dx;           // (b, CI, P)
     float* ds;           // (b, CI, P) or null
     const float* w1;     // (CM, CI) or null
@@ -2401,8 +2403,14 @@ __device__ __forceinline__ float pw_relu(float z) {      // max(0, z) on the bit
     const int zi = __float_as_int(z);                     // (an inline-asm v_max_f32 is invisible to hipcc's MFMA hazard handling:
     return __int_as_float(zi > 0 ? zi : 0);               //  it read the accumulators before they were written)
 }
-template <int CI, int CM, int CO, int MODE, int ACT = -1>
+// YMASK (ReLU / ReLU only): a.out holds the block's forward output y = max(0, z2).  The backward needs z2 for nothing but the
+// sign that gates the cotangent, and y > 0 <=> z2 > 0 -- so the whole z2 chain (the skip product and W2 h: 3 + 10 of the 93
+// MFMAs at width 10, and the O1 copy of h that only it consumes) is replaced by four 4-byte loads per lane.  It is also the
+// mask the forward kernel actually applied (its FMA order differs from the MFMA chain's: a z2 within rounding of 0 could come
+// out on the other side here).
+template <int CI, int CM, int CO, int MODE, int ACT = -1, bool YMASK = false>
 __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
+    static_assert(!YMASK || ACT == 1, "the output mask stands in for z2 only under ReLU");
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     constexpr int KI = (CI + 1 + 3) / 4;        // k-steps over [x ; 1]
     constexpr int TM = (CM + 15) / 16;          // 16-row tiles of the hidden layer
@@ -2460,7 +2468,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wstride = gridDim.x * 4;
 
     struct In {
-        float xa[KI], sa[KI], dz[4], sl[4];
+        float xa[KI], sa[KI], dz[4], sl[4], yo[4];
         f4 xb, sb;
     };
     // Loads go through buffer descriptors (one per tensor, built from the kernel arguments): a lane that has nothing to
@@ -2476,6 +2484,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, (int)((size_t)a.batch * CO * a.P * 4), 0x00020000);
     const size_t s_bytes = mode == 1 ? (size_t)a.batch * CI * a.P * 4 : (mode == 2 ? (size_t)a.batch * CO * (a.P / a.T) * a.sT * 4 : 0);
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mode ? a.s : a.x), 0, (int)s_bytes, 0x00020000);
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(YMASK ? a.out : a.dout), 0, (int)((size_t)a.batch * CO * a.P * 4), 0x00020000);
     // per-lane constants of the two layouts: channel row offsets (or OOB) and the constant-1 channel
     unsigned ka_off[KI];
     float ka_one[KI];
@@ -2516,9 +2525,14 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             in.xb = f4{__uint_as_float(v.x) + one_b, __uint_as_float(v.y) + one_b, __uint_as_float(v.z) + one_b, __uint_as_float(v.w) + one_b};
         }
         if constexpr (MODE == 1) {
+            if constexpr (!YMASK) {      // (the O1 copy of the skip input feeds the z2 chain only)
 #pragma unroll
-            for (int j = 0; j < KI; ++j)
-                in.sa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, 0)) + ka_one[j];
+                for (int j = 0; j < KI; ++j)
+                    in.sa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, 0)) + ka_one[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < KI; ++j) in.sa[j] = 0.f;
+            }
             const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, 0);
             in.sb = f4{__uint_as_float(v.x) + one_b, __uint_as_float(v.y) + one_b, __uint_as_float(v.z) + one_b, __uint_as_float(v.w) + one_b};
         } else {
@@ -2531,8 +2545,10 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         for (int r = 0; r < 4; ++r) {
             in.dz[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, 0));
             in.sl[r] = 0.f;
+            if constexpr (YMASK)
+                in.yo[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, 0));
         }
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 && !YMASK) {
             const unsigned pc = live_a ? pa : (unsigned)a.P - 1u;
             const unsigned os = (unsigned)b * CO * sP4 + ((pc / (unsigned)a.T) * (unsigned)a.sT + (unsigned)(a.sT - 1)) * 4u;
 #pragma unroll
@@ -2578,16 +2594,18 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             }
             // ---- O1: z2 = [Ws | b] [s ; 1] + W2 h  (the skip part first: it does not wait for the activation)
             f4 z2 = f4{cur.sl[0], cur.sl[1], cur.sl[2], cur.sl[3]};
-            if constexpr (MODE == 1) {
+            if constexpr (!YMASK) {
+                if constexpr (MODE == 1) {
 #pragma unroll
-                for (int j = 0; j < KI; ++j) z2 = PW_MFMA(Wsa[j], cur.sa[j], z2);
-            } else {
-                z2 = PW_MFMA(Wsa[CI / 4], cur.sa[CI / 4], z2);        // only the constant-1 channel (the bias) is there
+                    for (int j = 0; j < KI; ++j) z2 = PW_MFMA(Wsa[j], cur.sa[j], z2);
+                } else {
+                    z2 = PW_MFMA(Wsa[CI / 4], cur.sa[CI / 4], z2);        // only the constant-1 channel (the bias) is there
+                }
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < pw_tile_steps(CM, t); ++r) z2 = PW_MFMA(W2a[t][r], h[t][r], z2);
             }
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int r = 0; r < pw_tile_steps(CM, t); ++r) z2 = PW_MFMA(W2a[t][r], h[t][r], z2);
             if constexpr (ACT == 1) {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
@@ -2598,7 +2616,10 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             } else {
                 pw_act_tiles<TM>(zT, hT, dT, a.act1);                  // under the z2 chain
             }
-            if constexpr (ACT == 1) {
+            if constexpr (YMASK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z2[r] = cur.yo[r] > 0.f ? cur.dz[r] : 0.f;
+            } else if constexpr (ACT == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z2[r] = z2[r] > 0.f ? cur.dz[r] : 0.f;
             } else {
@@ -2671,13 +2692,13 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         if (c <= CI) out[(4 * q + r) * Gm::CB + CM + (c == CI ? 0 : 1 + c)] = accWs[r];
 }
 
-template <int CI, int CM, int CO, int MODE, int ACT = -1>
+template <int CI, int CM, int CO, int MODE, int ACT = -1, bool YMASK = false>
 static int launch_pw_bwd_mfma_m(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
     if (!a.x) return 0;
     a.batch = batch;
-    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE, ACT>;
+    auto kern = k_pointwise_bwd_mfma<CI, CM, CO, MODE, ACT, YMASK>;
     int per_cu = 0, dev = 0, cus = 256;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0));
     HIP_TRY(hipGetDevice(&dev));
@@ -2699,6 +2720,10 @@ template <int CI, int CM, int CO>
 static int launch_pw_bwd_mfma(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     if constexpr (CI == 10 && CM == 40 && CO == 10) {      // the reference's default width with its default activation (ReLU)
         if (a.x && a.act1 == 1 && a.act2 == 1 && env_int("TCFD_PW_BWD_RELU", 1)) {
+            if (a.out && env_int("TCFD_PW_BWD_YMASK", 1)) {      // the forward output was handed over: no z2 recompute
+                if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1, true>(a, batch, max_rows, dims, st);
+                if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1, true>(a, batch, max_rows, dims, st);
+            }
             if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1>(a, batch, max_rows, dims, st);
             if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1>(a, batch, max_rows, dims, st);
         }
@@ -2782,7 +2807,7 @@ static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, c
                               const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
                               const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
                               int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
-                              int per_sample, void* stream);
+                              int per_sample, void* stream, const void* out = nullptr);
 extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, void* dx, void* dskip,
                                       const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
                                       const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
@@ -2790,6 +2815,16 @@ extern "C" int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const voi
                                       int per_sample, void* stream) {
     return pointwise_bwd_impl(nullptr, x, skip, dout, dx, dskip, w1, b1, w2t, b2, wst, bs, partials, max_waves, dims, batch, ci, cm,
                               co, P, T, skip_T, act1, act2, skip_mode, per_sample, stream);
+}
+// The same with the block's forward output `out` (batch, co, P) handed over (may be NULL = the call above): kernels that can
+// read the mask of a ReLU output activation from it do so instead of recomputing the pre-activation.
+extern "C" int tcfd_fno_pointwise_bwd_out(const void* x, const void* skip, const void* dout, const void* out, void* dx, void* dskip,
+                                          const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
+                                          const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
+                                          int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
+                                          int per_sample, void* stream) {
+    return pointwise_bwd_impl(nullptr, x, skip, dout, dx, dskip, w1, b1, w2t, b2, wst, bs, partials, max_waves, dims, batch, ci, cm,
+                              co, P, T, skip_T, act1, act2, skip_mode, per_sample, stream, out);
 }
 // The single-layer form whose input is x1 (batch, 1, P) + pe (ci, P) (the `pe` mode of tcfd_fno_pointwise): weight-gradient
 // partial sums (and dx, if asked for) without the (batch, ci, P) input ever being materialised.
@@ -2804,7 +2839,7 @@ static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, c
                               const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst,
                               const void* bs, void* partials, int max_waves, int* dims, int batch, int ci,
                               int cm, int co, long P, int T, int skip_T, int act1, int act2, int skip_mode,
-                              int per_sample, void* stream) {
+                              int per_sample, void* stream, const void* out) {
     if (!dims) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: null dims");
     if (x && (!dout || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
         return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad argument");
@@ -2814,6 +2849,7 @@ static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, c
     PwBwdArgs a;
     a.pe = (const float*)pe;
     a.x = (const float*)x; a.s = (const float*)skip; a.dout = (const float*)dout; a.dx = (float*)dx; a.ds = (float*)dskip;
+    a.out = (const float*)out;
     a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
     a.wst = (const float*)wst; a.bs = (const float*)bs; a.partials = (float*)partials;
     a.P = P; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode; a.T = T; a.sT = skip_T;

@@ -619,11 +619,13 @@ def _sum_rows(mat: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return out
 
 
-def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta, need_dx: bool = True):
+def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta, need_dx: bool = True, out=None):
     """Gradients of the fused block from ``tcfd_fno_pointwise_bwd`` (one pass; weight gradients accumulated on MFMA,
     per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm or a width
     that is not instantiated -- the caller then recomputes the
-    block with torch einsums."""
+    block with torch einsums.  ``out``: the block's forward output if the caller still holds it (it is the next layer's
+    input, so it costs no memory): with ReLU activations the kernel reads the output mask from it instead of recomputing the
+    pre-activation (``tcfd_fno_pointwise_bwd_out``)."""
     has_l1, act1, act2, mode, eps = spec
     c1, c2 = _act_code(act1), _act_code(act2)
     if c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
@@ -658,11 +660,15 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     # zeros: the all-MFMA kernel writes only the entries of a row that mean something (one row per wave)
     partials = torch.zeros(max_waves, per_row, dtype=torch.float32, device=dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
+    ys = None
+    if (out is not None and c1 == 1 and c2 == 1 and out.dtype == torch.float32 and out.device == dev
+            and out.numel() == dz.numel() and out.shape[:2] == dz.shape[:2]):
+        ys = out.detach().contiguous()
     with torch.cuda.device(dev):
-        rc = lib.tcfd_fno_pointwise_bwd(ptr(xs), ptr(sk), ptr(dz), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t), ptr(b2v),
-                                        ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1, c2, mode, 0,
-                                        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-    _lib.check(rc, "tcfd_fno_pointwise_bwd")
+        rc = lib.tcfd_fno_pointwise_bwd_out(ptr(xs), ptr(sk), ptr(dz), ptr(ys), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t),
+                                            ptr(b2v), ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1,
+                                            c2, mode, 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "tcfd_fno_pointwise_bwd_out")
     tot = _sum_rows(partials, dims[5], per_row).float()
     A = tot[: COP * CB].view(COP, CB)
     ch = cm if has_l1 else ci
@@ -783,6 +789,14 @@ def _norm_proj_grads(eps, dz, xs, W, bias, gamma, beta, Mx, M1, stats, need_dx, 
     return (dx.view_as(x), None, None, None, cast(g_w, w), cast(g_b, bias), None, None, cast(g_gamma, gamma), cast(g_beta, beta))
 
 
+def _keeps_output(spec) -> bool:
+    """Whether the backward of a fused block wants the block's forward output (``tcfd_fno_pointwise_bwd_out``): two layers,
+    both activations ReLU, no folded LayerNorm."""
+    has_l1, act1, act2, _, eps = spec
+    return bool(has_l1) and eps is None and _act_code(act1) == 1 and _act_code(act2) == 1 \
+        and os.environ.get("TCFD_PW_BWD_YMASK", "1") != "0"
+
+
 class _PointwiseFn(torch.autograd.Function):
     """Fused pointwise block under autograd: the forward value comes from the HIP kernel (passed in), the backward
     recomputes the block from its inputs (nothing but the inputs is kept alive between forward and backward)."""
@@ -791,15 +805,19 @@ class _PointwiseFn(torch.autograd.Function):
     def forward(ctx, out, spec, *tensors):
         ctx.spec = spec
         ctx.present = [t is not None for t in tensors]
-        ctx.save_for_backward(*[t for t in tensors if t is not None])
+        # ReLU / ReLU blocks keep their output too (it IS the next block's input: no extra memory): its sign is the mask
+        ctx.keeps_out = _keeps_output(spec)
+        ctx.save_for_backward(*([out] if ctx.keeps_out else []), *[t for t in tensors if t is not None])
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, dout):
-        it = iter(ctx.saved_tensors)
+        saved = list(ctx.saved_tensors)
+        y = saved.pop(0) if ctx.keeps_out else None
+        it = iter(saved)
         tensors = [next(it) if p else None for p in ctx.present]
         need = ctx.needs_input_grad[2:]
-        hip = _hip_pointwise_backward(ctx.spec, dout, *tensors, need_dx=bool(need[0]))
+        hip = _hip_pointwise_backward(ctx.spec, dout, *tensors, need_dx=bool(need[0]), out=y)
         if hip is not None:
             return (None, None, *[g if n else None for g, n in zip(hip, need)])
         with torch.enable_grad():
@@ -824,19 +842,22 @@ class _SpectralLayerFn(torch.autograd.Function):
     def forward(ctx, out, x1, vh, cfg, v, *params):
         ctx.cfg = cfg
         ctx.present = [t is not None for t in params]
-        ctx.save_for_backward(x1, vh, v, *[t for t in params if t is not None])
+        ctx.keeps_out = _keeps_output(cfg[0])      # the layer output = the next layer's input: kept for its ReLU mask
+        ctx.save_for_backward(*([out] if ctx.keeps_out else []), x1, vh, v, *[t for t in params if t is not None])
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, dout):
         spec, n_conv, ccfg, fwd_cfg, inv_cfg = ctx.cfg
-        x1, vh, v, *rest = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
+        y = saved.pop(0) if ctx.keeps_out else None
+        x1, vh, v, *rest = saved
         it = iter(rest)
         params = [next(it) if p else None for p in ctx.present]
         conv_params, pw = params[:n_conv], params[n_conv:]
         need = ctx.needs_input_grad[5:]
         need_v = ctx.needs_input_grad[4]
-        hip = _hip_pointwise_backward(spec, dout, x1, v if spec[3] else None, *pw, None, None)
+        hip = _hip_pointwise_backward(spec, dout, x1, v if spec[3] else None, *pw, None, None, out=y)
         if hip is None:
             raise _lib.TcfdError("pointwise backward kernel not available for a layer that was admitted to the fused path")
         dx1, g_skip = hip[0], hip[1]
