@@ -987,7 +987,7 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
 def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(mode, dev, monkeypatch):
     """tcfd_fno_pointwise_bwd_out: the ReLU mask of the output activation read from the block's forward output (80 MFMAs per 16
     points) against the kernel that recomputes the pre-activation (93): same gradients to rounding -- the only elements that
-    may differ are those whose pre-activation is within rounding of zero -- and through the C ABI directly with out = NULL."""
+    may differ are those whose pre-activation is within rounding of zero; and the 71-MFMA form on top of it (TCFD_PW_BWD_YMASK=2)."""
     import torch.nn as nn
     from torch_cfd_amd import fno
 
@@ -1001,7 +1001,7 @@ def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(m
     s = torch.randn(*shape, device=dev) if mode == 1 else torch.randn(3, co, 12, 16, 6, device=dev)
     act = nn.ReLU()
     res = {}
-    for flag in ("1", "0"):
+    for flag in ("2", "1", "0"):     # 2 (default): + g2^T from a second read, the O1 side of the hidden layer by transposition
         monkeypatch.setenv("TCFD_PW_BWD_YMASK", flag)
         xs, ss = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
         for m in (lin1, lin2, skc):
@@ -1009,13 +1009,13 @@ def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(m
                 m.zero_grad(set_to_none=True)
         out = fno.hip_pointwise(xs, lin1, act, lin2, skip=ss, skip_conv=skc, act2=act, skip_last_slice=(mode == 2))
         assert out is not None and type(out.grad_fn).__name__.startswith("_PointwiseFn")
-        assert fno._keeps_output((True, act, act, mode, None)) == (flag == "1")
+        assert fno._keeps_output((True, act, act, mode, None)) == (flag != "0")
         torch.manual_seed(5)
         (out * torch.randn_like(out)).sum().backward()
         res[flag] = [xs.grad, ss.grad, lin1.weight.grad.clone(), lin1.bias.grad.clone(), lin2.weight.grad.clone(),
                      lin2.bias.grad.clone()] + ([skc.weight.grad.clone(), skc.bias.grad.clone()] if skc is not None else [])
-    for a, b in zip(res["1"], res["0"]):
-        assert torch.isfinite(a).all() and rel_l2(a, b) < 2e-6
+    for a2, a1, b in zip(res["2"], res["1"], res["0"]):
+        assert torch.isfinite(a2).all() and rel_l2(a2, b) < 2e-6 and rel_l2(a1, b) < 2e-6
 
 
 @pytest.mark.parametrize("random_feats", [False, True])

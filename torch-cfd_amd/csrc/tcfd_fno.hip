@@ -2408,7 +2408,12 @@ __device__ __forceinline__ float pw_relu(float z) {      // max(0, z) on the bit
 // MFMAs at width 10, and the O1 copy of h that only it consumes) is replaced by four 4-byte loads per lane.  It is also the
 // mask the forward kernel actually applied (its FMA order differs from the MFMA chain's: a z2 within rounding of 0 could come
 // out on the other side here).
-template <int CI, int CM, int CO, int MODE, int ACT = -1, bool YMASK = false>
+// YMASK = 2 goes on from there.  (i) g2^T is formed from a second read of dout / out in the [ch c][pt 4q .. 4q + 3] layout (16-byte
+// lanes of lines the first read brought in) instead of g2 . I: 3 MFMAs less.  (ii) The O1 side of the hidden layer -- z1 (for its
+// mask), dh = W2^T g2 and g1 = dh (.) mask, 9 + 9 MFMAs -- exists only to feed dx^T = g1^T W1 with an A operand; g1 in that
+// orientation is the TRANSPOSE of the OT tile g1^T the weight gradient needs anyway, and a transposition is one product with
+// the identity per k-step (12).  71 instead of 80 MFMAs per 16 points, and the O1 compares / selects go too.
+template <int CI, int CM, int CO, int MODE, int ACT = -1, int YMASK = 0>
 __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     static_assert(!YMASK || ACT == 1, "the output mask stands in for z2 only under ReLU");
     using Gm = PwBwdGeom<CI, CM, CO, true>;
@@ -2456,6 +2461,9 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         Idf[r] = c == cq ? 1.f : 0.f;                                // g2^T comes out with its columns in natural order
         Wsb[r] = (mode == 1 && cq >= 0 && c < CI) ? a.wst[c * CO + cq] : 0.f;
     }
+    float Idp[4];                                                    // identity over the 16 points, k-step r lists rows {4q + r}
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Idp[r] = c == 4 * q + r ? 1.f : 0.f;
     f4 accW2[TM], accW1[TM], accWs = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < TM; ++t) accW2[t] = accW1[t] = f4{0.f, 0.f, 0.f, 0.f};
@@ -2469,7 +2477,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 
     struct In {
         float xa[KI], sa[KI], dz[4], sl[4], yo[4];
-        f4 xb, sb;
+        f4 xb, sb, dzb, yob;
     };
     // Loads go through buffer descriptors (one per tensor, built from the kernel arguments): a lane that has nothing to
     // read -- padding channel, point beyond P -- passes an offset beyond the buffer and gets 0 from the bounds check.  No
@@ -2540,6 +2548,12 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
             for (int j = 0; j < KI; ++j) in.sa[j] = ka_one[j];
             in.sb = f4{one_b, one_b, one_b, one_b};
         }
+        if constexpr (YMASK == 2) {
+            const unsigned cbo = (c < CO && live_b) ? (unsigned)c * P4 + base_o + pb * 4u : OOB;
+            const u4 vd = __builtin_amdgcn_raw_buffer_load_b128(rd, cbo, 0, 0), vy = __builtin_amdgcn_raw_buffer_load_b128(ry, cbo, 0, 0);
+            in.dzb = f4{__uint_as_float(vd.x), __uint_as_float(vd.y), __uint_as_float(vd.z), __uint_as_float(vd.w)};
+            in.yob = f4{__uint_as_float(vy.x), __uint_as_float(vy.y), __uint_as_float(vy.z), __uint_as_float(vy.w)};
+        }
         const unsigned od = live_a ? base_o + pa * 4u : OOB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2575,8 +2589,10 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 z[t] = zT[t] = f4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (YMASK != 2) {
 #pragma unroll
-                for (int j = 0; j < KI; ++j) z[t] = PW_MFMA(W1a[t][j], cur.xa[j], z[t]);
+                    for (int j = 0; j < KI; ++j) z[t] = PW_MFMA(W1a[t][j], cur.xa[j], z[t]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < TM; ++t)
@@ -2634,22 +2650,48 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 dh[t] = dhT[t] = f4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (YMASK != 2) {
 #pragma unroll
-                for (int r = 0; r < RO; ++r) dh[t] = PW_MFMA(W2b[t][r], z2[r], dh[t]);
+                    for (int r = 0; r < RO; ++r) dh[t] = PW_MFMA(W2b[t][r], z2[r], dh[t]);
+                }
             }
+            if constexpr (YMASK == 2) {
 #pragma unroll
-            for (int r = 0; r < RO; ++r) g2T = PW_MFMA(z2[r], Idf[r], g2T);
+                for (int r = 0; r < 4; ++r) g2T[r] = cur.yob[r] > 0.f ? cur.dzb[r] : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < RO; ++r) g2T = PW_MFMA(z2[r], Idf[r], g2T);
+            }
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
                 for (int r = 0; r < RO; ++r) dhT[t] = PW_MFMA(z2[r], W2b[t][r], dhT[t]);
             // ---- dx^T, ds^T from the O1 tiles as A operands
             f4 dxT = f4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (YMASK == 2) {
+                // g1^T (OT) once, for the weight gradient below AND, transposed through the identity, for dx^T
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
+                for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < pw_tile_steps(CM, t); ++r)
-                    dxT = PW_MFMA(ACT == 1 ? (d1[t][r] > 0.f ? dh[t][r] : 0.f) : dh[t][r] * d1[t][r], W1b[t][r], dxT);
+                    for (int r = 0; r < 4; ++r) dhT[t][r] = dT[t][r] > 0.f ? dhT[t][r] : 0.f;
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    f4 g1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g1 = PW_MFMA(dhT[t][r], Idp[r], g1);
+                    dh[t] = g1;
+                }
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < pw_tile_steps(CM, t); ++r) dxT = PW_MFMA(dh[t][r], W1b[t][r], dxT);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < pw_tile_steps(CM, t); ++r)
+                        dxT = PW_MFMA(ACT == 1 ? (d1[t][r] > 0.f ? dh[t][r] : 0.f) : dh[t][r] * d1[t][r], W1b[t][r], dxT);
+            }
             if constexpr (MODE == 1) {
                 if (a.ds) {
                     f4 dsT = f4{0.f, 0.f, 0.f, 0.f};
@@ -2668,7 +2710,8 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     accW2[t] = PW_MFMA(g2T[r], hT[t][r], accW2[t]);
-                    accW1[t] = PW_MFMA(ACT == 1 ? (dT[t][r] > 0.f ? dhT[t][r] : 0.f) : dhT[t][r] * dT[t][r], cur.xb[r], accW1[t]);
+                    accW1[t] = PW_MFMA(YMASK == 2 ? dhT[t][r] : (ACT == 1 ? (dT[t][r] > 0.f ? dhT[t][r] : 0.f) : dhT[t][r] * dT[t][r]),
+                                       cur.xb[r], accW1[t]);
                 }
             if (a.dx && c < CI && live_b)
                 *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + c) * a.P + pb) = dxT;
@@ -2692,7 +2735,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         if (c <= CI) out[(4 * q + r) * Gm::CB + CM + (c == CI ? 0 : 1 + c)] = accWs[r];
 }
 
-template <int CI, int CM, int CO, int MODE, int ACT = -1, bool YMASK = false>
+template <int CI, int CM, int CO, int MODE, int ACT = -1, int YMASK = 0>
 static int launch_pw_bwd_mfma_m(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     using Gm = PwBwdGeom<CI, CM, CO, true>;
     dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL; dims[5] = 0;
@@ -2720,9 +2763,13 @@ template <int CI, int CM, int CO>
 static int launch_pw_bwd_mfma(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
     if constexpr (CI == 10 && CM == 40 && CO == 10) {      // the reference's default width with its default activation (ReLU)
         if (a.x && a.act1 == 1 && a.act2 == 1 && env_int("TCFD_PW_BWD_RELU", 1)) {
-            if (a.out && env_int("TCFD_PW_BWD_YMASK", 1)) {      // the forward output was handed over: no z2 recompute
-                if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1, true>(a, batch, max_rows, dims, st);
-                if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1, true>(a, batch, max_rows, dims, st);
+            const int ym = a.out ? env_int("TCFD_PW_BWD_YMASK", 2) : 0;   // the forward output was handed over: no z2 recompute
+            if (ym >= 2) {                                                // ... and no O1 side of the hidden layer (default)
+                if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1, 2>(a, batch, max_rows, dims, st);
+                if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1, 2>(a, batch, max_rows, dims, st);
+            } else if (ym == 1) {
+                if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1, 1>(a, batch, max_rows, dims, st);
+                if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1, 1>(a, batch, max_rows, dims, st);
             }
             if (a.skip_mode == 1) return launch_pw_bwd_mfma_m<CI, CM, CO, 1, 1>(a, batch, max_rows, dims, st);
             if (a.skip_mode == 2) return launch_pw_bwd_mfma_m<CI, CM, CO, 2, 1>(a, batch, max_rows, dims, st);
