@@ -339,11 +339,17 @@ def sfno_config5(dev, with_cpu=True):
             blk = lambda: fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
             assert blk() is not None
             t_blk = timeit(blk, 20)
-            # the backward of the same block (k_pointwise_bwd_mfma): reads x, skip, dout, writes dx, dskip = 5 A_H
+            # the backward of the same block (k_pointwise_bwd_mfma): reads x, skip, dout and the block's forward output (its ReLU
+            # mask, tcfd_fno_pointwise_bwd_out), writes dx, dskip = 6 A_H
             spec = (True, mlp.activation, act, 1, None)
+            y_blk = blk()
+            keeps = fno._keeps_output(spec)          # ReLU / ReLU (the reference's default): the 71-product kernel
             bwd = lambda: fno._hip_pointwise_backward(spec, x1, v, v, mlp.linear1.weight, mlp.linear1.bias, mlp.linear2.weight,
-                                                      mlp.linear2.bias, w.weight, w.bias, None, None)
+                                                      mlp.linear2.bias, w.weight, w.bias, None, None, out=y_blk if keeps else None)
             t_bwd = timeit(bwd, 10)
+            del y_blk
+            n_mfma = 71 if keeps else 93
+            useful_mac = 2300 if keeps else 2760
         del x1, v
         ach = 3 * A_H / (t_blk * 1e-3) / 1e9
         # L2 <-> memory bytes per launch from the rocprofv3 PMC passes of tests/prof_sfno.sh (profiles/sfno_traffic.json ships with
@@ -370,24 +376,28 @@ def sfno_config5(dev, with_cpu=True):
                                "activations as template parameters 475 us",
                 "kernels_from_profile": kern_table or None,
                 "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
-                                    "algo_bytes_per_launch": 5 * A_H, "avg_launch_ms": round(t_bwd, 4),
-                                    "achieved": round(5 * A_H / (t_bwd * 1e-3) / 1e9, 1),
-                                    "frac": round(5 * A_H / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "algo_bytes_per_launch": (6 if keeps else 5) * A_H, "avg_launch_ms": round(t_bwd, 4),
+                                    "achieved": round((6 if keeps else 5) * A_H / (t_bwd * 1e-3) / 1e9, 1),
+                                    "frac": round((6 if keeps else 5) * A_H / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "mfma": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
-                                             # issued: 93 v_mfma_f32_16x16x4_f32 (2048 flop each) per 16 points, tile padding included
-                                             "issued_flop_per_launch": 93 * 2048 * (A_H // 40 // 16),
-                                             "achieved": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12, 1),
-                                             "frac": round(93 * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
-                                             # useful: the block's own multiply-adds per point -- forward recompute W1 (10x40) +
-                                             # W2 (40x10) + Ws (10x10), input gradients W2^T, W1^T, Ws^T (the same three shapes) and
-                                             # the three weight-gradient outer products (again the same shapes): 3 x 900 = 2700 MAC,
-                                             # biases as a constant-1 channel +60 -> 2 x 2760 flop per point.  The rest of the issued
-                                             # work is the zero padding of width 10 / 40 into 16 x 16 x 4 tiles.
-                                             "useful_flop_per_launch": 2 * 2760 * (A_H // 40),
-                                             "useful_achieved": round(2 * 2760 * (A_H // 40) / (t_bwd * 1e-3) / 1e12, 1),
-                                             "useful_frac": round(2 * 2760 * (A_H // 40) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
-                                             "useful_over_issued": round(2 * 2760 * 16 / (93 * 2048), 3)},
-                                    "note": "matrix-pipe bound: 93 v_mfma_f32_16x16x4_f32 per 16 points (105 before the tile row map) = 1.6 ms of MFMA time per launch; peak = dense fp32 matrix rate, 256 flop/clk/CU x 256 CUs x 2.4 GHz"}}
+                                             # issued: v_mfma_f32_16x16x4_f32 (2048 flop each) per 16 points, tile padding included
+                                             "mfma_per_16_points": n_mfma,
+                                             "issued_flop_per_launch": n_mfma * 2048 * (A_H // 40 // 16),
+                                             "achieved": round(n_mfma * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12, 1),
+                                             "frac": round(n_mfma * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
+                                             # useful: the multiply-adds the block's backward needs per point.  Recomputing kernel
+                                             # (93): forward W1 (10x40) + W2 (40x10) + Ws (10x10), input gradients W2^T, W1^T, Ws^T
+                                             # and the three weight-gradient outer products: 3 x 900 MAC, biases as a constant-1
+                                             # channel + 60.  Output-mask kernel (71): the forward part is W1 alone (400 + 40).
+                                             # The rest of the issued work is the zero padding of width 10 / 40 into 16 x 16 x 4
+                                             # tiles, each intermediate in two orientations, and the 12 transposition products.
+                                             "useful_flop_per_launch": 2 * useful_mac * (A_H // 40),
+                                             "useful_achieved": round(2 * useful_mac * (A_H // 40) / (t_bwd * 1e-3) / 1e12, 1),
+                                             "useful_frac": round(2 * useful_mac * (A_H // 40) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
+                                             "useful_over_issued": round(2 * useful_mac * 16 / (n_mfma * 2048), 3)},
+                                    "note": f"matrix-pipe bound: {n_mfma} v_mfma_f32_16x16x4_f32 per 16 points (round 3: 105 -> 93 by the tile row map; "
+                                            "round 4: 93 -> 71 -- output mask read from the forward output, g2^T loaded, the channel-major "
+                                            "side of the hidden layer by transposition); peak = dense fp32 matrix rate, 256 flop/clk/CU x 256 CUs x 2.4 GHz"}}
     except Exception as e:
         roof = {"error": repr(e)}
     base = None
