@@ -378,6 +378,15 @@ int tcfd_fno_lift_fold(const void* v, const void* qs, const void* sq, const void
                        const void* gamma, const void* beta, double eps, void* w2t, void* fb, void* moments, void* scratch,
                        int batch, int C, int co, long P, void* stream);
 
+/* The kept modes of the lifting operator's projection WITHOUT the projection (fno/sfno.py:252-256: proj(norm(v + table)) is a
+ * per-sample affine map of the one input channel, and the truncated transform that follows it is linear):
+ *     out[b, o, k] = sum_c w2t[b, c, o] (vh[b, k] + table[c, k]) + fb[b, o] table[C, k]
+ * vh (batch, K) kept modes of the one-channel input, table (C + 1, K) kept modes of the C table channels and of the constant-1
+ * field (same plan, same padding, same normalisation: formed once per mesh), w2t (batch, C, co) / fb (batch, co) from
+ * tcfd_fno_lift_fold, out (batch, co, K); complex64 / fp32.  One launch; C <= 32. */
+int tcfd_fno_lift_spectrum(const void* vh, const void* table, const void* w2t, const void* fb, void* out, int batch, int C,
+                           int co, long K, void* stream);
+
 /* ---- SobolevLoss in three launches (fno/losses.py:263-315; BASELINE config 5 "forward + loss") -------------------------
  * x, y: (batch, n, n, nt) real, TIME-LAST and contiguous, read in place (no permuted copies, no x - y tensor).
  *   pass 1  per (b, row) slab: d = x - y while staging, one complex n-point FFT per time step of d_t + i y_t, Hermitian

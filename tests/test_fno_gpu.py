@@ -1019,6 +1019,38 @@ def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(m
 
 
 @pytest.mark.parametrize("random_feats", [False, True])
+@pytest.mark.parametrize("shape,modes,width", [((2, 16, 16, 10), (4, 4, 3), 4), ((3, 32, 64, 10), (8, 8, 5), 10), ((2, 96, 96, 6), (8, 8, 3), 8)])
+def test_lifting_operator_through_the_spectrum_equals_the_materialised_projection(shape, modes, width, random_feats, dev, monkeypatch):
+    """LiftingOperator._through_the_spectrum (kept modes of the projection as an affine map of the one-channel input's kept
+    modes, tcfd_fno_lift_spectrum; the tail from the projection's last time slice) against the path that writes the projected
+    tensor, and both against the torch modules composed as the reference composes them (fno/sfno.py:252-259)."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(11)
+    b, X, Y, T = shape
+    lift = fno.LiftingOperator(width, *modes, latent_steps=T, activation="ReLU", spatial_random_feats=random_feats).to(dev).eval()
+    with torch.no_grad():
+        lift.norm.weight.copy_(torch.rand_like(lift.norm.weight) + 0.5)
+        lift.norm.bias.copy_(torch.randn_like(lift.norm.bias) * 0.1)
+        v = (torch.randn(b, 1, X, Y, T, device=dev) * 1.5 + 0.3)
+        monkeypatch.setenv("TCFD_LIFT_SPECTRUM", "1")
+        assert lift._through_the_spectrum(v) is not None
+        a = lift(v)
+        monkeypatch.setenv("TCFD_LIFT_SPECTRUM", "0")
+        assert lift._through_the_spectrum(v) is None
+        c = lift(v)
+        v0 = lift.proj(lift.norm(lift.pe(v)))
+        ref = lift.activation(v0[..., -1:] + lift.mlp(lift.sconv(v0)))
+        assert a.shape == c.shape == ref.shape
+        assert rel_l2(c, ref) < 5e-6 and rel_l2(a, ref) < 5e-6 and rel_l2(a, c) < 5e-6
+        # a second input through the cached table modes
+        monkeypatch.setenv("TCFD_LIFT_SPECTRUM", "1")
+        v2 = torch.randn_like(v) * 0.2 - 1.0
+        v02 = lift.proj(lift.norm(lift.pe(v2)))
+        assert rel_l2(lift(v2), lift.activation(v02[..., -1:] + lift.mlp(lift.sconv(v02)))) < 5e-6
+
+
+@pytest.mark.parametrize("random_feats", [False, True])
 def test_lifting_projection_without_materialising_the_encoded_input(random_feats, dev):
     """hip_lift_project: proj(LayerNorm(v + positional encoding)) from the one-channel input, analytic statistics and
     the pe mode of the projection kernel, against the torch modules on the materialised tensor."""

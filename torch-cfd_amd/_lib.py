@@ -156,6 +156,7 @@ SIGNATURES = {
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_fno_pointwise_bwd_out": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
                                         _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "tcfd_fno_lift_spectrum": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "tcfd_fno_sample_outer_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _i, _vp]),
     "tcfd_fno_pointwise_bwd_pe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i), _i, _i, _i, _l, _i, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),

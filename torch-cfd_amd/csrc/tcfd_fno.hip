@@ -3131,6 +3131,57 @@ extern "C" int tcfd_fno_lift_fold(const void* v, const void* qs, const void* sq,
     return 0;
 }
 
+// ------------------------------------------------------------------ lifting operator: the spectrum of its projection
+// The lifting operator projects ONE input channel to `co` channels through a per-sample affine map of (v + table):
+//     v0[b, o](p) = sum_c w2t[b, c, o] (v[b](p) + q_c(p)) + fb[b, o]                  (tcfd_fno_lift_fold, fno/sfno.py:252-254)
+// and the first thing that happens to v0 is a truncated transform (SpectralConvT, :256).  The transform is linear, so
+//     V0^[b, o] = sum_c w2t[b, c, o] (V^[b] + Q^_c) + fb[b, o] 1^
+// with V^ the kept modes of the ONE-channel input, Q^_c those of the table channels and 1^ those of the constant field
+// (left zero padding in t included) -- the last two do not depend on the input and are formed once.  One transform of one
+// channel per sample instead of `co`, and v0 (an activation-sized tensor) is neither written nor read.
+// vh (b, K), table (C + 1, K) = [Q^_0 .. Q^_{C-1}, 1^] complex64; w2t (b, C, co), fb (b, co) fp32; out (b, co, K) complex64.
+#define LIFT_MAXC 32
+__global__ __launch_bounds__(256) void k_lift_spectrum(const cf* __restrict__ vh, const cf* __restrict__ table,
+                                                       const float* __restrict__ w2t, const float* __restrict__ fb,
+                                                       cf* __restrict__ out, int C, int co, long K) {
+    const long k = blockIdx.x * 256L + threadIdx.x;
+    const int b = blockIdx.y;
+    if (k >= K) return;
+    const cf v = vh[(size_t)b * K + k];
+    cf e[LIFT_MAXC];
+#pragma unroll
+    for (int c = 0; c < LIFT_MAXC; ++c)
+        if (c < C) {
+            const cf q = table[(size_t)c * K + k];
+            e[c] = mk<float>(v.x + q.x, v.y + q.y);
+        }
+    const cf one = table[(size_t)C * K + k];
+    const float* wb = w2t + (size_t)b * C * co;
+    for (int o = 0; o < co; ++o) {
+        const float f = fb[(size_t)b * co + o];
+        float re = f * one.x, im = f * one.y;
+#pragma unroll
+        for (int c = 0; c < LIFT_MAXC; ++c)
+            if (c < C) {
+                const float w = wb[(size_t)c * co + o];       // wave uniform: scalar loads
+                re = fmaf(w, e[c].x, re);
+                im = fmaf(w, e[c].y, im);
+            }
+        out[((size_t)b * co + o) * K + k] = mk<float>(re, im);
+    }
+}
+extern "C" int tcfd_fno_lift_spectrum(const void* vh, const void* table, const void* w2t, const void* fb, void* out, int batch,
+                                      int C, int co, long K, void* stream) {
+    if (!vh || !table || !w2t || !fb || !out || batch <= 0 || C <= 0 || co <= 0 || K <= 0)
+        return FAIL(TCFD_EINVAL, "lift_spectrum: bad argument");
+    if (C > LIFT_MAXC) return FAIL(TCFD_EINVAL, "lift_spectrum: %d table channels > %d", C, LIFT_MAXC);
+    if (batch > 65535) return FAIL(TCFD_EINVAL, "lift_spectrum: batch %d exceeds the grid's y range", batch);
+    hipLaunchKernelGGL(k_lift_spectrum, dim3((unsigned)((K + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       (const cf*)vh, (const cf*)table, (const float*)w2t, (const float*)fb, (cf*)out, C, co, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ small reductions of the training step
 // Column sums of a (rows, cols) fp32 matrix in double: the per-wave rows of partial weight-gradient sums of the pointwise
 // backward (2048 x ~1800 values).  torch's sum(dim=0) runs this shape at ~80 GB/s (0.19 ms per layer); here lanes run along

@@ -1191,25 +1191,13 @@ def _lift_table_constants(qf: torch.Tensor):
     return qd.sum(dim=0).float().contiguous(), qd.sum(), (qd * qd).sum()
 
 
-def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj, consts=None) -> Optional[torch.Tensor]:
-    """``proj(norm(v1 + q))`` of the lifting operator (fno/sfno.py:252-254) without ever forming ``v1 + q``.
-
-    v1 (b, 1, X, Y, T) is the single input channel, q (1, C, X, Y, T) the positional-encoding table that the reference
-    adds to it by broadcasting.  The LayerNorm statistics of the (C, X, Y, T) block of a sample follow from three
-    reductions over the ONE-channel input and constants of the table,
-        sum = C sum(v) + sum(q),   sum of squares = C sum(v^2) + 2 sum_p v_p (sum_c q_cp) + sum(q^2),
-    and the projection kernel rebuilds v + q[c] in registers (``pe`` mode of ``tcfd_fno_pointwise``): 84 MB + a 26 MB
-    L2-resident table are read instead of writing and re-reading an 839 MB tensor twice (config 5).  ``consts`` are the
-    table's constants when the caller has them cached (``SpaceTimePositionalEncoding.table_constants``).  Training (the
-    parameters of ``norm`` / ``proj`` require grad, the input is data): the same forward behind ``_LiftProjectFn``, whose
-    backward forms ``v1 + q`` once and reuses the forward's moments.  Returns None when the combination is not covered
-    (an input that itself requires grad included)."""
+def _lift_fold(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj, consts=None):
+    """First half of ``hip_lift_project``: the LayerNorm statistics of ``v1 + q`` from the one-channel input and the per-sample
+    folded projection, ``proj(norm(v1 + q))[b, o] = sum_c w2t[b, c, o] (v1[b] + q[c]) + fb[b, o]`` (``tcfd_fno_lift_fold``, two
+    launches).  Returns (v1 as (b, P), q as (C, P), w2t (b, C, co), fb (b, co), moments (b, 2)) or None when not covered."""
     if not v1.is_cuda or v1.dtype != torch.float32 or v1.shape[1] != 1 or not _is_pointwise(proj) or norm.num_groups != 1:
         return None
-    training = torch.is_grad_enabled() and any(p.requires_grad for m in (norm, proj) for p in m.parameters())
     if torch.is_grad_enabled() and (v1.requires_grad or q.requires_grad):
-        return None
-    if training and os.environ.get("TCFD_LIFT_PROJECT_GRAD", "1") == "0":
         return None
     for prm in list(norm.parameters()) + list(proj.parameters()):
         if prm.dtype != torch.float32 or prm.device != v1.device:
@@ -1240,6 +1228,34 @@ def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj
         _lib.check(lib.tcfd_fno_lift_fold(vf.data_ptr(), qs.data_ptr(), sq.data_ptr(), sq2.data_ptr(), Wc.data_ptr(), ptr(proj.bias),
                                           ptr(norm.weight), ptr(norm.bias), float(norm.eps), w2t.data_ptr(), fb.data_ptr(),
                                           moments.data_ptr(), scratch.data_ptr(), b, C, co, P, stream), "tcfd_fno_lift_fold")
+    return vf, qf, w2t, fb, moments
+
+
+def hip_lift_project(v1: torch.Tensor, q: torch.Tensor, norm: nn.GroupNorm, proj, consts=None) -> Optional[torch.Tensor]:
+    """``proj(norm(v1 + q))`` of the lifting operator (fno/sfno.py:252-254) without ever forming ``v1 + q``.
+
+    v1 (b, 1, X, Y, T) is the single input channel, q (1, C, X, Y, T) the positional-encoding table that the reference
+    adds to it by broadcasting.  The LayerNorm statistics of the (C, X, Y, T) block of a sample follow from three
+    reductions over the ONE-channel input and constants of the table,
+        sum = C sum(v) + sum(q),   sum of squares = C sum(v^2) + 2 sum_p v_p (sum_c q_cp) + sum(q^2),
+    and the projection kernel rebuilds v + q[c] in registers (``pe`` mode of ``tcfd_fno_pointwise``): 84 MB + a 26 MB
+    L2-resident table are read instead of writing and re-reading an 839 MB tensor twice (config 5).  ``consts`` are the
+    table's constants when the caller has them cached (``SpaceTimePositionalEncoding.table_constants``).  Training (the
+    parameters of ``norm`` / ``proj`` require grad, the input is data): the same forward behind ``_LiftProjectFn``, whose
+    backward forms ``v1 + q`` once and reuses the forward's moments.  Returns None when the combination is not covered
+    (an input that itself requires grad included)."""
+    training = torch.is_grad_enabled() and any(p.requires_grad for m in (norm, proj) for p in m.parameters())
+    if training and os.environ.get("TCFD_LIFT_PROJECT_GRAD", "1") == "0":
+        return None
+    fold = _lift_fold(v1, q, norm, proj, consts)
+    if fold is None:
+        return None
+    vf, qf, w2t, fb, moments = fold
+    b, co, C = v1.shape[0], proj.out_channels, qf.shape[0]
+    P = v1[0, 0].numel()
+    dev = v1.device
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     out = torch.empty(b, co, *v1.shape[2:], dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise(vf.data_ptr(), None, out.data_ptr(), None, None, w2t.data_ptr(), fb.data_ptr(), None, None,
@@ -1620,9 +1636,81 @@ class LiftingOperator(nn.Module):
             self.activation = nn.Identity()
             self.mlp = nn.Conv3d(width, width, kernel_size=1)
 
+    def _through_the_spectrum(self, vin):
+        """Inference form of the whole operator that never forms the projected tensor v0 = proj(norm(pe(v))) (b, width, X, Y, T):
+        its kept modes are an affine map of the kept modes of the ONE input channel (``tcfd_fno_lift_spectrum``: the transform
+        is linear, the projection a per-sample affine map of v + table), and the tail needs only v0's last time slice
+        (fno/sfno.py:258-259).  At config 5: one 1-channel transform + a 30 MB combine instead of the projection pass (0.18 ms,
+        writes 839 MB) and a 10-channel transform (0.19 ms, reads them back).  Same result to fp32 rounding.  None when not
+        covered (gradients, dtype, a grid off the FFT kernels, a convolution subclass)."""
+        conv = self.sconv
+        if (os.environ.get("TCFD_LIFT_SPECTRUM", "1") == "0" or not vin.is_cuda or vin.dtype != torch.float32 or vin.dim() != 5
+                or vin.shape[1] != 1 or vin.shape[0] == 0 or not _fused_xy(vin.shape[2], vin.shape[3])):
+            return None
+        if torch.is_grad_enabled() and (vin.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return None
+        cls = type(conv)
+        if cls.forward is not SpectralConvT.forward or cls.spectral_conv is not SpectralConvS.spectral_conv \
+                or cls._plain_args is not SpectralConvT._plain_args or any(p.dtype != torch.float32 for p in conv.parameters()):
+            return None
+        cargs = conv._plain_args(vin, None)
+        if cargs is None:
+            return None
+        weights, bias, delta, modes, t_pad, t_out, t_keep, norm = cargs
+        b, _, X, Y, T = vin.shape
+        q = self.pe.encoding(vin)
+        fold = _lift_fold(vin, q, self.norm, self.proj, consts=self.pe.table_constants(vin))
+        if fold is None:
+            return None
+        vf, qf, w2t, fb, _ = fold
+        C, co = qf.shape[0], self.proj.out_channels
+        if C > 32 or co != conv.in_channels:
+            return None
+        dev = vin.device
+        # kept modes of the table channels and of the constant field, and the table's last time slice: input independent
+        # (a table behind a learned projection -- spatial_random_feats -- changes with its weights: formed per call then)
+        fixed_table = isinstance(self.pe.proj, nn.Identity)
+        key = (dev, X, Y, T, tuple(modes), t_pad, t_out, norm, qf.data_ptr(), q._version)
+        cached = getattr(self, "_table_modes", None) if fixed_table else None
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                fields = torch.cat([qf.view(C, 1, X, Y, T), torch.ones(1, 1, X, Y, T, dtype=torch.float32, device=dev)])
+                th, _ = hip_truncated_rfftn(fields, modes, t_pad=t_pad, t_out=t_out, norm=norm)
+                q_last = qf.view(C, X * Y, T)[..., -1].contiguous()
+            cached = (key, th.reshape(C + 1, -1).contiguous(), q_last)
+            self._table_modes = cached if fixed_table else None
+        _, table, q_last = cached
+        vh, plan = hip_truncated_rfftn(vin, modes, t_pad=t_pad, t_out=t_out, norm=norm)
+        K = vh[0, 0].numel()
+        v0h = torch.empty(b, co, *vh.shape[2:], dtype=torch.complex64, device=dev)
+        lib = _lib.load()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        v_last = vf.view(b, X * Y, T)[..., -1].contiguous()
+        skip = torch.empty(b, co, X, Y, 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.tcfd_fno_lift_spectrum(vh.data_ptr(), table.data_ptr(), w2t.data_ptr(), fb.data_ptr(), v0h.data_ptr(),
+                                                  b, C, co, K, stream), "tcfd_fno_lift_spectrum")
+            # v0[..., -1:] alone: the projection kernel on the last time slice (a tenth of its points)
+            rc = lib.tcfd_fno_pointwise(v_last.data_ptr(), None, skip.data_ptr(), None, None, w2t.data_ptr(), fb.data_ptr(), None,
+                                        None, b, C, C, co, X * Y, 1, 0, 0, 0, 0, C * co, co, q_last.data_ptr(), stream)
+        if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
+            return None
+        _lib.check(rc, "tcfd_fno_pointwise")
+        oh = hip_contract(v0h, weights, bias, delta, modes)
+        x1 = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
+        if isinstance(self.mlp, PointwiseFFN):
+            out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=skip, act2=self.activation,
+                                skip_last_slice=True)
+        else:
+            out = hip_pointwise(x1, None, None, self.mlp, skip=skip, act2=self.activation, skip_last_slice=True)
+        return out if out is not None else self.activation(skip + self.mlp(x1))
+
     def forward(self, v):
         assert self.latent_steps <= v.size(-1)
         vin = v
+        out = self._through_the_spectrum(vin)
+        if out is not None:
+            return out
         v = hip_lift_project(vin, self.pe.encoding(vin), self.norm, self.proj,
                              consts=self.pe.table_constants(vin)) if vin.shape[1] == 1 else None
         if v is None:
