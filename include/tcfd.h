@@ -367,6 +367,11 @@ int tcfd_fno_reduce_frames(const void* x, void* out, const void* w2t, const void
                            int ci, long P, int T, void* stream);
 int tcfd_fno_inverse_trunc_residual(const tcfd_fno_plan* p, const void* vh, void* out, const void* res, int res_T, int batch, int c,
                                     int t_keep, double inv_scale, void* ws, size_t ws_bytes, void* stream);
+/* out = transform, plus last (batch * c, X, Y) at the LAST kept step only (training: the gradient of an input of which only the
+ * last time slice was used joins the adjoint of the forward transform in its store loop, compact -- no zero-filled
+ * activation-sized tensor in between; fno/sfno.py:258-259). */
+int tcfd_fno_inverse_trunc_last(const tcfd_fno_plan* p, const void* vh, void* out, const void* last, int batch, int c, int t_keep,
+                                double inv_scale, void* ws, size_t ws_bytes, void* stream);
 
 /* Lifting operator, proj(LayerNormnd(v + q)) with v ONE channel (fno/sfno.py:252-254, fno/base.py:61-83): the three
  * per-sample sums over v (sum, sum of squares, dot product with the table's channel sum qs) and, from them and the table's

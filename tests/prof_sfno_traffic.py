@@ -21,7 +21,10 @@ ALGO = {  # kernel-name prefix -> (algorithmic bytes per launch, what moves)
     "k_x<float, 256, 8, 16, true": (W + V, "read planes, write kept kx"),
     "k_x<float, 256, 8, 16, false": (V + W, "read kept kx, write planes"),
     "k_contract_mfma": (2 * V + 4 * C * C * mx * my * mt * 8, "spectrum in / out + the four weight blocks"),
-    "k_pointwise<10, 10, 10": (A_1 + A_H, "lifting projection: read the one-channel input (+ L2-resident table), write activation"),
+    # (inference forms the projection's LAST time slice only -- LiftingOperator._through_the_spectrum; the full projection, A_1 + A_H,
+    #  runs in training)
+    "k_pointwise<10, 10, 10": ((A_1 + A_H) // T, "lifting projection, last time slice: one-channel input (+ L2-resident table) -> (b, C, X, Y, 1)"),
+    "k_lift_spectrum": (V // C + V + (C + 1) * (V // (b * C)), "kept modes of the one-channel input + table modes -> kept modes of the projection"),
     "k_pointwise<10, 10, 1": (A_H + A_1, "channel reduction"),
     "k_loss_rows": (2 * A_1 + 2 * LP, "read x, y; write two half-spectrum plane sets"),
     "k_loss_cols": (2 * LP, "read the plane sets"),

@@ -887,6 +887,31 @@ def test_spectral_conv_backward_is_the_adjoint(dev):
     assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1e-3)
 
 
+@pytest.mark.parametrize("width,grid", [(4, 16), (10, 32)])
+def test_compact_skip_gradient_of_the_lifting_tail_equals_the_zero_filled_form(width, grid, dev, monkeypatch):
+    """The t-summed gradient of the lifting operator's skip (last time slice of its input) kept compact and added to the last step
+    by the adjoint transform's store loop (tcfd_fno_inverse_trunc_last) against the zero-filled activation-sized tensor it
+    replaces: the same additions, so every gradient of a training step agrees to rounding."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(2)
+    model = fno.SFNO(4, 4, 3, width=width, num_spectral_layers=2, latent_steps=10).to(dev).train()
+    x = torch.randn(2, grid, grid, 10, device=dev)
+    y = torch.randn(2, grid, grid, 10, device=dev)
+    loss_fn = fno.SobolevLoss(n_grid=grid, norm_order=0, relative=True).to(dev)
+    grads = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_COMPACT_SKIP_GRAD", flag)
+        model.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        loss_fn(model(xin), y).backward()
+        grads[flag] = [xin.grad.clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    assert len(grads["1"]) == len(grads["0"]) > 10
+    # (the same additions in the same order; the bound allows for the LayerNorm moments, whose chunk sums meet in atomics)
+    for a, b in zip(grads["1"], grads["0"]):
+        assert torch.isfinite(a).all() and rel_l2(a, b) < 1e-6
+
+
 def test_sfno_training_step_gradients_golden(dev):
     """Tiny SFNO + SobolevLoss: loss, input gradient and EVERY parameter gradient against the reference's autograd.
     Under autograd the spectral convolutions run _SpectralConvFn (HIP forward + HIP backward), the loss transform

@@ -399,6 +399,21 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, 
         constexpr int NV = 16 / (int)sizeof(T);
         for (int q = 0; q < count; ++q) {
             const b128* s4 = reinterpret_cast<const b128*>(ex + (size_t)q * P * Y);
+            if (accT < 0) {   // accb (slab, y) joins the LAST kept step only: the gradient of a skip input whose last time slice
+                              // alone was used (lifting operator, fno/sfno.py:258-259) meets the transform's here, compact
+                const T* rl = accb + (size_t)(base + q) * Y;
+                for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+                    union { b128 v; T e[NV]; } s_;
+                    s_.v = s4[i];
+#pragma unroll
+                    for (int u = 0; u < NV; ++u) {
+                        const int idx = i * NV + u, row = idx / t_keep;
+                        if (idx - row * t_keep == t_keep - 1) s_.e[u] += rl[row];
+                    }
+                    __builtin_nontemporal_store(s_.v, d4 + (size_t)q * n4 + i);
+                }
+                continue;
+            }
             const T* rb = accb + (size_t)(base + q) * Y * accT + (accT - 1);
             for (int i = threadIdx.x; i < n4; i += blockDim.x) {
                 union { b128 v; T e[NV]; } s_;
@@ -995,6 +1010,24 @@ extern "C" int tcfd_fno_inverse_trunc_residual(const tcfd_fno_plan* p, const voi
     if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
     return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st, nullptr,
                             (const float*)res, res_T);
+}
+// out = transform, plus last (batch * c, X, Y) at the LAST kept step only: the adjoint of "use the last time slice of the input"
+// joining the adjoint of the forward transform in its store loop (training: the lifting operator's skip, fno/sfno.py:258-259)
+extern "C" int tcfd_fno_inverse_trunc_last(const tcfd_fno_plan* p, const void* vh, void* out, const void* last, int batch, int c,
+                                           int t_keep, double inv_scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !vh || !out || !last || batch <= 0 || c <= 0 || t_keep <= 0 || t_keep > p->T_out)
+        return FAIL(TCFD_EINVAL, "fno_inverse_trunc_last: bad argument");
+    if (!ws || ws_bytes < tcfd_fno_workspace_bytes(p, batch, c, c)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (p->dtype == TCFD_C128) {
+        if ((rc = do_inv_x<double>(p, (const cx<double>*)vh, (cx<double>*)ws, (long)batch * c, st))) return rc;
+        return do_inv_ty<double>(p, (const cx<double>*)ws, (double*)out, (long)batch * c * p->X, t_keep, inv_scale, st, nullptr,
+                                 (const double*)last, -1);
+    }
+    if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
+    return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st, nullptr,
+                            (const float*)last, -1);
 }
 extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
                                       double inv_scale, void* ws, size_t ws_bytes, void* stream) {

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(1024) void k_inv_ty_dft(const cx<T>* __restrict__ w
     if (accb) {
         for (long i = threadIdx.x; i < total; i += blockDim.x) {
             const long row = i / t_keep;                     // (slab, y) row of the residual array
-            dst[i] = slab[i] + accb[(size_t)((size_t)base * Y + row) * accT + (accT - 1)];
+            if (accT > 0) dst[i] = slab[i] + accb[(size_t)((size_t)base * Y + row) * accT + (accT - 1)];
+            else dst[i] = slab[i] + ((i - row * t_keep) == t_keep - 1 ? accb[(size_t)base * Y + row] : (T)0);   // accT < 0: last step only
         }
     } else if (acc) {
         const T* a = acc + (size_t)base * slab_elems;

@@ -353,10 +353,12 @@ def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[
 
 
 def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward",
-                         scale: Optional[float] = None, accumulate: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         scale: Optional[float] = None, accumulate: Optional[torch.Tensor] = None,
+                         add_last: Optional[torch.Tensor] = None) -> torch.Tensor:
     """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep).
     ``accumulate``: a contiguous tensor of the output's shape that the result is ADDED to, in place, by the transform's own
-    store loop (``tcfd_fno_inverse_trunc_acc``) -- it is returned."""
+    store loop (``tcfd_fno_inverse_trunc_acc``) -- it is returned.  ``add_last``: (b, C, X, Y[, 1]) added to the LAST kept step
+    only, by the same store loop (``tcfd_fno_inverse_trunc_last``)."""
     X, Y, T, t_pad, t_out, mx, my, mt = plan.key
     b, c = vh.shape[:2]
     if tuple(vh.shape[2:]) != (2 * mx, 2 * my, mt) or not vh.is_complex():
@@ -372,6 +374,16 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
     ws = plan.workspace(b, c, c)
     _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     is_ = is_ if scale is None else float(scale)
+    if add_last is not None:
+        if accumulate is not None or add_last.numel() != b * c * X * Y or add_last.dtype != plan.real or add_last.device != vh.device:
+            raise ValueError("add_last must be a (b, C, X, Y) tensor of the output's precision and device, without accumulate")
+        last = add_last.detach().contiguous()
+        with torch.cuda.device(vh.device):
+            rc = plan.lib.tcfd_fno_inverse_trunc_last(plan.handle, vh.data_ptr(), out.data_ptr(), last.data_ptr(), b, c, t_keep, is_,
+                                                      ws.data_ptr(), ws.numel(),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
+        _lib.check(rc, "tcfd_fno_inverse_trunc_last")
+        return out
     with torch.cuda.device(vh.device):
         rc = plan.lib.tcfd_fno_inverse_trunc_acc(plan.handle, vh.data_ptr(), out.data_ptr(),
                                                  out.data_ptr() if accumulate is not None else None, b, c, t_keep, is_,
@@ -422,14 +434,15 @@ def _c2r_weights(mt: int, T: int, device, dtype: torch.dtype = torch.float32) ->
     return c
 
 
-def _fwd_trunc_vjp(z, cfg, accumulate=None):
-    """F^T(z) for the truncated forward transform F (cfg of ``_FwdTruncFn``); ``accumulate``: added to, in place."""
+def _fwd_trunc_vjp(z, cfg, accumulate=None, add_last=None):
+    """F^T(z) for the truncated forward transform F (cfg of ``_FwdTruncFn``); ``accumulate``: added to, in place; ``add_last``:
+    (b, c, X, Y[, 1]) added to the last time step only."""
     (b, c, X, Y, T), modes, t_pad, t_out, norm = cfg
     Tp = T + t_pad
     fs, _ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
     plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device, _real_of(z.dtype))       # its inverse reconstructs Tp steps
     zh = (z / _c2r_weights(modes[2], Tp, z.device, z.dtype)).contiguous()
-    return hip_truncated_irfftn(zh, plan, T, scale=fs, accumulate=accumulate)
+    return hip_truncated_irfftn(zh, plan, T, scale=fs, accumulate=accumulate, add_last=add_last)
 
 
 def _inv_trunc_vjp(dy, cfg):
@@ -619,7 +632,8 @@ def _sum_rows(mat: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return out
 
 
-def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta, need_dx: bool = True, out=None):
+def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta, need_dx: bool = True, out=None,
+                            compact_skip: bool = False):
     """Gradients of the fused block from ``tcfd_fno_pointwise_bwd`` (one pass; weight gradients accumulated on MFMA,
     per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm or a width
     that is not instantiated -- the caller then recomputes the
@@ -682,7 +696,10 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
         g_w1 = Bm[:cm, :ci].reshape(w1.shape)
         g_b1 = Bm[:cm, ci].contiguous() if b1 is not None else None
     if mode == 2:   # the skip's last time slice was broadcast over t: its gradient is the t-sum of dL/dz2
-        g_skip = torch.empty_like(skip, memory_format=torch.contiguous_format)
+        # (compact_skip: the sums alone, (b, co, X, Y, 1) -- the caller joins them to the last step of another gradient itself)
+        g_skip = (torch.empty(*skip.shape[:-1], 1, dtype=skip.dtype, device=dev) if compact_skip
+                  else torch.empty_like(skip, memory_format=torch.contiguous_format))
+        sT = 1 if compact_skip else sT
         with torch.cuda.device(dev):
             _lib.check(lib.tcfd_sum_t_into_last(ds.data_ptr(), g_skip.data_ptr(), ds.numel() // T, T, sT,
                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tcfd_sum_t_into_last")
@@ -857,14 +874,19 @@ class _SpectralLayerFn(torch.autograd.Function):
         conv_params, pw = params[:n_conv], params[n_conv:]
         need = ctx.needs_input_grad[5:]
         need_v = ctx.needs_input_grad[4]
-        hip = _hip_pointwise_backward(spec, dout, x1, v if spec[3] else None, *pw, None, None, out=y)
+        # the lifting tail (skip = last time slice of v): its t-summed gradient stays compact and joins the last step of the
+        # transform's adjoint in that transform's store loop -- no zero-filled (b, C, X, Y, T) tensor written and read back
+        compact = spec[3] == 2 and need_v and os.environ.get("TCFD_COMPACT_SKIP_GRAD", "1") != "0"
+        hip = _hip_pointwise_backward(spec, dout, x1, v if spec[3] else None, *pw, None, None, out=y, compact_skip=compact)
         if hip is None:
             raise _lib.TcfdError("pointwise backward kernel not available for a layer that was admitted to the fused path")
         dx1, g_skip = hip[0], hip[1]
         gh = _inv_trunc_vjp(dx1, inv_cfg)
         gv, cgrads = _contract_vjp(gh, vh, conv_params, ccfg, need_v, list(need[:n_conv]) + [False] * 8)
         dv = None
-        if need_v:
+        if need_v and compact:
+            dv = _fwd_trunc_vjp(gv, fwd_cfg, add_last=g_skip)
+        elif need_v:
             acc = g_skip if (g_skip is not None and g_skip.is_contiguous() and g_skip.shape == v.shape) else None
             dv = _fwd_trunc_vjp(gv, fwd_cfg, accumulate=acc)
             if acc is None and g_skip is not None:
