@@ -1700,7 +1700,8 @@ class LiftingOperator(nn.Module):
                 th, _ = hip_truncated_rfftn(fields, modes, t_pad=t_pad, t_out=t_out, norm=norm)
                 q_last = qf.view(C, X * Y, T)[..., -1].contiguous()
             cached = (key, th.reshape(C + 1, -1).contiguous(), q_last)
-            self._table_modes = cached if fixed_table else None
+            # (not kept when formed inside a stream capture: its memory then belongs to the graph's private pool)
+            self._table_modes = cached if (fixed_table and not torch.cuda.is_current_stream_capturing()) else None
         _, table, q_last = cached
         vh, plan = hip_truncated_rfftn(vin, modes, t_pad=t_pad, t_out=t_out, norm=norm)
         K = vh[0, 0].numel()
