@@ -1043,6 +1043,25 @@ def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(m
         assert torch.isfinite(a2).all() and rel_l2(a2, b) < 2e-6 and rel_l2(a1, b) < 2e-6
 
 
+@pytest.mark.parametrize("chunk_mb", ["0.5", "1", "2.5"])
+def test_chunked_inference_layers_are_bit_identical(chunk_mb, dev, monkeypatch):
+    """SFNO inference with the inverse transform + pointwise block of every layer run a few samples at a time through one reused
+    buffer (hip_layer_tail_chunked: the convolution output then stays in the Infinity Cache) against the whole-batch calls:
+    the same kernels on the same per-sample data -- bit-identical, ragged last chunk included."""
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(4)
+    model = fno.SFNO(8, 8, 3, width=10, num_spectral_layers=3, latent_steps=10).to(dev).eval()
+    x = torch.randn(5, 32, 32, 10, device=dev)          # 410 KB of convolution output per sample: chunks of 1, 2 and 5 + ragged ends
+    with torch.no_grad():
+        monkeypatch.setenv("TCFD_FNO_CHUNK_MB", "0")
+        ref = model(x)
+        monkeypatch.setenv("TCFD_FNO_CHUNK_MB", chunk_mb)
+        assert fno._cache_chunk(5, 10 * 32 * 32 * 10 * 4) == {"0.5": 1, "1": 2, "2.5": 5}[chunk_mb]
+        out = model(x)
+    assert torch.isfinite(out).all() and torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("random_feats", [False, True])
 @pytest.mark.parametrize("shape,modes,width", [((2, 16, 16, 10), (4, 4, 3), 4), ((3, 32, 64, 10), (8, 8, 5), 10), ((2, 96, 96, 6), (8, 8, 3), 8)])
 def test_lifting_operator_through_the_spectrum_equals_the_materialised_projection(shape, modes, width, random_feats, dev, monkeypatch):

@@ -354,7 +354,7 @@ def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[
 
 def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward",
                          scale: Optional[float] = None, accumulate: Optional[torch.Tensor] = None,
-                         add_last: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         add_last: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep).
     ``accumulate``: a contiguous tensor of the output's shape that the result is ADDED to, in place, by the transform's own
     store loop (``tcfd_fno_inverse_trunc_acc``) -- it is returned.  ``add_last``: (b, C, X, Y[, 1]) added to the LAST kept step
@@ -369,6 +369,9 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
                 or not accumulate.is_contiguous()):
             raise ValueError("accumulate must be a contiguous tensor of the output's shape, precision and device")
         out = accumulate
+    elif out is not None:       # a caller-owned buffer (the chunked inference layers reuse one: it then stays in the Infinity Cache)
+        if tuple(out.shape) != (b, c, X, Y, t_keep) or out.dtype != plan.real or out.device != vh.device or not out.is_contiguous():
+            raise ValueError("out must be a contiguous tensor of the output's shape, precision and device")
     else:
         out = torch.empty(b, c, X, Y, t_keep, dtype=plan.real, device=vh.device)
     ws = plan.workspace(b, c, c)
@@ -896,6 +899,71 @@ class _SpectralLayerFn(torch.autograd.Function):
         return (None, None, None, None, dv, *cgrads, *pgrads)
 
 
+def _cache_chunk(batch: int, per_sample_bytes: int) -> int:
+    """Samples per chunk of the chunked inference layers: the convolution output of a chunk (the tensor the inverse transform
+    writes and the pointwise block reads straight back) is to stay inside the 256 MB Infinity Cache beside what streams past
+    it.  ``TCFD_FNO_CHUNK_MB`` is its size; 0 (the default) turns chunking off -- MEASURED SLOWER at config 5: forward 4.48 ms
+    whole batch, 4.90 / 5.42 / 8.08 ms at 160 / 96 / 48 MB.  Under the profiler the chunk launches are slower than their share
+    of the whole-batch launch (k_pointwise 55 us for 3 of 32 samples against 43, k_inv_ty2 26 against 22): a launch of 3 samples
+    is ~100 workgroups per XCD-round short of filling the chip for long, and nothing shows the Infinity Cache serving x1 any
+    faster than HBM serves it to kernels that are at 0.8 of their vector-issue bound anyway.  Kept as an opt-in experiment."""
+    mb = float(os.environ.get("TCFD_FNO_CHUNK_MB", "0"))
+    if mb <= 0 or per_sample_bytes <= 0:
+        return batch
+    return max(1, min(batch, int(mb * 2 ** 20 // per_sample_bytes)))
+
+
+def hip_layer_tail_chunked(oh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm, lin1, act1, lin2, skip, skip_conv=None,
+                           act2=None, skip_last_slice: bool = False) -> Optional[torch.Tensor]:
+    """Inverse transform + pointwise block of an inference layer, a few samples at a time.
+
+    Samples are independent in every kernel of the layer, and the convolution output x1 = irfftn(oh) is written by one kernel
+    only to be read back by the next: 839 MB out to HBM and in again per layer at config 5 -- 2 of the layer's 5 passes over the
+    activations.  Run chunk by chunk through ONE reused chunk-sized buffer, x1 never leaves the memory-side cache (the
+    solver's batch chunking of DESIGN section 4, applied to the FNO layer).  Same kernels on the same per-sample data:
+    bit-identical to the whole-batch calls.  None when the pointwise block is not covered (the caller composes the layer)."""
+    X, Y, T, t_pad, t_out, mx, my, mt = plan.key[:8]
+    b, co = oh.shape[:2]
+    real = plan.real
+    bc = _cache_chunk(b, co * X * Y * t_keep * (8 if real == torch.float64 else 4))
+    out = torch.empty(b, lin2.out_channels, X, Y, t_keep, dtype=real, device=oh.device)
+    x1 = torch.empty(min(bc, b), co, X, Y, t_keep, dtype=real, device=oh.device)
+    for s0 in range(0, b, bc):
+        s1 = min(b, s0 + bc)
+        xc = hip_truncated_irfftn(oh[s0:s1], plan, t_keep, norm=norm, out=x1[: s1 - s0])
+        r = hip_pointwise(xc, lin1, act1, lin2, skip=skip[s0:s1], skip_conv=skip_conv, act2=act2,
+                          skip_last_slice=skip_last_slice, out=out[s0:s1])
+        if r is None:
+            return None
+    return out
+
+
+def hip_inference_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None) -> Optional[torch.Tensor]:
+    """``act2(FFN(conv(v)) + skip_conv(v))`` (fno/sfno.py:607-614) without gradients: forward transform and contraction on the
+    whole batch, inverse transform + pointwise block chunk by chunk (``hip_layer_tail_chunked``).  None when not covered."""
+    if (torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for m in (conv, lin1, lin2, skip_conv) if m is not None
+                                                              for p in m.parameters()))):
+        return None
+    if (not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5 or v.shape[0] == 0 or not _fused_xy(v.shape[2], v.shape[3])
+            or not hasattr(conv, "_plain_args") or float(os.environ.get("TCFD_FNO_CHUNK_MB", "0")) <= 0):
+        return None
+    cls = type(conv)
+    if cls.forward not in (SpectralConvS.forward, SpectralConvT.forward) or cls.spectral_conv is not SpectralConvS.spectral_conv \
+            or cls._plain_args not in (SpectralConvS._plain_args, SpectralConvT._plain_args) \
+            or any(p.dtype != torch.float32 for p in conv.parameters()):
+        return None
+    cargs = conv._plain_args(v, None)
+    if cargs is None:
+        return None
+    weights, bias, delta, modes, t_pad, t_out, t_keep, norm = cargs
+    b = v.shape[0]
+    if _cache_chunk(b, weights[0].shape[1] * v.shape[2] * v.shape[3] * t_keep * 4) >= b:
+        return None          # one chunk: the plain calls
+    vh, plan = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
+    oh = hip_contract(vh, weights, bias, delta, modes)
+    return hip_layer_tail_chunked(oh, plan, t_keep, norm, lin1, act1, lin2, v, skip_conv=skip_conv, act2=act2)
+
+
 def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, skip_last_slice: bool = False,
                        out_steps: Optional[int] = None) -> Optional[torch.Tensor]:
     """Training form of one SFNO layer, ``act2(FFN(conv(v)) + skip_conv(v))`` (fno/sfno.py:607-614) or of the lifting tail
@@ -965,7 +1033,8 @@ def _is_pointwise(conv) -> bool:
 
 
 def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, act2=None,
-                  skip_last_slice: bool = False, norm: Optional[nn.GroupNorm] = None) -> Optional[torch.Tensor]:
+                  skip_last_slice: bool = False, norm: Optional[nn.GroupNorm] = None,
+                  out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """out = act2( lin2(act1(lin1(x))) [+ skip_conv(skip) | + skip[..., -1:]] ) in ONE fused HIP kernel
     (``tcfd_fno_pointwise``); ``lin1=None`` makes it a single 1x1x1 convolution.  Returns ``None`` when the
     combination is not covered (channel counts, activation type, dtype, autograd) -- the caller then runs its
@@ -1017,7 +1086,11 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
             return None
         mode, s_t, sT = 2, skip.contiguous(), skip.shape[-1]
     x = x.contiguous()
-    out = torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=x.device)
+    elif (tuple(out.shape) != (b, co) + tuple(x.shape[2:]) or out.dtype != torch.float32 or out.device != x.device
+          or not out.is_contiguous() or (torch.is_grad_enabled() and out.requires_grad)):
+        raise ValueError("out must be a contiguous float32 tensor of the block's output shape on x's device (forward only)")
 
     def mat(conv, transpose):
         w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
@@ -1720,6 +1793,10 @@ class LiftingOperator(nn.Module):
             return None
         _lib.check(rc, "tcfd_fno_pointwise")
         oh = hip_contract(v0h, weights, bias, delta, modes)
+        lin = (self.mlp.linear1, self.mlp.activation, self.mlp.linear2) if isinstance(self.mlp, PointwiseFFN) else (None, None, self.mlp)
+        out = hip_layer_tail_chunked(oh, plan, t_keep, norm, *lin, skip, act2=self.activation, skip_last_slice=True)
+        if out is not None:
+            return out
         x1 = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
         if isinstance(self.mlp, PointwiseFFN):
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=skip, act2=self.activation,
@@ -1905,6 +1982,10 @@ class SFNO(FNOBase):
                 continue
             fused = hip_spectral_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
             if fused is not None:       # training: the whole layer as one autograd node
+                v = fused
+                continue
+            fused = hip_inference_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
+            if fused is not None:       # inference: the convolution output stays in the Infinity Cache, chunk by chunk
                 v = fused
                 continue
             x1 = conv(v)
