@@ -16,7 +16,13 @@ for act in os.environ.get("ACTS", "ReLU,GELU").split(","):
     spec = (True, getattr(nn, act)(), getattr(nn, act)(), 1, None)
     for flag in sys.argv[1:] or ["5", "2", "4"]:
         os.environ["TCFD_PW_BWD"] = flag
-        run = lambda: fno._hip_pointwise_backward(spec, dout, x, s, lin1.weight, lin1.bias, lin2.weight, lin2.bias, skc.weight, skc.bias, None, None)
+        # WITH_OUT=1 (default): the block's forward output is handed over, as the autograd nodes do (ReLU: the 71-product kernel)
+        y = None
+        if os.environ.get("WITH_OUT", "1") == "1":
+            with torch.no_grad():
+                y = fno.hip_pointwise(x, lin1, spec[1], lin2, skip=s, skip_conv=skc, act2=spec[2])
+        run = lambda: fno._hip_pointwise_backward(spec, dout, x, s, lin1.weight, lin1.bias, lin2.weight, lin2.bias, skc.weight, skc.bias,
+                                                  None, None, out=y)
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
