@@ -1318,6 +1318,15 @@ __device__ __forceinline__ void pw_skip_conv(const PwArgs& a, const vf (&sv)[CI]
 
 // ACT >= 0: both activations are that code at compile time (the reference's ReLU / ReLU and GELU / GELU layers): the
 // run-time switch inside the hidden-unit loop costs ~25 scalar instructions and several taken branches per unit.
+// activations are read once and outlive every cache: TCFD_PW_NT_LOADS=1 at build time marks the reads non-temporal as well
+#ifndef TCFD_PW_NT_LOADS
+#define TCFD_PW_NT_LOADS 1
+#endif
+#if TCFD_PW_NT_LOADS
+#define PW_LOAD(p_) __builtin_nontemporal_load(p_)
+#else
+#define PW_LOAD(p_) (*(p_))
+#endif
 template <int CI, int CM, int CO, bool HAS_L1, int V, int ACT = -1>
 __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     typedef typename PwVec<V>::type vf;
@@ -1333,14 +1342,14 @@ __global__ __launch_bounds__(256) void k_pointwise(PwArgs a) {
     } else {
         const float* xb = a.x + (size_t)b * CI * a.P + p;
 #pragma unroll
-        for (int i = 0; i < CI; ++i) x[i] = *reinterpret_cast<const vf*>(xb + (size_t)i * a.P);
+        for (int i = 0; i < CI; ++i) x[i] = PW_LOAD(reinterpret_cast<const vf*>(xb + (size_t)i * a.P));
     }
     pw_core<CI, CM, CO, HAS_L1, vf, ACT>(a, b, x, o);
     if (a.skip_mode == 1) {
         const float* sb = a.s + (size_t)b * CI * a.P + p;
         vf sv[CI];
 #pragma unroll
-        for (int i = 0; i < CI; ++i) sv[i] = *reinterpret_cast<const vf*>(sb + (size_t)i * a.P);
+        for (int i = 0; i < CI; ++i) sv[i] = PW_LOAD(reinterpret_cast<const vf*>(sb + (size_t)i * a.P));
         pw_skip_conv<CI, CO, vf>(a, sv, o);
     } else if (a.skip_mode == 2) {
         const long xy = p / a.T;   // V = 2 needs an even T: both points of a lane share (x, y)
