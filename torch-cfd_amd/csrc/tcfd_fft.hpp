@@ -277,6 +277,14 @@ __device__ __forceinline__ void store_stream(cx<T>* p, cx<T> v) {
     __builtin_nontemporal_store(w, reinterpret_cast<vec2*>(p));
 }
 
+// load with the same hint: data that is read exactly once by this launch
+template <typename T>
+__device__ __forceinline__ cx<T> load_stream(const cx<T>* p) {
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const vec2 w = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+    return mk<T>(w.x, w.y);
+}
+
 // called once by tile_fft after the FIRST exchange barrier of a transform (every lane of the group has then
 // consumed whatever the input registers were built from); default: nothing
 struct NoHook {

@@ -69,6 +69,15 @@ extern "C" int tcfd_version(void) { return TCFD_ABI_VERSION; }
 // ------------------------------------------------------------------ per-size configuration
 // COL_EPT / ROW_EPT = elements per lane of one transform in the column / row kernels,
 // COLS = columns per tile of the column kernels, ROW_THREADS = workgroup size of the row kernels.
+// TCFD_NT_COL_IN=1 (build time): the advection a column pass transforms is read exactly once and dead afterwards
+#ifndef TCFD_NT_COL_IN
+#define TCFD_NT_COL_IN 0
+#endif
+#if TCFD_NT_COL_IN
+#define TCFD_COL_LD(p_) load_stream(p_)
+#else
+#define TCFD_COL_LD(p_) (*(p_))
+#endif
 template <typename T, int N> struct Cfg;
 #define TCFD_CFG(T, N, CEPT_, COLS_, REPT_, RTHR_)                                     \
     template <> struct Cfg<T, N> {                                                     \
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
         const int jin = XLF ? xl_col_row(j) : j;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            x[t] = col_live ? a.in[inbase + (wq + (size_t)(jin + t * G)) * in_ld] : mk<T>((T)0, (T)0);
+            x[t] = col_live ? TCFD_COL_LD(a.in + inbase + (wq + (size_t)(jin + t * G)) * in_ld) : mk<T>((T)0, (T)0);
         stage_tables();
         if (!(a.ablate & 1) && tile_live) col_fft<T, NT, EPT, DIR, C, XLF ? 1 : 0, XL>(x, lds, a.tw, ctw, j, c);
         if constexpr (NEEDS_TABLES) __syncthreads();  // row tables visible (a one-pass transform has no barrier)
@@ -702,14 +711,23 @@ struct RawPair {
 
 // nyq (packed Nyquist column, see emit_planes): column N/2 of the planes is not there; the Nyquist element of a row
 // is the imaginary part of its element 0 and comes out of pack_herm
+// TCFD_NT_ROW_LOADS=1 (build time): the planes a row pass reads are read exactly once by that launch -- non-temporal loads
+#ifndef TCFD_NT_ROW_LOADS
+#define TCFD_NT_ROW_LOADS 0
+#endif
+#if TCFD_NT_ROW_LOADS
+#define TCFD_ROW_LD(p_) load_stream(p_)
+#else
+#define TCFD_ROW_LD(p_) (*(p_))
+#endif
 template <typename T, int N, int EPT, int NYQ = 0>
 __device__ __forceinline__ void load_raw(RawPair<T, EPT>& r, const cx<T>* __restrict__ rowA,
                                          const cx<T>* __restrict__ rowB, int j) {
     constexpr int G = N / EPT;
 #pragma unroll
     for (int t = 0; t < EPT / 2; ++t) {
-        r.a[t] = rowA[j + t * G];
-        r.b[t] = rowB[j + t * G];
+        r.a[t] = TCFD_ROW_LD(rowA + j + t * G);
+        r.b[t] = TCFD_ROW_LD(rowB + j + t * G);
     }
     if constexpr (!NYQ) {
         r.an = rowA[N / 2];
