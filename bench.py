@@ -373,7 +373,7 @@ def sfno_config5(dev, with_cpu=True):
                                "VALU issue with the ReLUs and address arithmetic), beside 0.31 ms of HBM time at 8 TB/s.  Until round 4 the "
                                "run-time activation switch inside the hidden-unit loop added 1,224 scalar instructions and ~10 taken "
                                "branches per wave (SQ_INSTS_SALU ~ SQ_INSTS_VALU in profiles/r04_sfno_pmc.txt): 571 us; with the "
-                               "activations as template parameters 475 us",
+                               "activations as template parameters 475 us; with the two inputs read non-temporally (late round 4) 444 us",
                 "kernels_from_profile": kern_table or None,
                 "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
                                     "algo_bytes_per_launch": (6 if keeps else 5) * A_H, "avg_launch_ms": round(t_bwd, 4),
