@@ -2455,6 +2455,17 @@ __device__ __forceinline__ float pw_relu(float z) {      // max(0, z) on the bit
 // mask), dh = W2^T g2 and g1 = dh (.) mask, 9 + 9 MFMAs -- exists only to feed dx^T = g1^T W1 with an A operand; g1 in that
 // orientation is the TRANSPOSE of the OT tile g1^T the weight gradient needs anyway, and a transposition is one product with
 // the identity per k-step (12).  71 instead of 80 MFMAs per 16 points, and the O1 compares / selects go too.
+// TCFD_PWB_NT=1 (build time): the kernel's tensors as streaming data -- buffer loads with the nt bit (aux 2), non-temporal stores
+#ifndef TCFD_PWB_NT
+#define TCFD_PWB_NT 0
+#endif
+#if TCFD_PWB_NT
+#define PWB_AUX 2
+#define PWB_STORE(p_, v_) __builtin_nontemporal_store((v_), (p_))
+#else
+#define PWB_AUX 0
+#define PWB_STORE(p_, v_) (*(p_) = (v_))
+#endif
 template <int CI, int CM, int CO, int MODE, int ACT = -1, int YMASK = 0>
 __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
     static_assert(!YMASK || ACT == 1, "the output mask stands in for z2 only under ReLU");
@@ -2569,21 +2580,21 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         const float one_b = live_b ? cb_one : 0.f;
 #pragma unroll
         for (int j = 0; j < KI; ++j)
-            in.xa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, 0)) + ka_one[j];
+            in.xa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, PWB_AUX)) + ka_one[j];
         {
-            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, 0);
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, PWB_AUX);
             in.xb = f4{__uint_as_float(v.x) + one_b, __uint_as_float(v.y) + one_b, __uint_as_float(v.z) + one_b, __uint_as_float(v.w) + one_b};
         }
         if constexpr (MODE == 1) {
             if constexpr (!YMASK) {      // (the O1 copy of the skip input feeds the z2 chain only)
 #pragma unroll
                 for (int j = 0; j < KI; ++j)
-                    in.sa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, 0)) + ka_one[j];
+                    in.sa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ka_off[j] == OOB || oa == OOB) ? OOB : ka_off[j] + oa, 0, PWB_AUX)) + ka_one[j];
             } else {
 #pragma unroll
                 for (int j = 0; j < KI; ++j) in.sa[j] = 0.f;
             }
-            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, 0);
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (cb_off == OOB || ob == OOB) ? OOB : cb_off + ob, 0, PWB_AUX);
             in.sb = f4{__uint_as_float(v.x) + one_b, __uint_as_float(v.y) + one_b, __uint_as_float(v.z) + one_b, __uint_as_float(v.w) + one_b};
         } else {
 #pragma unroll
@@ -2592,24 +2603,24 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
         }
         if constexpr (YMASK == 2) {
             const unsigned cbo = (c < CO && live_b) ? (unsigned)c * P4 + base_o + pb * 4u : OOB;
-            const u4 vd = __builtin_amdgcn_raw_buffer_load_b128(rd, cbo, 0, 0), vy = __builtin_amdgcn_raw_buffer_load_b128(ry, cbo, 0, 0);
+            const u4 vd = __builtin_amdgcn_raw_buffer_load_b128(rd, cbo, 0, PWB_AUX), vy = __builtin_amdgcn_raw_buffer_load_b128(ry, cbo, 0, PWB_AUX);
             in.dzb = f4{__uint_as_float(vd.x), __uint_as_float(vd.y), __uint_as_float(vd.z), __uint_as_float(vd.w)};
             in.yob = f4{__uint_as_float(vy.x), __uint_as_float(vy.y), __uint_as_float(vy.z), __uint_as_float(vy.w)};
         }
         const unsigned od = live_a ? base_o + pa * 4u : OOB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            in.dz[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, 0));
+            in.dz[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, PWB_AUX));
             in.sl[r] = 0.f;
             if constexpr (YMASK)
-                in.yo[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, 0));
+                in.yo[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (co_off[r] == OOB || od == OOB) ? OOB : co_off[r] + od, 0, PWB_AUX));
         }
         if constexpr (MODE == 2 && !YMASK) {
             const unsigned pc = live_a ? pa : (unsigned)a.P - 1u;
             const unsigned os = (unsigned)b * CO * sP4 + ((pc / (unsigned)a.T) * (unsigned)a.sT + (unsigned)(a.sT - 1)) * 4u;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                in.sl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cs_off[r] != OOB ? cs_off[r] + os : OOB, 0, 0));
+                in.sl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cs_off[r] != OOB ? cs_off[r] + os : OOB, 0, PWB_AUX));
         }
     };
 #define PW_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
@@ -2739,10 +2750,10 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
                     f4 dsT = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < RO; ++r) dsT = PW_MFMA(z2[r], Wsb[r], dsT);
-                    if (c < CI && live_b) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + c) * a.P + pb) = dsT;
+                    if (c < CI && live_b) PWB_STORE(reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + c) * a.P + pb), dsT);
                 }
             } else if constexpr (MODE == 2) {
-                if (a.ds && c < CO && live_b) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CO + c) * a.P + pb) = g2T;
+                if (a.ds && c < CO && live_b) PWB_STORE(reinterpret_cast<f4*>(a.ds + ((size_t)b * CO + c) * a.P + pb), g2T);
             }
             // ---- weight gradients: contractions over the 16 points, OT tiles on both sides
 #pragma unroll
@@ -2756,7 +2767,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_bwd_mfma(PwBwdArgs a) {
                                        cur.xb[r], accW1[t]);
                 }
             if (a.dx && c < CI && live_b)
-                *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + c) * a.P + pb) = dxT;
+                PWB_STORE(reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + c) * a.P + pb), dxT);
         }
         cur = nxt;
     }
