@@ -279,6 +279,108 @@ def cpu_baseline_sfno(budget_s):
                       f"samples/s unchanged), {reps} call(s) at {per * 1e3:.0f} ms with {threads} threads"}
 
 
+FNO_KINDS = {0: "fwd_ty", 1: "fwd_x", 2: "contract", 3: "inv_x", 4: "inv_ty", 5: "pointwise", 6: "pointwise_bwd", 7: "pointwise_1layer",
+             8: "contract_wgrad", 9: "other"}
+
+
+def fno_kernel_times(fn, dev, reps=3, cap=4096):
+    """Per-kernel-kind launch durations of the FNO library while `fn` runs `reps` times: HIP events recorded by the library
+    around every launch on its launch stream (tcfd_fno_profile_begin / _end) -- i.e. the kernels as they run INSIDE the model,
+    behind each other's cache state, which is what a rocprofv3 kernel trace of the same command sees.
+    Returns {kind: {"launches": per call of fn, "avg_ms": ..., "total_ms": per call}}."""
+    import ctypes
+
+    from torch_cfd_amd import _lib
+    lib = _lib.load()
+    fn(); torch.cuda.synchronize(dev)
+    _lib.check(lib.tcfd_fno_profile_begin(cap), "tcfd_fno_profile_begin")
+    try:
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+    finally:
+        count = ctypes.c_int(0)
+        kinds = (ctypes.c_int * cap)()
+        ms = (ctypes.c_float * cap)()
+        _lib.check(lib.tcfd_fno_profile_end(cap, ctypes.byref(count), kinds, ms), "tcfd_fno_profile_end")
+    out = {}
+    for i in range(min(count.value, cap)):
+        d = out.setdefault(FNO_KINDS.get(kinds[i], str(kinds[i])), {"n": 0, "t": 0.0, "max": 0.0})
+        d["n"] += 1; d["t"] += ms[i]; d["max"] = max(d["max"], ms[i])
+    return {k: {"launches": d["n"] // reps, "avg_ms": round(d["t"] / d["n"], 4), "max_ms": round(d["max"], 4),
+                "total_ms": round(d["t"] / reps, 4)} for k, d in out.items()}
+
+
+def sfno_width_line(dev, width, b=32, act="ReLU", steps=3):
+    """One line per model width ("additionally report width 32"; 16 / 20 are the reference's other widths,
+    fno/sfno_pytest.py:261 and its notebooks): SFNO(24,24,5,width) on (b,256,256,10) -- forward, forward + loss, one training step
+    (median), on the 21.5 A_H byte model of the width-10 line, and the in-model duration of the pointwise backward kernel."""
+    from torch_cfd_amd import fno
+
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = fno.SFNO(24, 24, 5, width=width, num_spectral_layers=4, activation=act).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(b, 256, 256, 10, generator=g).to(dev)
+    y = torch.randn(b, 256, 256, 10, generator=g).to(dev)
+    loss_fn = fno.SobolevLoss(n_grid=256, norm_order=0, relative=True).to(dev)
+
+    def timeit(fn, n):
+        fn(); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    with torch.no_grad():
+        t_fwd = timeit(lambda: model(x), 5)
+        t_all = timeit(lambda: loss_fn(model(x), y), 5)
+    model.train()
+
+    def train_step():
+        model.zero_grad(set_to_none=True)
+        loss_fn(model(x), y).backward()
+
+    train_step(); torch.cuda.synchronize(dev)
+    per = []
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); train_step(); e1.record(); torch.cuda.synchronize(dev)
+        per.append(e0.elapsed_time(e1))
+    t_train = sorted(per)[len(per) // 2]
+    kt = fno_kernel_times(train_step, dev, reps=2)
+    fell_back = []
+    saved = fno._pointwise_reference
+
+    def spy(*a, **k):
+        fell_back.append(1)
+        return saved(*a, **k)
+    fno._pointwise_reference = spy
+    try:
+        train_step(); torch.cuda.synchronize(dev)
+    finally:
+        fno._pointwise_reference = saved
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9
+    A_H = b * width * 256 * 256 * 10 * 4
+    algo_gb = 21.5 * A_H / 1e9
+    # MACs per point of the forward's pointwise blocks (4 hidden-layer blocks incl. the lifting tail): W1 + W2 (+ Ws)
+    pw_flop = 2.0 * b * 256 * 256 * 10 * (4 * 2 * 4 * width * width + 3 * width * width)
+    del model, x, y
+    torch.cuda.empty_cache()
+    return {"workload": f"SFNO(24,24,5,width={width},layers=4,{act}) on x ({b},256,256,10) fp32, synthetic",
+            "forward_ms": round(t_fwd, 3), "forward_plus_loss_ms": round(t_all, 3), "train_step_ms": round(t_train, 2),
+            "algo_GB": round(algo_gb, 2), "algo_GBps": round(algo_gb / (t_all * 1e-3), 1),
+            "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4),
+            "pointwise_fp32_TFLOPs_in_forward": round(pw_flop / (t_fwd * 1e-3) / 1e12, 1),
+            "also_compute_bound": f"the forward's pointwise blocks alone are {pw_flop / 1e12:.3f} TFLOP = "
+                                  f"{pw_flop / 157.3e12 * 1e3:.2f} ms at the 157.3 TFLOP/s fp32 peak (vector = matrix rate on gfx950)",
+            "train_step_ms_per_GB": round(t_train / algo_gb, 3), "einsum_recompute_fallbacks_in_a_training_step": len(fell_back),
+            "train_kernels": {k: v for k, v in kt.items() if k in ("pointwise_bwd", "pointwise", "inv_ty", "fwd_ty")},
+            "peak_memory_GB": round(peak_gb, 1)}
+
+
 def sfno_config5(dev, with_cpu=True):
     """Secondary measurement (BASELINE configs[4], SURVEY 8d "C5"): SFNO(24,24,5, width 10, 4 layers) forward +
     SobolevLoss on x = randn(32,256,256,10) fp32, random-init weights (seed 0); plus one training step
@@ -309,7 +411,22 @@ def sfno_config5(dev, with_cpu=True):
         # default, which BASELINE configs[4] is quoted on, is ReLU): exact GELU as a packed branch-free 2^-s(|v|) evaluation
         gelu_model = fno.SFNO(24, 24, 5, width=10, num_spectral_layers=4, activation="GELU").to(dev).eval()
         t_gelu = timeit(lambda: gelu_model(x), 10)
-        del gelu_model
+    # ... and its training step (GELU keeps the block's pre-activation for the backward: tcfd_fno_pointwise_pre)
+    gelu_model.train()
+
+    def gelu_train_step():
+        gelu_model.zero_grad(set_to_none=True)
+        loss_fn(gelu_model(x), y).backward()
+    gelu_train_step(); gelu_train_step(); torch.cuda.synchronize(dev)
+    gper = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); gelu_train_step(); e1.record(); torch.cuda.synchronize(dev)
+        gper.append(e0.elapsed_time(e1))
+    t_train_gelu = sorted(gper)[1]
+    gelu_kernels = fno_kernel_times(gelu_train_step, dev, reps=2)
+    del gelu_model
+    torch.cuda.empty_cache()
     model.train()
 
     def train_step():
@@ -325,6 +442,11 @@ def sfno_config5(dev, with_cpu=True):
         e0.record(); train_step(); e1.record(); torch.cuda.synchronize(dev)
         per_step.append(e0.elapsed_time(e1))
     t_train = sorted(per_step)[len(per_step) // 2]
+    train_kernels = fno_kernel_times(train_step, dev, reps=2)
+    model.eval()
+    with torch.no_grad():
+        fwd_kernels = fno_kernel_times(lambda: model(x), dev, reps=3)
+    model.train()
     algo_gb = 21.5 * 32 * 10 * 256 * 256 * 10 * 4 / 1e9
     # roofline of the dominant kernel of the forward (k_pointwise<10,40,10>: FFN + skip conv + activation of a hidden layer
     # in one pass, 4 launches = 2.3 of the 5.4 ms): it reads the spectral-conv output and the layer input and writes the
@@ -343,7 +465,7 @@ def sfno_config5(dev, with_cpu=True):
             # mask, tcfd_fno_pointwise_bwd_out), writes dx, dskip = 6 A_H
             spec = (True, mlp.activation, act, 1, None)
             y_blk = blk()
-            keeps = fno._keeps_output(spec)          # ReLU / ReLU (the reference's default): the 71-product kernel
+            keeps = fno._saved_kind(spec, 10, 40, 10, 256 * 256 * 10) == 1    # ReLU / ReLU (the reference's default): the 71-product kernel
             bwd = lambda: fno._hip_pointwise_backward(spec, x1, v, v, mlp.linear1.weight, mlp.linear1.bias, mlp.linear2.weight,
                                                       mlp.linear2.bias, w.weight, w.bias, None, None, out=y_blk if keeps else None)
             t_bwd = timeit(bwd, 10)
@@ -351,6 +473,17 @@ def sfno_config5(dev, with_cpu=True):
             n_mfma = 71 if keeps else 93
             useful_mac = 2300 if keeps else 2760
         del x1, v
+        # `roofline` prices the kernel AS IT RUNS INSIDE model(x) (library events around each launch, fno_kernel_times): that is
+        # what profiles/r05_sfno_forward_kernel_stats.csv shows.  The isolated loop on fresh randn tensors above reads slower
+        # (every launch finds its two 839 MB inputs cold in every cache; in the model the skip input was written one kernel
+        # earlier and part of it is still in the 256 MB Infinity Cache) and is reported beside it as `isolated_launch_ms`.
+        pw_in_model = fwd_kernels.get("pointwise", {})
+        t_iso, t_bwd_iso = t_blk, t_bwd
+        if pw_in_model.get("launches") == 4:
+            t_blk = pw_in_model["avg_ms"]
+        bwd_in_model = train_kernels.get("pointwise_bwd", {})
+        if bwd_in_model.get("launches") == 4:
+            t_bwd = bwd_in_model["avg_ms"]
         ach = 3 * A_H / (t_blk * 1e-3) / 1e9
         # L2 <-> memory bytes per launch from the rocprofv3 PMC passes of tests/prof_sfno.sh (profiles/sfno_traffic.json ships with
         # the repo, it is not re-measured by this run): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the guide's gfx950 correction
@@ -365,6 +498,8 @@ def sfno_config5(dev, with_cpu=True):
         roof = {"kernel": "k_pointwise<10,40,10> (FFN + skip conv + activation of one hidden layer)", "bound": "hbm",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "algo_bytes_per_launch": 3 * A_H, "avg_launch_ms": round(t_blk, 4), "launches_per_forward": 4,
+                "timed": "HIP events recorded by the library around each launch inside model(x) (tcfd_fno_profile_begin/_end), 3 forwards",
+                "isolated_launch_ms": round(t_iso, 4), "kernels_in_model": fwd_kernels,
                 "traffic": tj.get(pw_key, {}).get("traffic_bytes") if pw_key else None,
                 "traffic_source": ("profiles/sfno_traffic.json (rocprofv3 --pmc passes of tests/bench_sfno.py, tests/prof_sfno.sh): "
                                    "bytes between L2 and the memory side per launch; the 839 MB activations exceed the Infinity Cache"
@@ -377,6 +512,8 @@ def sfno_config5(dev, with_cpu=True):
                 "kernels_from_profile": kern_table or None,
                 "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
                                     "algo_bytes_per_launch": (6 if keeps else 5) * A_H, "avg_launch_ms": round(t_bwd, 4),
+                                    "timed": "library events around each launch inside the training step, 2 steps",
+                                    "isolated_launch_ms": round(t_bwd_iso, 4), "kernels_in_training_step": train_kernels,
                                     "achieved": round((6 if keeps else 5) * A_H / (t_bwd * 1e-3) / 1e9, 1),
                                     "frac": round((6 if keeps else 5) * A_H / (t_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "mfma": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
@@ -410,7 +547,9 @@ def sfno_config5(dev, with_cpu=True):
             "gpu_over_cpu": round(32 / (t_all * 1e-3) / base["value"], 1) if base and base.get("value") else None,
             "workload": "SFNO(24,24,5,width=10,layers=4) forward + SobolevLoss, x (32,256,256,10) fp32, synthetic",
             "forward_ms": round(t_fwd, 3), "forward_plus_loss_ms": round(t_all, 3), "train_step_ms": round(t_train, 2),
-            "forward_ms_with_gelu": round(t_gelu, 3),
+            "forward_ms_with_gelu": round(t_gelu, 3), "train_step_ms_gelu": round(t_train_gelu, 2),
+            "train_step_ms_gelu_each": [round(t, 2) for t in gper],
+            "gelu_training_kernels": {k: v for k, v in gelu_kernels.items() if k in ("pointwise_bwd", "pointwise")},
             "train_step_ms_each": [round(t, 2) for t in per_step],
             "samples_per_s": round(32 / (t_all * 1e-3), 1), "algo_GB": round(algo_gb, 2),
             "algo_GBps": round(algo_gb / (t_all * 1e-3), 1), "frac_of_hbm_peak": round(algo_gb / (t_all * 1e-3) / HBM_PEAK_GBS, 4)}
@@ -485,6 +624,7 @@ def other_baseline_configs(dev, with_cpu=True):
     for name, n, B, real, steps, fused, forced in (("C1_128x1_f64", 128, 1, torch.float64, 200, True, True),
                                                    ("C2_256x16_f32", 256, 16, torch.float32, 400, True, False),
                                                    ("C4_shard_512x64_f64", 512, 64, torch.float64, 40, False, False),
+                                                   ("C4_shard_512x64_f32", 512, 64, torch.float32, 40, False, False),   # "also report c64"
                                                    ("n768x64_f64", 768, 64, torch.float64, 20, False, False),   # n = 3 * 2^k: radix-12 first pass
                                                    ("n2048x16_f64", 2048, 16, torch.float64, 6, False, False)):  # one field per chunk
         torch.set_default_dtype(real)
@@ -546,7 +686,12 @@ def host_only_run(args, world, rank, real_stdout):
         dist.barrier()
     el = time.perf_counter() - t0
     rates = [args.steps / el]
+    spans = [[lo, hi]]
     if dist.is_initialized():
+        mine = torch.tensor([lo, hi], dtype=torch.int64)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)          # what every rank REALLY took (the test compares it with shard_batch)
+        spans = [g.tolist() for g in got]
         t = torch.tensor([el], dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
@@ -557,7 +702,7 @@ def host_only_run(args, world, rank, real_stdout):
            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 6), "higher_is_better": True,
            "scaling": args.scaling, "vs_baseline": None, "dtype": None, "data": "none (host-only launcher check, no kernels)",
            "dry_run": True, "backend": "gloo", "world_size": dist.get_world_size() if dist.is_initialized() else 1,
-           "fields_of_rank0": [lo, hi], "per_rank_steps_per_s": [round(r, 1) for r in rates],
+           "fields_of_rank0": [lo, hi], "fields_of_every_rank": spans, "per_rank_steps_per_s": [round(r, 1) for r in rates],
            "spawned_by_bench": os.environ.get("BENCH_SPAWNED") == "1"}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
@@ -1012,6 +1157,13 @@ def main():
             out["sfno_config5"] = sfno_config5(dev, with_cpu=not args.no_cpu_baseline)
         except Exception as e:  # secondary measurement: never takes the headline line down
             out["sfno_config5"] = {"error": repr(e)}
+        for key, width, act in (("sfno_w16_gelu", 16, "GELU"), ("sfno_w20", 20, "ReLU"), ("sfno_w20_gelu", 20, "GELU"),
+                                ("sfno_w32", 32, "ReLU")):
+            try:      # the reference's other widths / activation (fno/sfno_pytest.py:261, its notebooks, fno/train.py:303); SURVEY 8d: width 32
+                out[key] = sfno_width_line(dev, width, act=act)
+            except Exception as e:
+                out[key] = {"error": repr(e)}
+            torch.cuda.empty_cache()
         try:
             out["sfno_notebook_training"] = sfno_notebook_training(dev)
         except Exception as e:
@@ -1024,6 +1176,30 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
+        # the numbers a reader wants first, LAST in the line (a truncated tail of stdout still shows them) and on stderr
+        def pick(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        out["summary"] = {
+            "steps_per_s": out["value"], "n_gpus": world, "roofline_frac": pick(out, "roofline", "frac"),
+            "step_algo_frac_of_peak": out["step_algo_frac_of_peak"],
+            "strong_scaling_proxy_predicted_speedup_8": pick(out, "strong_scaling_proxy", "predicted_speedup", "8"),
+            "c4_8gpu_proxy_speedup_whole_job": pick(out, "c4_ensemble", "strong_scaling_proxy_8gpu", "predicted_speedup_whole_job"),
+            "c4_sample_steps_per_s": pick(out, "c4_ensemble", "sample_steps_per_s"),
+            "C2_steps_per_s": pick(out, "other_configs", "C2_256x16_f32", "steps_per_s"),
+            "C4_shard_f64_steps_per_s": pick(out, "other_configs", "C4_shard_512x64_f64", "steps_per_s"),
+            "C4_shard_f32_steps_per_s": pick(out, "other_configs", "C4_shard_512x64_f32", "steps_per_s"),
+            "C5_forward_plus_loss_ms": pick(out, "sfno_config5", "forward_plus_loss_ms"),
+            "C5_frac_of_hbm_peak": pick(out, "sfno_config5", "frac_of_hbm_peak"),
+            "C5_train_step_ms": pick(out, "sfno_config5", "train_step_ms"),
+            "C5_train_step_ms_gelu": pick(out, "sfno_config5", "train_step_ms_gelu"),
+            "w20_train_step_ms": pick(out, "sfno_w20", "train_step_ms"), "w32_train_step_ms": pick(out, "sfno_w32", "train_step_ms"),
+            "w32_forward_plus_loss_ms": pick(out, "sfno_w32", "forward_plus_loss_ms"),
+            "cpu_baseline_steps_per_s": pick(out, "cpu_baseline", "value"),
+            "multi_gpu_curve_measured": world > 1,
+        }
+        sys.stderr.write("bench summary: " + json.dumps(out["summary"]) + "\n")
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

@@ -52,7 +52,7 @@ typedef enum { TCFD_C64 = 0, TCFD_C128 = 1 } tcfd_dtype;
 typedef struct tcfd_ns2d_plan tcfd_ns2d_plan;
 typedef struct tcfd_fno_plan tcfd_fno_plan;
 
-#define TCFD_ABI_VERSION 5   /* what tcfd_version() of a library built from THIS header returns */
+#define TCFD_ABI_VERSION 6   /* what tcfd_version() of a library built from THIS header returns */
 
 #ifndef TCFD_H_TYPES_ONLY   /* (the library's second compilation unit wants the types without the prototypes) */
 
@@ -191,6 +191,9 @@ int tcfd_irfft2(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, l
  * Same workspace as tcfd_irfft2. */
 int tcfd_irfft2_subsample(const tcfd_ns2d_plan* plan, const void* x_hat, void* out_real, long batch, int factor,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The largest factor tcfd_irfft2_subsample takes for this plan (a power of two: 4 at n = 80, 8 at n = 64 / 96 / 160, 16 at
+ * n = 128 / 256 / 320, ... 64 at most): a host asks before choosing between the one-pass and the two-call path. */
+int tcfd_irfft2_subsample_max_factor(const tcfd_ns2d_plan* plan);
 
 /* ---- FNO / SFNO spectral convolution (fp32 and fp64) -------------------------------
  * Replaces SpectralConv.forward (fno/base.py:229-237) with SpectralConvS.spectral_conv
@@ -265,27 +268,19 @@ int tcfd_fno_pointwise(const void* x, const void* skip, void* out, const void* w
                        const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
                        int T, int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride,
                        const void* pe, void* stream);
+/* The same, also storing the block's PRE-activation z2 (batch, co, P) into `pre` (NULL: exactly the call above): the training
+ * forward of a block whose output activation is neither ReLU nor the identity -- its backward reads act2'(z2) from it
+ * (tcfd_fno_pointwise_bwd_out) instead of recomputing W2.h + Ws.skip. */
+int tcfd_fno_pointwise_pre(const void* x, const void* skip, void* out, void* pre, const void* w1, const void* b1, const void* w2t,
+                           const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
+                           int T, int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride,
+                           const void* pe, void* stream);
 /* The same block in float64 (every array double; no positional-encoding input; w2_bstride / b2_bstride as in
  * tcfd_fno_pointwise: per-batch-element offsets of w2t / b2, 0 = shared): what an SFNO converted
  * with .double() (fno/base.py:342-349) runs.  Widths 4, 6, 8, 10, 12, 16, 20, 24, 32, any hidden width. */
 int tcfd_fno_pointwise_f64(const void* x, const void* skip, void* out, const void* w1, const void* b1, const void* w2t,
                            const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P, int T,
                            int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride, void* stream);
-/* Spectral convolution + the pointwise block that follows it in an SFNO layer, v <- act(FFN(conv(v)) + W v)
- * (fno/sfno.py:607-614) or the lifting tail act(v[..., -1:] + FFN(conv(v))) (:258-259), with the convolution's output
- * kept on chip: the inverse t/y transforms of all `cout` channels of a row (b, x) and the pointwise block run in one
- * workgroup.  Arguments: those of tcfd_fno_spectral_conv, then those of tcfd_fno_pointwise (its x is the convolution:
- * ci = cout, w1 required, shared weights); out (batch, co_pw, X, Y, t_keep).  Bit-identical to the two calls.  Returns
- * TCFD_EINVAL with "not instantiated" in tcfd_last_error() -- before anything is launched -- when the shape is not
- * covered (odd t_keep, a row that does not fit a workgroup's 160 KB of LDS, widths other than 8 / 10); callers then
- * make the two calls.  Measured SLOWER than the two calls at SFNO config 5 (one row-sized workgroup per CU), so the
- * Python models use it only under TCFD_FNO_FUSE_TAIL=1. */
-int tcfd_fno_spectral_conv_pointwise(const tcfd_fno_plan* plan, const void* v, const void* const* weights,
-                                     const void* const* bias, float delta, void* out, int batch, int cin, int cout,
-                                     int t_keep, float fwd_scale, float inv_scale, int use_mfma, void* workspace,
-                                     size_t workspace_bytes, const void* skip, const void* w1, const void* b1,
-                                     const void* w2t, const void* b2, const void* wst, const void* bs, int cm, int co_pw,
-                                     int act1, int act2, int skip_mode, int skip_T, void* stream);
 /* pe (ci, P) or NULL: when given, x is ONE channel (batch, 1, P) and the block input is x + pe[c] -- the lifting
  * operator's "input + positional encoding" (fno/sfno.py:109-113) without materialising the (batch, ci, P) tensor.
  * w2_bstride / b2_bstride: element offsets of w2t / b2 per batch element (0 = shared weights); a per-sample
@@ -314,6 +309,15 @@ int tcfd_sum_t_into_last(const void* d, void* g, long rows, int T, int sT, void*
 int tcfd_ns2d_profile_begin(tcfd_ns2d_plan* plan, int max_records);
 int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* kinds, float* ms);
 
+/* Per-launch event timing of the FNO kernels (measurement aid, process-wide; the counterpart of tcfd_ns2d_profile_begin / _end).
+ * Between begin and end every transform / contraction / pointwise launch is bracketed by a pair of HIP events recorded on its
+ * launch stream (up to max_records launches).  profile_end synchronises on them and returns, per launch, the kind
+ * (0 forward t/y transform, 1 forward x transform, 2 contraction, 3 inverse x transform, 4 inverse t/y transform, 5 two-layer
+ * pointwise block, 6 pointwise backward, 7 single-layer pointwise forms, 8 contraction weight gradient, 9 other) and its
+ * duration in milliseconds.  Not for concurrent use with measured work on other threads. */
+int tcfd_fno_profile_begin(int max_records);
+int tcfd_fno_profile_end(int capacity, int* count, int* kinds, float* ms);
+
 /* Backward of tcfd_fno_pointwise (shared weights): one pass over x / skip / dout recomputes the
  * block per point and writes dx (batch, ci, P), dskip (skip_mode 1: (batch, ci, P), may be NULL; skip_mode 2:
  * dL/d(pre-activation) (batch, co, P), which the caller sums over t into the skip's last time slice) and per-wave partial weight
@@ -327,14 +331,21 @@ int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, vo
                            const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
                            void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
                            int skip_T, int act1, int act2, int skip_mode, int per_sample, void* stream);
-/* The same with the block's forward OUTPUT `out` (batch, co, P) handed over (NULL: exactly the call above).  With ReLU as the
- * output activation its mask is read from `out` (y > 0 <=> z2 > 0: the mask the forward kernel applied) instead of recomputing the
- * pre-activation z2 -- 80 instead of 93 matrix instructions per 16 points at the reference's default width.  Other activation
- * pairs ignore `out`.  (torch's own ReLU backward reads the saved result the same way.) */
+/* The same with what the forward kept handed over in `out` (batch, co, P) (NULL: exactly the call above):
+ *   act2 = ReLU:            the block's forward OUTPUT -- its mask is read from it (y > 0 <=> z2 > 0: the mask the forward kernel
+ *                           applied; torch's own ReLU backward reads the saved result the same way);
+ *   act2 = GELU/SiLU/tanh:  the block's PRE-activation z2 (tcfd_fno_pointwise_pre) -- act2'(z2) is evaluated from it.
+ * Nothing of z2 = W2.h + Ws.skip is then recomputed, and for the two-layer form with P % 4 == 0 the call runs the tiled
+ * all-matrix-instruction kernel of csrc/tcfd_fno_bwd.hip at the widths 10, 16, 20, 24, 32 with cm = 4 ci (59 / 88 / 196 / 244 /
+ * 352 v_mfma_f32_16x16x4_f32 per 16 points).  Without `out` those widths above 14 return "not instantiated". */
 int tcfd_fno_pointwise_bwd_out(const void* x, const void* skip, const void* dout, const void* out, void* dx, void* dskip,
                                const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
                                void* partials, int max_waves, int* dims, int batch, int ci, int cm, int co, long P, int T,
                                int skip_T, int act1, int act2, int skip_mode, int per_sample, void* stream);
+/* What tcfd_fno_pointwise_bwd_out wants in `out` for the two-layer block ci -> cm -> co at P points per sample: 0 nothing is
+ * read, 1 the forward output, 2 the pre-activation (tcfd_fno_pointwise_pre).  A host asks BEFORE the forward, so that it only
+ * keeps / produces a tensor the backward kernel will read. */
+int tcfd_fno_pointwise_bwd_saved(int ci, int cm, int co, long P, int act1, int act2);
 /* The single-layer form (w1 NULL, no skip, no activations) whose input is x1 (batch, 1, P) + pe (ci, P) -- the `pe` mode of
  * tcfd_fno_pointwise -- so the weight gradients of the lifting operator's projection need no materialised (batch, ci, P) input. */
 int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const void* dout, void* dx, const void* w2t, const void* b2,

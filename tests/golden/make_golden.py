@@ -397,6 +397,36 @@ def gen_grads():
     save("fno_grads.npz", **out)
 
 
+def gen_grads_wide():
+    """Reference gradients at the widths the reference itself uses besides its default 10 -- 16 (fno/sfno_pytest.py:258-270)
+    and 20 (examples/ex2_SFNO_train_fnodata.ipynb) -- with GELU (fno/train.py:303) and ReLU: tiny SFNOs under a SobolevLoss,
+    loss + input gradient + every parameter gradient (torch autograd through torch.fft on the CPU, fp32)."""
+    torch.set_default_dtype(torch.float32)
+    from fno.sfno import SFNO
+    from fno.losses import SobolevLoss
+
+    out = {}
+    for tag, width, act, layers in (("w16_gelu", 16, "GELU", 2), ("w16_relu", 16, "ReLU", 2), ("w20_gelu", 20, "GELU", 2)):
+        g = torch.Generator().manual_seed(1600 + width + len(act))
+        torch.manual_seed(width)
+        model = SFNO(4, 4, 3, width=width, num_spectral_layers=layers, activation=act, latent_steps=10).train()
+        with torch.no_grad():
+            for b_ in model.output_operator.conv.bias:
+                b_.copy_(torch.randn(b_.shape, generator=g) * 0.05)
+        x = torch.randn(2, 16, 16, 10, generator=g).requires_grad_(True)
+        target = torch.randn(2, 16, 16, 10, generator=g)
+        pred = model(x)
+        loss = SobolevLoss(n_grid=16, norm_order=0, relative=True)(pred, target)
+        loss.backward()
+        out[f"{tag}_x"], out[f"{tag}_target"], out[f"{tag}_pred"] = npy(x), npy(target), npy(pred)
+        out[f"{tag}_loss"], out[f"{tag}_gx"] = npy(loss), npy(x.grad)
+        for k, v in model.state_dict().items():
+            out[f"{tag}_sd_" + k] = npy(v)
+        for k, v in model.named_parameters():
+            out[f"{tag}_g_" + k] = npy(v.grad) if v.grad is not None else np.zeros(0, dtype=np.float32)
+    save("fno_grads_wide.npz", **out)
+
+
 def gen_imex():
     """IMEXStepper orders 1 / 1.5 / 2 (equations.py:110-246) on the spectral operator, 3 steps, fp64."""
     from torch_cfd.equations import IMEXStepper
@@ -464,7 +494,7 @@ def gen_legacy_cn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "sfno_padding", "grads", "imex",
+    which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "sfno_padding", "grads", "grads_wide", "imex",
                              "helmholtz", "legacy_cn"]
     for w in which:
         globals()["gen_" + w]()

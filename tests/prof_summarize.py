@@ -11,6 +11,7 @@ out = sys.argv[1]
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"void (k_\w+)<(.*)>\(", name)
     if m:
         return f"{m.group(1)}<{m.group(2)[:28]}>"

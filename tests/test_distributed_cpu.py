@@ -129,6 +129,69 @@ def test_record_handover_world2(total, batch, dst):
     assert [r[1] for r in res if r[1]][0] == (total, 3, 4, 4)
 
 
+@pytest.mark.parametrize("total,batch,dst", [(37, 2, 0), (37, 2, 5), (16, 1, 0), (5, 1, 5)])
+def test_record_handover_world8(total, batch, dst):
+    """The BASELINE config-4 layout scaled down (fno/data_gen/data_gen_McWilliams2d.py:119-174: 512 samples in batches of 64 over
+    8 GPUs): 8 ranks, >= 2 batches per rank, a ragged last batch / last rank (37 = 8 x 4 + 5), ranks with NO sample (5 over 8),
+    the result at rank 0 or at an inner rank."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_handover_worker, args=(r, world, port, total, batch, 3, q, dst)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == ["none"] * 7 + ["ok"], res
+    assert [r[1] for r in res if r[1]][0] == (total, 3, 4, 4)
+
+
+def _handover_subgroup_worker(rank, world, port, total, batch, n_rec, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch_cfd_amd.distributed import TRAJECTORY_FIELDS, RecordHandover, batch_layout
+
+        members = [1, 3, 4, 6]                  # a job on four of the eight ranks; the result at GLOBAL rank 4 (group rank 2)
+        group = dist.new_group(members)
+        if rank not in members:
+            q.put(("outside", None))
+            return
+        grank, gworld = dist.get_rank(group), len(members)
+        layout = batch_layout(total, gworld, batch)
+        ho = RecordHandover(TRAJECTORY_FIELDS, total, n_rec, (4, 4), torch.float32, layout, "cpu", dst=2, group=group)
+        for start, count in layout[grank]:
+            for rec in range(n_rec):
+                ho.push(start, rec, _fake_packed(start, count, rec))
+        full = ho.finish()
+        if grank == 2:
+            ok = all(torch.equal(full[name][:, rec], _fake_packed(0, total, rec)[:, f])
+                     for f, name in enumerate(TRAJECTORY_FIELDS) for rec in range(n_rec))
+            q.put(("ok" if ok else "mismatch", tuple(full["vorticity"].shape)))
+        else:
+            q.put(("none" if full is None else "unexpected", None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_record_handover_in_a_subgroup_of_world8():
+    world, total = 8, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_handover_subgroup_worker, args=(r, world, port, total, 2, 2, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == ["none"] * 3 + ["ok"] + ["outside"] * 4, res
+
+
 def test_record_handover_without_process_group_and_order_check():
     from torch_cfd_amd.distributed import RecordHandover, batch_layout
 
@@ -240,6 +303,24 @@ def test_bench_spawns_its_own_ranks(scaling):
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["spawned_by_bench"] is True and out["dry_run"] is True
     assert out["scaling"] == scaling and len(out["per_rank_steps_per_s"]) == 2
     assert out["fields_of_rank0"] == ([0, 64] if scaling == "weak" else [0, 32])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_eight_ranks(scaling):
+    """What the driver's SCALE run does first: `python bench.py --gpus 8` through the script's own spawner (gloo, --host-only:
+    no kernels) -- eight ranks rendezvous, ONE JSON line, every rank took the span `shard_batch` gives it."""
+    import json
+
+    from torch_cfd_amd.distributed import shard_batch
+
+    r, lines = _run_bench(["--gpus", "8", "--steps", "3", "--host-only", "--scaling", scaling])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["spawned_by_bench"] is True
+    assert len(out["per_rank_steps_per_s"]) == 8
+    want = ([list(shard_batch(64, k, 8)) for k in range(8)] if scaling == "strong" else [[64 * k, 64 * (k + 1)] for k in range(8)])
+    assert out["fields_of_every_rank"] == want
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -960,14 +960,59 @@ def test_sfno_training_step_gradients_golden(dev):
             raise AssertionError("no descent along the negative gradient")
 
 
+@pytest.mark.parametrize("tag,width,act", [("w16_gelu", 16, "GELU"), ("w16_relu", 16, "ReLU"), ("w20_gelu", 20, "GELU")])
+def test_sfno_training_step_gradients_golden_at_widths_16_and_20(tag, width, act, dev, monkeypatch):
+    """Tiny SFNOs at the reference's other widths (16: fno/sfno_pytest.py:258-270, 20: its notebooks) with GELU
+    (fno/train.py:303) and ReLU under a SobolevLoss: prediction, loss, input gradient and EVERY parameter gradient against
+    the reference's autograd (make_golden.gen_grads_wide) -- with the einsum recompute of the pointwise block forbidden:
+    every block runs the tiled all-MFMA backward kernel (csrc/tcfd_fno_bwd.hip)."""
+    from torch_cfd_amd import fno
+
+    def no_fallback(*a, **k):
+        raise AssertionError("a pointwise block fell back to the einsum recompute")
+    monkeypatch.setattr(fno, "_pointwise_reference", no_fallback)
+    g = load_golden("fno_grads_wide.npz")
+    model = fno.SFNO(4, 4, 3, width=width, num_spectral_layers=2, activation=act, latent_steps=10).train()
+    pre = tag + "_sd_"
+    keys = sorted(k[len(pre):] for k in g.files if k.startswith(pre))
+    assert sorted(model.state_dict().keys()) == keys
+    model.load_state_dict({k: torch.from_numpy(g[pre + k]) for k in keys})
+    model = model.to(dev)
+    x = torch.from_numpy(g[f"{tag}_x"]).to(dev).requires_grad_(True)
+    target = torch.from_numpy(g[f"{tag}_target"]).to(dev)
+    pred = model(x)
+    assert rel_l2(pred, g[f"{tag}_pred"]) < 1e-5
+    loss = fno.SobolevLoss(n_grid=16, norm_order=0, relative=True).to(dev)(pred, target)
+    assert float(loss.detach()) == pytest.approx(float(g[f"{tag}_loss"]), rel=2e-5)
+    loss.backward()
+    assert rel_l2(x.grad, g[f"{tag}_gx"]) < 5e-5
+    checked = 0
+    for k, p in model.named_parameters():
+        ref = g[f"{tag}_g_" + k]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        err = float((p.grad.detach().cpu() - torch.from_numpy(ref)).norm())
+        assert err < 5e-5 * float(torch.from_numpy(ref).norm()) + 2e-9, k
+        checked += 1
+    assert checked >= 20
+
+
 @pytest.mark.parametrize("ci,cm,co,two,mode,act", [
     (10, 40, 10, True, 1, "ReLU"), (10, 40, 10, True, 1, "GELU"), (10, 40, 10, True, 0, "SiLU"), (8, 32, 8, True, 1, "Tanh"),
     (10, 10, 1, False, 0, None), (10, 10, 10, False, 1, "ReLU"), (4, 16, 4, True, 1, "ReLU"),
     (10, 40, 10, True, 2, "GELU"), (4, 16, 4, True, 2, "ReLU"), (10, 40, 10, True, 2, "ReLU"),
     (6, 24, 6, True, 1, "ReLU"), (12, 48, 12, True, 0, "GELU"), (14, 56, 14, True, 1, "SiLU"), (10, 40, 10, True, 0, None),
+    # the widths the reference itself trains at besides 10 (16: fno/sfno_pytest.py:261, 20: its notebooks) and 24 / 32:
+    # the tiled all-MFMA kernel (csrc/tcfd_fno_bwd.hip), ReLU from the saved output, the others from the saved pre-activation
+    (16, 64, 16, True, 1, "ReLU"), (16, 64, 16, True, 1, "GELU"), (16, 64, 16, True, 2, "GELU"), (16, 64, 16, True, 0, "SiLU"),
+    (20, 80, 20, True, 1, "ReLU"), (20, 80, 20, True, 1, "GELU"), (20, 80, 20, True, 2, "ReLU"), (24, 96, 24, True, 1, "Tanh"),
+    (24, 96, 24, True, 2, "GELU"), (32, 128, 32, True, 1, "ReLU"), (32, 128, 32, True, 1, "GELU"), (32, 128, 32, True, 2, "ReLU"),
+    (32, 128, 32, True, 0, None), (10, 40, 10, True, 1, "SiLU"),
 ])
 @pytest.mark.parametrize("X", [7, 6])   # P = 630 (not a multiple of 4: the LDS-staged kernels) / 540 (P % 16 = 12: the all-MFMA kernel, ragged last group)
-def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, X, dev):
+def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, X, dev, monkeypatch):
     """tcfd_fno_pointwise_bwd (input / skip gradients + MFMA-accumulated weight and bias gradients) against torch
     autograd of the same block written with einsums in float64; ragged point counts."""
     import torch.nn as nn
@@ -987,7 +1032,14 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
     out = fno.hip_pointwise(x, lin1, a1, lin2, skip=s, skip_conv=skc, act2=a2, skip_last_slice=(mode == 2))
     assert out is not None and out.grad_fn is not None
     t = torch.randn_like(out)
+    # every two-layer combination of this list has a backward KERNEL when the point count is a multiple of four: a wide
+    # width must not reach the einsum recompute (237 ms against 35 ms per training step when it did)
+    if two and X == 6:
+        def no_fallback(*a_, **k_):
+            raise AssertionError(f"{ci} -> {cm} -> {co} ({act}, mode {mode}) fell back to the einsum recompute")
+        monkeypatch.setattr(fno, "_pointwise_reference", no_fallback)
     (out * t).sum().backward()
+    monkeypatch.undo()
     got = {"x": x.grad, "s": s.grad if s is not None else None}
     for name, m in (("lin1", lin1), ("lin2", lin2), ("skip", skc)):
         if m is not None:
@@ -1008,58 +1060,42 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
             assert got[k] is not None and rel_l2(got[k], v) < 2e-5, k
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_pointwise_backward_with_the_output_mask_equals_the_recomputing_kernel(mode, dev, monkeypatch):
-    """tcfd_fno_pointwise_bwd_out: the ReLU mask of the output activation read from the block's forward output (80 MFMAs per 16
-    points) against the kernel that recomputes the pre-activation (93): same gradients to rounding -- the only elements that
-    may differ are those whose pre-activation is within rounding of zero; and the 71-MFMA form on top of it (TCFD_PW_BWD_YMASK=2)."""
+@pytest.mark.parametrize("act", ["ReLU", "GELU", "SiLU"])
+@pytest.mark.parametrize("width,mode", [(10, 1), (10, 2), (8, 1), (4, 2)])
+def test_tiled_backward_from_the_kept_tensor_equals_the_recomputing_kernel(width, mode, act, dev, monkeypatch):
+    """The tiled all-MFMA backward (csrc/tcfd_fno_bwd.hip) reads the derivative of the output activation from what the forward
+    kept -- the output's sign for ReLU, the pre-activation (tcfd_fno_pointwise_pre) otherwise -- and never recomputes
+    z2 = W2.h + Ws.s; the LDS-staged one-wave kernel (TCFD_PW_BWD_TILES=0) recomputes everything from x and s alone.  Same
+    gradients to rounding (ReLU: the only elements that may differ are those whose pre-activation is within rounding of zero)."""
     import torch.nn as nn
     from torch_cfd_amd import fno
 
-    torch.manual_seed(17 + mode)
-    ci = co = 10
-    cm = 40
+    torch.manual_seed(17 + mode + width)
+    ci = co = width
+    cm = 4 * width
     shape = (3, ci, 12, 16, 10)
     lin1, lin2 = nn.Conv3d(ci, cm, 1).to(dev), nn.Conv3d(cm, co, 1).to(dev)
     skc = nn.Conv3d(ci, co, 1).to(dev) if mode == 1 else None
     x = torch.randn(*shape, device=dev)
     s = torch.randn(*shape, device=dev) if mode == 1 else torch.randn(3, co, 12, 16, 6, device=dev)
-    act = nn.ReLU()
+    a = getattr(nn, act)()
     res = {}
-    for flag in ("2", "1", "0"):     # 2 (default): + g2^T from a second read, the O1 side of the hidden layer by transposition
-        monkeypatch.setenv("TCFD_PW_BWD_YMASK", flag)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_PW_BWD_TILES", flag)
         xs, ss = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
         for m in (lin1, lin2, skc):
             if m is not None:
                 m.zero_grad(set_to_none=True)
-        out = fno.hip_pointwise(xs, lin1, act, lin2, skip=ss, skip_conv=skc, act2=act, skip_last_slice=(mode == 2))
+        out = fno.hip_pointwise(xs, lin1, a, lin2, skip=ss, skip_conv=skc, act2=a, skip_last_slice=(mode == 2))
         assert out is not None and type(out.grad_fn).__name__.startswith("_PointwiseFn")
-        assert fno._keeps_output((True, act, act, mode, None)) == (flag != "0")
+        want = 0 if flag == "0" else (1 if act == "ReLU" else 2)      # nothing / the output / the pre-activation
+        assert fno._saved_kind((True, a, a, mode, None), ci, cm, co, 12 * 16 * 10) == want
         torch.manual_seed(5)
         (out * torch.randn_like(out)).sum().backward()
         res[flag] = [xs.grad, ss.grad, lin1.weight.grad.clone(), lin1.bias.grad.clone(), lin2.weight.grad.clone(),
                      lin2.bias.grad.clone()] + ([skc.weight.grad.clone(), skc.bias.grad.clone()] if skc is not None else [])
-    for a2, a1, b in zip(res["2"], res["1"], res["0"]):
-        assert torch.isfinite(a2).all() and rel_l2(a2, b) < 2e-6 and rel_l2(a1, b) < 2e-6
-
-
-@pytest.mark.parametrize("chunk_mb", ["0.5", "1", "2.5"])
-def test_chunked_inference_layers_are_bit_identical(chunk_mb, dev, monkeypatch):
-    """SFNO inference with the inverse transform + pointwise block of every layer run a few samples at a time through one reused
-    buffer (hip_layer_tail_chunked: the convolution output then stays in the Infinity Cache) against the whole-batch calls:
-    the same kernels on the same per-sample data -- bit-identical, ragged last chunk included."""
-    from torch_cfd_amd import fno
-
-    torch.manual_seed(4)
-    model = fno.SFNO(8, 8, 3, width=10, num_spectral_layers=3, latent_steps=10).to(dev).eval()
-    x = torch.randn(5, 32, 32, 10, device=dev)          # 410 KB of convolution output per sample: chunks of 1, 2 and 5 + ragged ends
-    with torch.no_grad():
-        monkeypatch.setenv("TCFD_FNO_CHUNK_MB", "0")
-        ref = model(x)
-        monkeypatch.setenv("TCFD_FNO_CHUNK_MB", chunk_mb)
-        assert fno._cache_chunk(5, 10 * 32 * 32 * 10 * 4) == {"0.5": 1, "1": 2, "2.5": 5}[chunk_mb]
-        out = model(x)
-    assert torch.isfinite(out).all() and torch.equal(out, ref)
+    for t, b in zip(res["1"], res["0"]):
+        assert torch.isfinite(t).all() and rel_l2(t, b) < 5e-6
 
 
 @pytest.mark.parametrize("random_feats", [False, True])
@@ -1183,11 +1219,23 @@ def test_reference_shape_suite_sfno_resolutions(n, T, dev):
     from torch_cfd_amd import fno
 
     torch.manual_seed(0)
-    model = fno.SFNO(8, 8, 5, width=10, num_spectral_layers=2).to(dev).eval()
+    model = fno.SFNO(8, 8, 4, width=16).to(dev).eval()       # the reference's own numbers: modes 8 / 8 / 4, width 16, 4 layers
     with torch.no_grad():
         assert model(torch.randn(2, n, n, T, device=dev)).shape == (2, n, n, T)
         for out_steps in (10, 20, 40):
             assert model(torch.randn(2, n, n, 10, device=dev), out_steps=out_steps).shape == (2, n, n, out_steps)
+    if n == 64:      # ... and the same model trains on the HIP kernels: no einsum recompute at the reference's width
+        def no_fallback(*a, **k):
+            raise AssertionError("the pointwise block of a width-16 layer fell back to the einsum recompute")
+        saved, fno._pointwise_reference = fno._pointwise_reference, no_fallback
+        try:
+            model.train()
+            x = torch.randn(2, n, n, 10, device=dev, requires_grad=True)
+            model(x).square().mean().backward()
+        finally:
+            fno._pointwise_reference = saved
+        assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
 
 
 def test_reference_shape_suite_layers(dev):
@@ -1298,9 +1346,6 @@ def test_fp64_spectral_layers_against_oracle(pad, steps, dev):
     y = convS(x.to(dev))
     ref = OF.spectral_conv(x, _blocks(convS.weight), (5, 4, 3), _blocks(convS.bias), delta=0.4)
     assert y.dtype == torch.float64 and rel_l2(y, ref) < 1e-12
-    with torch.no_grad():
-        comp = fno.fp64_spectral_conv(x.to(dev), list(convS.weight), convS._bias_list(), convS.delta, convS.modes)
-    assert rel_l2(y, comp) < 1e-12
     convT = fno.SpectralConvT(3, 3, 5, 4, 3, delta=0.1, bias=True, temporal_padding=bool(pad)).to(dev)
     _randomise(convT, seed=2)
     xg = x.to(dev).requires_grad_(True)
@@ -1354,40 +1399,6 @@ def test_fp64_helmholtz_postprocessed_layer_is_divergence_free(dev):
     assert (div.abs().max() / yh.abs().max()).item() < 1e-12
 
 
-@pytest.mark.parametrize("width,expansion,n,T", [(10, 4, 64, 10), (8, 2, 64, 6), (10, 4, 256, 10)])
-def test_fused_layer_tail_is_bit_identical_to_the_two_kernel_path(width, expansion, n, T, dev, monkeypatch):
-    """The SFNO layer tail in ONE kernel (inverse t/y transform + pointwise block, ``tcfd_fno_spectral_conv_pointwise``)
-    against ``hip_spectral_conv`` followed by ``hip_pointwise``: same arithmetic in the same order, so exactly equal --
-    for a hidden layer (skip convolution) and for the lifting tail (broadcast of the last input slice).  The two-kernel
-    path itself is checked against the reference's goldens and the oracle above."""
-    from torch_cfd_amd import fno
-
-    torch.manual_seed(width * 100 + n)
-    conv = fno.SpectralConvS(width, width, 6, 6, 3).to(dev)
-    convt = fno.SpectralConvT(width, width, 6, 6, 3, out_steps=T, bias=True).to(dev)
-    mlp = fno.PointwiseFFN(width, width, expansion * width, "GELU").to(dev)
-    w = torch.nn.Conv3d(width, width, 1).to(dev)
-    act = torch.nn.ReLU()
-    with torch.no_grad():
-        for prm in list(conv.parameters()) + list(convt.parameters()):
-            prm.mul_(1e3)   # the default gain 1e-4 would leave only the skip term visible
-        v = torch.randn(3, width, n, n, T, device=dev)
-        fused = fno.hip_conv_pointwise(conv, v, mlp, v, skip_conv=w, act2=act)
-        assert fused is not None, "hidden-layer tail was expected to be covered"
-        two = fno.hip_pointwise(conv(v), mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
-        assert torch.equal(fused, two)
-        assert rel_l2(fused, act(mlp(conv(v)) + w(v))) < 2e-6          # and the torch modules on the device
-        fused_l = fno.hip_conv_pointwise(convt, v, mlp, v, act2=act, skip_last_slice=True)
-        assert fused_l is not None
-        two_l = fno.hip_pointwise(convt(v), mlp.linear1, mlp.activation, mlp.linear2, skip=v, act2=act, skip_last_slice=True)
-        assert torch.equal(fused_l, two_l)
-    # not covered: gradients wanted, an odd number of output steps -> None before anything runs
-    assert fno.hip_conv_pointwise(conv, v.requires_grad_(), mlp, v, skip_conv=w, act2=act) is None
-    with torch.no_grad():
-        v5 = torch.randn(1, width, n, n, 5, device=dev)
-        assert fno.hip_conv_pointwise(conv, v5, mlp, v5, skip_conv=w, act2=act) is None
-
-
 @pytest.mark.parametrize("dtype", [torch.complex64, torch.complex128])
 def test_weighted_sqnorm_kernel(dtype, dev):
     """The one-pass reduction behind SobolevLoss against the torch expression it replaces."""
@@ -1415,33 +1426,6 @@ def test_weighted_sqnorm_batch_beyond_65535(dev):
     got = fno.hip_weighted_sqnorm(z, w2)
     ref = (z.abs().double() ** 2 * w2.double()).sum(dim=(-2, -1))
     assert got.shape == (70000,) and rel_l2(got, ref) < 1e-6
-
-
-@pytest.mark.parametrize("mode", [1, 2])
-def test_pointwise_backward_kernels_agree(mode, dev, monkeypatch):
-    """The all-MFMA backward (default) against the LDS-staged two-/four-wave kernels on the same inputs (TCFD_PW_BWD)."""
-    import torch.nn as nn
-    from torch_cfd_amd import fno
-
-    torch.manual_seed(5)
-    ci, cm, co = 10, 40, 10
-    lin1, lin2 = nn.Conv3d(ci, cm, 1).to(dev), nn.Conv3d(cm, co, 1).to(dev)
-    skc = nn.Conv3d(ci, co, 1).to(dev) if mode == 1 else None
-    x = torch.randn(2, ci, 16, 12, 10, device=dev)
-    s = torch.randn(2, ci, 16, 12, 10, device=dev) if mode == 1 else torch.randn(2, co, 16, 12, 6, device=dev)
-    dout = torch.randn(2, co, 16, 12, 10, device=dev)
-    spec = (True, nn.GELU(), nn.GELU(), mode, None)
-    res = {}
-    for flag in ("5", "2", "4"):
-        monkeypatch.setenv("TCFD_PW_BWD", flag)
-        res[flag] = fno._hip_pointwise_backward(spec, dout, x, s, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
-                                                skc.weight if skc else None, skc.bias if skc else None, None, None)
-        torch.cuda.synchronize()
-    for flag in ("2", "4"):
-        for got, ref in zip(res["5"], res[flag]):
-            assert (got is None) == (ref is None)
-            if got is not None:
-                assert rel_l2(got, ref) < 5e-6
 
 
 @pytest.mark.parametrize("width,mode,act", [(10, 1, "GELU"), (4, 2, "ReLU"), (8, 0, "SiLU"), (32, 1, "Tanh")])

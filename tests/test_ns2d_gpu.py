@@ -469,6 +469,28 @@ def test_fused_c2r_subsample_is_bit_identical_to_the_two_steps(dev, n, factor, c
         plan.irfft2_subsample(xh, 3)
 
 
+@pytest.mark.parametrize("n,factor", [(256, 32), (160, 16), (80, 8), (64, 16), (128, 32)])
+def test_subsample_factors_beyond_the_fused_kernel_take_the_two_step_path(dev, n, factor):
+    """The one-pass c2r + subsample takes a factor up to the lanes of one row transform (16 at n = 256, 8 at n = 64 / 160,
+    4 at n = 80: tcfd_irfft2_subsample_max_factor); larger power-of-two factors ran before that kernel existed and must
+    keep running -- irfft2 + F.interpolate -- instead of raising (fno/data_gen/data_gen_McWilliams2d.py:158-163 takes any size)."""
+    import torch_cfd_amd as tc
+    from torch_cfd_amd.data_gen import spectral_to_physical
+    from torch_cfd_amd.equations import fft_plan
+
+    g = torch.Generator().manual_seed(n + factor)
+    x = torch.randn(2, n, n, generator=g, dtype=torch.float64)
+    xh = torch.fft.rfft2(x).to(dev)
+    plan = fft_plan(n, torch.complex128, dev)
+    limit = plan.lib.tcfd_irfft2_subsample_max_factor(plan.handle)
+    assert 2 <= limit < factor and plan.subsample_factor(n // factor) == 0 and plan.subsample_factor(n // limit) == limit
+    with pytest.raises(tc._lib.TcfdError):
+        plan.irfft2_subsample(xh, factor)
+    got = spectral_to_physical(xh, n // factor, torch.float64)
+    ref = torch.nn.functional.interpolate(x.reshape(-1, 1, n, n), size=(n // factor, n // factor), mode="bilinear").reshape(2, n // factor, n // factor)
+    assert got.shape == ref.shape and rel_l2(got.cpu(), ref) < 1e-13
+
+
 def test_linearity_of_transforms_and_roundtrip(dev):
     import torch_cfd_amd as tc
 

@@ -103,6 +103,25 @@ def test_oracle_sfno_matches_reference_golden(steps):
     assert rel_l2(y, g[f"y{steps}"]) < 2e-6
 
 
+@pytest.mark.parametrize("tag,width,act", [("w16_gelu", 16, "GELU"), ("w16_relu", 16, "ReLU"), ("w20_gelu", 20, "GELU")])
+def test_oracle_sfno_at_the_reference_widths_16_and_20_matches_reference_golden(tag, width, act):
+    """The widths / activation the reference trains with besides its default (fno/sfno_pytest.py:258-270, fno/train.py:303,
+    its notebooks): the oracle's forward, loss and input gradient (autograd through the restatement) against
+    make_golden.gen_grads_wide."""
+    from oracle import fno as OF
+    from oracle import sfno as OS
+
+    g = load_golden("fno_grads_wide.npz")
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_sd_")}
+    x = torch.from_numpy(g[f"{tag}_x"]).requires_grad_(True)
+    y = OS.sfno_forward(sd, x, (4, 4, 3), width=width, num_hidden=1, out_steps=10, activation=act)
+    assert rel_l2(y, g[f"{tag}_pred"]) < 2e-6
+    loss = OF.sobolev_loss(y, torch.from_numpy(g[f"{tag}_target"]), n_grid=16, norm_order=0, relative=True)
+    assert float(loss.detach()) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5)
+    loss.backward()
+    assert rel_l2(x.grad, g[f"{tag}_gx"]) < 1e-5
+
+
 @pytest.mark.parametrize("n", [16, 24])
 @pytest.mark.parametrize("steps", [10, 20])
 def test_oracle_sfno_with_spatial_padding_matches_reference_golden(n, steps):

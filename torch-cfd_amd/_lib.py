@@ -24,10 +24,10 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_NAME = "libtcfd_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_loss.hip")
+SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_fno_pw.hip", "tcfd_fno_bwd.hip", "tcfd_loss.hip")
 
 TCFD_C64, TCFD_C128 = 0, 1
-ABI_VERSION = 5   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
+ABI_VERSION = 6   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -69,10 +69,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 # compile jobs: (source, extra flags, object).  tcfd_ns2d.hip is compiled twice -- unit 0 = C ABI + float64 kernels, unit 1 =
-# float32 kernels -- so that the three hipcc processes take ~3 minutes side by side instead of 7 for the solver file alone.
+# float32 kernels -- and the FNO kernels are three files (transforms + contraction / pointwise block / tiled backward), so that
+# the hipcc processes take ~3.5 minutes side by side instead of 7 + 5 one after the other.
 JOBS = (("tcfd_ns2d.hip", ("-DTCFD_UNIT=0",), "tcfd_ns2d.o"),
         ("tcfd_ns2d.hip", ("-DTCFD_UNIT=1",), "tcfd_ns2d_f32.o"),
         ("tcfd_fno.hip", (), "tcfd_fno.o"),
+        ("tcfd_fno_pw.hip", (), "tcfd_fno_pw.o"),
+        ("tcfd_fno_bwd.hip", (), "tcfd_fno_bwd.o"),
         ("tcfd_loss.hip", (), "tcfd_loss.o"))
 
 
@@ -126,6 +129,7 @@ SIGNATURES = {
     "tcfd_rfft2": (_i, [_vp, _vp, _vp, _l, _vp]),
     "tcfd_irfft2": (_i, [_vp, _vp, _vp, _l, _vp, _sz, _vp]),
     "tcfd_irfft2_subsample": (_i, [_vp, _vp, _vp, _l, _i, _vp, _sz, _vp]),
+    "tcfd_irfft2_subsample_max_factor": (_i, [_vp]),
     "tcfd_fno_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i]),
     "tcfd_fno_plan_create_resample": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tcfd_fno_plan_create_dtype": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
@@ -143,15 +147,14 @@ SIGNATURES = {
     "tcfd_fno_contract_wgrad": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _d, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_fno_pointwise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
                                 _l, _vp, _vp]),
+    "tcfd_fno_pointwise_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
+                                    _l, _vp, _vp]),
     "tcfd_fno_pointwise_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l, _l,
                                     _vp]),
     "tcfd_row_moments_f64": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_sum_rows_slices": (_i, [_l]),
     "tcfd_sum_rows": (_i, [_vp, _vp, _vp, _l, _l, _vp]),
     "tcfd_sum_t_into_last": (_i, [_vp, _vp, _l, _i, _i, _vp]),
-    "tcfd_fno_spectral_conv_pointwise": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_float, _vp, _i,
-                                              _i, _i, _i, ctypes.c_float, ctypes.c_float, _i, _vp, _sz,
-                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_fno_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),
                                     _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
@@ -159,6 +162,9 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_fno_lift_spectrum": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "tcfd_fno_sample_outer_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _i, _vp]),
+    "tcfd_fno_profile_begin": (_i, [_i]),
+    "tcfd_fno_profile_end": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
+    "tcfd_fno_pointwise_bwd_saved": (_i, [_i, _i, _i, _l, _i, _i]),
     "tcfd_fno_pointwise_bwd_pe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i), _i, _i, _i, _l, _i, _vp]),
     "tcfd_ns2d_profile_begin": (_i, [_vp, _i]),
     "tcfd_ns2d_profile_end": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),

@@ -1,0 +1,520 @@
+// tcfd_fno_bwd.hip -- backward of the fused pointwise block of an SFNO layer for EVERY width up to 32, gfx950
+//   out = act2( W2 . act1(W1 . x + b1) + b2  [+ Ws . s + bs | + s[..., -1:]] )        (fno/base.py:86-111, fno/sfno.py:607-614)
+// The reference trains at width 10 (fno/train.py:293), 16 (fno/sfno_pytest.py:258-270) and 20 (its notebooks), with ReLU or GELU
+// (fno/train.py:303).  The weights live in LDS as ready-made operand fragments and every channel dimension is tiled, so ONE
+// kernel serves every width 4 ... 32.  (Rounds 3 / 4 had a register-resident kernel for widths <= 14 -- 71 products per 16 points
+// at width 10, the transpositions as products with the identity -- and LDS-staged multi-wave kernels before that; this kernel
+// measured faster at width 10 and replaced them)
+//
+// A wave owns 16 points at a time.  Lane l = (q, c) = (l >> 4, l & 15); v_mfma_f32_16x16x4_f32 takes A[row c][k q] and
+// B[k q][col c] from lane (q, c) and leaves D[row 4q + r][col c] in register r.  A D tile of a matrix M therefore is, register by
+// register, the B operand of X . M and the A operand of M^T . Y (k-step r contracts over the rows {4q + r}).
+//
+// Every tensor is read ONCE, as 16-byte lanes along the points: lane (q, c) holds channel slot c at points 4q .. 4q + 3, which is
+// the D-tile layout of the POINT-major matrix ("OT": rows = points, columns = channels).  The channel-major orientation a
+// contraction over channels needs is the TRANSPOSE of such a tile, and a 16 x 16 transposition is one ds_write_b128 + four
+// ds_read_b32 through a wave-private 1.25 KB of LDS (pitch 20 floats: conflict free both ways) -- ~20 LDS cycles against the
+// 4 x 32 matrix-pipe cycles of a product with the identity, and the LDS pipe is idle here otherwise.  Per group of 16 points:
+//   g2^T = dout (.) act2'(.)                       registers (ReLU: sign of the saved output y; others: the saved pre-activation z2)
+//   x, g2     <- transposes of x^T, g2^T            (TI + TO tiles)
+//   dh^T  = g2 ^T-chain  W2                          A = g2 tile,  B = W2 fragment     TM x ksteps(CO)
+//   z1^T  = x  ^T-chain  W1^T + b1                   A = x tile,   B = W1 fragment     TM x ksteps(CI)
+//   h^T = act1(z1^T),  g1^T = dh^T (.) act1'(z1^T)   registers
+//   g1    <- transposes of g1^T                      (TM tiles)
+//   dx^T  = g1 . W1   (A = g1 tile),  ds^T = g2 . Ws (A = g2 tile)                      TI x (ksteps(CM) + ksteps(CO))
+//   dW2 += g2^T ^T h^T,  dW1 += g1^T ^T x^T,  dWs += g2^T ^T s^T    (contractions over the 16 points, OT tiles on both sides)
+//   db2 += sum g2^T,  db1 += sum g1^T                 plain adds
+// The forward output (ReLU) or pre-activation (GELU, SiLU, tanh) of the block comes from the caller: nothing of z2 is recomputed,
+// and the hidden layer exists in ONE orientation.  Matrix instructions per 16 points: width 10: 59 (the round-4 kernel: 71),
+// 16: 88, 20: 196, 24: 244, 32: 352.  A partly filled channel tile deals its channels to the rows 4q + r with r < ceil(n / 4)
+// (slot -> channel map `Ch::chan`), so the k-steps that would multiply padding are never issued.
+// Weight fragments: groups of four consecutive k-steps interleaved per lane, one ds_read_b128 at an immediate offset per group.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "tcfd_fno_common.hpp"
+#include "tcfd_fno_pw.hpp"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// a channel dimension of N channels cut into 16-slot tiles
+template <int N>
+struct Ch {
+    static constexpr int T = (N + 15) / 16;
+    __host__ __device__ static constexpr int n(int t) { return N - 16 * t >= 16 ? 16 : N - 16 * t; }
+    __host__ __device__ static constexpr int rv(int t) { return (n(t) + 3) / 4; }          // k-steps that hold channels
+    __host__ __device__ static constexpr int chan(int t, int slot) {                          // channel of a tile slot, or -1
+        const int q = slot >> 2, r = slot & 3, i = q * rv(t) + r;
+        return (r < rv(t) && i < n(t)) ? 16 * t + i : -1;
+    }
+};
+
+__device__ __forceinline__ float relu_bits(float z) {      // max(0, z) on the bit pattern: ONE v_max_i32 (see tcfd_fno.hip pw_relu)
+    const int zi = __float_as_int(z);
+    return __int_as_float(zi > 0 ? zi : 0);
+}
+
+// cotangent through an activation whose saved value is `v`: the OUTPUT for ReLU (y > 0 <=> z > 0), the PRE-activation otherwise
+template <int ACT>
+__device__ __forceinline__ float gate_saved(float g, float v) {
+    if constexpr (ACT == 0) return g;
+    else if constexpr (ACT == 1) return v > 0.f ? g : 0.f;
+    else { float h, d; pw_act_pair<ACT>(v, h, d); return g * d; }
+}
+__device__ __forceinline__ float gate_saved_rt(float g, float v, int act) {
+    switch (act) {
+        case 0: return g;
+        case 1: return gate_saved<1>(g, v);
+        case 2: return gate_saved<2>(g, v);
+        case 3: return gate_saved<3>(g, v);
+        default: return gate_saved<4>(g, v);
+    }
+}
+
+template <int CI, int CM, int CO>
+struct TilesGeom {
+    using IT = Ch<CI>;
+    using HT = Ch<CM>;
+    using OT = Ch<CO>;
+    static constexpr int TI = IT::T, TM = HT::T, TO = OT::T;
+    static constexpr int G_W1A = 0;                          // [t][ti]  B of z1^T:  W1[hid(t, c)][ci(ti, 4q + j)]
+    static constexpr int G_W2B = G_W1A + TM * TI;            // [t][to]  B of dh^T:  W2[co(to, 4q + r)][hid(t, c)]
+    static constexpr int G_W1B = G_W2B + TM * TO;            // [t][ti]  B of dx^T:  W1[hid(t, 4q + r)][ci(ti, c)]
+    static constexpr int G_WSB = G_W1B + TM * TI;            // [to][ti] B of ds^T:  Ws[co(to, 4q + r)][ci(ti, c)]
+    static constexpr int NG = G_WSB + TO * TI;               // groups of 4 fragments = 1 KB each
+    static constexpr int SCR = (TI + TO > TM ? TI + TO : TM);   // transposition tiles per wave
+    static constexpr int TILE = 16 * 20;                     // floats per tile (pitch 20)
+    static constexpr size_t LDS = ((size_t)NG * 256 + (size_t)4 * SCR * TILE) * sizeof(float);
+};
+
+#define PWB_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
+
+// MODE = skip_mode (0 none, 1 skip convolution, 2 broadcast last slice).  ACT >= 0: both activations are that code at compile
+// time; ACT = -1: a.act1 / a.act2 at run time (one uniform switch per tile set).  WPS = waves per SIMD the registers must allow.
+template <int CI, int CM, int CO, int MODE, int ACT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
+    using Gm = TilesGeom<CI, CM, CO>;
+    using IT = typename Gm::IT;
+    using HT = typename Gm::HT;
+    using OT = typename Gm::OT;
+    using Lay = PwBwdGeom<CI, CM, CO, true>;
+    constexpr int TI = Gm::TI, TM = Gm::TM, TO = Gm::TO;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const ldsw = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, q = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- weight fragments -> LDS (once per workgroup): float (group g, lane l, k-step i) at g * 256 + 4 l + i = g * 256 + tid.
+    // Every load is unconditional (index clamped, value selected afterwards): all of a thread's loads are in flight together
+    // (a load behind a lane condition sits in its own exec-masked block and is waited for on the spot)
+    {
+        const int fl = tid >> 2, fi = tid & 3, fq = fl >> 4, fc = fl & 15;
+        auto pick = [](const float* w, int idx, bool ok) { const float v = w[ok ? idx : 0]; return ok ? v : 0.f; };
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int hc = HT::chan(t, fc), hk = HT::chan(t, 4 * fq + fi);
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const int ik = IT::chan(ti, 4 * fq + fi), ic = IT::chan(ti, fc);
+                ldsw[(Gm::G_W1A + t * TI + ti) * 256 + tid] = pick(a.w1, hc * CI + ik, hc >= 0 && ik >= 0);
+                ldsw[(Gm::G_W1B + t * TI + ti) * 256 + tid] = pick(a.w1, hk * CI + ic, hk >= 0 && ic >= 0);
+            }
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const int ok = OT::chan(to, 4 * fq + fi);
+                ldsw[(Gm::G_W2B + t * TO + to) * 256 + tid] = pick(a.w2t, hc * CO + ok, hc >= 0 && ok >= 0);
+            }
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const int ok = OT::chan(to, 4 * fq + fi);
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const int ic = IT::chan(ti, fc);
+                    ldsw[(Gm::G_WSB + to * TI + ti) * 256 + tid] = pick(a.wst, ic * CO + ok, ok >= 0 && ic >= 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const f4* const wf = reinterpret_cast<const f4*>(ldsw) + lane;            // group g: wf[g * 64]
+    float* const sc = smem + Gm::NG * 256 + wave * (Gm::SCR * Gm::TILE);       // this wave's transposition tiles
+    float* const sc_w = sc + c * 20 + 4 * q;                                   // ds_write_b128: LDS[slot c][pt 4q .. 4q + 3]
+    const float* const sc_r = sc + (4 * q) * 20 + c;                           // 4 x ds_read_b32: LDS[slot 4q + r][pt c]
+    auto put = [&](int k, f4 v) { *reinterpret_cast<f4*>(sc_w + k * Gm::TILE) = v; };
+    auto get = [&](int k) { const float* p = sc_r + k * Gm::TILE; return f4{p[0], p[20], p[40], p[60]}; };
+
+    // ---- per-lane constants
+    float b1v[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { const int hc = HT::chan(t, c); b1v[t] = (hc >= 0 && a.b1) ? a.b1[hc] : 0.f; }
+    f4 accW2[TO][TM], accW1[TM][TI], accWs[TO][TI];
+    float accB1[TM], accB2[TO];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        accB1[t] = 0.f;
+#pragma unroll
+        for (int to = 0; to < TO; ++to) accW2[to][t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) accW1[t][ti] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        accB2[to] = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) accWs[to][ti] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int gpb = (int)((a.P + 15) / 16);                 // groups of 16 points per batch element
+    const int total = gpb * a.batch;                        // (the launcher checks the 31-bit range)
+    const int wid = blockIdx.x * 4 + wave, wstride = gridDim.x * 4;
+    const unsigned P4 = (unsigned)a.P * 4u;
+    constexpr unsigned OOB = 0xffffffffu;                    // beyond every buffer: the bounds check returns 0
+    unsigned i_off[TI], o_off[TO];                           // byte offset of this lane's channel row inside ONE sample, or OOB
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) { const int ch = IT::chan(ti, c); i_off[ti] = ch >= 0 ? (unsigned)ch * P4 : OOB; }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) { const int ch = OT::chan(to, c); o_off[to] = ch >= 0 ? (unsigned)ch * P4 : OOB; }
+
+    struct In {
+        f4 xb[TI], sb[TI], dzb[TO], yob[TO];
+    };
+    // Buffer descriptors are built per SAMPLE (wave-uniform scalar arithmetic): offsets stay 32-bit whatever the batch size, and
+    // a lane with nothing to read -- padding slot, point beyond P -- passes OOB and gets 0: no lane condition guards a load, the
+    // next group's loads are straight-line code that stays in flight across the current group's products.
+    auto load = [&](int G, In& in) {
+        const int b = G / gpb;
+        const unsigned pb = (unsigned)(G - b * gpb) * 16u + 4u * q;
+        const bool live = pb < (unsigned)a.P;                 // P % 4 == 0: a 16-byte lane is all live or all dead
+        const unsigned po = pb * 4u;
+        const int ibytes = (int)((unsigned)CI * P4), obytes = (int)((unsigned)CO * P4);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * CI * a.P, 0, ibytes, 0x00020000);
+        const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout) + (size_t)b * CO * a.P, 0, obytes, 0x00020000);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const unsigned off = (live && i_off[ti] != OOB) ? i_off[ti] + po : OOB;
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            in.xb[ti] = f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            if constexpr (MODE == 1) {
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.s) + (size_t)b * CI * a.P, 0, ibytes, 0x00020000);
+                const u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                in.sb[ti] = f4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+            } else {
+                in.sb[ti] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const unsigned off = (live && o_off[to] != OOB) ? o_off[to] + po : OOB;
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rd, off, 0, 0);
+            in.dzb[to] = f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            if (a.out) {                                      // (kernel-argument uniform)
+                const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.out) + (size_t)b * CO * a.P, 0, obytes, 0x00020000);
+                const u4 w = __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0);
+                in.yob[to] = f4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+            } else {
+                in.yob[to] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    In cur;
+    load(wid < total ? wid : total - 1, cur);
+    for (int G = wid; G < total; G += wstride) {
+        In nxt;
+        load(G + wstride < total ? G + wstride : total - 1, nxt);   // unconditional (clamped): no branch around the prefetch
+        __builtin_amdgcn_sched_barrier(0);                          // ... and issued HERE, a whole iteration ahead of its use
+        const int b = G / gpb;
+        const long pb = (long)(G - b * gpb) * 16 + 4 * q;
+        const bool live = pb < a.P;
+
+        // ---- g2^T from the saved output / pre-activation; x^T and g2^T go through the transposition tiles
+        f4 g2T[TO];
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                g2T[to][r] = ACT >= 0 ? gate_saved<(ACT >= 0 ? ACT : 0)>(cur.dzb[to][r], cur.yob[to][r])
+                                      : gate_saved_rt(cur.dzb[to][r], cur.yob[to][r], a.act2);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) put(ti, cur.xb[ti]);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) put(TI + to, g2T[to]);
+        // register-only work while the tiles are on their way: the skip convolution's weight gradient, the output bias gradient
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            accB2[to] += (g2T[to][0] + g2T[to][1]) + (g2T[to][2] + g2T[to][3]);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ti = 0; ti < TI; ++ti) accWs[to][ti] = PWB_MFMA(g2T[to][r], cur.sb[ti][r], accWs[to][ti]);
+            }
+        }
+        if constexpr (MODE == 2) {     // dL/dz2 itself is the skip gradient before its t-sum (tcfd_sum_t_into_last)
+            if (a.ds) {
+#pragma unroll
+                for (int to = 0; to < TO; ++to) {
+                    const int ch = OT::chan(to, c);
+                    if (ch >= 0 && live) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CO + ch) * a.P + pb) = g2T[to];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        f4 xa[TI], g2[TO];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) xa[ti] = get(ti);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) g2[to] = get(TI + to);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- dh^T[t] = sum over co of g2 (A) x W2 (B);  z1^T[t] = b1 + sum over ci of x (A) x W1^T (B).  Two hidden tiles at a
+        // time so that consecutive matrix instructions never wait for each other's accumulator (40-cycle dependent latency)
+        f4 dhT[TM], zT[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) { dhT[t] = f4{0.f, 0.f, 0.f, 0.f}; zT[t] = f4{b1v[t], b1v[t], b1v[t], b1v[t]}; }
+#pragma unroll
+        for (int t0 = 0; t0 < TM; t0 += 2) {
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const f4 w0 = wf[(Gm::G_W2B + t0 * TO + to) * 64];
+                const f4 w1 = wf[(Gm::G_W2B + (t0 + 1 < TM ? t0 + 1 : t0) * TO + to) * 64];
+#pragma unroll
+                for (int r = 0; r < OT::rv(to); ++r) {
+                    dhT[t0] = PWB_MFMA(g2[to][r], w0[r], dhT[t0]);
+                    if (t0 + 1 < TM) dhT[t0 + 1] = PWB_MFMA(g2[to][r], w1[r], dhT[t0 + 1]);
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const f4 w0 = wf[(Gm::G_W1A + t0 * TI + ti) * 64];
+                const f4 w1 = wf[(Gm::G_W1A + (t0 + 1 < TM ? t0 + 1 : t0) * TI + ti) * 64];
+#pragma unroll
+                for (int j = 0; j < IT::rv(ti); ++j) {
+                    zT[t0] = PWB_MFMA(xa[ti][j], w0[j], zT[t0]);
+                    if (t0 + 1 < TM) zT[t0 + 1] = PWB_MFMA(xa[ti][j], w1[j], zT[t0 + 1]);
+                }
+            }
+        }
+        // ---- h^T = act1(z1^T) (in zT),  g1^T = dh^T (.) act1'(z1^T) (in dhT)
+        if constexpr (ACT == 1) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dhT[t][r] = zT[t][r] > 0.f ? dhT[t][r] : 0.f;
+                    zT[t][r] = relu_bits(zT[t][r]);
+                }
+        } else {
+#define PWB_ACT_ALL(ACT_)                                                  \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t)                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                    \
+            float hv, dv;                                                  \
+            pw_act_pair<(ACT_)>(zT[t][r], hv, dv);                           \
+            zT[t][r] = hv;                                                 \
+            dhT[t][r] *= dv;                                               \
+        }
+            if constexpr (ACT >= 0) { PWB_ACT_ALL(ACT >= 0 ? ACT : 0) }
+            else {
+                switch (a.act1) {
+                    case 1: PWB_ACT_ALL(1) break;
+                    case 2: PWB_ACT_ALL(2) break;
+                    case 3: PWB_ACT_ALL(3) break;
+                    case 4: PWB_ACT_ALL(4) break;
+                    default: break;
+                }
+            }
+#undef PWB_ACT_ALL
+        }
+        if (a.dx) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) put(t, dhT[t]);
+        }
+        // ---- weight gradients: contractions over the 16 points (while the g1 tiles are on their way)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            accB1[t] += (dhT[t][0] + dhT[t][1]) + (dhT[t][2] + dhT[t][3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int to = 0; to < TO; ++to) accW2[to][t] = PWB_MFMA(g2T[to][r], zT[t][r], accW2[to][t]);
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) accW1[t][ti] = PWB_MFMA(dhT[t][r], cur.xb[ti][r], accW1[t][ti]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- dx^T = g1 (A, the transposed tiles) x W1 (B);  ds^T = g2 (A) x Ws (B).  Two accumulators per output tile (dependent latency)
+        if (a.dx) {
+            f4 dxT[TI][2];
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) dxT[ti][0] = dxT[ti][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const f4 g1 = get(t);
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const f4 w = wf[(Gm::G_W1B + t * TI + ti) * 64];
+#pragma unroll
+                    for (int r = 0; r < HT::rv(t); ++r) dxT[ti][r & 1] = PWB_MFMA(g1[r], w[r], dxT[ti][r & 1]);
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const int ch = IT::chan(ti, c);
+                if (ch >= 0 && live) *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + ch) * a.P + pb) = dxT[ti][0] + dxT[ti][1];
+            }
+        }
+        if constexpr (MODE == 1) {
+            if (a.ds) {
+                f4 dsT[TI][2];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) dsT[ti][0] = dsT[ti][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int to = 0; to < TO; ++to)
+#pragma unroll
+                    for (int ti = 0; ti < TI; ++ti) {
+                        const f4 w = wf[(Gm::G_WSB + to * TI + ti) * 64];
+#pragma unroll
+                        for (int r = 0; r < OT::rv(to); ++r) dsT[ti][r & 1] = PWB_MFMA(g2[to][r], w[r], dsT[ti][r & 1]);
+                    }
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const int ch = IT::chan(ti, c);
+                    if (ch >= 0 && live) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + ch) * a.P + pb) = dsT[ti][0] + dsT[ti][1];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+    }
+
+    // ---- this wave's row of partial sums, in the layout of tcfd_fno_pointwise_bwd:
+    //      A (COP x CB) = [dW2 | db2 | dWs],  B (CM1 x CIP) = [dW1 | db1]
+    float* out = a.partials + (size_t)wid * Lay::TOTAL;
+    float* o1 = out + Lay::N_A;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int hc = HT::chan(t, c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hq = HT::chan(t, 4 * q + r);
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const int oq = OT::chan(to, 4 * q + r);
+                if (oq >= 0 && hc >= 0) out[oq * Lay::CB + hc] = accW2[to][t][r];
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const int ic = IT::chan(ti, c);
+                if (hq >= 0 && ic >= 0) o1[hq * Lay::CIP + ic] = accW1[t][ti][r];
+            }
+        }
+        float s = accB1[t];                                   // lanes (q, c), q = 0 .. 3, hold partial sums of the same channel
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0 && hc >= 0) o1[hc * Lay::CIP + CI] = s;
+    }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const int oc = OT::chan(to, c);
+        float s = accB2[to];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0 && oc >= 0) out[oc * Lay::CB + CM] = s;
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oq = OT::chan(to, 4 * q + r);
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const int ic = IT::chan(ti, c);
+                    if (oq >= 0 && ic >= 0) out[oq * Lay::CB + CM + 1 + ic] = accWs[to][ti][r];
+                }
+            }
+        }
+    }
+}
+#undef PWB_MFMA
+
+template <int CI, int CM, int CO, int MODE, int ACT, int WPS>
+int launch_tiles(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
+    FnoProfScope prof(FNO_K_POINTWISE_BWD, st);
+    using Gm = TilesGeom<CI, CM, CO>;
+    a.batch = batch;
+    auto kern = k_pwb_tiles<CI, CM, CO, MODE, ACT, WPS>;
+    static int lds_set_dev[64] = {0};
+    int dev = 0, cus = 256, per_cu = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !lds_set_dev[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS));
+        if (dev >= 0 && dev < 64) lds_set_dev[dev] = 1;
+    }
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, Gm::LDS));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const long groups = ((a.P + 15) / 16) * batch;
+    if (groups >= (1L << 30)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: %ld groups of 16 points exceed the kernel's index range", groups);
+    if ((size_t)(CI > CO ? CI : CO) * (size_t)a.P * 4 >= ((size_t)1 << 32))
+        return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: a SAMPLE of 4 GiB and more is beyond the kernel's 32-bit buffer offsets");
+    long blocks = std::min<long>({(groups + 3) / 4, (long)max_rows / 4, (long)std::max(per_cu, 1) * cus});
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), Gm::LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    dims[5] = (int)(blocks * 4);     // every wave writes its row, also one that found no work
+    return 0;
+}
+
+// both activations ReLU, both GELU (the reference's choices, fno/train.py:303), or anything at run time
+template <int CI, int CM, int CO, int MODE, int WPS>
+int launch_tiles_act(const PwBwdArgs& a, int batch, int max_rows, int* dims, hipStream_t st) {
+    if (a.act1 == 1 && a.act2 == 1) return launch_tiles<CI, CM, CO, MODE, 1, WPS>(a, batch, max_rows, dims, st);
+    if (a.act1 == 2 && a.act2 == 2) return launch_tiles<CI, CM, CO, MODE, 2, WPS>(a, batch, max_rows, dims, st);
+    return launch_tiles<CI, CM, CO, MODE, -1, WPS>(a, batch, max_rows, dims, st);
+}
+
+template <int CI, int CM, int CO, int WPS>
+int launch_tiles_mode(const PwBwdArgs& a, int batch, int max_rows, int* dims, hipStream_t st) {
+    using Lay = PwBwdGeom<CI, CM, CO, true>;
+    dims[0] = Lay::COP; dims[1] = Lay::CB; dims[2] = Lay::CM1; dims[3] = Lay::CIP; dims[4] = Lay::TOTAL; dims[5] = 0;
+    if (!a.x) {                                               // layout query: dims[5] = rows a launch that fills the device writes
+        int dev = 0, cus = 256, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+            auto kern = k_pwb_tiles<CI, CM, CO, 1, 1, WPS>;   // (every MODE / ACT variant of a width has the same WPS and LDS)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TilesGeom<CI, CM, CO>::LDS);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, TilesGeom<CI, CM, CO>::LDS) == hipSuccess)
+                dims[5] = std::max(per_cu, 1) * cus * 4;
+        }
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (a.skip_mode == 1) return launch_tiles_act<CI, CM, CO, 1, WPS>(a, batch, max_rows, dims, st);
+    if (a.skip_mode == 2) return launch_tiles_act<CI, CM, CO, 2, WPS>(a, batch, max_rows, dims, st);
+    return launch_tiles<CI, CM, CO, 0, -1, WPS>(a, batch, max_rows, dims, st);
+}
+
+}  // namespace
+
+// The widths the reference's own code uses (10: fno/train.py:293; 16: fno/sfno_pytest.py:261; 20: its notebooks) and the
+// even widths around them (4 ... 16, 24, 32), with its channel expansion of 4 (fno/sfno.py:479).  The kernel needs the block's saved output /
+// pre-activation unless the output activation is the identity.
+int tcfd_pwb_tiles_dispatch(const PwBwdArgs& a, int batch, int ci, int cm, int co, int max_rows, int* dims, hipStream_t st,
+                            int* handled) {
+    *handled = 0;
+    if (a.pe || a.per_sample || a.P % 4 != 0) return 0;                                      // (known at the layout query too)
+    if (a.x && (max_rows < 4 || !a.w1 || (a.act2 != 0 && !a.out))) return 0;
+#define PWT_CASE(CI_, CM_, CO_, WPS_)                                                          \
+    if (ci == CI_ && cm == CM_ && co == CO_) {                                                  \
+        *handled = 1;                                                                           \
+        return launch_tiles_mode<CI_, CM_, CO_, WPS_>(a, batch, max_rows, dims, st);            \
+    }
+    PWT_CASE(4, 16, 4, 2) PWT_CASE(6, 24, 6, 2) PWT_CASE(8, 32, 8, 2) PWT_CASE(10, 40, 10, 2) PWT_CASE(12, 48, 12, 2)
+    PWT_CASE(14, 56, 14, 2) PWT_CASE(16, 64, 16, 2) PWT_CASE(20, 80, 20, 1) PWT_CASE(24, 96, 24, 1) PWT_CASE(32, 128, 32, 1)
+#undef PWT_CASE
+    return 0;
+}

@@ -2917,9 +2917,20 @@ TCFD_DISPATCHED(rfft2_dispatch, (const tcfd_ns2d_plan* p, const void* x, void* o
 TCFD_DISPATCHED(irfft2_dispatch, (const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, void* ws, hipStream_t st),
                 (p, xh, out, batch, ws, st), (irfft2_impl<T_, N_>(p, xh, out, batch, ws, st)))
 
+template <typename T, int N>
+static int irfft2_sub_max_impl(const tcfd_ns2d_plan*) {
+    using Gm = RowGeom<T, N, Cfg<T, N>::ROW_EPT>;
+    return Gm::G < 64 ? Gm::G : 64;
+}
+TCFD_DISPATCHED(irfft2_sub_max_dispatch, (const tcfd_ns2d_plan* p), (p), (irfft2_sub_max_impl<T_, N_>(p)))
 TCFD_DISPATCHED(irfft2_sub_dispatch, (const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, int S, void* ws, hipStream_t st),
                 (p, xh, out, batch, S, ws, st), (irfft2_sub_impl<T_, N_>(p, xh, out, batch, S, ws, st)))
 
+// largest factor tcfd_irfft2_subsample accepts for this plan (the lanes of one row transform, 64 at most); < 0: bad plan
+TCFD_API int tcfd_irfft2_subsample_max_factor(const tcfd_ns2d_plan* p) {
+    if (!p) return fail(TCFD_EINVAL, "irfft2_subsample_max_factor: null plan");
+    return irfft2_sub_max_dispatch(p);
+}
 TCFD_API int tcfd_irfft2_subsample(const tcfd_ns2d_plan* p, const void* xh, void* out, long batch, int factor, void* ws,
                                    size_t ws_bytes, void* stream) {
     if (!p || !xh || !out || batch <= 0) return fail(TCFD_EINVAL, "irfft2_subsample: bad argument");

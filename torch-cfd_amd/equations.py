@@ -226,7 +226,8 @@ class _HipPlan:
         if not out_size or out_size >= self.n or self.n % out_size:
             return 0
         f = self.n // out_size
-        return f if (f & (f - 1)) == 0 and f <= 64 else 0
+        # the kernel's own bound (the lanes of one row transform: 16 at n = 256, 8 at n = 64, ...); above it the two calls run
+        return f if (f & (f - 1)) == 0 and f <= self.lib.tcfd_irfft2_subsample_max_factor(self.handle) else 0
 
     def irfft2_subsample(self, xh, factor: int):
         """``F.interpolate(irfft2(xh), size=(n / factor,) * 2, mode="bilinear")`` as one pass (tcfd_irfft2_subsample)."""

@@ -223,115 +223,7 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     return out
 
 
-# ----------------------------------------------------------------------------- fp64 by composition (cross-check of the fp64 kernels)
-def _fp64_kept_rows(n: int, mx: int, device):
-    rows = torch.cat([torch.arange(mx), torch.arange(n - mx, n)]).to(device)
-    return rows, (-rows) % n
-
-
-def fp64_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, scale: float = 1.0) -> torch.Tensor:
-    """Kept modes of rfftn(left_pad_t(v)) in float64: (b, C, n, n, T) -> (b, C, 2mx, 2my, mt) complex128.
-
-    Round 2's fp64 path, kept as an independent cross-check of the fp64 instantiation of the fused kernels (the
-    layers no longer call it): the 3-D transform is composed from the solver's fp64 2-D
-    transforms (HIP rfft2 / irfft2 with their hand-written adjoints, ``autograd.py``) and small device tensor ops:
-    the short DFT in t is a matmul with a (T, mt) table, the 2-D FFT of the complex result is rfft2(Re) + i rfft2(Im)
-    with the columns beyond n/2 taken from the Hermitian mirror.  Square power-of-two grids only; differentiable."""
-    from .autograd import Rfft2
-    from .equations import fft_plan
-
-    b, c, X, Y, T = v.shape
-    mx, my, mt = modes
-    if X != Y:
-        raise NotImplementedError("fp64 spectral convolutions run on the square-grid fp64 transforms: X == Y required")
-    if 2 * my >= Y or 2 * mx > X:
-        raise ValueError("fp64 spectral convolution: need 2*modes_y < Y and 2*modes_x <= X")
-    n, Tp = X, T + t_pad
-    plan = fft_plan(n, torch.complex128, v.device)
-    kt = torch.arange(mt, device=v.device, dtype=torch.float64)
-    tt = torch.arange(T, device=v.device, dtype=torch.float64) + t_pad
-    ang = -2 * math.pi * tt[:, None] * kt[None, :] / Tp
-    a_re = (v @ torch.cos(ang)).permute(0, 1, 4, 2, 3).contiguous()            # (b, C, mt, X, Y)
-    a_im = (v @ torch.sin(ang)).permute(0, 1, 4, 2, 3).contiguous()
-    h_re, h_im = Rfft2.apply(a_re, plan), Rfft2.apply(a_im, plan)              # (b, C, mt, n, n/2+1)
-    rows, neg_rows = _fp64_kept_rows(n, mx, v.device)
-    mirror_cols = torch.arange(my, 0, -1, device=v.device)                     # ky = n - my .. n - 1  <->  n - ky = my .. 1
-
-    def kept(h):   # full-spectrum entries F[kx, ky] at the kept (kx, ky), from the half spectrum h
-        low = h[..., rows, :my]
-        high = h[..., neg_rows, :][..., mirror_cols].conj()
-        return torch.cat([low, high], dim=-1)                                  # (b, C, mt, 2mx, 2my)
-
-    vh = kept(h_re) + 1j * kept(h_im)
-    return (vh * scale).permute(0, 1, 3, 4, 2)                                 # (b, C, 2mx, 2my, mt)
-
-
-def fp64_contract(vh: torch.Tensor, weights, bias, delta: float, modes) -> torch.Tensor:
-    """The 4-corner contraction on truncated complex128 spectra (einsum per block, device ops)."""
-    mx, my, mt = modes
-    cplx = lambda w: (w if w.is_complex() else torch.view_as_complex(w.contiguous())).to(torch.complex128)
-    rows = (slice(0, mx), slice(mx, 2 * mx))
-    cols = (slice(0, my), slice(my, 2 * my))
-    co = weights[0].shape[1]
-    out = torch.zeros(vh.shape[0], co, 2 * mx, 2 * my, mt, dtype=torch.complex128, device=vh.device)
-    for iy in range(2):
-        for ix in range(2):
-            k = ix + 2 * iy
-            blk = torch.einsum("bixyt,ioxyt->boxyt", vh[:, :, rows[ix], cols[iy], :], cplx(weights[k]))
-            if bias is not None:
-                blk = blk + delta * cplx(bias[k])[None, None]
-            out[:, :, rows[ix], cols[iy], :] = blk
-    return out
-
-
-def fp64_truncated_irfftn(oh: torch.Tensor, n: int, t_out: int, t_keep: int, scale: float) -> torch.Tensor:
-    """irfftn (c2r semantics of torch in t: Im of the DC / Nyquist kt dropped) of a spectrum that is zero outside the
-    kept modes: (b, C, 2mx, 2my, mt) complex128 -> (b, C, n, n, t_keep) float64; ``scale`` relative to the
-    unnormalised inverse.  The complex 2-D inverse of each kt slice is irfft2 of its Hermitian part + i irfft2 of its
-    anti-Hermitian part."""
-    from .autograd import Irfft2
-    from .equations import fft_plan
-
-    b, c, r2, c2, mt = oh.shape
-    mx, my = r2 // 2, c2 // 2
-    plan = fft_plan(n, torch.complex128, oh.device)
-    rows, neg_rows = _fp64_kept_rows(n, mx, oh.device)
-    s = oh.permute(0, 1, 4, 2, 3)                                              # (b, C, mt, 2mx, 2my)
-    low, high = s[..., :my], s[..., my:]                                       # ky = 0..my-1 ; ky = n-my..n-1
-    shape = (b, c, mt, n, n // 2 + 1)
-    p_half = torch.zeros(shape, dtype=torch.complex128, device=oh.device)      # S[kx, ky], ky <= n/2
-    m_half = torch.zeros(shape, dtype=torch.complex128, device=oh.device)      # conj S[-kx, -ky], ky <= n/2
-    p_half[..., rows, :my] = low
-    # the mirror image lands on the rows -kx (kx = n - mx has its partner at row mx, OUTSIDE the kept rows)
-    m_half[..., neg_rows, 0] = low[..., 0].conj()
-    m_half[..., neg_rows, 1: my + 1] = high.flip(-1).conj()                    # ky = 1..my  <-  -ky = n-1 .. n-my
-    herm, anti = 0.5 * (p_half + m_half), -0.5j * (p_half - m_half)
-    z_re, z_im = Irfft2.apply(herm, plan), Irfft2.apply(anti, plan)            # (b, C, mt, n, n), each / n^2
-    kt = torch.arange(mt, device=oh.device, dtype=torch.float64)
-    tt = torch.arange(t_out - t_keep, t_out, device=oh.device, dtype=torch.float64)
-    ang = 2 * math.pi * kt[:, None] * tt[None, :] / t_out
-    ck = torch.where((kt == 0) | (2 * kt == t_out), 1.0, 2.0)[:, None]
-    out = torch.einsum("bckxy,kt->bcxyt", z_re, ck * torch.cos(ang)) - torch.einsum("bckxy,kt->bcxyt", z_im, ck * torch.sin(ang))
-    return out * (scale * n * n)
-
-
-def fp64_spectral_conv(v, weights, bias, delta, modes, t_pad=0, t_out=None, t_keep=None, norm="backward", post=None):
-    """The spectral convolution in float64 through the composite transforms above (forward and backward)."""
-    if not v.is_cuda:
-        raise _lib.TcfdError("expected a HIP device tensor (torch-cfd_amd has no CPU fallback)")
-    if any(w.dtype not in (torch.float64, torch.complex128) for w in weights):   # loud, like torch's einsum on mixed dtypes
-        raise TypeError("float64 input to a spectral convolution with float32 parameters: call .double() on the layer")
-    b, ci, X, Y, T = v.shape
-    t_out = T + t_pad if t_out is None else t_out
-    t_keep = t_out if t_keep is None else t_keep
-    fs, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
-    vh = fp64_truncated_rfftn(v, modes, t_pad, fs)
-    oh = fp64_contract(vh, weights, bias, float(delta), modes)
-    if post is not None:
-        oh = post(oh).to(torch.complex128)
-    return fp64_truncated_irfftn(oh, X, t_out, t_keep, is_)
-
-
+# ----------------------------------------------------------------------------- the pruned transforms and the contraction, one call each
 def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward",
                         scale: Optional[float] = None):
     """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) real -> (b, C, 2mx, 2my, mt) complex of the same precision
@@ -640,9 +532,9 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     """Gradients of the fused block from ``tcfd_fno_pointwise_bwd`` (one pass; weight gradients accumulated on MFMA,
     per-wave partial sums added here).  None when the combination is not covered: a folded LayerNorm or a width
     that is not instantiated -- the caller then recomputes the
-    block with torch einsums.  ``out``: the block's forward output if the caller still holds it (it is the next layer's
-    input, so it costs no memory): with ReLU activations the kernel reads the output mask from it instead of recomputing the
-    pre-activation (``tcfd_fno_pointwise_bwd_out``)."""
+    block with torch einsums.  ``out``: what the forward kept for this call (``_saved_kind``): the block's forward output
+    (ReLU: the kernel reads the output mask from it) or its pre-activation (other activations), handed to
+    ``tcfd_fno_pointwise_bwd_out`` -- nothing of the pre-activation is recomputed then."""
     has_l1, act1, act2, mode, eps = spec
     c1, c2 = _act_code(act1), _act_code(act2)
     if c1 is None or c2 is None or not x.is_cuda or x.dtype != torch.float32:
@@ -673,13 +565,13 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     dx = torch.empty_like(xs) if need_dx else None
     ds = torch.empty_like(sk) if mode == 1 else (torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=dev)
                                                  if mode == 2 else None)
-    max_waves = 2048
+    max_waves = max(2048, int(dims[5]))     # (the layout query of the tiled kernel reports the rows of a launch that fills the device)
     # zeros: the all-MFMA kernel writes only the entries of a row that mean something (one row per wave)
     partials = torch.zeros(max_waves, per_row, dtype=torch.float32, device=dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
     ys = None
-    if (out is not None and c1 == 1 and c2 == 1 and out.dtype == torch.float32 and out.device == dev
-            and out.numel() == dz.numel() and out.shape[:2] == dz.shape[:2]):
+    if (out is not None and out.dtype == torch.float32 and out.device == dev and out.numel() == dz.numel()
+            and out.shape[:2] == dz.shape[:2]):
         ys = out.detach().contiguous()
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise_bwd_out(ptr(xs), ptr(sk), ptr(dz), ptr(ys), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t),
@@ -809,12 +701,16 @@ def _norm_proj_grads(eps, dz, xs, W, bias, gamma, beta, Mx, M1, stats, need_dx, 
     return (dx.view_as(x), None, None, None, cast(g_w, w), cast(g_b, bias), None, None, cast(g_gamma, gamma), cast(g_beta, beta))
 
 
-def _keeps_output(spec) -> bool:
-    """Whether the backward of a fused block wants the block's forward output (``tcfd_fno_pointwise_bwd_out``): two layers,
-    both activations ReLU, no folded LayerNorm."""
+def _saved_kind(spec, ci: int, cm: int, co: int, P: int) -> int:
+    """What the backward kernel of a fused block wants the forward to keep (``tcfd_fno_pointwise_bwd_saved``): 0 nothing,
+    1 the block's OUTPUT (ReLU output activation: its sign is the mask; it is the next layer's input anyway, so it costs no
+    memory), 2 the PRE-activation of the output activation (GELU / SiLU / tanh on the tiled all-MFMA kernel: one more
+    activation-sized tensor per block instead of recomputing W2.h + Ws.skip in the backward)."""
     has_l1, act1, act2, _, eps = spec
-    return bool(has_l1) and eps is None and _act_code(act1) == 1 and _act_code(act2) == 1 \
-        and os.environ.get("TCFD_PW_BWD_YMASK", "1") != "0"
+    c1, c2 = _act_code(act1), _act_code(act2)
+    if not has_l1 or eps is not None or c1 is None or c2 is None:
+        return 0
+    return int(_lib.load().tcfd_fno_pointwise_bwd_saved(int(ci), int(cm), int(co), int(P), c1, c2))
 
 
 class _PointwiseFn(torch.autograd.Function):
@@ -822,24 +718,25 @@ class _PointwiseFn(torch.autograd.Function):
     recomputes the block from its inputs (nothing but the inputs is kept alive between forward and backward)."""
 
     @staticmethod
-    def forward(ctx, out, spec, *tensors):
+    def forward(ctx, out, kept, spec, *tensors):
         ctx.spec = spec
         ctx.present = [t is not None for t in tensors]
-        # ReLU / ReLU blocks keep their output too (it IS the next block's input: no extra memory): its sign is the mask
-        ctx.keeps_out = _keeps_output(spec)
-        ctx.save_for_backward(*([out] if ctx.keeps_out else []), *[t for t in tensors if t is not None])
+        # ``kept`` (see _saved_kind): the block's output (ReLU: its sign is the mask; it IS the next block's input, no extra
+        # memory) or its pre-activation (other activations), or None
+        ctx.keeps = kept is not None
+        ctx.save_for_backward(*([kept] if ctx.keeps else []), *[t for t in tensors if t is not None])
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, dout):
         saved = list(ctx.saved_tensors)
-        y = saved.pop(0) if ctx.keeps_out else None
+        y = saved.pop(0) if ctx.keeps else None
         it = iter(saved)
         tensors = [next(it) if p else None for p in ctx.present]
-        need = ctx.needs_input_grad[2:]
+        need = ctx.needs_input_grad[3:]
         hip = _hip_pointwise_backward(ctx.spec, dout, *tensors, need_dx=bool(need[0]), out=y)
         if hip is not None:
-            return (None, None, *[g if n else None for g, n in zip(hip, need)])
+            return (None, None, None, *[g if n else None for g, n in zip(hip, need)])
         with torch.enable_grad():
             leaves = [t.detach().requires_grad_(True) if (t is not None and n) else (t.detach() if t is not None else None)
                       for t, n in zip(tensors, need)]
@@ -847,7 +744,7 @@ class _PointwiseFn(torch.autograd.Function):
             wanted = [l for l, n in zip(leaves, need) if l is not None and n]
             got = iter(torch.autograd.grad(out, wanted, dout, allow_unused=True))
         grads = [next(got) if (l is not None and n) else None for l, n in zip(leaves, need)]
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class _SpectralLayerFn(torch.autograd.Function):
@@ -859,24 +756,24 @@ class _SpectralLayerFn(torch.autograd.Function):
     config 5)."""
 
     @staticmethod
-    def forward(ctx, out, x1, vh, cfg, v, *params):
+    def forward(ctx, out, kept, x1, vh, cfg, v, *params):
         ctx.cfg = cfg
         ctx.present = [t is not None for t in params]
-        ctx.keeps_out = _keeps_output(cfg[0])      # the layer output = the next layer's input: kept for its ReLU mask
-        ctx.save_for_backward(*([out] if ctx.keeps_out else []), x1, vh, v, *[t for t in params if t is not None])
+        ctx.keeps = kept is not None               # the layer output (ReLU mask) or the pre-activation, see _saved_kind
+        ctx.save_for_backward(*([kept] if ctx.keeps else []), x1, vh, v, *[t for t in params if t is not None])
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, dout):
         spec, n_conv, ccfg, fwd_cfg, inv_cfg = ctx.cfg
         saved = list(ctx.saved_tensors)
-        y = saved.pop(0) if ctx.keeps_out else None
+        y = saved.pop(0) if ctx.keeps else None
         x1, vh, v, *rest = saved
         it = iter(rest)
         params = [next(it) if p else None for p in ctx.present]
         conv_params, pw = params[:n_conv], params[n_conv:]
-        need = ctx.needs_input_grad[5:]
-        need_v = ctx.needs_input_grad[4]
+        need = ctx.needs_input_grad[6:]
+        need_v = ctx.needs_input_grad[5]
         # the lifting tail (skip = last time slice of v): its t-summed gradient stays compact and joins the last step of the
         # transform's adjoint in that transform's store loop -- no zero-filled (b, C, X, Y, T) tensor written and read back
         compact = spec[3] == 2 and need_v and os.environ.get("TCFD_COMPACT_SKIP_GRAD", "1") != "0"
@@ -896,72 +793,7 @@ class _SpectralLayerFn(torch.autograd.Function):
                 dv = dv + g_skip
         pgrads = [g if n else None for g, n in zip(hip[2:8], need[n_conv:])]
         cgrads = [g if n else None for g, n in zip(cgrads, need[:n_conv])]
-        return (None, None, None, None, dv, *cgrads, *pgrads)
-
-
-def _cache_chunk(batch: int, per_sample_bytes: int) -> int:
-    """Samples per chunk of the chunked inference layers: the convolution output of a chunk (the tensor the inverse transform
-    writes and the pointwise block reads straight back) is to stay inside the 256 MB Infinity Cache beside what streams past
-    it.  ``TCFD_FNO_CHUNK_MB`` is its size; 0 (the default) turns chunking off -- MEASURED SLOWER at config 5: forward 4.48 ms
-    whole batch, 4.90 / 5.42 / 8.08 ms at 160 / 96 / 48 MB.  Under the profiler the chunk launches are slower than their share
-    of the whole-batch launch (k_pointwise 55 us for 3 of 32 samples against 43, k_inv_ty2 26 against 22): a launch of 3 samples
-    is ~100 workgroups per XCD-round short of filling the chip for long, and nothing shows the Infinity Cache serving x1 any
-    faster than HBM serves it to kernels that are at 0.8 of their vector-issue bound anyway.  Kept as an opt-in experiment."""
-    mb = float(os.environ.get("TCFD_FNO_CHUNK_MB", "0"))
-    if mb <= 0 or per_sample_bytes <= 0:
-        return batch
-    return max(1, min(batch, int(mb * 2 ** 20 // per_sample_bytes)))
-
-
-def hip_layer_tail_chunked(oh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm, lin1, act1, lin2, skip, skip_conv=None,
-                           act2=None, skip_last_slice: bool = False) -> Optional[torch.Tensor]:
-    """Inverse transform + pointwise block of an inference layer, a few samples at a time.
-
-    Samples are independent in every kernel of the layer, and the convolution output x1 = irfftn(oh) is written by one kernel
-    only to be read back by the next: 839 MB out to HBM and in again per layer at config 5 -- 2 of the layer's 5 passes over the
-    activations.  Run chunk by chunk through ONE reused chunk-sized buffer, x1 never leaves the memory-side cache (the
-    solver's batch chunking of DESIGN section 4, applied to the FNO layer).  Same kernels on the same per-sample data:
-    bit-identical to the whole-batch calls.  None when the pointwise block is not covered (the caller composes the layer)."""
-    X, Y, T, t_pad, t_out, mx, my, mt = plan.key[:8]
-    b, co = oh.shape[:2]
-    real = plan.real
-    bc = _cache_chunk(b, co * X * Y * t_keep * (8 if real == torch.float64 else 4))
-    out = torch.empty(b, lin2.out_channels, X, Y, t_keep, dtype=real, device=oh.device)
-    x1 = torch.empty(min(bc, b), co, X, Y, t_keep, dtype=real, device=oh.device)
-    for s0 in range(0, b, bc):
-        s1 = min(b, s0 + bc)
-        xc = hip_truncated_irfftn(oh[s0:s1], plan, t_keep, norm=norm, out=x1[: s1 - s0])
-        r = hip_pointwise(xc, lin1, act1, lin2, skip=skip[s0:s1], skip_conv=skip_conv, act2=act2,
-                          skip_last_slice=skip_last_slice, out=out[s0:s1])
-        if r is None:
-            return None
-    return out
-
-
-def hip_inference_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None) -> Optional[torch.Tensor]:
-    """``act2(FFN(conv(v)) + skip_conv(v))`` (fno/sfno.py:607-614) without gradients: forward transform and contraction on the
-    whole batch, inverse transform + pointwise block chunk by chunk (``hip_layer_tail_chunked``).  None when not covered."""
-    if (torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for m in (conv, lin1, lin2, skip_conv) if m is not None
-                                                              for p in m.parameters()))):
-        return None
-    if (not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5 or v.shape[0] == 0 or not _fused_xy(v.shape[2], v.shape[3])
-            or not hasattr(conv, "_plain_args") or float(os.environ.get("TCFD_FNO_CHUNK_MB", "0")) <= 0):
-        return None
-    cls = type(conv)
-    if cls.forward not in (SpectralConvS.forward, SpectralConvT.forward) or cls.spectral_conv is not SpectralConvS.spectral_conv \
-            or cls._plain_args not in (SpectralConvS._plain_args, SpectralConvT._plain_args) \
-            or any(p.dtype != torch.float32 for p in conv.parameters()):
-        return None
-    cargs = conv._plain_args(v, None)
-    if cargs is None:
-        return None
-    weights, bias, delta, modes, t_pad, t_out, t_keep, norm = cargs
-    b = v.shape[0]
-    if _cache_chunk(b, weights[0].shape[1] * v.shape[2] * v.shape[3] * t_keep * 4) >= b:
-        return None          # one chunk: the plain calls
-    vh, plan = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
-    oh = hip_contract(vh, weights, bias, delta, modes)
-    return hip_layer_tail_chunked(oh, plan, t_keep, norm, lin1, act1, lin2, v, skip_conv=skip_conv, act2=act2)
+        return (None, None, None, None, None, dv, *cgrads, *pgrads)
 
 
 def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, skip_last_slice: bool = False,
@@ -1001,18 +833,20 @@ def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, ski
     if _pointwise_bwd_layout(lin1 is not None, b, co_conv, cm, lin2.out_channels, X * Y * t_keep, t_keep, T if mode == 2 else 0,
                              c1, c2, mode) is None:
         return None
+    spec = (lin1 is not None, act1, act2, mode, None)
+    kind = _saved_kind(spec, co_conv, cm, lin2.out_channels, X * Y * t_keep)
     with torch.no_grad():
         vh, plan = hip_truncated_rfftn(v, modes, t_pad=t_pad, t_out=t_out, norm=norm)
         oh = hip_contract(vh, weights, bias, delta, modes)
         x1 = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
+        z2 = torch.empty(b, lin2.out_channels, X, Y, t_keep, dtype=torch.float32, device=v.device) if kind == 2 else None
         out = hip_pointwise(x1, lin1, act1, lin2, skip=v if mode else None, skip_conv=skip_conv, act2=act2,
-                            skip_last_slice=skip_last_slice)
+                            skip_last_slice=skip_last_slice, pre=z2)
     if out is None:
         return None
-    spec = (lin1 is not None, act1, act2, mode, None)
     cfg = (spec, len(conv_params), (float(delta), tuple(modes), True, bias is not None),
            (tuple(v.shape), tuple(modes), t_pad, t_out, norm), ((X, Y, T, t_pad, t_out) + tuple(modes), t_keep, norm))
-    return _SpectralLayerFn.apply(out, x1, vh, cfg, v, *conv_params, *pw_t)
+    return _SpectralLayerFn.apply(out, out if kind == 1 else z2, x1, vh, cfg, v, *conv_params, *pw_t)
 
 
 _ACT_CODES = {nn.Identity: 0, nn.ReLU: 1, nn.GELU: 2, nn.SiLU: 3, nn.Tanh: 4}
@@ -1034,11 +868,12 @@ def _is_pointwise(conv) -> bool:
 
 def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, act2=None,
                   skip_last_slice: bool = False, norm: Optional[nn.GroupNorm] = None,
-                  out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                  out: Optional[torch.Tensor] = None, pre: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """out = act2( lin2(act1(lin1(x))) [+ skip_conv(skip) | + skip[..., -1:]] ) in ONE fused HIP kernel
     (``tcfd_fno_pointwise``); ``lin1=None`` makes it a single 1x1x1 convolution.  Returns ``None`` when the
     combination is not covered (channel counts, activation type, dtype, autograd) -- the caller then runs its
-    torch modules."""
+    torch modules.  ``pre`` (forward only, float32, the output's shape): also receives the pre-activation of ``act2``
+    (``tcfd_fno_pointwise_pre``: what the backward of a GELU / SiLU / tanh block reads instead of recomputing it)."""
     c1, c2 = _act_code(act1), _act_code(act2)
     if (c1 is None or c2 is None or not x.is_cuda or x.dtype not in (torch.float32, torch.float64) or not _is_pointwise(lin2)
             or (lin1 is not None and not _is_pointwise(lin1)) or (skip_conv is not None and not _is_pointwise(skip_conv))):
@@ -1059,16 +894,21 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
         if any(t is not None and t.requires_grad for t in tensors):
             # training: HIP forward, backward by recomputing the block with channel einsums under autograd
             # (torch's own Conv3d 1x1x1 backward takes SECONDS per layer at this size on ROCm)
-            with torch.no_grad():
-                out = hip_pointwise(x, lin1, act1, lin2, skip=skip, skip_conv=skip_conv, act2=act2,
-                                    skip_last_slice=skip_last_slice, norm=norm)
-            if out is None:
-                return None
             spec = (lin1 is not None, act1, act2, 1 if skip_conv is not None else (2 if skip_last_slice else 0),
                     norm.eps if norm is not None else None)
+            kind = _saved_kind(spec, x.shape[1], lin1.out_channels if lin1 is not None else x.shape[1], lin2.out_channels,
+                               x[0, 0].numel())
+            with torch.no_grad():
+                z2 = (torch.empty(x.shape[0], lin2.out_channels, *x.shape[2:], dtype=torch.float32, device=x.device)
+                      if kind == 2 else None)
+                out = hip_pointwise(x, lin1, act1, lin2, skip=skip, skip_conv=skip_conv, act2=act2,
+                                    skip_last_slice=skip_last_slice, norm=norm, pre=z2)
+            if out is None:
+                return None
             pw = lambda m, a: getattr(m, a) if m is not None else None
-            return _PointwiseFn.apply(out, spec, x, skip, pw(lin1, "weight"), pw(lin1, "bias"), lin2.weight, lin2.bias,
-                                      pw(skip_conv, "weight"), pw(skip_conv, "bias"), pw(norm, "weight"), pw(norm, "bias"))
+            return _PointwiseFn.apply(out, out if kind == 1 else z2, spec, x, skip, pw(lin1, "weight"), pw(lin1, "bias"),
+                                      lin2.weight, lin2.bias, pw(skip_conv, "weight"), pw(skip_conv, "bias"), pw(norm, "weight"),
+                                      pw(norm, "bias"))
     b, ci = x.shape[:2]
     co = lin2.out_channels
     cm = lin1.out_channels if lin1 is not None else ci
@@ -1091,6 +931,9 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     elif (tuple(out.shape) != (b, co) + tuple(x.shape[2:]) or out.dtype != torch.float32 or out.device != x.device
           or not out.is_contiguous() or (torch.is_grad_enabled() and out.requires_grad)):
         raise ValueError("out must be a contiguous float32 tensor of the block's output shape on x's device (forward only)")
+    if pre is not None and (pre.shape != out.shape or pre.dtype != torch.float32 or pre.device != x.device
+                            or not pre.is_contiguous() or norm is not None):
+        raise ValueError("pre must be a contiguous float32 tensor of the block's output shape on x's device (no folded LayerNorm)")
 
     def mat(conv, transpose):
         w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
@@ -1131,9 +974,9 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
         b2 = folded_bias
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        rc = lib.tcfd_fno_pointwise(x.data_ptr(), ptr(s_t), out.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst),
-                                    ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs, None,
-                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        rc = lib.tcfd_fno_pointwise_pre(x.data_ptr(), ptr(s_t), out.data_ptr(), ptr(pre), ptr(w1), ptr(b1), ptr(w2t), ptr(b2),
+                                        ptr(wst), ptr(bs), b, ci, cm, co, P, T, sT, c1, c2, mode, w2_bs, b2_bs, None,
+                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
         _note_torch_modules(f"pointwise block {ci} -> {cm} -> {co}")
         return None
@@ -1198,86 +1041,6 @@ def _hip_pointwise_f64(x, lin1, c1, lin2, skip, skip_conv, c2, skip_last_slice, 
         _note_torch_modules(f"float64 pointwise block {ci} -> {cm} -> {co}")
         return None
     _lib.check(rc, "tcfd_fno_pointwise_f64")
-    return out
-
-
-def hip_conv_pointwise(conv, v: torch.Tensor, mlp, skip: torch.Tensor, skip_conv=None, act2=None,
-                       skip_last_slice: bool = False, out_steps: Optional[int] = None) -> Optional[torch.Tensor]:
-    """``act2(mlp(conv(v)) + skip_conv(skip))`` (an SFNO layer, fno/sfno.py:607-614) or ``act2(skip[..., -1:] + mlp(conv(v)))``
-    (the lifting tail, :258-259) with the convolution's output kept on chip (``tcfd_fno_spectral_conv_pointwise``:
-    inverse t/y transform and pointwise block in one kernel; bit-identical to ``hip_spectral_conv`` + ``hip_pointwise``).
-    Inference path only; returns ``None`` -- before anything runs -- when the layer is not covered (autograd, fp64,
-    post-processed or resampled convolutions, widths other than 8 / 10, rows that do not fit a workgroup) and the caller
-    makes the two calls.  NOT the default: at config 5 it is slower than the two kernels (7.5 vs 5.9 ms per forward --
-    one row-sized workgroup per CU cannot hide what 4-8 small ones do); ``TCFD_FNO_FUSE_TAIL=1`` switches the models to it."""
-    if (not isinstance(mlp, PointwiseFFN) or not isinstance(conv, SpectralConvS) or not v.is_cuda or v.dtype != torch.float32
-            or v.dim() != 5 or not _pow2_xy(v.shape[2], v.shape[3])):
-        return None
-    if isinstance(conv, SpectralConvT) and not isinstance(conv.postprocess, nn.Identity):
-        return None
-    lin1, lin2 = mlp.linear1, mlp.linear2
-    c1, c2 = _act_code(mlp.activation), _act_code(act2)
-    if c1 is None or c2 is None or not (_is_pointwise(lin1) and _is_pointwise(lin2)) or (
-            skip_conv is not None and not _is_pointwise(skip_conv)):
-        return None
-    mods = [m for m in (conv, lin1, lin2, skip_conv) if m is not None]
-    if torch.is_grad_enabled() and (v.requires_grad or skip.requires_grad or any(
-            p.requires_grad for m in mods for p in m.parameters())):
-        return None
-    if any(p.dtype not in (torch.float32, torch.complex64) or p.device != v.device for m in mods for p in m.parameters()):
-        return None
-    b, ci, X, Y, T = v.shape
-    mx, my, mt = conv.modes
-    weights, bias = list(conv.weight), conv._bias_list()
-    cw = weights[0].shape[1]                                     # channels of the convolution's output
-    t_pad = T if getattr(conv, "temporal_padding", False) else 0
-    if out_steps is None:
-        out_steps = getattr(conv, "out_steps", None) or T
-    t_out, t_keep = out_steps + t_pad, out_steps
-    cm, co = lin1.out_channels, lin2.out_channels
-    if lin1.in_channels != cw or lin2.in_channels != cm or b == 0 or skip.dtype != torch.float32 or skip.device != v.device:
-        return None
-    mode, sT = 0, 0
-    if skip_conv is not None:
-        if tuple(skip.shape) != (b, cw, X, Y, t_keep) or skip_conv.in_channels != cw or skip_conv.out_channels != co:
-            return None
-        mode = 1
-    elif skip_last_slice:
-        if skip.shape[1] != co or tuple(skip.shape[2:-1]) != (X, Y) or skip.shape[0] != b:
-            return None
-        mode, sT = 2, skip.shape[-1]
-
-    def as_real(w, shape):
-        w = torch.view_as_real(w.detach()) if w.is_complex() else w.detach()
-        w = w.to(torch.float32).contiguous()
-        return w if tuple(w.shape) == shape else None
-
-    ws_ = [as_real(w, (ci, cw, mx, my, mt, 2)) for w in weights]
-    bs_ = [as_real(x, (mx, my, mt, 2)) for x in bias] if bias is not None else None
-    if any(w is None for w in ws_) or (bs_ is not None and any(x is None for x in bs_)):
-        return None
-    mat = lambda c_, tr: (c_.weight.detach().reshape(c_.out_channels, c_.in_channels).t() if tr else
-                          c_.weight.detach().reshape(c_.out_channels, c_.in_channels)).contiguous()
-    vec = lambda c_: c_.bias.detach().contiguous() if (c_ is not None and c_.bias is not None) else None
-    w1, w2t = mat(lin1, False), mat(lin2, True)
-    wst = mat(skip_conv, True) if skip_conv is not None else None
-    b1, b2, bsk = vec(lin1), vec(lin2), vec(skip_conv)
-    ptr = lambda t: t.data_ptr() if t is not None else None
-    v = v.detach().contiguous()
-    skip = skip.detach().contiguous()
-    plan = _plan((X, Y, T, t_pad, t_out, mx, my, mt), v.device)
-    out = torch.empty(b, co, X, Y, t_keep, dtype=torch.float32, device=v.device)
-    ws = plan.workspace(b, ci, cw)
-    fs, is_ = _norm_scales(conv.norm, X * Y * (T + t_pad), X * Y * t_out)
-    with torch.cuda.device(v.device):
-        rc = plan.lib.tcfd_fno_spectral_conv_pointwise(
-            plan.handle, v.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None, float(conv.delta),
-            out.data_ptr(), b, ci, cw, t_keep, fs, is_, 1, ws.data_ptr(), ws.numel(),
-            skip.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(wst), ptr(bsk), cm, co, c1, c2, mode, sT,
-            ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
-    if rc == -1 and b"not instantiated" in plan.lib.tcfd_last_error():
-        return None
-    _lib.check(rc, "tcfd_fno_spectral_conv_pointwise")
     return out
 
 
@@ -1794,9 +1557,6 @@ class LiftingOperator(nn.Module):
         _lib.check(rc, "tcfd_fno_pointwise")
         oh = hip_contract(v0h, weights, bias, delta, modes)
         lin = (self.mlp.linear1, self.mlp.activation, self.mlp.linear2) if isinstance(self.mlp, PointwiseFFN) else (None, None, self.mlp)
-        out = hip_layer_tail_chunked(oh, plan, t_keep, norm, *lin, skip, act2=self.activation, skip_last_slice=True)
-        if out is not None:
-            return out
         x1 = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
         if isinstance(self.mlp, PointwiseFFN):
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=skip, act2=self.activation,
@@ -1818,10 +1578,6 @@ class LiftingOperator(nn.Module):
             v = hip_pointwise(vp, None, None, self.proj, norm=self.norm)  # LayerNormnd folded into the projection
             if v is None:
                 v = self.proj(self.norm(vp))
-        if os.environ.get("TCFD_FNO_FUSE_TAIL", "0") == "1":   # opt-in: measured slower (see hip_conv_pointwise)
-            out = hip_conv_pointwise(self.sconv, v, self.mlp, v, act2=self.activation, skip_last_slice=True)
-            if out is not None:
-                return out
         lin = (self.mlp.linear1, self.mlp.activation, self.mlp.linear2) if isinstance(self.mlp, PointwiseFFN) else (None, None, self.mlp)
         out = hip_spectral_layer(self.sconv, v, *lin, act2=self.activation, skip_last_slice=True)
         if out is not None:             # training: convolution + tail as one autograd node
@@ -1974,18 +1730,9 @@ class SFNO(FNOBase):
             out_steps = self.out_steps if self.out_steps is not None else v.size(-1)
         v_res = v
         v = self.lifting_operator(v.unsqueeze(1))
-        fuse = os.environ.get("TCFD_FNO_FUSE_TAIL", "0") == "1"   # opt-in: measured slower (see hip_conv_pointwise)
         for conv, mlp, w, act in zip(self.spectral_conv, self.mlp, self.w, self.activations):
-            fused = hip_conv_pointwise(conv, v, mlp, v, skip_conv=w, act2=act) if fuse else None
-            if fused is not None:
-                v = fused
-                continue
             fused = hip_spectral_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
             if fused is not None:       # training: the whole layer as one autograd node
-                v = fused
-                continue
-            fused = hip_inference_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
-            if fused is not None:       # inference: the convolution output stays in the Infinity Cache, chunk by chunk
                 v = fused
                 continue
             x1 = conv(v)
