@@ -280,7 +280,7 @@ def cpu_baseline_sfno(budget_s):
 
 
 FNO_KINDS = {0: "fwd_ty", 1: "fwd_x", 2: "contract", 3: "inv_x", 4: "inv_ty", 5: "pointwise", 6: "pointwise_bwd", 7: "pointwise_1layer",
-             8: "contract_wgrad", 9: "other", 10: "pointwise_1layer_bwd", 11: "pointwise_fwd_ty"}
+             8: "contract_wgrad", 9: "other", 10: "pointwise_1layer_bwd"}
 
 
 def fno_kernel_times(fn, dev, reps=3, cap=4096):

@@ -275,17 +275,6 @@ int tcfd_fno_pointwise_pre(const void* x, const void* skip, void* out, void* pre
                            const void* b2, const void* wst, const void* bs, int batch, int ci, int cm, int co, long P,
                            int T, int skip_T, int act1, int act2, int skip_mode, long w2_bstride, long b2_bstride,
                            const void* pe, void* stream);
-/* The two-layer block (both activations `act` = 1 ReLU or 2 GELU, skip_mode 1 or 2) AND the forward t/y transform of its output
- * as the FIRST stage of `plan`'s spectral convolution, in one kernel: out (batch, co, X, Y, T) with T = the plan's T_in is written as
- * tcfd_fno_pointwise writes it (bit-identical), and its transform W1 (batch, co, X, 2 my mt) lands at the start of `workspace` --
- * the next layer's tcfd_fno_spectral_conv(plan, v = NULL, ...) starts from there and never reads `out` (fno/sfno.py:607-614: the
- * layer output feeds the next layer's SpectralConv; one activation-sized read per hidden layer less).  TCFD_EINVAL with "not
- * instantiated" in tcfd_last_error(), nothing launched, for shapes it does not cover (fp32 plans; Y = 64 / 128 / 256 with T <= 10
- * even; widths 4 / 8 / 10 with cm = 4 ci): the caller then makes the two calls. */
-int tcfd_fno_pointwise_fwd_ty(const tcfd_fno_plan* plan, const void* x, const void* skip, void* out, const void* w1,
-                              const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs, int batch, int ci,
-                              int cm, int co, int skip_T, int act, int skip_mode, double fwd_scale, void* workspace,
-                              size_t workspace_bytes, void* stream);
 /* The same block in float64 (every array double; no positional-encoding input; w2_bstride / b2_bstride as in
  * tcfd_fno_pointwise: per-batch-element offsets of w2t / b2, 0 = shared): what an SFNO converted
  * with .double() (fno/base.py:342-349) runs.  Widths 4, 6, 8, 10, 12, 16, 20, 24, 32, any hidden width. */
@@ -325,7 +314,7 @@ int tcfd_ns2d_profile_end(tcfd_ns2d_plan* plan, int capacity, int* count, int* k
  * launch stream (up to max_records launches).  profile_end synchronises on them and returns, per launch, the kind
  * (0 forward t/y transform, 1 forward x transform, 2 contraction, 3 inverse x transform, 4 inverse t/y transform, 5 two-layer
  * pointwise block, 6 its backward, 7 single-layer pointwise forms, 8 contraction weight gradient, 9 other, 10 backward of the
- * single-layer forms, 11 pointwise block fused with the next layer's forward t/y transform) and its duration in milliseconds.  Not for concurrent use with measured work on other threads. */
+ * single-layer forms) and its duration in milliseconds.  Not for concurrent use with measured work on other threads. */
 int tcfd_fno_profile_begin(int max_records);
 int tcfd_fno_profile_end(int capacity, int* count, int* kinds, float* ms);
 

@@ -1130,73 +1130,6 @@ def test_lifting_operator_through_the_spectrum_equals_the_materialised_projectio
         assert rel_l2(lift(v2), lift.activation(v02[..., -1:] + lift.mlp(lift.sconv(v02)))) < 5e-6
 
 
-@pytest.mark.parametrize("n,width,act,mode", [(256, 10, "ReLU", 1), (256, 10, "GELU", 2), (128, 10, "ReLU", 2), (64, 10, "GELU", 1),
-                                              (64, 4, "ReLU", 1), (64, 8, "GELU", 2), (256, 8, "ReLU", 1)])
-def test_pointwise_block_fused_with_the_next_forward_transform_is_bit_identical(n, width, act, mode, dev):
-    """tcfd_fno_pointwise_fwd_ty: the block of a layer AND the forward t / y transform of its output for the next layer's
-    SpectralConv (fno/sfno.py:607-614) in one kernel -- the block's output equals hip_pointwise's bit for bit (same arithmetic in
-    the same order), and the next convolution started from the workspace (no read of its input) equals the convolution of that
-    output bit for bit (the transform code is k_fwd_ty2's)."""
-    import torch.nn as nn
-    from torch_cfd_amd import fno
-
-    torch.manual_seed(n + width)
-    b, T = 3, 10
-    mlp = fno.PointwiseFFN(width, width, 4 * width, act).to(dev)
-    w = nn.Conv3d(width, width, 1).to(dev) if mode == 1 else None
-    nxt = fno.SpectralConvS(width, width, 8, 6, 5).to(dev)
-    a2 = getattr(nn, act)()
-    with torch.no_grad():
-        for p_ in nxt.parameters():
-            p_.copy_(torch.randn_like(p_) * 0.3)
-        x1 = torch.randn(b, width, n, n, T, device=dev)
-        skip = torch.randn(b, width, n, n, T, device=dev) if mode == 1 else torch.randn(b, width, n, n, 7, device=dev)
-        two = fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=skip, skip_conv=w, act2=a2, skip_last_slice=(mode == 2))
-        conv_two = nxt(two)
-        one = fno.hip_pointwise_fwd_ty(x1, mlp.linear1, mlp.activation, mlp.linear2, skip, w, a2, mode == 2, nxt)
-        assert one is not None, "shape not covered by the fused kernel"
-        assert torch.equal(one, two)
-        weights, bias, delta, modes, t_pad, t_out, t_keep, norm = nxt._plain_args(one)
-        conv_one = fno.hip_spectral_conv(torch.full_like(one, float("nan")), weights, bias, delta, modes, t_pad, t_out, t_keep, norm,
-                                         w1_in_workspace=True)      # (the input tensor must not be read: it holds NaNs)
-        assert torch.equal(conv_one, conv_two)
-    # not covered -> None, nothing launched: an odd number of steps, a width the kernel is not instantiated for, gradients on
-    with torch.no_grad():
-        assert fno.hip_pointwise_fwd_ty(x1[..., :7].contiguous(), mlp.linear1, mlp.activation, mlp.linear2,
-                                        skip[..., :7].contiguous() if mode == 1 else skip, w, a2, mode == 2, nxt) is None
-    assert fno.hip_pointwise_fwd_ty(x1.clone().requires_grad_(), mlp.linear1, mlp.activation, mlp.linear2, skip, w, a2, mode == 2, nxt) is None
-
-
-@pytest.mark.parametrize("act", ["ReLU", "GELU"])
-def test_sfno_inference_with_fused_layer_hand_off_equals_the_kernel_by_kernel_forward(act, dev, monkeypatch):
-    """SFNO.forward under no_grad hands every hidden layer's t / y transform to the kernel that produced the layer's input
-    (lifting tail and hidden blocks: TCFD_FNO_FUSE_NEXT, default on); the model output equals the kernel-by-kernel forward
-    bit for bit, also for the training-mode path taken under no_grad (eval() is not what switches it)."""
-    from torch_cfd_amd import fno
-
-    torch.manual_seed(3)
-    model = fno.SFNO(8, 8, 5, width=10, num_spectral_layers=3, activation=act).to(dev).eval()
-    x = torch.randn(2, 64, 64, 10, device=dev)
-    outs = {}
-    with torch.no_grad():
-        for flag in ("1", "0"):
-            monkeypatch.setenv("TCFD_FNO_FUSE_NEXT", flag)
-            outs[flag] = model(x)
-            outs[flag + "_20"] = model(x, out_steps=20)
-    assert torch.equal(outs["1"], outs["0"]) and torch.equal(outs["1_20"], outs["0_20"])
-    monkeypatch.setenv("TCFD_FNO_FUSE_NEXT", "1")
-    launched = []
-    real = fno.hip_pointwise_fwd_ty
-    monkeypatch.setattr(fno, "hip_pointwise_fwd_ty", lambda *a, **k: (launched.append(1), real(*a, **k))[1])
-    with torch.no_grad():
-        model(x)
-    assert len(launched) == 3          # lifting tail + the first two hidden blocks (the last one feeds the reduction)
-    model.train()
-    xg = x.clone().requires_grad_(True)
-    model(xg).sum().backward()         # training still runs (the fused hand-off declines under autograd)
-    assert torch.isfinite(xg.grad).all()
-
-
 @pytest.mark.parametrize("random_feats", [False, True])
 def test_lifting_projection_without_materialising_the_encoded_input(random_feats, dev):
     """hip_lift_project: proj(LayerNorm(v + positional encoding)) from the one-channel input, analytic statistics and

@@ -149,7 +149,6 @@ SIGNATURES = {
                                 _l, _vp, _vp]),
     "tcfd_fno_pointwise_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l,
                                     _l, _vp, _vp]),
-    "tcfd_fno_pointwise_fwd_ty": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _sz, _vp]),
     "tcfd_fno_pointwise_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _l, _l,
                                     _vp]),
     "tcfd_row_moments_f64": (_i, [_vp, _vp, _i, _l, _vp]),

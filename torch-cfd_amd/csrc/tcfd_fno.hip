@@ -32,7 +32,6 @@
 #include "../../include/tcfd.h"
 #include "tcfd_fft.hpp"
 #include "tcfd_fno_common.hpp"
-#include "tcfd_fno_pw.hpp"
 
 using namespace tcfd;
 typedef cx<float> cf;
@@ -974,8 +973,7 @@ static int spectral_conv_impl(const tcfd_fno_plan* p, const void* v, const void*
     ct* V = (ct*)(base + al256((size_t)batch * cmax * p->X * Q * sizeof(ct)));
     ct* O = (ct*)((unsigned char*)V + al256((size_t)batch * cin * 2 * p->mx * Q * sizeof(ct)));
     int rc;
-    // v == NULL: the first stage has run already -- W1 of the input sits at the start of the workspace (tcfd_fno_pointwise_fwd_ty)
-    if (v && (rc = do_fwd_ty<T>(p, (const T*)v, W, (long)batch * cin * p->X, (T)fwd_scale, st))) return rc;
+    if ((rc = do_fwd_ty<T>(p, (const T*)v, W, (long)batch * cin * p->X, (T)fwd_scale, st))) return rc;
     if ((rc = do_fwd_x<T>(p, W, V, (long)batch * cin, st))) return rc;
     if ((rc = do_contract<T>(contract_args<T>(V, O, weights, bias, delta, batch, cin, cout, p->mx, p->my, p->mt), use_mfma, st)))
         return rc;
@@ -984,14 +982,13 @@ static int spectral_conv_impl(const tcfd_fno_plan* p, const void* v, const void*
 }
 
 // Full spectral convolution.  v (b, ci, X, Y, T_in) real -> out (b, co, X, Y, t_keep) real (the last t_keep of the T_out
-// reconstructed steps) in the plan's precision.  v == NULL: the input's forward t/y transform is already in the workspace
-// (written there by tcfd_fno_pointwise_fwd_ty, the previous layer's pointwise block), the call starts at the x transform.  weights[k] (ci, co, mx, my, mt, 2), bias[k] (mx, my, mt, 2) or NULL.
+// reconstructed steps) in the plan's precision.  weights[k] (ci, co, mx, my, mt, 2), bias[k] (mx, my, mt, 2) or NULL.
 // fwd_scale / inv_scale: normalisation of rfftn / irfftn ("backward": 1 and 1/(X*Y*T_out)).
 extern "C" int tcfd_fno_spectral_conv(const tcfd_fno_plan* p, const void* v, const void* const* weights,
                                       const void* const* bias, double delta, void* out, int batch, int cin, int cout,
                                       int t_keep, double fwd_scale, double inv_scale, int use_mfma, void* ws,
                                       size_t ws_bytes, void* stream) {
-    if (!p || !weights || !out) return FAIL(TCFD_EINVAL, "fno_spectral_conv: null argument");
+    if (!p || !v || !weights || !out) return FAIL(TCFD_EINVAL, "fno_spectral_conv: null argument");
     if (batch <= 0 || cin <= 0 || cout <= 0 || t_keep <= 0 || t_keep > p->T_out)
         return FAIL(TCFD_EINVAL, "fno_spectral_conv: bad sizes");
     const size_t need = tcfd_fno_workspace_bytes(p, batch, cin, cout);
@@ -1079,198 +1076,6 @@ extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, vo
     return tcfd_fno_inverse_trunc_acc(p, vh, out, nullptr, batch, c, t_keep, inv_scale, ws, ws_bytes, stream);
 }
 
-// ------------------------------------------------------------------ pointwise block + the NEXT layer's forward t/y transform
-// v' = act(FFN(x1) + Ws v) is written by k_pointwise and read straight back by the next layer's k_fwd_ty2: one activation-sized
-// read per hidden layer (839 MB at config 5).  Here ONE workgroup owns the row (b, x) of all CO channels: 256 lanes run the
-// pointwise block on NPT packed pairs of points each (the arithmetic of k_pointwise, pw_core / pw_skip_conv, in the same
-// order: identical output bits), store v' AND keep it in registers (NPT x CO packed pairs), then feed the channel slabs
-// [y][t] three at a time through the transform of k_fwd_ty2 (same code: 16 lanes x 16 elements per 256-point transform, the
-// t-DFT on the kept ky) out of 30 KB of LDS -- the 100 KB a whole row of channels needs (the fused tail of round 2, one
-// workgroup per CU, measured slower) never has to be resident.  The pair loop is unrolled: no store sits between the
-// scalar weight loads of different pairs, and the next pair's loads are hoisted above the current pair's arithmetic.
-template <int Y, int EPT, int NPT, int CI, int CM, int CO, int MODE, int ACT>
-__global__ __launch_bounds__(256) void k_pw_fwd_ty(PwArgs a, cf* __restrict__ w1out, const cf* __restrict__ tw_y,
-                                                   const cf* __restrict__ tw_tf, int T, int t_pad, int mt, int my, float scale,
-                                                   int X, unsigned mt_magic) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int G = Y / EPT, NC = 3;                 // three channel slabs per round: 3 x P x G = 240 of the 256 lanes at T = 10
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / X, xr = blockIdx.x - b * X;
-    const int PS = Y * T, NPAIR = PS / 2, P = (T + 1) / 2, Tp = T + t_pad, Q = 2 * my * mt;
-    const size_t per = (size_t)PS * sizeof(float) > (size_t)P * Y * sizeof(cf) ? (size_t)PS * sizeof(float) : (size_t)P * Y * sizeof(cf);
-    cf* twt = reinterpret_cast<cf*>(smem_raw + (size_t)NC * per);
-    for (int i = tid; i < mt * Tp; i += 256) twt[i] = tw_tf[i];
-    // ---- phase 1: the block on this row's points (pair k = tid + 256 j holds points 2k, 2k + 1 of the row)
-    v2f keep[NPT][CO];
-    const long row0 = (long)xr * PS;                                        // first point of the row inside a channel
-    {
-        v2f xin[NPT][CI], sin[NPT][MODE == 1 ? CI : 1];
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {                                      // every load of the row first
-            const int k = tid + 256 * j;
-            const bool live = k < NPAIR;
-            const float* xb = a.x + (size_t)b * CI * a.P + row0 + 2 * (live ? k : 0);
-#pragma unroll
-            for (int i = 0; i < CI; ++i) xin[j][i] = PW_LOAD(reinterpret_cast<const v2f*>(xb + (size_t)i * a.P));
-            if constexpr (MODE == 1) {
-                const float* sb = a.s + (size_t)b * CI * a.P + row0 + 2 * (live ? k : 0);
-#pragma unroll
-                for (int i = 0; i < CI; ++i) sin[j][i] = PW_LOAD(reinterpret_cast<const v2f*>(sb + (size_t)i * a.P));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int k = tid + 256 * j;
-            const bool live = k < NPAIR;
-            v2f o[CO];
-            pw_core<CI, CM, CO, true, v2f, ACT>(a, b, xin[j], o);
-            if constexpr (MODE == 1) {
-                pw_skip_conv<CI, CO, v2f>(a, sin[j], o);
-            } else if constexpr (MODE == 2) {
-                const long xy = (long)xr * Y + (2 * (live ? k : 0)) / T;    // T even: both points of a pair share (x, y)
-                const long sP = (a.P / a.T) * a.sT;
-                const float* sb = a.s + (size_t)b * CO * sP + xy * a.sT + (a.sT - 1);
-#pragma unroll
-                for (int c = 0; c < CO; ++c) o[c] += (v2f)sb[(size_t)c * sP];
-            }
-#pragma unroll
-            for (int c = 0; c < CO; ++c) keep[j][c] = pw_act(o[c], ACT);
-        }
-        float* ob = a.out + (size_t)b * CO * a.P + row0;
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int k = tid + 256 * j;
-            if (k < NPAIR) {
-#pragma unroll
-                for (int c = 0; c < CO; ++c) __builtin_nontemporal_store(keep[j][c], reinterpret_cast<v2f*>(ob + (size_t)c * a.P + 2 * k));
-            }
-        }
-    }
-    // ---- phase 2: the channel slabs through the forward t/y transform, NC at a time (k_fwd_ty2's body)
-    const int tr = tid / G, jj = tid % G;
-    const int s = tr / P, p = tr - s * P;                                    // slab of the round, time pair
-    const float hsc = 0.5f * scale;
-#pragma unroll
-    for (int c0 = 0; c0 < CO; c0 += NC) {
-        constexpr int dummy = 0; (void)dummy;
-        const int nc = CO - c0 < NC ? CO - c0 : NC;
-        __syncthreads();                                                     // the previous round's spectra have been consumed
-#pragma unroll
-        for (int u = 0; u < NC; ++u) {
-            if (c0 + u < CO) {
-                v2f* slab = reinterpret_cast<v2f*>(smem_raw + (size_t)u * per);
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) {
-                    const int k = tid + 256 * j;
-                    if (k < NPAIR) slab[k] = keep[j][c0 + u < CO ? c0 + u : 0];
-                }
-            }
-        }
-        __syncthreads();
-        const bool active = s < nc;
-        cf x[EPT];
-        if (active) {
-            const float* sl = reinterpret_cast<const float*>(smem_raw + (size_t)s * per) + (size_t)jj * T + 2 * p;
-#pragma unroll
-            for (int t = 0; t < EPT; ++t) x[t] = *reinterpret_cast<const cf*>(sl + (size_t)t * G * T);
-        }
-        __syncthreads();      // every transform of the round has its input: the slab bytes become the exchange buffers
-        cf* lds = reinterpret_cast<cf*>(smem_raw + (size_t)(active ? s : 0) * per) + (size_t)p * Y;
-        if (active) {
-            tile_fft<float, Y, EPT, -1, 1, true, false>(x, lds, tw_y, jj, 0);
-#pragma unroll
-            for (int t = 0; t < EPT; ++t) lds[jj + t * G] = x[t];
-        }
-        __syncthreads();
-        if (active) {
-            cf* dst = w1out + ((size_t)((size_t)b * CO + c0 + s) * X + xr) * Q;
-            const cf* zbase = reinterpret_cast<const cf*>(smem_raw + (size_t)s * per);
-            const int ntask = (my + 1) * mt;
-            for (int task = p * G + jj; task < ntask; task += P * G) {
-                const int ky = mt == 1 ? task : (int)__umulhi((unsigned)task, mt_magic);
-                const int kt = task - ky * mt;
-                const int kyn = ky ? Y - ky : 0;
-                const cf* w = twt + (size_t)kt * Tp + t_pad;
-                float sce = 0, sdf = 0, scf = 0, sde = 0;
-                for (int pp = 0; pp < P; ++pp) {
-                    const cf za = zbase[(size_t)pp * Y + ky], zb = zbase[(size_t)pp * Y + kyn];
-                    const float c0r = za.x + zb.x, d0 = za.y - zb.y;
-                    const float c1 = za.y + zb.y, d1 = zb.x - za.x;
-                    const cf w0 = w[2 * pp];
-                    sce += c0r * w0.x; sdf += d0 * w0.y; scf += c0r * w0.y; sde += d0 * w0.x;
-                    if (2 * pp + 1 < T) {
-                        const cf w1v = w[2 * pp + 1];
-                        sce += c1 * w1v.x; sdf += d1 * w1v.y; scf += c1 * w1v.y; sde += d1 * w1v.x;
-                    }
-                }
-                if (ky < my) dst[(size_t)ky * mt + kt] = mk<float>((sce - sdf) * hsc, (scf + sde) * hsc);
-                if (ky >= 1) dst[(size_t)(2 * my - ky) * mt + kt] = mk<float>((sce + sdf) * hsc, (scf - sde) * hsc);
-            }
-        }
-    }
-}
-
-template <int Y, int NPT, int CI, int CM, int CO>
-static int launch_pw_fwd_ty(const tcfd_fno_plan* p, const PwArgs& a, cf* w1out, int batch, float scale, hipStream_t st) {
-    FnoProfScope prof(FNO_K_POINTWISE_FWD_TY, st);
-    constexpr int EPT = TyCfg2<Y, float>::EPT;
-    const int T = p->T_in, P = (T + 1) / 2;
-    const size_t per = std::max((size_t)Y * T * sizeof(float), (size_t)P * Y * sizeof(cf));
-    const size_t lds = 3 * per + (size_t)p->mt * p->Tp * sizeof(cf);
-    const unsigned magic = p->mt > 1 ? (unsigned)(((1ull << 32) + p->mt - 1) / p->mt) : 0u;
-    const dim3 grid((unsigned)((long)batch * p->X));
-#define PWFT_LAUNCH(MODE_, ACT_)                                                                                              \
-    {                                                                                                                        \
-        auto kern = k_pw_fwd_ty<Y, EPT, NPT, CI, CM, CO, MODE_, ACT_>;                                                       \
-        int rc = set_lds_attr(kern, lds);                                                                                    \
-        if (rc) return rc;                                                                                                   \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, w1out, (const cf*)p->tw_y, (const cf*)p->tw_tf, T, p->t_pad,   \
-                           p->mt, p->my, scale, p->X, magic);                                                                \
-    }
-    if (a.skip_mode == 1 && a.act1 == 1) PWFT_LAUNCH(1, 1)
-    else if (a.skip_mode == 1 && a.act1 == 2) PWFT_LAUNCH(1, 2)
-    else if (a.skip_mode == 2 && a.act1 == 1) PWFT_LAUNCH(2, 1)
-    else if (a.skip_mode == 2 && a.act1 == 2) PWFT_LAUNCH(2, 2)
-    else return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: not instantiated (skip_mode %d, activation %d)", a.skip_mode, a.act1);
-#undef PWFT_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// out = act(W2 . act(W1 . x + b1) + b2 + Ws . skip + bs | + skip[..., -1:])  (tcfd_fno_pointwise, two-layer form, both activations
-// `act` = ReLU or GELU)  AND  the forward t/y transform of `out` as the plan's first stage -- W1 (batch, co, X, 2 my mt) at the
-// start of `workspace`, where the next tcfd_fno_spectral_conv(plan, v = NULL, ...) picks it up.  out (batch, co, X, Y, T) with T = the plan's T_in.
-// TCFD_EINVAL with "not instantiated" in tcfd_last_error() (nothing launched) for shapes the kernel does not cover (widths other
-// than 4 / 8 / 10 with cm = 4 ci, fp64 plans, odd T, Y other than 64 / 128 / 256, T > 10): callers then make the two calls.
-extern "C" int tcfd_fno_pointwise_fwd_ty(const tcfd_fno_plan* p, const void* x, const void* skip, void* out, const void* w1,
-                                         const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,
-                                         int batch, int ci, int cm, int co, int skip_T, int act, int skip_mode,
-                                         double fwd_scale, void* ws, size_t ws_bytes, void* stream) {
-    if (!p || !x || !out || !w1 || !w2t || !ws || batch <= 0) return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: bad argument");
-    if (skip_mode != 1 && skip_mode != 2) return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: not instantiated (skip_mode %d)", skip_mode);
-    if (!skip || (skip_mode == 1 && !wst) || (skip_mode == 2 && skip_T <= 0)) return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: skip input missing");
-    const int T = p->T_in;
-    if (p->dtype != TCFD_C64 || (T & 1) || !fft_len(p->Y) || force_dft() || (act != 1 && act != 2))
-        return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: not instantiated (fp32 plans, even T, FFT lengths, ReLU / GELU)");
-    if (ws_bytes < tcfd_fno_workspace_bytes(p, batch, co, co)) return FAIL(TCFD_EWORKSPACE, "workspace too small");
-    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)(skip_mode == 1 ? skip : nullptr)) % 8 != 0)
-        return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: not instantiated (unaligned)");
-    PwArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = (const float*)x; a.s = (const float*)skip; a.out = (float*)out;
-    a.w1 = (const float*)w1; a.b1 = (const float*)b1; a.w2t = (const float*)w2t; a.b2 = (const float*)b2;
-    a.wst = (const float*)wst; a.bs = (const float*)bs;
-    a.P = (long)p->X * p->Y * T; a.T = T; a.sT = skip_T; a.act1 = a.act2 = act; a.skip_mode = skip_mode; a.cm = cm;
-    const int npair = p->Y * T / 2, npt = (npair + 255) / 256;
-    hipStream_t st = (hipStream_t)stream;
-#define PWFT_CASE(Y_, NPT_, CI_, CM_, CO_)                                                                   \
-    if (p->Y == Y_ && npt == NPT_ && ci == CI_ && cm == CM_ && co == CO_)                                     \
-        return launch_pw_fwd_ty<Y_, NPT_, CI_, CM_, CO_>(p, a, (cf*)ws, batch, (float)fwd_scale, st);
-    PWFT_CASE(256, 5, 10, 40, 10) PWFT_CASE(256, 5, 8, 32, 8) PWFT_CASE(128, 3, 10, 40, 10) PWFT_CASE(64, 2, 10, 40, 10)
-    PWFT_CASE(64, 2, 4, 16, 4) PWFT_CASE(64, 2, 8, 32, 8)
-#undef PWFT_CASE
-    return FAIL(TCFD_EINVAL, "fno_pointwise_fwd_ty: not instantiated (Y = %d, T = %d, channels %d -> %d -> %d)", p->Y, T, ci, cm, co);
-}
 // Contraction alone on caller-provided truncated spectra (tests, MFMA vs VALU cross-check); dtype TCFD_C64 / TCFD_C128.
 extern "C" int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, double delta,
                                  void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma,

@@ -35,8 +35,7 @@ static int env_int(const char* name, int dflt) {
 // HIP events on ITS launch stream (the solver's tcfd_ns2d_profile_begin / _end, process-wide here: the pointwise entry points
 // have no plan).  Off: one load of a global flag per launch.  kinds:
 enum { FNO_K_FWD_TY = 0, FNO_K_FWD_X = 1, FNO_K_CONTRACT = 2, FNO_K_INV_X = 3, FNO_K_INV_TY = 4, FNO_K_POINTWISE = 5,
-       FNO_K_POINTWISE_BWD = 6, FNO_K_POINTWISE_1 = 7 /* single-layer forms */, FNO_K_CONTRACT_WGRAD = 8, FNO_K_OTHER = 9, FNO_K_POINTWISE_BWD_1 = 10 /* backward of the single-layer forms */,
-       FNO_K_POINTWISE_FWD_TY = 11 /* pointwise block + the next layer's forward t/y transform in one kernel */ };
+       FNO_K_POINTWISE_BWD = 6, FNO_K_POINTWISE_1 = 7 /* single-layer forms */, FNO_K_CONTRACT_WGRAD = 8, FNO_K_OTHER = 9, FNO_K_POINTWISE_BWD_1 = 10 /* backward of the single-layer forms */ };
 extern bool tcfd_fno_prof_on;                       // tcfd_fno.hip
 int tcfd_fno_prof_open(int kind, hipStream_t st);   // -> record index or -1
 void tcfd_fno_prof_close(int idx, hipStream_t st);

@@ -168,10 +168,8 @@ def dense_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_p
 
 def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad: int = 0,
                       t_out: Optional[int] = None, t_keep: Optional[int] = None, norm: str = "backward",
-                      use_mfma: bool = True, w1_in_workspace: bool = False) -> torch.Tensor:
+                      use_mfma: bool = True) -> torch.Tensor:
     """irfftn(contract(rfftn(left_pad_t(v, t_pad))), s=(X, Y, t_out))[..., -t_keep:] on the HIP kernels.
-    ``w1_in_workspace`` (inference, see ``hip_pointwise_fwd_ty``): the forward t/y transform of ``v`` was written into the plan's
-    workspace by the kernel that produced ``v``; the call starts at the x transform and does not read ``v``.
 
     v (b, Ci, X, Y, T) fp32 or fp64 HIP tensor (fp64: FNOBase.double(), fno/base.py:342-349 -- the same kernels,
     instantiated for double); weights: 4 tensors (Ci, Co, mx, my, mt) complex or (Ci, Co, mx, my, mt, 2) real of the
@@ -218,7 +216,7 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     fs, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     with torch.cuda.device(v.device):
         rc = plan.lib.tcfd_fno_spectral_conv(
-            plan.handle, None if w1_in_workspace else v.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None,
+            plan.handle, v.data_ptr(), _ptr_array(ws_), _ptr_array(bs_) if bs_ is not None else None,
             float(delta), out.data_ptr(), b, ci, co, t_keep, fs, is_, 1 if use_mfma else 0,
             ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_spectral_conv")
@@ -986,58 +984,6 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
     return out
 
 
-def hip_pointwise_fwd_ty(x: torch.Tensor, lin1, act1, lin2, skip, skip_conv, act2, skip_last_slice: bool,
-                         next_conv) -> Optional[torch.Tensor]:
-    """The block of ``hip_pointwise`` (two layers, ReLU or GELU) AND the forward t/y transform of its output as the first stage of
-    ``next_conv``'s spectral convolution, in ONE kernel (``tcfd_fno_pointwise_fwd_ty``): the output -- bit-identical to
-    ``hip_pointwise`` -- is written once and not read back by the next layer, whose ``hip_spectral_conv(..., w1_in_workspace=True)``
-    starts at the x transform (fno/sfno.py:607-614: a layer's output feeds the next layer's SpectralConv).  Inference only.
-    None (nothing launched) when the shape is not covered; the caller then makes the two calls."""
-    if (torch.is_grad_enabled() and (x.requires_grad or skip.requires_grad or any(
-            p.requires_grad for m in (lin1, lin2, skip_conv, next_conv) if m is not None for p in m.parameters()))):
-        return None
-    c1, c2 = _act_code(act1), _act_code(act2)
-    if (c1 != c2 or c1 not in (1, 2) or lin1 is None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5
-            or skip is None or skip.dtype != torch.float32 or not _is_pointwise(lin1) or not _is_pointwise(lin2)
-            or (skip_conv is not None and not _is_pointwise(skip_conv)) or type(next_conv) is not SpectralConvS
-            or os.environ.get("TCFD_FNO_FUSE_NEXT", "1") == "0"):
-        return None
-    b, ci, X, Y, T = x.shape
-    cm, co = lin1.out_channels, lin2.out_channels
-    if (lin1.in_channels != ci or lin2.in_channels != cm or next_conv.weight[0].shape[0] != co or not _fused_xy(X, Y)
-            or any(p.dtype != torch.float32 for m in (lin1, lin2, skip_conv) if m is not None for p in m.parameters())):
-        return None
-    mode = 1 if skip_conv is not None else (2 if skip_last_slice else 0)
-    if mode == 1 and (skip.shape != x.shape or skip_conv.in_channels != ci or skip_conv.out_channels != co):
-        return None
-    if mode == 2 and (skip.shape[1] != co or skip.shape[2:-1] != x.shape[2:-1]):
-        return None
-    if mode == 0:
-        return None
-    weights, _, _, modes, t_pad, t_out, _, norm = next_conv._plain_args(torch.empty(0, co, X, Y, T, device="meta"))
-    plan = _plan((X, Y, T, t_pad, t_out) + tuple(modes), x.device, torch.float32)
-    ws = plan.workspace(b, co, weights[0].shape[1])
-    fs, _ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
-    x, s_t = x.contiguous(), skip.contiguous()
-    out = torch.empty(b, co, X, Y, T, dtype=torch.float32, device=x.device)
-    mat = lambda conv, tr: (conv.weight.detach().reshape(conv.out_channels, conv.in_channels).t() if tr
-                            else conv.weight.detach().reshape(conv.out_channels, conv.in_channels)).contiguous()
-    bias = lambda c: c.bias.detach().contiguous() if (c is not None and c.bias is not None) else None
-    w1, w2t, wst = mat(lin1, False), mat(lin2, True), (mat(skip_conv, True) if skip_conv is not None else None)
-    b1, b2, bs = bias(lin1), bias(lin2), bias(skip_conv)
-    ptr = lambda t: t.data_ptr() if t is not None else None
-    lib = _lib.load()
-    with torch.cuda.device(x.device):
-        rc = lib.tcfd_fno_pointwise_fwd_ty(plan.handle, x.data_ptr(), s_t.data_ptr(), out.data_ptr(), ptr(w1), ptr(b1), ptr(w2t), ptr(b2),
-                                           ptr(wst), ptr(bs), b, ci, cm, co, skip.shape[-1] if mode == 2 else 0, c1, mode, fs,
-                                           ws.data_ptr(), ws.numel(),
-                                           ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-    if rc == -1 and b"not instantiated" in lib.tcfd_last_error():
-        return None
-    _lib.check(rc, "tcfd_fno_pointwise_fwd_ty")
-    return out
-
-
 def _hip_pointwise_f64(x, lin1, c1, lin2, skip, skip_conv, c2, skip_last_slice, norm=None) -> Optional[torch.Tensor]:
     """The block in float64 (``tcfd_fno_pointwise_f64``); forward only -- under autograd (or for a width that is not
     instantiated) ``None``: the layer's torch modules then run, on the device.  ``norm`` (LayerNormnd in front of a
@@ -1548,7 +1494,7 @@ class LiftingOperator(nn.Module):
             self.activation = nn.Identity()
             self.mlp = nn.Conv3d(width, width, kernel_size=1)
 
-    def _through_the_spectrum(self, vin, next_conv=None):
+    def _through_the_spectrum(self, vin):
         """Inference form of the whole operator that never forms the projected tensor v0 = proj(norm(pe(v))) (b, width, X, Y, T):
         its kept modes are an affine map of the kept modes of the ONE input channel (``tcfd_fno_lift_spectrum``: the transform
         is linear, the projection a per-sample affine map of v + table), and the tail needs only v0's last time slice
@@ -1613,31 +1559,18 @@ class LiftingOperator(nn.Module):
         lin = (self.mlp.linear1, self.mlp.activation, self.mlp.linear2) if isinstance(self.mlp, PointwiseFFN) else (None, None, self.mlp)
         x1 = hip_truncated_irfftn(oh, plan, t_keep, norm=norm)
         if isinstance(self.mlp, PointwiseFFN):
-            if next_conv is not None:   # the tail AND the first hidden layer's forward t / y transform in one kernel
-                out = hip_pointwise_fwd_ty(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip, None, self.activation,
-                                           True, next_conv)
-                if out is not None:
-                    return out, True
             out = hip_pointwise(x1, self.mlp.linear1, self.mlp.activation, self.mlp.linear2, skip=skip, act2=self.activation,
                                 skip_last_slice=True)
         else:
             out = hip_pointwise(x1, None, None, self.mlp, skip=skip, act2=self.activation, skip_last_slice=True)
-        return (out if out is not None else self.activation(skip + self.mlp(x1))), False
+        return out if out is not None else self.activation(skip + self.mlp(x1))
 
     def forward(self, v):
-        return self.forward_into(v, None)[0]
-
-    def forward_into(self, v, next_conv):
-        """``forward(v)`` plus a flag: True when the operator's last kernel also wrote the forward t / y transform of its output
-        into ``next_conv``'s workspace (inference, ``hip_pointwise_fwd_ty``) -- the caller then skips that stage."""
         assert self.latent_steps <= v.size(-1)
         vin = v
-        res = self._through_the_spectrum(vin, next_conv)
-        if res is not None:
-            return res
-        return self._forward_materialised(vin), False
-
-    def _forward_materialised(self, vin):
+        out = self._through_the_spectrum(vin)
+        if out is not None:
+            return out
         v = hip_lift_project(vin, self.pe.encoding(vin), self.norm, self.proj,
                              consts=self.pe.table_constants(vin)) if vin.shape[1] == 1 else None
         if v is None:
@@ -1796,29 +1729,13 @@ class SFNO(FNOBase):
         if out_steps is None:
             out_steps = self.out_steps if self.out_steps is not None else v.size(-1)
         v_res = v
-        convs = list(self.spectral_conv)
-        if type(self.lifting_operator) is LiftingOperator:
-            # ready: the lifting tail already wrote the forward t / y transform of its output for the first hidden layer
-            v, ready = self.lifting_operator.forward_into(v.unsqueeze(1), convs[0] if convs else None)
-        else:
-            v, ready = self.lifting_operator(v.unsqueeze(1)), False
-        for i, (conv, mlp, w, act) in enumerate(zip(convs, self.mlp, self.w, self.activations)):
-            fused = None if ready else hip_spectral_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
+        v = self.lifting_operator(v.unsqueeze(1))
+        for conv, mlp, w, act in zip(self.spectral_conv, self.mlp, self.w, self.activations):
+            fused = hip_spectral_layer(conv, v, mlp.linear1, mlp.activation, mlp.linear2, skip_conv=w, act2=act)
             if fused is not None:       # training: the whole layer as one autograd node
                 v = fused
                 continue
-            if ready:                   # inference: the previous block wrote W1 of v into the plan's workspace
-                weights, bias, delta, modes, t_pad, t_out, t_keep, norm = conv._plain_args(v)
-                x1 = hip_spectral_conv(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, w1_in_workspace=True)
-            else:
-                x1 = conv(v)
-            ready = False
-            nxt = convs[i + 1] if i + 1 < len(convs) else None
-            fused = (hip_pointwise_fwd_ty(x1, mlp.linear1, mlp.activation, mlp.linear2, v, w, act, False, nxt)
-                     if nxt is not None else None)
-            if fused is not None:       # ... and this one writes W1 of ITS output: the next layer does not read v at all
-                v, ready = fused, True
-                continue
+            x1 = conv(v)
             fused = hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
             v = fused if fused is not None else act(mlp(x1) + w(v))
         out = self.output_operator.fused_forward(v, v_res, self.reduction, out_steps) if type(self.output_operator) is OutConv else None
