@@ -461,17 +461,17 @@ def sfno_config5(dev, with_cpu=True):
             blk = lambda: fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=v, skip_conv=w, act2=act)
             assert blk() is not None
             t_blk = timeit(blk, 20)
-            # the backward of the same block (k_pointwise_bwd_mfma): reads x, skip, dout and the block's forward output (its ReLU
-            # mask, tcfd_fno_pointwise_bwd_out), writes dx, dskip = 6 A_H
+            # the backward of the same block (k_pwb_tiles, csrc/tcfd_fno_tiles.hip): reads x, skip, dout and the block's forward output
+            # (its ReLU mask, tcfd_fno_pointwise_bwd_out), writes dx, dskip = 6 A_H
             spec = (True, mlp.activation, act, 1, None)
             y_blk = blk()
-            keeps = fno._saved_kind(spec, 10, 40, 10, 256 * 256 * 10) == 1    # ReLU / ReLU (the reference's default): the 71-product kernel
+            keeps = fno._saved_kind(spec, 10, 40, 10, 256 * 256 * 10) == 1    # ReLU / ReLU (the reference's default): the output is handed over
             bwd = lambda: fno._hip_pointwise_backward(spec, x1, v, v, mlp.linear1.weight, mlp.linear1.bias, mlp.linear2.weight,
                                                       mlp.linear2.bias, w.weight, w.bias, None, None, out=y_blk if keeps else None)
             t_bwd = timeit(bwd, 10)
             del y_blk
-            n_mfma = 71 if keeps else 93
-            useful_mac = 2300 if keeps else 2760
+            n_mfma = 59                              # v_mfma_f32_16x16x4_f32 per 16 points at width 10 (header of tcfd_fno_tiles.hip)
+            useful_mac = 2260                        # W1 x, W2^T g2, W1^T g1, Ws^T g2, three weight-gradient outer products, biases
         del x1, v
         # `roofline` prices the kernel AS IT RUNS INSIDE model(x) (library events around each launch, fno_kernel_times): that is
         # what profiles/r05_sfno_forward_kernel_stats.csv shows.  The isolated loop on fresh randn tensors above reads slower
@@ -510,7 +510,7 @@ def sfno_config5(dev, with_cpu=True):
                                "branches per wave (SQ_INSTS_SALU ~ SQ_INSTS_VALU in profiles/r04_sfno_pmc.txt): 571 us; with the "
                                "activations as template parameters 475 us; with the two inputs read non-temporally (late round 4) 444 us",
                 "kernels_from_profile": kern_table or None,
-                "backward_kernel": {"kernel": "k_pointwise_bwd_mfma<10,40,10> (+ the host-side sum of its per-wave partials)",
+                "backward_kernel": {"kernel": "k_pwb_tiles<10,40,10> (tiled all-MFMA backward of the block; in-model launch time)",
                                     "algo_bytes_per_launch": (6 if keeps else 5) * A_H, "avg_launch_ms": round(t_bwd, 4),
                                     "timed": "library events around each launch inside the training step, 2 steps",
                                     "isolated_launch_ms": round(t_bwd_iso, 4), "kernels_in_training_step": train_kernels,
@@ -522,19 +522,18 @@ def sfno_config5(dev, with_cpu=True):
                                              "issued_flop_per_launch": n_mfma * 2048 * (A_H // 40 // 16),
                                              "achieved": round(n_mfma * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12, 1),
                                              "frac": round(n_mfma * 2048 * (A_H // 40 // 16) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
-                                             # useful: the multiply-adds the block's backward needs per point.  Recomputing kernel
-                                             # (93): forward W1 (10x40) + W2 (40x10) + Ws (10x10), input gradients W2^T, W1^T, Ws^T
-                                             # and the three weight-gradient outer products: 3 x 900 MAC, biases as a constant-1
-                                             # channel + 60.  Output-mask kernel (71): the forward part is W1 alone (400 + 40).
-                                             # The rest of the issued work is the zero padding of width 10 / 40 into 16 x 16 x 4
-                                             # tiles, each intermediate in two orientations, and the 12 transposition products.
+                                             # useful: the multiply-adds the block's backward needs per point -- W1 x (for the mask and
+                                             # h: 400), W2^T g2 (400), W1^T g1 (400), Ws^T g2 (100), the three outer products (400 + 400 + 100)
+                                             # and the bias sums (60); nothing of z2 is recomputed (the output's sign is the mask).  The rest
+                                             # of the issued work is the zero padding of width 10 / 40 into 16 x 16 x 4 tiles.
                                              "useful_flop_per_launch": 2 * useful_mac * (A_H // 40),
                                              "useful_achieved": round(2 * useful_mac * (A_H // 40) / (t_bwd * 1e-3) / 1e12, 1),
                                              "useful_frac": round(2 * useful_mac * (A_H // 40) / (t_bwd * 1e-3) / 1e12 / 157.3, 4),
                                              "useful_over_issued": round(2 * useful_mac * 16 / (n_mfma * 2048), 3)},
-                                    "note": f"matrix-pipe bound: {n_mfma} v_mfma_f32_16x16x4_f32 per 16 points (round 3: 105 -> 93 by the tile row map; "
-                                            "round 4: 93 -> 71 -- output mask read from the forward output, g2^T loaded, the channel-major "
-                                            "side of the hidden layer by transposition); peak = dense fp32 matrix rate, 256 flop/clk/CU x 256 CUs x 2.4 GHz"}}
+                                    "note": f"{n_mfma} v_mfma_f32_16x16x4_f32 per 16 points (round 3: 105 -> 93 by the tile row map; round 4: 71 -- output "
+                                            "mask from the forward output, transpositions as products with the identity; round 5: 59 -- the "
+                                            "transpositions through wave-private LDS, every tensor read once as 16-byte lanes, weights as LDS "
+                                            "fragments: one kernel for every width 4 ... 32); peak = dense fp32 matrix rate, 256 flop/clk/CU x 256 CUs x 2.4 GHz"}}
     except Exception as e:
         roof = {"error": repr(e)}
     base = None

@@ -336,7 +336,7 @@ int tcfd_fno_pointwise_bwd(const void* x, const void* skip, const void* dout, vo
  *                           applied; torch's own ReLU backward reads the saved result the same way);
  *   act2 = GELU/SiLU/tanh:  the block's PRE-activation z2 (tcfd_fno_pointwise_pre) -- act2'(z2) is evaluated from it.
  * Nothing of z2 = W2.h + Ws.skip is then recomputed, and for the two-layer form with P % 4 == 0 the call runs the tiled
- * all-matrix-instruction kernel of csrc/tcfd_fno_bwd.hip at the widths 10, 16, 20, 24, 32 with cm = 4 ci (59 / 88 / 196 / 244 /
+ * all-matrix-instruction kernel of csrc/tcfd_fno_tiles.hip at the widths 10, 16, 20, 24, 32 with cm = 4 ci (59 / 88 / 196 / 244 /
  * 352 v_mfma_f32_16x16x4_f32 per 16 points).  Without `out` those widths above 14 return "not instantiated". */
 int tcfd_fno_pointwise_bwd_out(const void* x, const void* skip, const void* dout, const void* out, void* dx, void* dskip,
                                const void* w1, const void* b1, const void* w2t, const void* b2, const void* wst, const void* bs,

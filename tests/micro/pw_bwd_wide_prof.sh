@@ -1,4 +1,4 @@
-# rocprofv3 kernel stats + PMC passes of the tiled pointwise backward (csrc/tcfd_fno_bwd.hip) at the config-5 grid.
+# rocprofv3 kernel stats + PMC passes of the tiled pointwise backward (csrc/tcfd_fno_tiles.hip) at the config-5 grid.
 # usage (on the GPU box): bash tests/micro/pw_bwd_wide_prof.sh <tag> <widths ...>   (env ACTS, B, TCFD_PW_BWD_TILES) -> gpurun_out/prof_<tag>/summary.txt
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp

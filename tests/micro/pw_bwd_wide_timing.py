@@ -1,5 +1,5 @@
 """Pointwise backward at the config-5 grid (b, W, 256, 256, 10) for every width the tiled all-MFMA kernel serves
-(csrc/tcfd_fno_bwd.hip): ms per call, issued / useful matrix rate.  Widths 4 / 8 / 10 also run the LDS-staged recomputing kernel
+(csrc/tcfd_fno_tiles.hip): ms per call, issued / useful matrix rate.  Widths 4 / 8 / 10 also run the LDS-staged recomputing kernel
 (TCFD_PW_BWD_TILES=0).  usage: pw_bwd_wide_timing.py [widths ...]   (env B = batch, default 32)"""
 import json, os, sys
 import torch, torch.nn as nn

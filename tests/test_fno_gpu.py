@@ -777,8 +777,47 @@ def test_fused_sobolev_loss_against_oracle_and_composed_path(n, b, nt, tag, dev,
     assert torch.isfinite(xg.grad).all()
 
 
+@pytest.mark.parametrize("width,act", [(16, "ReLU"), (16, "GELU"), (24, "SiLU"), (32, "ReLU"), (32, "GELU"), (20, "GELU")])
+@pytest.mark.parametrize("mode", [1, 2, 0])
+@pytest.mark.parametrize("X", [6, 7])      # P = 6 * 9 * 10 = 540 (P % 16 = 12: ragged last tile) / 630 (P % 4 = 2: the vector kernel serves)
+def test_wide_forward_block_on_the_matrix_pipe_equals_the_vector_kernel(width, act, mode, X, dev, monkeypatch):
+    """k_pwf_tiles (csrc/tcfd_fno_tiles.hip: the block of a wide layer as v_mfma_f32_16x16x4_f32 on 16-point tiles, widths 16 / 24 / 32
+    and, opt-in, 20) against k_pointwise (TCFD_PW_FWD_TILES=0) and against float64 torch modules; also the pre-activation output the
+    training forward of a GELU layer asks for (tcfd_fno_pointwise_pre)."""
+    import torch.nn as nn
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(width + mode)
+    mlp = fno.PointwiseFFN(width, width, 4 * width, act).to(dev)
+    w = nn.Conv3d(width, width, 1).to(dev) if mode == 1 else None
+    a2 = getattr(nn, act)()
+    x1 = torch.randn(3, width, X, 9, 10, device=dev)
+    skip = torch.randn(3, width, X, 9, 10, device=dev) if mode == 1 else (torch.randn(3, width, X, 9, 6, device=dev) if mode == 2 else None)
+    res = {}
+    with torch.no_grad():
+        for flag in ("2", "0"):
+            monkeypatch.setenv("TCFD_PW_FWD_TILES", flag)
+            pre = torch.empty_like(x1)
+            out = fno.hip_pointwise(x1, mlp.linear1, mlp.activation, mlp.linear2, skip=skip, skip_conv=w, act2=a2,
+                                    skip_last_slice=(mode == 2), pre=pre)
+            assert out is not None
+            res[flag] = (out, pre)
+    with torch.no_grad():       # float64 reference from the fp32 parameters
+        import torch.nn.functional as F
+        conv = lambda m, t: F.conv3d(t, m.weight.double(), m.bias.double())
+        z = conv(mlp.linear2, mlp.activation(conv(mlp.linear1, x1.double())))
+        if mode == 1:
+            z = z + conv(w, skip.double())
+        elif mode == 2:
+            z = z + skip.double()[..., -1:]
+        ref = a2(z)
+    for flag in ("2", "0"):
+        assert rel_l2(res[flag][0], ref) < 2e-6 and rel_l2(res[flag][1], z) < 2e-6, flag
+    assert rel_l2(res["2"][0], res["0"][0]) < 1e-6
+
+
 @pytest.mark.parametrize("width,act", [(10, "ReLU"), (32, "GELU"), (8, "SiLU"), (20, "Tanh"), (7, "ReLU"), (13, "GELU"), (31, "ReLU"),
-                                       (48, "GELU"), (64, "ReLU")])
+                                       (48, "GELU"), (64, "ReLU"), (16, "ReLU"), (24, "GELU")])
 def test_fused_pointwise_block_matches_torch_modules(width, act, dev):
     """tcfd_fno_pointwise vs the same layer evaluated with torch modules (PointwiseFFN + skip conv + act),
     the lifting tail (last-slice broadcast) and the single-convolution forms."""
@@ -965,7 +1004,7 @@ def test_sfno_training_step_gradients_golden_at_widths_16_and_20(tag, width, act
     """Tiny SFNOs at the reference's other widths (16: fno/sfno_pytest.py:258-270, 20: its notebooks) with GELU
     (fno/train.py:303) and ReLU under a SobolevLoss: prediction, loss, input gradient and EVERY parameter gradient against
     the reference's autograd (make_golden.gen_grads_wide) -- with the einsum recompute of the pointwise block forbidden:
-    every block runs the tiled all-MFMA backward kernel (csrc/tcfd_fno_bwd.hip)."""
+    every block runs the tiled all-MFMA backward kernel (csrc/tcfd_fno_tiles.hip)."""
     from torch_cfd_amd import fno
 
     def no_fallback(*a, **k):
@@ -1005,7 +1044,7 @@ def test_sfno_training_step_gradients_golden_at_widths_16_and_20(tag, width, act
     (10, 40, 10, True, 2, "GELU"), (4, 16, 4, True, 2, "ReLU"), (10, 40, 10, True, 2, "ReLU"),
     (6, 24, 6, True, 1, "ReLU"), (12, 48, 12, True, 0, "GELU"), (14, 56, 14, True, 1, "SiLU"), (10, 40, 10, True, 0, None),
     # the widths the reference itself trains at besides 10 (16: fno/sfno_pytest.py:261, 20: its notebooks) and 24 / 32:
-    # the tiled all-MFMA kernel (csrc/tcfd_fno_bwd.hip), ReLU from the saved output, the others from the saved pre-activation
+    # the tiled all-MFMA kernel (csrc/tcfd_fno_tiles.hip), ReLU from the saved output, the others from the saved pre-activation
     (16, 64, 16, True, 1, "ReLU"), (16, 64, 16, True, 1, "GELU"), (16, 64, 16, True, 2, "GELU"), (16, 64, 16, True, 0, "SiLU"),
     (20, 80, 20, True, 1, "ReLU"), (20, 80, 20, True, 1, "GELU"), (20, 80, 20, True, 2, "ReLU"), (24, 96, 24, True, 1, "Tanh"),
     (24, 96, 24, True, 2, "GELU"), (32, 128, 32, True, 1, "ReLU"), (32, 128, 32, True, 1, "GELU"), (32, 128, 32, True, 2, "ReLU"),
@@ -1063,7 +1102,7 @@ def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, 
 @pytest.mark.parametrize("act", ["ReLU", "GELU", "SiLU"])
 @pytest.mark.parametrize("width,mode", [(10, 1), (10, 2), (8, 1), (4, 2)])
 def test_tiled_backward_from_the_kept_tensor_equals_the_recomputing_kernel(width, mode, act, dev, monkeypatch):
-    """The tiled all-MFMA backward (csrc/tcfd_fno_bwd.hip) reads the derivative of the output activation from what the forward
+    """The tiled all-MFMA backward (csrc/tcfd_fno_tiles.hip) reads the derivative of the output activation from what the forward
     kept -- the output's sign for ReLU, the pre-activation (tcfd_fno_pointwise_pre) otherwise -- and never recomputes
     z2 = W2.h + Ws.s; the LDS-staged one-wave kernel (TCFD_PW_BWD_TILES=0) recomputes everything from x and s alone.  Same
     gradients to rounding (ReLU: the only elements that may differ are those whose pre-activation is within rounding of zero)."""

@@ -24,7 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_NAME = "libtcfd_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_fno_pw.hip", "tcfd_fno_bwd.hip", "tcfd_loss.hip")
+SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_fno_pw.hip", "tcfd_fno_tiles.hip", "tcfd_loss.hip")
 
 TCFD_C64, TCFD_C128 = 0, 1
 ABI_VERSION = 6   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
@@ -75,7 +75,7 @@ JOBS = (("tcfd_ns2d.hip", ("-DTCFD_UNIT=0",), "tcfd_ns2d.o"),
         ("tcfd_ns2d.hip", ("-DTCFD_UNIT=1",), "tcfd_ns2d_f32.o"),
         ("tcfd_fno.hip", (), "tcfd_fno.o"),
         ("tcfd_fno_pw.hip", (), "tcfd_fno_pw.o"),
-        ("tcfd_fno_bwd.hip", (), "tcfd_fno_bwd.o"),
+        ("tcfd_fno_tiles.hip", (), "tcfd_fno_tiles.o"),
         ("tcfd_loss.hip", (), "tcfd_loss.o"))
 
 

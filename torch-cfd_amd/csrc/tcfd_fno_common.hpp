@@ -1,6 +1,6 @@
 // tcfd_fno_common.hpp -- host-side helpers shared by the translation units of the FNO kernels
 // (tcfd_fno.hip: plans, pruned transforms, contraction; tcfd_fno_pw.hip: pointwise block forward / backward, LayerNorm
-//  statistics, lifting operator, small reductions; tcfd_fno_bwd.hip: the tiled all-MFMA pointwise backward).
+//  statistics, lifting operator, small reductions; tcfd_fno_tiles.hip: the tiled all-MFMA pointwise backward).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -157,6 +157,11 @@ extern "C" int tcfd_fno_reduce_frames(const void* x, void* out, const void* w2t,
 
 static int pw_dispatch(PwArgs a, int batch, int ci, int cm, int co, hipStream_t st) {
     const bool l1 = a.w1 != nullptr;
+    if (l1) {     // wide layers: the block as matrix instructions (tcfd_fno_tiles.hip)
+        int handled = 0;
+        const int rc = tcfd_pwf_tiles_dispatch(a, batch, ci, cm, co, st, &handled);
+        if (handled) return rc;
+    }
 #define PW_CASE(CI_, CM_, CO_)                                                             \
     if (ci == CI_ && cm == CM_ && co == CO_)                                                \
         return l1 ? launch_pw<CI_, CM_, CO_, true>(a, batch, st) : launch_pw<CI_, CM_, CO_, false>(a, batch, st);
@@ -309,7 +314,7 @@ extern "C" int tcfd_fno_pointwise_f64(const void* x, const void* skip, void* out
 // a constant-1 channel appended to h / x makes the bias gradients fall out of the same products.  The accumulators
 // (28 registers at width 10) live across the wave's whole grid-stride loop; every wave writes its partial sums
 // once, the caller adds the partials (deterministic, no atomics).
-// (PwBwdArgs, PwBwdGeom, pw_act_pair: tcfd_fno_pw.hpp, shared with tcfd_fno_bwd.hip)
+// (PwBwdArgs, PwBwdGeom, pw_act_pair: tcfd_fno_pw.hpp, shared with tcfd_fno_tiles.hip)
 
 __device__ __forceinline__ float pw_dact(float z, int act) {   // d act / dz
     switch (act) {
@@ -628,7 +633,7 @@ extern "C" int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const v
     return pointwise_bwd_impl(pe, x1, nullptr, dout, dx, nullptr, nullptr, nullptr, w2t, b2, nullptr, nullptr, partials, max_waves,
                               dims, batch, ci, ci, co, P, 0, 0, 0, 0, 0, per_sample, stream);
 }
-// The two-layer block runs the tiled all-MFMA kernel of tcfd_fno_bwd.hip (every even width 4 ... 16, 20, 24, 32 with cm = 4 ci,
+// The two-layer block runs the tiled all-MFMA kernel of tcfd_fno_tiles.hip (every even width 4 ... 16, 20, 24, 32 with cm = 4 ci,
 // P % 4 == 0): ReLU from the saved output, every other activation from the saved pre-activation.  TCFD_PW_BWD_TILES=0 keeps it
 // out -- the LDS-staged one-wave kernel below (widths 4 / 8 / 10, recomputes everything) then serves as the cross-check.
 static bool pwb_tiles_selected() { return env_int("TCFD_PW_BWD_TILES", 1) != 0; }

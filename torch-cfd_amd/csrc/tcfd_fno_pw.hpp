@@ -1,6 +1,6 @@
 // tcfd_fno_pw.hpp -- what the backward kernels of the fused pointwise block share across translation units
 // (tcfd_fno.hip: the LDS-staged kernels and the register-resident all-MFMA kernel of widths <= 14;
-//  tcfd_fno_bwd.hip: the tiled all-MFMA kernel of every width up to 32).
+//  tcfd_fno_tiles.hip: the tiled all-MFMA kernel of every width up to 32).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -233,7 +233,9 @@ __device__ __forceinline__ void pw_skip_conv(const PwArgs& a, const vf (&sv)[CI]
 #define PW_LOAD(p_) (*(p_))
 #endif
 
-// tcfd_fno_bwd.hip: the tiled all-MFMA backward (two-layer form, P % 4 == 0).  Returns 0 and sets *handled = 1 when it took the
+// tcfd_fno_tiles.hip: the tiled all-MFMA backward (two-layer form, P % 4 == 0).  Returns 0 and sets *handled = 1 when it took the
 // call (or answered the layout query), leaves *handled = 0 for combinations it does not cover.
 int tcfd_pwb_tiles_dispatch(const PwBwdArgs& a, int batch, int ci, int cm, int co, int max_rows, int* dims, hipStream_t st,
                             int* handled);
+// tcfd_fno_tiles.hip: the forward block of the wide layers on the matrix pipe (same contract: *handled = 0 -> not covered)
+int tcfd_pwf_tiles_dispatch(const PwArgs& a, int batch, int ci, int cm, int co, hipStream_t st, int* handled);

@@ -1,4 +1,4 @@
-// tcfd_fno_bwd.hip -- backward of the fused pointwise block of an SFNO layer for EVERY width up to 32, gfx950
+// tcfd_fno_tiles.hip -- backward of the fused pointwise block of an SFNO layer for EVERY width up to 32, gfx950
 //   out = act2( W2 . act1(W1 . x + b1) + b2  [+ Ws . s + bs | + s[..., -1:]] )        (fno/base.py:86-111, fno/sfno.py:607-614)
 // The reference trains at width 10 (fno/train.py:293), 16 (fno/sfno_pytest.py:258-270) and 20 (its notebooks), with ReLU or GELU
 // (fno/train.py:303).  The weights live in LDS as ready-made operand fragments and every channel dimension is tiled, so ONE
@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "tcfd_fno_common.hpp"
@@ -225,12 +226,18 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         }
     };
 
-    In cur;
+    // Prefetch distance: the loads of group G + PF strides are issued while group G is computed.  The launch is a memory-LATENCY
+    // problem before it is anything else: a wave keeps 1 KB per tensor in flight, and at ~2 us of loaded HBM latency 8 ... 16 waves
+    // per CU with one group in flight cap the chip near 3 TB/s (measured: every width 4 ... 16 sat there).  Two groups in flight
+    // where the registers allow (WPS >= 2, i.e. the narrow widths), one at the wide widths (matrix bound, one wave per SIMD).
+    constexpr int PF = WPS >= 2 ? 2 : 1;
+    In cur, nx1;
     load(wid < total ? wid : total - 1, cur);
+    if constexpr (PF == 2) load(wid + wstride < total ? wid + wstride : total - 1, nx1);
     for (int G = wid; G < total; G += wstride) {
         In nxt;
-        load(G + wstride < total ? G + wstride : total - 1, nxt);   // unconditional (clamped): no branch around the prefetch
-        __builtin_amdgcn_sched_barrier(0);                          // ... and issued HERE, a whole iteration ahead of its use
+        load(G + PF * wstride < total ? G + PF * wstride : total - 1, nxt);   // unconditional (clamped): no branch around the prefetch
+        __builtin_amdgcn_sched_barrier(0);                          // ... and issued HERE, PF iterations ahead of its use
         const int b = G / gpb;
         const long pb = (long)(G - b * gpb) * 16 + 4 * q;
         const bool live = pb < a.P;
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        cur = nxt;
+        if constexpr (PF == 2) { cur = nx1; nx1 = nxt; } else { cur = nxt; }
     }
 
     // ---- this wave's row of partial sums, in the layout of tcfd_fno_pointwise_bwd:
@@ -498,6 +505,276 @@ int launch_tiles_mode(const PwBwdArgs& a, int batch, int max_rows, int* dims, hi
     return launch_tiles<CI, CM, CO, 0, -1, WPS>(a, batch, max_rows, dims, st);
 }
 
+
+// ------------------------------------------------------------------ the FORWARD block on the same tiles (wide layers)
+//   out = act2( W2 . act1(W1 . x + b1) + b2  [+ Ws . s + bs | + s[..., -1:]] ),  optionally also the pre-activation (training)
+// k_pointwise keeps the channels of a point in registers and runs 9 W^2 multiply-adds per point on the vector unit: above
+// width 20 it is one point per lane (two need > 128 registers) and reaches ~55 TFLOP/s of the 157 (width 32: 7.1 ms per launch
+// at config-5 size).  Here the same products run as v_mfma_f32_16x16x4_f32 on 16-point tiles with the machinery of the
+// backward kernel above: x^T, s^T read once as 16-byte lanes and transposed through wave-private LDS, z1^T = x W1^T + b1,
+// h^T = act1(z1^T), its transpose h, out^T = h-chain W2^T + s-chain Ws^T + biases, weights as LDS fragments.  Matrix
+// instructions per 16 points: width 16: 36, 20: 75, 24: 96, 32: 144 (no padding at 16 / 32).  Exact fp32 multiply-adds in another
+// order than k_pointwise's: equal to rounding, not bit for bit.
+template <int CI, int CM, int CO>
+struct TilesFwdGeom {
+    using IT = Ch<CI>;
+    using HT = Ch<CM>;
+    using OT = Ch<CO>;
+    static constexpr int TI = IT::T, TM = HT::T, TO = OT::T;
+    static constexpr int G_W1A = 0;                          // [t][ti]  B of z1^T:   W1[hid(t, c)][ci(ti, 4q + j)]
+    static constexpr int G_W2C = G_W1A + TM * TI;            // [t][to]  B of out^T:  W2[co(to, c)][hid(t, 4q + r)]
+    static constexpr int G_WSC = G_W2C + TM * TO;            // [ti][to] B of out^T:  Ws[co(to, c)][ci(ti, 4q + j)]
+    static constexpr int NG = G_WSC + TI * TO;
+    static constexpr int SCR = (2 * TI > TM ? 2 * TI : TM);
+    static constexpr int TILE = 16 * 20;
+    static constexpr size_t LDS = ((size_t)NG * 256 + (size_t)4 * SCR * TILE) * sizeof(float);
+};
+
+#define PWF_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
+template <int CI, int CM, int CO, int MODE, int ACT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_pwf_tiles(PwArgs a, int batch) {
+    using Gm = TilesFwdGeom<CI, CM, CO>;
+    using IT = typename Gm::IT;
+    using HT = typename Gm::HT;
+    using OT = typename Gm::OT;
+    constexpr int TI = Gm::TI, TM = Gm::TM, TO = Gm::TO;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const ldsw = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, q = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const int fl = tid >> 2, fi = tid & 3, fq = fl >> 4, fc = fl & 15;
+        auto pick = [](const float* w, int idx, bool ok) { const float v = w[ok ? idx : 0]; return ok ? v : 0.f; };
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int hc = HT::chan(t, fc), hk = HT::chan(t, 4 * fq + fi);
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const int ik = IT::chan(ti, 4 * fq + fi);
+                ldsw[(Gm::G_W1A + t * TI + ti) * 256 + tid] = pick(a.w1, hc * CI + ik, hc >= 0 && ik >= 0);
+            }
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const int oc = OT::chan(to, fc);
+                ldsw[(Gm::G_W2C + t * TO + to) * 256 + tid] = pick(a.w2t, hk * CO + oc, hk >= 0 && oc >= 0);
+            }
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const int ik = IT::chan(ti, 4 * fq + fi);
+#pragma unroll
+                for (int to = 0; to < TO; ++to) {
+                    const int oc = OT::chan(to, fc);
+                    ldsw[(Gm::G_WSC + ti * TO + to) * 256 + tid] = pick(a.wst, ik * CO + oc, ik >= 0 && oc >= 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const f4* const wf = reinterpret_cast<const f4*>(ldsw) + lane;
+    float* const sc = smem + Gm::NG * 256 + wave * (Gm::SCR * Gm::TILE);
+    float* const sc_w = sc + c * 20 + 4 * q;
+    const float* const sc_r = sc + (4 * q) * 20 + c;
+    auto put = [&](int k, f4 v) { *reinterpret_cast<f4*>(sc_w + k * Gm::TILE) = v; };
+    auto get = [&](int k) { const float* p = sc_r + k * Gm::TILE; return f4{p[0], p[20], p[40], p[60]}; };
+
+    float b1v[TM], b2v[TO];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { const int hc = HT::chan(t, c); b1v[t] = (hc >= 0 && a.b1) ? a.b1[hc] : 0.f; }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const int oc = OT::chan(to, c);
+        b2v[to] = oc >= 0 ? ((a.b2 ? a.b2[oc] : 0.f) + ((MODE == 1 && a.bs) ? a.bs[oc] : 0.f)) : 0.f;
+    }
+    const int gpb = (int)((a.P + 15) / 16);
+    const int total = gpb * batch;
+    const int wid = blockIdx.x * 4 + wave, wstride = gridDim.x * 4;
+    const unsigned P4 = (unsigned)a.P * 4u;
+    constexpr unsigned OOB = 0xffffffffu;
+    unsigned i_off[TI];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) { const int ch = IT::chan(ti, c); i_off[ti] = ch >= 0 ? (unsigned)ch * P4 : OOB; }
+    const long sP = MODE == 2 ? (a.P / a.T) * a.sT : 0;
+
+    struct In {
+        f4 xb[TI], sb[TI];
+        float sl[TO][4];
+    };
+    auto load = [&](int G, In& in) {
+        const int b = G / gpb;
+        const unsigned pb = (unsigned)(G - b * gpb) * 16u + 4u * q;
+        const bool live = pb < (unsigned)a.P;
+        const unsigned po = pb * 4u;
+        const int ibytes = (int)((unsigned)CI * P4);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * CI * a.P, 0, ibytes, 0x00020000);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const unsigned off = (live && i_off[ti] != OOB) ? i_off[ti] + po : OOB;
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 2);        // (aux 2: non-temporal, read once)
+            in.xb[ti] = f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            if constexpr (MODE == 1) {
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.s) + (size_t)b * CI * a.P, 0, ibytes, 0x00020000);
+                const u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2);
+                in.sb[ti] = f4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+            } else {
+                in.sb[ti] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in.sl[to][r] = 0.f;
+        if constexpr (MODE == 2) {     // the skip's last time slice, broadcast over t: lane (q, c) needs it at its four points
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.s) + (size_t)b * CO * sP, 0, (int)((unsigned)(CO * sP) * 4u), 0x00020000);
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const int oc = OT::chan(to, c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned pt = pb + r;
+                    const unsigned off = (live && oc >= 0) ? ((unsigned)oc * (unsigned)sP + (pt / (unsigned)a.T) * (unsigned)a.sT + (unsigned)(a.sT - 1)) * 4u : OOB;
+                    in.sl[to][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                }
+            }
+        }
+    };
+
+    constexpr int PF = 2;                                    // two groups of loads in flight per wave (see k_pwb_tiles)
+    In cur, nx1;
+    load(wid < total ? wid : total - 1, cur);
+    load(wid + wstride < total ? wid + wstride : total - 1, nx1);
+    for (int G = wid; G < total; G += wstride) {
+        In nxt;
+        load(G + PF * wstride < total ? G + PF * wstride : total - 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int b = G / gpb;
+        const long pb = (long)(G - b * gpb) * 16 + 4 * q;
+        const bool live = pb < a.P;
+        // ---- x^T (and s^T) through the transposition tiles
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            put(ti, cur.xb[ti]);
+            if constexpr (MODE == 1) put(TI + ti, cur.sb[ti]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f4 xa[TI], sa[MODE == 1 ? TI : 1];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            xa[ti] = get(ti);
+            if constexpr (MODE == 1) sa[ti] = get(TI + ti);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- out^T starts from the biases and the skip convolution (independent of the hidden layer)
+        f4 oT[TO][2];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            oT[to][0] = f4{b2v[to] + cur.sl[to][0], b2v[to] + cur.sl[to][1], b2v[to] + cur.sl[to][2], b2v[to] + cur.sl[to][3]};
+            oT[to][1] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int to = 0; to < TO; ++to) {
+                    const f4 w = wf[(Gm::G_WSC + ti * TO + to) * 64];
+#pragma unroll
+                    for (int j = 0; j < IT::rv(ti); ++j) oT[to][j & 1] = PWF_MFMA(sa[ti][j], w[j], oT[to][j & 1]);
+                }
+        }
+        // ---- z1^T = b1 + x-chain W1^T, two hidden tiles at a time
+        f4 zT[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) zT[t] = f4{b1v[t], b1v[t], b1v[t], b1v[t]};
+#pragma unroll
+        for (int t0 = 0; t0 < TM; t0 += 2) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const f4 w0 = wf[(Gm::G_W1A + t0 * TI + ti) * 64];
+                const f4 w1 = wf[(Gm::G_W1A + (t0 + 1 < TM ? t0 + 1 : t0) * TI + ti) * 64];
+#pragma unroll
+                for (int j = 0; j < IT::rv(ti); ++j) {
+                    zT[t0] = PWF_MFMA(xa[ti][j], w0[j], zT[t0]);
+                    if (t0 + 1 < TM) zT[t0 + 1] = PWF_MFMA(xa[ti][j], w1[j], zT[t0 + 1]);
+                }
+            }
+        }
+        // ---- h^T = act1(z1^T), transposed tile by tile
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (ACT == 1) zT[t][r] = relu_bits(zT[t][r]);
+                else if constexpr (ACT == 2) zT[t][r] = gelu_f(zT[t][r]);
+                else zT[t][r] = pw_act(zT[t][r], a.act1);
+            }
+            put(t, zT[t]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- out^T += h-chain W2^T
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const f4 h = get(t);
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const f4 w = wf[(Gm::G_W2C + t * TO + to) * 64];
+#pragma unroll
+                for (int r = 0; r < HT::rv(t); ++r) oT[to][r & 1] = PWF_MFMA(h[r], w[r], oT[to][r & 1]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const int oc = OT::chan(to, c);
+            f4 z = oT[to][0] + oT[to][1], y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (ACT == 1) y[r] = relu_bits(z[r]);
+                else if constexpr (ACT == 2) y[r] = gelu_f(z[r]);
+                else y[r] = pw_act(z[r], a.act2);
+            }
+            if (oc >= 0 && live) {
+                const size_t o = ((size_t)b * CO + oc) * a.P + pb;
+                if (a.pre) __builtin_nontemporal_store(z, reinterpret_cast<f4*>(a.pre + o));
+                __builtin_nontemporal_store(y, reinterpret_cast<f4*>(a.out + o));
+            }
+        }
+        cur = nx1; nx1 = nxt;
+    }
+}
+#undef PWF_MFMA
+
+template <int CI, int CM, int CO, int MODE, int ACT, int WPS>
+int launch_fwd_tiles(const PwArgs& a, int batch, hipStream_t st) {
+    FnoProfScope prof(FNO_K_POINTWISE, st);
+    using Gm = TilesFwdGeom<CI, CM, CO>;
+    auto kern = k_pwf_tiles<CI, CM, CO, MODE, ACT, WPS>;
+    int dev = 0, cus = 256, per_cu = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, Gm::LDS));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const long groups = ((a.P + 15) / 16) * batch;
+    long blocks = std::min<long>((groups + 3) / 4, (long)std::max(per_cu, 1) * cus);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), Gm::LDS, st, a, batch);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int CI, int CM, int CO, int MODE, int WPS>
+int launch_fwd_tiles_act(const PwArgs& a, int batch, hipStream_t st) {
+    if (a.act1 == 1 && a.act2 == 1) return launch_fwd_tiles<CI, CM, CO, MODE, 1, WPS>(a, batch, st);
+    if (a.act1 == 2 && a.act2 == 2) return launch_fwd_tiles<CI, CM, CO, MODE, 2, WPS>(a, batch, st);
+    return launch_fwd_tiles<CI, CM, CO, MODE, -1, WPS>(a, batch, st);
+}
+template <int CI, int CM, int CO, int WPS>
+int launch_fwd_tiles_mode(const PwArgs& a, int batch, hipStream_t st) {
+    if (a.skip_mode == 1) return launch_fwd_tiles_act<CI, CM, CO, 1, WPS>(a, batch, st);
+    if (a.skip_mode == 2) return launch_fwd_tiles_act<CI, CM, CO, 2, WPS>(a, batch, st);
+    return launch_fwd_tiles<CI, CM, CO, 0, -1, WPS>(a, batch, st);
+}
+
 }  // namespace
 
 // The widths the reference's own code uses (10: fno/train.py:293; 16: fno/sfno_pytest.py:261; 20: its notebooks) and the
@@ -516,5 +793,28 @@ int tcfd_pwb_tiles_dispatch(const PwBwdArgs& a, int batch, int ci, int cm, int c
     PWT_CASE(4, 16, 4, 2) PWT_CASE(6, 24, 6, 2) PWT_CASE(8, 32, 8, 2) PWT_CASE(10, 40, 10, 2) PWT_CASE(12, 48, 12, 2)
     PWT_CASE(14, 56, 14, 2) PWT_CASE(16, 64, 16, 2) PWT_CASE(20, 80, 20, 1) PWT_CASE(24, 96, 24, 1) PWT_CASE(32, 128, 32, 1)
 #undef PWT_CASE
+    return 0;
+}
+
+// Forward block of the wide layers on the matrix pipe (k_pwf_tiles): widths 24 / 32 with cm = 4 ci, shared weights, P % 4 == 0,
+// the (batch, C, P) layout.  Measured at the config-5 grid, per launch (profiles/r05_pw_fwd_tiles_timing.json): width 24 2.61 ms
+// against 3.19 for k_pointwise, width 32 3.75 against 6.60 -- and width 16 1.76 against 1.45, width 20 2.13 against 1.66 (36 / 75
+// products per 16 points leave the per-tile overhead -- two LDS transpositions, address arithmetic -- uncovered), so those two
+// stay on the packed vector kernel unless TCFD_PW_FWD_TILES=2 asks for them (cross-check); =0 keeps k_pointwise everywhere.
+int tcfd_pwf_tiles_dispatch(const PwArgs& a, int batch, int ci, int cm, int co, hipStream_t st, int* handled) {
+    *handled = 0;
+    const int mode = env_int("TCFD_PW_FWD_TILES", 1);
+    if (!mode || a.pe || a.frame || !a.w1 || a.P % 4 != 0 || a.w2_bstride || a.b2_bstride) return 0;
+    if (a.skip_mode == 2 && (a.T <= 0 || a.sT <= 0)) return 0;
+    if ((size_t)(ci > co ? ci : co) * (size_t)a.P * 4 >= ((size_t)1 << 32)) return 0;
+    if (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.pre | (uintptr_t)(a.skip_mode == 1 ? a.s : nullptr)) % 16 != 0) return 0;
+#define PWF_CASE(CI_, CM_, CO_, WPS_)                                                          \
+    if (ci == CI_ && cm == CM_ && co == CO_) {                                                  \
+        *handled = 1;                                                                           \
+        return launch_fwd_tiles_mode<CI_, CM_, CO_, WPS_>(a, batch, st);                        \
+    }
+    PWF_CASE(24, 96, 24, 2) PWF_CASE(32, 128, 32, 2)
+    if (mode >= 2) { PWF_CASE(16, 64, 16, 2) PWF_CASE(20, 80, 20, 2) }
+#undef PWF_CASE
     return 0;
 }
