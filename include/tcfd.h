@@ -27,8 +27,11 @@
  *   - tuning switches (TCFD_* environment variables) are read once,
  *     at plan creation, and frozen in the plan.
  *   - complex data are interleaved (re, im) pairs of the plan's real type,
- *     half spectra are (batch, n, m) row-major with m = n/2 + 1, n = 2^k,
- *     8 <= n <= 2048.
+ *     half spectra are (batch, n, m) row-major with m = n/2 + 1.  Solver plans:
+ *     n = 2^k (8 ... 2048), 3 * 2^k (96 ... 1536) or 5 * 2^k (80 ... 1280); every
+ *     other even n is served above this boundary (dense device transforms,
+ *     torch-cfd_amd/mixed_radix.py).  FNO plans: X, Y in [4, 1024] (FFT kernels for
+ *     2^k, 3 * 2^k, 5 * 2^k; pruned direct DFTs otherwise, tcfd_fno_plan_supports).
  */
 #ifndef TCFD_H
 #define TCFD_H
@@ -59,7 +62,8 @@ typedef struct tcfd_fno_plan tcfd_fno_plan;
 const char* tcfd_last_error(void);
 /* ABI revision of the library that was loaded.  It changes whenever an entry point changes its argument list or the
  * meaning of an argument (round 3 turned the float scalars of the tcfd_fno_* calls into doubles and gave tcfd_fno_contract
- * a dtype: revision 1 -> 4, the build round).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
+ * a dtype: revision 1 -> 4; round 5: 6, tcfd_fno_pointwise_pre / _bwd_saved / _profile_*, tcfd_fno_spectral_conv_pointwise
+ * removed).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
  * first call: a stale prebuilt library would otherwise be called with the wrong argument layout and return garbage
  * (torch-cfd_amd/_lib.py::load does). */
 int tcfd_version(void);
@@ -222,6 +226,10 @@ int tcfd_fno_plan_create(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad
  * Only tcfd_fno_inverse_trunc may be called with such a plan. */
 int tcfd_fno_plan_create_resample(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt,
                                   int Xs, int Ys);
+/* 1 when the plan's kernels take a call that keeps `t_keep` output steps, 0 when not: FFT lengths always do; the pruned direct-DFT
+ * kernels of the other lengths hold one (Y x time) slab in 150 KB of LDS and know at most 16 time modes.  A host asks before it
+ * prefers the library to its own fallback. */
+int tcfd_fno_plan_supports(const tcfd_fno_plan* plan, int t_keep);
 /* The general constructor: as _resample (Xs = X, Ys = Y for an ordinary plan) with the precision, TCFD_C64 or TCFD_C128. */
 int tcfd_fno_plan_create_dtype(tcfd_fno_plan** plan, int X, int Y, int T_in, int t_pad, int T_out, int mx, int my, int mt,
                                int Xs, int Ys, int dtype);

@@ -210,6 +210,21 @@ def test_record_handover_without_process_group_and_order_check():
         ho2.finish()
 
 
+def test_record_handover_close_is_idempotent_and_safe_before_finish():
+    """A hand-over dropped before ``finish`` (an exception in the stepping loop) releases what it holds: ``close`` after a few
+    pushes, twice, and then ``finish`` reports the records that never came instead of hanging."""
+    from torch_cfd_amd.distributed import RecordHandover, batch_layout
+
+    layout = batch_layout(5, 1, 2)
+    ho = RecordHandover(("a", "b"), 5, 2, (4, 4), torch.float32, layout, "cpu")
+    ho.push(0, 0, _fake_packed(0, 2, 0, F=2))
+    ho.close()
+    ho.close()
+    with pytest.raises(RuntimeError, match="never pushed"):
+        ho.finish()
+    del ho
+
+
 def _mismatch_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -596,6 +596,39 @@ def test_any_size_kernels_agree_with_the_dense_transforms(X, Y, dev, monkeypatch
         assert rel_l2(a, b) < 5e-6
 
 
+def test_direct_dft_geometries_the_library_cannot_hold_run_the_dense_transforms(dev):
+    """The pruned direct-DFT kernels (sizes off the FFT lengths) keep one (Y x time) slab in 150 KB of LDS and know at most 16
+    time modes; ``tcfd_fno_plan_supports`` says so BEFORE anything is launched and the layer runs the dense GEMM transforms
+    instead of raising (Y = 1000 with 12 time modes in float64: 192 KB).  Also more than 65 535 (batch x channel) planes through
+    the direct-DFT x transform (several launches on shifted pointers)."""
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(2)
+    conv = fno.SpectralConvS(2, 2, 4, 8, 12).double().to(dev)
+    _randomise(conv, seed=4)
+    v = torch.randn(1, 2, 12, 1000, 24, dtype=torch.float64)
+    assert not fno._library_takes(12, 1000, 24, 0, 24, (4, 8, 12), 24, dev, torch.float64)
+    assert fno._library_takes(12, 1000, 24, 0, 24, (4, 8, 3), 24, dev, torch.float32)       # a small slab: the kernels take it
+    with torch.no_grad():
+        y = conv(v.to(dev))
+    ref = OF.spectral_conv(v, _blocks(conv.weight), (4, 8, 12), None, delta=conv.delta)
+    assert rel_l2(y, ref) < 1e-11
+    # training through the same geometry: differentiable dense transforms, no kernel launch fails
+    vg = v.to(dev).requires_grad_(True)
+    conv(vg).square().sum().backward()
+    assert torch.isfinite(vg.grad).all()
+    # 66 000 planes of 12 x 12 x 4
+    small = fno.SpectralConvS(2, 2, 3, 3, 2).to(dev)
+    _randomise(small, seed=5)
+    big = torch.randn(33000, 2, 12, 12, 4)
+    with torch.no_grad():
+        out = small(big.to(dev))
+    pick = [0, 1, 17000, 32767, 32768, 32999]
+    ref = OF.spectral_conv(big[pick], _blocks(small.weight), (3, 3, 2), None, delta=small.delta)
+    assert rel_l2(out[pick], ref) < 2e-6
+
+
 @pytest.mark.parametrize("X,Y", [(96, 96), (48, 80), (272, 272)])
 def test_dense_path_layers_against_oracle(X, Y, dev):
     """SpectralConvS / SpectralConvT on grids that are not powers of two (96^2 data, the 256 + 2 * 8 grid of a padded

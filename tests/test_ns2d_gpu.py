@@ -674,40 +674,6 @@ def test_split_and_plain_plans_agree(n, tag, dev, monkeypatch):
         assert rel_l2(a, b) < tol
 
 
-@pytest.mark.parametrize("n,tag,B,forcing", [(64, "f64", 1, "kolmogorov"), (128, "f64", 1, "kolmogorov"), (256, "f32", 16, None),
-                                            (256, "f64", 3, "sincos"), (128, "f32", 5, "kolmogorov_vort")])
-def test_plane_split_column_passes_agree_with_the_fused_ones(n, tag, B, forcing, dev, monkeypatch):
-    """The round-4 experiment for the small-grid regime (BASELINE configs 1 and 2), kept opt-in because it measured SLOWER
-    (TCFD_PSPLIT=1; 256^2 x 16 fp32: 8457 -> 7182 steps/s): column passes split by PLANE -- four workgroups per tile, each
-    emits one of the four planes, one of them stores the state / accumulator into the buffers that are not being read.
-    Same arithmetic, other transform factorisation (wide tiles): multi-step calls (the ping-pong of both buffers over
-    5 stages x k steps), per-call steps and dw/dt must agree with the default pass to round-off, and with the oracle."""
-    from oracle import ns2d as O
-
-    real = REAL[tag]
-    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 11 + s, real)) for s in range(min(B, 4))])
-    w0 = w0.repeat((B + w0.shape[0] - 1) // w0.shape[0], 1, 1)[:B].contiguous().to(dev)
-    res = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("TCFD_PSPLIT", flag)      # read at plan creation
-        _, op = build_op(n, tag, forcing, dev)
-        a7, d7 = op(w0, 1e-3, steps=7)
-        b = w0
-        for _ in range(3):
-            b, db = op(b, 1e-3)
-        res[flag] = (a7, d7, b, db)
-    monkeypatch.delenv("TCFD_PSPLIT")
-    tols = (1e-13, 1e-10, 1e-13, 1e-10) if tag == "f64" else (1e-6, 5e-4, 1e-6, 5e-4)   # dw/dt amplifies round-off by |w| / |dw|
-    for x, y, tol in zip(res["0"], res["1"], tols):
-        assert rel_l2(x, y) < tol
-    # and the plane-split pass itself against the oracle
-    monkeypatch.setenv("TCFD_PSPLIT", "1")
-    _, op = build_op(n, tag, forcing, dev)
-    t = oracle_tables(n, tag, forcing)
-    ref, _ = O.advance(w0[:2].cpu(), 1e-3, t, steps=7)
-    assert rel_l2(op(w0[:2], 1e-3, steps=7)[0], ref) < (1e-10 if tag == "f64" else 1e-5)
-
-
 @pytest.mark.parametrize("n", [512, 1024])
 def test_cross_lane_column_transforms_agree_with_stockham(n, dev, monkeypatch):
     """512-point column tiles (512^2 and the split 1024^2 plans, fp64) run their transforms with one LDS exchange +
@@ -753,31 +719,29 @@ def test_batch_chunking_is_bit_identical(n, tag, B, dev, monkeypatch):
             assert torch.equal(a, b), chunk
 
 
-@pytest.mark.parametrize("n,tag", [(64, "f64"), (512, "f64"), (1024, "f64"), (512, "f32"), (1024, "f32"), (256, "f32")])
+@pytest.mark.parametrize("n,tag", [(64, "f64"), (512, "f64"), (1024, "f64"), (1024, "f32"), (256, "f32")])
 def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
-    """Row pass: LDS-DMA staged rows (6), register staged rows (5) and the round-1 two-planes-per-transform kernel
-    (4) are the same arithmetic in a different order: explicit terms and a step agree to round-off.  The plan
-    reports which kernel it launches (sizes without whole-wave groups fall back from 6 to 5)."""
+    """Row pass: the register-staged Stockham kernel (TCFD_ROWS_V=5) and the cross-lane kernel (7: 1024 points fp64 only,
+    the default there) are the same arithmetic in a different order: explicit terms and a step agree to round-off.  The plan
+    reports which kernel it launches; the values of removed kernels (4, 6) mean 5."""
     from oracle import ns2d as O
 
     real = REAL[tag]
     B = 2
     w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, real)) for s in range(B)]).to(dev)
     res, kern = {}, {}
-    for v in ("4", "5", "6", "7"):
+    for v in ("5", "7", "4", "0"):
         monkeypatch.setenv("TCFD_ROWS_V", v)
         _, op = build_op(n, tag, "kolmogorov", dev)
         out, _ = op(w0, 1e-3, steps=2)
         kern[v] = op._plan(w0).info()["rows_kernel"]
         res[v] = (out, op.explicit_terms(w0))
     monkeypatch.delenv("TCFD_ROWS_V")
-    assert kern["4"] == 4 and kern["5"] == 5 and kern["6"] in (5, 6)
-    assert kern["7"] == (7 if (n, tag) == (1024, "f64") else 5)   # cross-lane transforms: 1024 points fp64 only
-    if (n, tag) in ((512, "f64"), (1024, "f64"), (512, "f32"), (1024, "f32")):
-        assert kern["6"] == 6
+    x7 = 7 if (n, tag) == (1024, "f64") else 5    # cross-lane transforms: 1024 points fp64 only
+    assert kern["5"] == 5 and kern["4"] == 5 and kern["7"] == x7 and kern["0"] == x7
     tols = (1e-13, 1e-12) if tag == "f64" else (5e-7, 2e-6)
-    for v in ("4", "5", "7"):
-        for a, b, tol in zip(res[v], res["6"], tols):
+    for v in ("7", "4", "0"):
+        for a, b, tol in zip(res[v], res["5"], tols):
             assert rel_l2(a, b) < tol, v
 
 
@@ -968,6 +932,29 @@ def test_fused_vjp_of_the_explicit_terms_matches_the_tensor_op_path(n, tag, B, f
     tol = 1e-11 if tag == "f64" else 2e-5
     assert rel_l2(vals["1"], vals["0"]) < (1e-12 if tag == "f64" else 2e-5)
     assert rel_l2(grads["1"], grads["0"]) < tol
+
+
+@pytest.mark.parametrize("forcing,steps", [("kolmogorov", 1), (None, 2)])
+def test_gradient_penalty_through_the_fused_nodes(forcing, steps, dev, monkeypatch):
+    """The other second-order use: d/dw of |dL/dw|^2 -- a gradient penalty -- through FusedExplicitTerms and
+    StageUpdate (first stage of a step: no previous accumulator; later stages and the second step: with one), fused nodes
+    against the tensor-op path."""
+    from oracle import ns2d as O
+
+    n, B = 32, 2
+    grid, op = build_op(n, "f64", forcing, dev)
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, 11 + s, torch.float64)) for s in range(B)]).to(dev)
+    pen = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_FUSED_VJP", flag)
+        monkeypatch.setenv("TCFD_FUSED_STAGE", flag)
+        w = w0.clone().requires_grad_(True)
+        out, dwdt = op(w, 2e-3, steps=steps)
+        loss = out.abs().pow(4).sum() + dwdt.abs().pow(2).sum() * 1e-4
+        (gw,) = torch.autograd.grad(loss, w, create_graph=True)
+        (gp,) = torch.autograd.grad(gw.abs().pow(2).sum(), w)
+        pen[flag] = gp
+    assert torch.linalg.norm(pen["0"]) > 0 and rel_l2(pen["1"], pen["0"]) < 1e-9
 
 
 def test_second_order_gradients_through_the_fused_nodes(dev, monkeypatch):

@@ -162,6 +162,7 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "tcfd_fno_lift_spectrum": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "tcfd_fno_sample_outer_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _i, _vp]),
+    "tcfd_fno_plan_supports": (_i, [_vp, _i]),
     "tcfd_fno_profile_begin": (_i, [_i]),
     "tcfd_fno_profile_end": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     "tcfd_fno_pointwise_bwd_saved": (_i, [_i, _i, _i, _l, _i, _i]),

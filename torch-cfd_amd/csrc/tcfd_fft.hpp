@@ -500,24 +500,6 @@ __device__ __forceinline__ void tile_fft_rt(cx<T> (&x)[EPT], cx<T>* lds, int j, 
     static_assert(pass_tw_single<N, EPT>(), "register twiddles need one table entry per pass");
     Passes<T, N, EPT, DIR, C, PAD, WGSYNC, 1, Hook, 2>::run(x, lds, nullptr, j, c, hook, j, trg);
 }
-// ---- LDS-DMA (global -> LDS without a register round trip) ---------------------------------
-// One wave-instruction moves 64 x 16 bytes: lane l's 16 bytes at `gsrc` (per-lane address) land at LDS byte
-// address lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  The load is invisible to hipcc's s_waitcnt
-// bookkeeping: the consumer waits with wait_vmem_all() itself.  M0 is compiler-reserved: saved and restored.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);   // provably uniform for the "s" constraint
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// LDS byte address of a pointer into shared memory, as a wave-uniform scalar
-__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
-    const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)a);
-}
 
 }  // namespace tcfd
 

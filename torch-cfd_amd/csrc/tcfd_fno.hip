@@ -693,10 +693,15 @@ static int launch_x_dft(const tcfd_fno_plan* p, const cx<T>* in, cx<T>* out, lon
     auto kern = k_x_dft<T, FWD>;
     int rc = set_lds_attr(kern, lds);
     if (rc) return rc;
-    if (bc > 65535) return FAIL(TCFD_EINVAL, "fno: batch x channels = %ld exceeds the grid's z range", bc);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((Q + 255) / 256), (unsigned)((n_out + 15) / 16), (unsigned)bc), dim3(256), lds, st, in,
-                       out, (const ct*)p->tw_x, p->X, FWD ? p->X : p->Xs, p->mx, Q);
-    HIP_TRY(hipGetLastError());
+    // blockIdx.z = plane (batch x channel): at most 65535 per launch, more in several launches on shifted pointers
+    const size_t in_plane = (size_t)(FWD ? p->X : 2 * p->mx) * Q, out_plane = (size_t)(FWD ? 2 * p->mx : p->X) * Q;
+    for (long z0 = 0; z0 < bc; z0 += 65535) {
+        const long nz = std::min<long>(65535, bc - z0);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((Q + 255) / 256), (unsigned)((n_out + 15) / 16), (unsigned)nz), dim3(256), lds, st,
+                           in + (size_t)z0 * in_plane, out + (size_t)z0 * out_plane, (const ct*)p->tw_x, p->X, FWD ? p->X : p->Xs,
+                           p->mx, Q);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 template <typename T>
@@ -979,6 +984,22 @@ static int spectral_conv_impl(const tcfd_fno_plan* p, const void* v, const void*
         return rc;
     if ((rc = do_inv_x<T>(p, O, W, (long)batch * cout, st))) return rc;
     return do_inv_ty<T>(p, W, (T*)out, (long)batch * cout * p->X, t_keep, (T)inv_scale, st);
+}
+
+// Whether the plan's kernels take a call that keeps `t_keep` output steps: always for the FFT lengths; the pruned direct-DFT
+// kernels of the other lengths hold a whole (Y x time) slab in LDS and know at most 16 time modes (launch_*_dft above).  A host asks
+// before it picks the library over its own fallback (the Python layers: dense GEMM transforms).
+extern "C" int tcfd_fno_plan_supports(const tcfd_fno_plan* p, int t_keep) {
+    if (!p || t_keep <= 0 || t_keep > p->T_out) return 0;
+    const bool dft_y = !fft_len(p->Y) || force_dft();
+    if (!dft_y) return 1;
+    if (p->mt > 16) return 0;
+    const size_t ct = csize(p), rt = ct / 2;
+    const size_t fwd = ((size_t)p->Y + (size_t)p->mt * p->Tp) * ct + (size_t)p->Y * p->mt * ct;
+    const size_t Q = (size_t)2 * p->my * p->mt;
+    const size_t inv = ((size_t)p->Y + (size_t)t_keep * p->mt) * ct + (Q + 2 * p->mt + 2 * (size_t)(p->my + 1) * p->mt) * ct +
+                       (size_t)p->Y * t_keep * rt;
+    return fwd <= 150 * 1024 && inv <= 150 * 1024;
 }
 
 // Full spectral convolution.  v (b, ci, X, Y, T_in) real -> out (b, co, X, Y, t_keep) real (the last t_keep of the T_out

@@ -190,13 +190,7 @@ struct ColArgs {
     int nyq;       // 1: packed Nyquist column (see emit_planes): no lone tile for column m - 1, the lanes of column 0 own it too
     int nt_planes; // plane stores with the non-temporal hint (small cache-resident problems, see launch_cols)
     int pair_xcd;  // block->tile map: 0 = batch fastest; LG = 2 / 4: the LG tiles that share a 128-byte line on one XCD
-    int psplit;    // 1 (MODE_A / MODE_CA, grid.y = 4): workgroup blockIdx.y emits plane blockIdx.y only.  A small problem's launch
-                   // is ONE round of workgroups whose run time is the dependency chain of one workgroup -- forward transform,
-                   // update, FOUR inverse transforms one after the other, 16 plane stores per lane.  Split by plane the chain
-                   // is one forward + one inverse transform; the forward part is recomputed by the four workgroups of a tile
-                   // (from the caches: the machine is idle otherwise), only y = 0 stores the accumulator and the state -- to
-                   // OTHER buffers than the ones read (h_out, u_out: the host alternates them), the siblings still read those.
-    cx<T>* h_out;  // RK accumulator write (== h unless psplit)
+    cx<T>* h_out;  // RK accumulator write (NULL: == h)
 };
 
 // SP = 1 ("split"): the workgroup owns the rows of ONE parity q of the column (i = 2 s + q) and runs N/2-point
@@ -272,9 +266,8 @@ __device__ __forceinline__ void emit_planes(const ColArgs<T>& a, const cx<T> (&u
     const T ky = valid ? a.ky[jc] : (T)0;
     const bool nyq_lane = nyq_tile && c == 0;
     const T ky_n = nyq_tile ? a.ky[a.m - 1] : (T)0;
-    const int f_first = a.psplit ? (int)blockIdx.y : 0, f_end = a.psplit ? f_first + 1 : 4;
 #pragma unroll 1
-    for (int f = f_first; f < f_end; ++f) {
+    for (int f = 0; f < 4; ++f) {
         cx<T> x[EPT];
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
@@ -516,7 +509,7 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
             }
             return;
         } else {  // MODE_CA / MODE_C : Runge-Kutta accumulate + Crank-Nicolson solve
-            const bool writer = !a.psplit || blockIdx.y == 0;   // plane-split launches: ONE of the four sibling workgroups stores h / u
+            constexpr bool writer = true;
             // packed Nyquist column (tile 0, a row per thread): its reads go out first, in the shadow of the tile's own
             constexpr int NYQ_PER = (NT + C * G - 1) / (C * G);
             [[maybe_unused]] cx<T> nyq_u[NYQ_PER], nyq_w0[NYQ_PER];
@@ -774,205 +767,6 @@ __device__ __forceinline__ void pack_herm(cx<T> (&x)[EPT], const RawPair<T, EPT>
     group_sync<WG>();
 }
 
-template <typename T, int N, int EPT, int THR>
-__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect3(
-    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
-    long npairs, int ld, int kc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using Gm = RowGeom<T, N, EPT, THR>;
-    constexpr int G = Gm::G;
-    constexpr bool WG = (G > 64);
-    const int grp = threadIdx.x / G;
-    const int j = threadIdx.x % G;
-    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
-    const long stride = (long)gridDim.x * Gm::GROUPS;
-    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
-    // every group runs the same number of iterations (the barriers are workgroup wide);
-    // out-of-range iterations recompute the last pair and skip the store
-    const long iters = (npairs + stride - 1) / stride;
-    const cx<T>* P0 = planes;
-    const cx<T>* P1 = planes + plane_stride;
-    const cx<T>* P2 = planes + 2 * plane_stride;
-    const cx<T>* P3 = planes + 3 * plane_stride;
-
-    RawPair<T, EPT> ra, rb;
-    {
-        const size_t off = (size_t)(pair < npairs ? pair : npairs - 1) * 2 * (size_t)ld;
-        load_raw<T, N, EPT>(ra, P0 + off, P1 + off, j);
-        load_raw<T, N, EPT>(rb, P2 + off, P3 + off, j);
-    }
-    for (long it = 0; it < iters; ++it, pair += stride) {
-        const bool valid = pair < npairs;
-        const long cur = valid ? pair : npairs - 1;
-        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
-        const size_t off1 = ((size_t)cur * 2 + 1) * (size_t)ld;  // second row of this pair
-        const size_t offn = (size_t)nxt * 2 * (size_t)ld;        // first row of the next pair
-        cx<T> x[EPT], z1[EPT], p[EPT];
-
-        pack_herm<T, N, EPT, WG>(z1, ra, lds, j);
-        load_raw<T, N, EPT>(ra, P0 + off1, P1 + off1, j);             // in flight during the transform
-        tile_fft<T, N, EPT, +1, 1, true, WG>(z1, lds, tw, j, 0);      // vx + i vy   (row 0)
-        pack_herm<T, N, EPT, WG>(x, rb, lds, j);
-        load_raw<T, N, EPT>(rb, P2 + off1, P3 + off1, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);       // dx w + i dy w
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) p[t].x = -(x[t].x * z1[t].x + x[t].y * z1[t].y);
-
-        pack_herm<T, N, EPT, WG>(z1, ra, lds, j);
-        load_raw<T, N, EPT>(ra, P0 + offn, P1 + offn, j);             // next pair, row 0
-        tile_fft<T, N, EPT, +1, 1, true, WG>(z1, lds, tw, j, 0);
-        pack_herm<T, N, EPT, WG>(x, rb, lds, j);
-        load_raw<T, N, EPT>(rb, P2 + offn, P3 + offn, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) p[t].y = -(x[t].x * z1[t].x + x[t].y * z1[t].y);
-
-        tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
-        unpack_store_pair<T, N, EPT>(p, lds, adv + (size_t)cur * 2 * ld, adv + ((size_t)cur * 2 + 1) * ld, j, valid, kc);
-    }
-}
-
-// ---- row pass for the split column transforms ("v4") -----------------------------------------
-// Row pair = (r, r + N/2).  The planes hold, for every field, the N/2-point column transforms of the even
-// spectral rows (E, workspace rows [0, N/2)) and of the odd ones (O, rows [N/2, N)); the column transform is
-// completed here:  x[r] = E[r] + w O[r],  x[r + N/2] = E[r] - w O[r],  w = exp(+2 pi i r / N).
-// Symmetrically the advection spectra A_r, A_{r+N/2} leave as S = A_r + A_{r+N/2} and
-// D = (A_r - A_{r+N/2}) exp(-2 pi i r / N), which the two parity workgroups of the column pass transform
-// with N/2 points each.  Same loads, stores and transforms per pair as k_rows_advect3.
-template <typename T, int EPT>
-struct HalfQuad {  // un-mirrored half rows of E and O of one plane (+ the Nyquist elements)
-    cx<T> e[EPT / 2], o[EPT / 2];
-    cx<T> en, on;
-};
-
-template <typename T, int N, int EPT>
-__device__ __forceinline__ void load_half(HalfQuad<T, EPT>& h, const cx<T>* __restrict__ rowE,
-                                          const cx<T>* __restrict__ rowO, int j) {
-    constexpr int G = N / EPT;
-#pragma unroll
-    for (int t = 0; t < EPT / 2; ++t) {
-        h.e[t] = rowE[j + t * G];
-        h.o[t] = rowO[j + t * G];
-    }
-    h.en = rowE[N / 2];
-    h.on = rowO[N / 2];
-}
-
-// h.o <- w * h.o (done once per pair; both output rows reuse it)
-template <typename T, int EPT>
-__device__ __forceinline__ void twist_half(HalfQuad<T, EPT>& h, cx<T> w) {
-#pragma unroll
-    for (int t = 0; t < EPT / 2; ++t) h.o[t] = cmul(h.o[t], w);
-    h.on = cmul(h.on, w);
-}
-
-// RawPair of output row r (SIGN=+1) or r + N/2 (SIGN=-1) from the twisted half quads of planes (a, b)
-template <typename T, int EPT, int SIGN>
-__device__ __forceinline__ void combine_halves(RawPair<T, EPT>& r, const HalfQuad<T, EPT>& ha,
-                                               const HalfQuad<T, EPT>& hb) {
-#pragma unroll
-    for (int t = 0; t < EPT / 2; ++t) {
-        r.a[t] = SIGN > 0 ? ha.e[t] + ha.o[t] : ha.e[t] - ha.o[t];
-        r.b[t] = SIGN > 0 ? hb.e[t] + hb.o[t] : hb.e[t] - hb.o[t];
-    }
-    r.an = SIGN > 0 ? ha.en + ha.on : ha.en - ha.on;
-    r.bn = SIGN > 0 ? hb.en + hb.on : hb.en - hb.on;
-}
-
-template <typename T, int N, int EPT, int THR>
-__global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_advect4(
-    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
-    long npairs, int ld, int kc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using Gm = RowGeom<T, N, EPT, THR>;
-    constexpr int G = Gm::G;
-    constexpr bool WG = (G > 64);
-    constexpr int N2 = N / 2;
-    const int grp = threadIdx.x / G;
-    const int j = threadIdx.x % G;
-    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw) + (size_t)grp * Gm::LDS_PER_GROUP;
-    const long stride = (long)gridDim.x * Gm::GROUPS;
-    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
-    const long iters = (npairs + stride - 1) / stride;
-    // pair p -> batch b = p / N2, row r = p % N2; E row = b*N + r, O row = b*N + N2 + r
-    auto erow = [&](long p) { return (size_t)((p / N2) * N + (p % N2)) * (size_t)ld; };
-    const size_t oskip = (size_t)N2 * ld;
-
-    HalfQuad<T, EPT> h0, h1;
-    {
-        const size_t off = erow(pair < npairs ? pair : npairs - 1);
-        load_half<T, N, EPT>(h0, planes + off, planes + off + oskip, j);
-        load_half<T, N, EPT>(h1, planes + plane_stride + off, planes + plane_stride + off + oskip, j);
-    }
-    for (long it = 0; it < iters; ++it, pair += stride) {
-        const bool valid = pair < npairs;
-        const long cur = valid ? pair : npairs - 1;
-        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
-        const size_t off = erow(cur), offn = erow(nxt);
-        const int r = (int)(cur % N2);
-        const cx<T> wf = tw[r];            // exp(-2 pi i r / N)
-        const cx<T> wi = cconj(wf);        // exp(+2 pi i r / N)
-        const cx<T>* P2 = planes + 2 * plane_stride;
-        const cx<T>* P3 = planes + 3 * plane_stride;
-        cx<T> x[EPT], z1r[EPT], z1s[EPT], p[EPT];
-        RawPair<T, EPT> raw;
-
-        twist_half<T, EPT>(h0, wi);
-        twist_half<T, EPT>(h1, wi);
-        combine_halves<T, EPT, +1>(raw, h0, h1);
-        pack_herm<T, N, EPT, WG>(z1r, raw, lds, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(z1r, lds, tw, j, 0);     // vx + i vy, row r
-        combine_halves<T, EPT, -1>(raw, h0, h1);
-        load_half<T, N, EPT>(h0, P2 + off, P2 + off + oskip, j);      // planes 2, 3: in flight during the transform
-        load_half<T, N, EPT>(h1, P3 + off, P3 + off + oskip, j);
-        pack_herm<T, N, EPT, WG>(z1s, raw, lds, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(z1s, lds, tw, j, 0);     // vx + i vy, row r + N/2
-
-        twist_half<T, EPT>(h0, wi);
-        twist_half<T, EPT>(h1, wi);
-        combine_halves<T, EPT, +1>(raw, h0, h1);
-        pack_herm<T, N, EPT, WG>(x, raw, lds, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);       // dx w + i dy w, row r
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) p[t].x = -(x[t].x * z1r[t].x + x[t].y * z1r[t].y);
-        combine_halves<T, EPT, -1>(raw, h0, h1);
-        load_half<T, N, EPT>(h0, planes + offn, planes + offn + oskip, j);  // next pair, planes 0 and 1
-        load_half<T, N, EPT>(h1, planes + plane_stride + offn, planes + plane_stride + offn + oskip, j);
-        pack_herm<T, N, EPT, WG>(x, raw, lds, j);
-        tile_fft<T, N, EPT, +1, 1, true, WG>(x, lds, tw, j, 0);
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) p[t].y = -(x[t].x * z1s[t].x + x[t].y * z1s[t].y);
-
-        tile_fft<T, N, EPT, -1, 1, true, WG>(p, lds, tw, j, 0);
-        // unpack the two real-row spectra and fold them for the parity workgroups of the column pass
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(j + t * G, 0)] = p[t];
-        group_sync<WG>();
-        const T half = (T)0.5;
-        cx<T>* outS = adv + off;
-        cx<T>* outD = adv + off + oskip;
-#pragma unroll
-        for (int t = 0; t < EPT / 2; ++t) {
-            const int k = j + t * G;
-            const cx<T> A = p[t];
-            const cx<T> Bm = lds[lds_addr<EPT, 1, true>((N - k) % N, 0)];
-            const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of row r
-            const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of row r + N/2
-            if (valid && k < kc) {
-                outS[k] = X0 + X1;
-                outD[k] = cmul(X0 - X1, wf);
-            }
-        }
-        if (j == 0 && valid && N / 2 < kc) {
-            const cx<T> A = p[EPT / 2];
-            const cx<T> X0 = mk<T>(A.x, (T)0), X1 = mk<T>(A.y, (T)0);
-            outS[N / 2] = X0 + X1;
-            outD[N / 2] = cmul(X0 - X1, wf);
-        }
-        group_sync<WG>();
-    }
-}
-
 // ---- row pass of the VECTOR-JACOBIAN PRODUCT of the explicit terms -----------------------------------------------
 // F(w) = M . R( -(dxw u + dyw v) ) [+ f],  u, v, dxw, dyw = I(a_f w).  For a cotangent g:  nbar = R^T(M g) is a real field
 // (plane 4 holds the column-transformed M g / c), and the cotangents of the four inverse transforms are nbar times the
@@ -1028,15 +822,18 @@ __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS)) void k_rows_vjp
 }
 
 // ---- row pass, one plane per transform ("v5") --------------------------------------------------
-// The kernels above ride two PLANES of one row through a complex transform, so the transformed velocity rows
-// of BOTH rows of a pair stay live while the gradient planes are transformed (z1r, z1s, x, p + two half quads:
-// 256 VGPR + 84 AGPR, one wave per SIMD at 1024^2 fp64).  Here the two ROWS of a pair ride through one transform
-// of ONE plane:  Z = P(row a) + i P(row b)  ->  real part = field on row a, imaginary part = field on row b, and
+// Round 1 rode two PLANES of one row through a complex transform, so the transformed velocity rows of BOTH rows of a pair
+// stayed live while the gradient planes were transformed (256 VGPR + 84 AGPR, one wave per SIMD at 1024^2 fp64; kernels v3 / v4,
+// removed in round 5 with the LDS-DMA staged v6 -- docs/history/DESIGN_rounds_1-4.md section 4).  Here the two ROWS of a pair ride
+// through one transform of ONE plane:  Z = P(row a) + i P(row b)  ->  real part = field on row a, imaginary part = field on row b, and
 //     p.x = -(vx_a dxw_a + vy_a dyw_a),  p.y = -(vx_b dxw_b + vy_b dyw_b)
 // accumulates plane by plane (order u^, dx w^, v^, dy w^): one kept transform + the working one + the product +
 // the next plane's half rows in flight -- half the live state, same loads / stores / transform count.
-// SP = 0: rows (2p, 2p+1).  SP = 1 (split column plans): rows (r, r + N/2), built from the E / O half-length column
-// transforms as  a = E + w O,  b = E - w O,  w = exp(+2 pi i r / N), and stored folded (S, D) as in k_rows_advect4.
+// SP = 0: rows (2p, 2p+1).  SP = 1 (split column plans): rows (r, r + N/2).  The planes then hold, for every field, the
+// N/2-point column transforms of the even spectral rows (E, workspace rows [0, N/2)) and of the odd ones (O, rows [N/2, N)); the
+// column transform is completed here,  a = E + w O,  b = E - w O,  w = exp(+2 pi i r / N), and the advection spectra A_r, A_{r+N/2}
+// leave folded as S = A_r + A_{r+N/2},  D = (A_r - A_{r+N/2}) exp(-2 pi i r / N), which the two parity workgroups of the column
+// pass transform with N/2 points each.
 template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int NYQ = 0>
 __global__ __launch_bounds__((RowGeom<T, N, EPT, THR>::THREADS), MINW) void k_rows_advect5(
     const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
@@ -1259,172 +1056,6 @@ __global__ __launch_bounds__(128, MINW) void k_rows_advect7(
     }
 }
 
-// ---- row pass, LDS-DMA staged ("v6") -------------------------------------------------------------
-// v5 with the HBM side taken off the register file: the two half rows of the NEXT plane are copied HBM -> LDS by
-// LDS-DMA (global_load_lds_dwordx4: no VGPRs, 1 KB per wave-instruction) while the current plane is transformed,
-// and stay in flight across the exchange barriers of the transform (raw barriers, see group_sync<2>).  The packed
-// Hermitian sequence is then read straight from the staged rows -- the mirrored half from the mirrored LDS
-// address -- so the mirror exchange of pack_herm (one half-row of LDS stores per transform) is gone as well.
-// Per group: the transform's exchange buffer (N elements) + one staging buffer (2 x (N/2 + 2) elements).
-// Needs whole-wave groups whose half rows are a whole number of 1 KB pieces per wave.
-template <typename T, int N, int EPT, int THR>
-struct RowGeom6 {
-    static constexpr int G = N / EPT;
-    static constexpr int THREADS = G >= THR ? G : THR;
-    static constexpr int GROUPS = THREADS / G;
-    static constexpr int WAVES = G / 64;                          // waves per group
-    static constexpr int ROWB = (N / 2) * (int)sizeof(cx<T>);     // bytes of a half row without its Nyquist element
-    static constexpr int PIECES = ROWB / 1024;                    // LDS-DMA pieces per half row
-    static constexpr int SROW = N / 2 + 2;                        // staging pitch in elements (row + Nyquist + pad)
-    // exchange buffer (N elements + one: element N holds a copy of element 0 for the mirrored reads of the unpack)
-    static constexpr int XBUF = N + 2;
-    static constexpr size_t GROUP_BYTES = (size_t)(XBUF + 2 * SROW) * sizeof(cx<T>);
-    static constexpr size_t LDS_BYTES = GROUP_BYTES * GROUPS;
-    static constexpr bool OK = is_pow2c(N) && is_pow2c(EPT) && (G % 64 == 0) && (ROWB % (1024 * (WAVES > 0 ? WAVES : 1)) == 0) && pass_tw_single<N, EPT>();
-};
-
-template <typename T, int N, int EPT, int THR, int SP, int MINW>
-__global__ __launch_bounds__((RowGeom6<T, N, EPT, THR>::THREADS), MINW) void k_rows_advect6(
-    const cx<T>* __restrict__ planes, size_t plane_stride, cx<T>* __restrict__ adv, const cx<T>* __restrict__ tw,
-    long npairs, int ld, int kc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using Gm = RowGeom6<T, N, EPT, THR>;
-    static_assert(Gm::OK, "v6 needs whole-wave groups and half rows that split into 1 KB pieces per wave");
-    constexpr int G = Gm::G;
-    constexpr int SYNC = Gm::WAVES > 1 ? 2 : 0;
-    constexpr int N2 = N / 2;
-    const int grp = threadIdx.x / G;
-    const int j = threadIdx.x % G;
-    const int wv = j / 64, lane = j % 64;
-    // Twiddles: a global load INSIDE the pair loop would make hipcc wait for vmcnt(0) at its use -- and with it for
-    // the staged rows that are meant to stay in flight.  The squared-twiddle transform needs ONE table entry per
-    // pass and lane: they are read here, once, and live in registers (3 entries = 12 VGPRs at 1024 points fp64);
-    // the address arithmetic of the transforms uses an asm-opaque copy of j (below) and is redone per transform.
-    unsigned char* gbase = smem_raw + (size_t)grp * Gm::GROUP_BYTES;
-    constexpr int NTW = pass_tw_count<N, EPT>() > 0 ? pass_tw_count<N, EPT>() : 1;
-    cx<T> trg[NTW];
-    load_pass_tw<T, N, EPT>(trg, tw, j);
-    cx<T>* lds = reinterpret_cast<cx<T>*>(gbase);          // exchange buffer of the transforms
-    cx<T>* SA = lds + Gm::XBUF;                            // staged half row a (or E)
-    cx<T>* SB = SA + Gm::SROW;                             // staged half row b (or O)
-    const unsigned sa_addr = lds_byte_address(SA), sb_addr = lds_byte_address(SB);
-    const long stride = (long)gridDim.x * Gm::GROUPS;
-    long pair = (long)blockIdx.x * Gm::GROUPS + grp;
-    const long iters = (npairs + stride - 1) / stride;
-    auto row_a = [&](long p) -> size_t {
-        return SP ? (size_t)((p / N2) * N + (p % N2)) * (size_t)ld : (size_t)p * 2 * (size_t)ld;
-    };
-    const size_t second = SP ? (size_t)N2 * ld : (size_t)ld;
-
-    auto stage = [&](const cx<T>* rowA) {
-        const unsigned char* ga = reinterpret_cast<const unsigned char*>(rowA) + lane * 16;
-        const unsigned char* gb = reinterpret_cast<const unsigned char*>(rowA + second) + lane * 16;
-#pragma unroll
-        for (int c = 0; c < Gm::PIECES / Gm::WAVES; ++c) {
-            const int piece = c * Gm::WAVES + wv;
-            glds16(ga + piece * 1024, sa_addr + piece * 1024);
-            glds16(gb + piece * 1024, sb_addr + piece * 1024);
-        }
-        if (j == 0) {   // the Nyquist elements: one 16-byte piece each (fp32: element N/2 and one element of row padding)
-            glds16(rowA + N2, sa_addr + N2 * (unsigned)sizeof(cx<T>));
-            glds16(rowA + second + N2, sb_addr + N2 * (unsigned)sizeof(cx<T>));
-        }
-    };
-    stage(planes + row_a(pair < npairs ? pair : npairs - 1));
-
-    for (long it = 0; it < iters; ++it, pair += stride) {
-        const bool valid = pair < npairs;
-        const long cur = valid ? pair : npairs - 1;
-        const long nxt = (pair + stride < npairs) ? pair + stride : npairs - 1;
-        const size_t off = row_a(cur), offn = row_a(nxt);
-        cx<T> wf = mk<T>((T)1, (T)0), wi = wf;
-        if constexpr (SP) {
-            wf = tw[(int)(cur % N2)];   // exp(-2 pi i r / N)
-            wi = cconj(wf);
-        }
-        cx<T> za[EPT], x[EPT], p[EPT];
-        // staged rows -> Hermitian-packed sequence Z = A~ + i B~ -> transform; the next plane is staged as soon as
-        // every lane of the group is past its reads (first exchange barrier of the transform)
-        auto field = [&](cx<T>(&out)[EPT], const cx<T>* nextA) {
-            wait_vmem_all();                               // this wave's pieces have landed
-            group_sync<SYNC>();                            // ... and the other waves' pieces
-#pragma unroll
-            for (int t = 0; t < EPT; ++t) {
-                const int e = j + t * G;
-                const bool lower = t < EPT / 2;            // e < N/2: own element, else the mirror image of N - e
-                const int k = lower ? e : N - e;
-                cx<T> a = SA[k], b = SB[k];
-                if constexpr (SP) {
-                    const cx<T> o = cmul(b, wi);
-                    b = a - o;
-                    a = a + o;
-                }
-                if (k == 0 || k == N2) { a.y = 0; b.y = 0; }   // c2r drops Im of DC / Nyquist
-                out[t] = lower ? mk<T>(a.x - b.y, a.y + b.x) : mk<T>(a.x + b.y, b.x - a.y);
-            }
-            auto hook = [&]() { stage(nextA); };
-            int jo = j;
-            asm volatile("" : "+v"(jo));   // per-transform address arithmetic instead of ~40 loop-invariant address registers
-            tile_fft_rt<T, N, EPT, +1, 1, true, SYNC>(out, lds, jo, 0, hook, trg);
-        };
-        field(za, planes + 2 * plane_stride + off);   // vx   (next: dx w)
-        field(x, planes + plane_stride + off);        // dx w (next: v^)
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(za[t].x * x[t].x, za[t].y * x[t].y);
-        field(za, planes + 3 * plane_stride + off);   // vy   (next: dy w)
-        field(x, planes + offn);                      // dy w (next: u^ of the next pair)
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) p[t] = mk<T>(-(p[t].x + za[t].x * x[t].x), -(p[t].y + za[t].y * x[t].y));
-
-        int jf = j;
-        asm volatile("" : "+v"(jf));   // as in field(): keep the address arithmetic inside the iteration
-        NoHook nohook;
-        tile_fft_rt<T, N, EPT, -1, 1, true, SYNC>(p, lds, jf, 0, nohook, trg);
-        // unpack the two real-row spectra (mirror through the exchange buffer; element N = element 0, so that the
-        // mirrored index N - k needs no wrap-around and, the swizzle term being the same for every t, ONE address)
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) lds[lds_addr<EPT, 1, true>(jf + t * G, 0)] = p[t];
-        if (jf == 0) lds[N] = p[0];
-        group_sync<SYNC>();
-        const T half = (T)0.5;
-        cx<T>* out0 = adv + off;
-        cx<T>* out1 = adv + off + second;
-        const cx<T>* mir = lds + lds_addr<EPT, 1, true>(N - jf, 0);
-#pragma unroll
-        for (int t = 0; t < EPT / 2; ++t) {
-            const int k = jf + t * G;
-            const cx<T> A = p[t];
-            cx<T> Bm;
-            if constexpr (G % (EPT * EPT) == 0) Bm = mir[-t * G];
-            else Bm = lds[lds_addr<EPT, 1, true>(N - k, 0)];
-            const cx<T> X0 = mk<T>((A.x + Bm.x) * half, (A.y - Bm.y) * half);   // spectrum of the first row
-            const cx<T> X1 = mk<T>((A.y + Bm.y) * half, (Bm.x - A.x) * half);   // spectrum of the second row
-            if (valid && k < kc) {
-                if constexpr (SP) {   // folded for the parity workgroups of the column pass
-                    out0[k] = X0 + X1;
-                    out1[k] = cmul(X0 - X1, wf);
-                } else {
-                    out0[k] = X0;
-                    out1[k] = X1;
-                }
-            }
-        }
-        if (jf == 0 && valid && N2 < kc) {
-            const cx<T> A = p[EPT / 2];
-            const cx<T> X0 = mk<T>(A.x, (T)0), X1 = mk<T>(A.y, (T)0);
-            if constexpr (SP) {
-                out0[N2] = X0 + X1;
-                out1[N2] = cmul(X0 - X1, wf);
-            } else {
-                out0[N2] = X0;
-                out1[N2] = X1;
-            }
-        }
-        group_sync<SYNC>();
-    }
-    wait_vmem_all();   // the last iteration staged one more plane: nothing may be in flight into LDS at wave end
-}
-
 // real (rows, N) -> half spectrum (rows, m): first half of rfft2
 template <typename T, int N, int EPT>
 __global__ __launch_bounds__((RowGeom<T, N, EPT>::THREADS)) void k_rows_r2c(const T* __restrict__ in,
@@ -1591,15 +1222,15 @@ struct Tuning {
     int pair_xcd;            // TCFD_PAIR_XCD: put the 2 / 4 column tiles that share a 128-byte line on one XCD (0 off, 2 pairs only)
     int ablate;              // TCFD_ABLATE: timing ablations (results are WRONG when non-zero)
     int nt_planes;           // TCFD_NT_PLANES: non-temporal plane stores (-1: for the small-tile launches only)
-    int rows_v;              // TCFD_ROWS_V: 0 = per size; 6 = LDS-DMA staged rows, 5 = register-staged rows (one plane per
-                             // transform), 4 = two planes per transform (round 1)
+    int rows_v;              // TCFD_ROWS_V: 0 = per size; 5 = register-staged rows with Stockham exchanges, 7 = cross-lane
+                             // transforms (1024 points fp64 only).  (4 / 6 -- round 1's two-plane kernels, LDS-DMA staging --
+                             // were removed in round 5; the values now mean 5)
     int cols_xl;             // TCFD_COLS_XL: cross-lane column transforms where available (1 = default)
     int nyq_pack;            // TCFD_NYQ_PACK: packed Nyquist column in the step (1 = default where the plan allows it)
     int chunk;               // TCFD_CHUNK: fields per chunk of a batched call (0 = whole batch at once, -1 = cache sized)
     int graph;               // TCFD_GRAPH: hipGraph replay of interior steps (1 = on; off by default since round 4: plain stream
                              // launches measured 3-13 % faster than replay for every small problem, tests/micro/graph_crossover.py)
     int overlap;             // TCFD_OVERLAP: two half batches on two streams (opt-in experiment)
-    int psplit;              // TCFD_PSPLIT=1: the four planes of a column pass on four workgroups (opt-in: measured slower)
     int round_fields;        // n = 3 * 2^k: fields whose column tiles fill the resident workgroup slots exactly once (0: not used)
     size_t cache_bytes;      // last-level (Infinity Cache / MALL) size of the plan's device: what a chunk is sized for
     int cache_source;        // 0 = built-in 256 MB, 1 = KFD topology of this device, 2 = TCFD_CACHE_MB
@@ -1850,7 +1481,6 @@ TCFD_API int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const
     p->tune.nyq_pack = env_int("TCFD_NYQ_PACK", 1);
     p->tune.graph = env_int("TCFD_GRAPH", -1);
     p->tune.overlap = env_int("TCFD_OVERLAP", 0);
-    p->tune.psplit = env_int("TCFD_PSPLIT", 0);
     p->tune.cache_bytes = last_level_cache_bytes(&p->tune.cache_source);
     {
         const int per_line = dtype == TCFD_C128 ? 8 : 16;  // complex elements per 128-byte line
@@ -1864,7 +1494,7 @@ TCFD_API int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const
     }
     (void)fill_round_fields(p);
     p->nyq = (p->tune.nyq_pack && n >= 64 && (n & (n - 1)) == 0 && p->keep_cols > 0 && p->keep_cols <= p->m - 1 &&
-              (p->tune.rows_v == 0 || p->tune.rows_v == 5 || p->tune.rows_v == 7)) ? 1 : 0;
+              true) ? 1 : 0;
     // per pass (TCFD_NYQ_PACK = 3: the opening pass of a call only, for A/B runs; the row pass reads either form)
     p->nyq_a = p->nyq;
     p->nyq_ca = p->nyq && p->tune.nyq_pack != 3;
@@ -1887,26 +1517,12 @@ static size_t field_bytes(const tcfd_ns2d_plan* p, long batch) {
 }
 
 static long chunk_fields(const tcfd_ns2d_plan* p, long batch);
-// plane-split column passes (ColArgs::psplit) exist for the small power-of-two grids; they alternate two RK accumulators
-static bool psplit_capable(const tcfd_ns2d_plan* p) {
-    return p->tune.psplit == 1 && p->n >= 64 && p->n <= 256 && (p->n & (p->n - 1)) == 0 && p->tune.split != 1;
-}
-// MEASURED SLOWER and therefore opt-in (TCFD_PSPLIT=1): 256^2 x 16 fp32 8457 -> 7182 steps/s with the wide tiles, 7507 with
-// the narrow ones.  The premise -- a one-round launch lasts as long as ONE workgroup's chain of five transforms -- is
-// wrong at this size: what the four sibling workgroups re-read (advection, accumulator, state: 3 x 4.2 MB x 4 per launch)
-// comes through the fabric from the Infinity Cache, not from an idle L2 (the XCDs' L2s are not coherent: every kernel
-// boundary writes back and invalidates), and that traffic is what a 12 us kernel is made of.
-static bool psplit_now(const tcfd_ns2d_plan* p, long batch, int wide_cols) {
-    (void)batch; (void)wide_cols;
-    return psplit_capable(p) && p->tune.psplit == 1;
-}
-
 // Scratch of the batched calls.  They run chunk by chunk through ONE chunk-sized set of 8 fields (h, adv, 4 planes,
 // line-aligned state, second state), so the need does not grow with the batch beyond one chunk -- except for irfft2,
 // which stages ONE field of the whole batch.  (1024^2 x 64 fp64: 0.55 GB instead of the 4.4 GB of an unchunked step.)
 TCFD_API size_t tcfd_ns2d_workspace_bytes(const tcfd_ns2d_plan* p, long batch) {
     if (!p || batch <= 0) return 0;
-    return std::max((size_t)(psplit_capable(p) ? 9 : 8) * field_bytes(p, chunk_fields(p, batch)), field_bytes(p, batch));
+    return std::max((size_t)8 * field_bytes(p, chunk_fields(p, batch)), field_bytes(p, batch));
 }
 
 // ------------------------------------------------------------------ optional per-launch event timing
@@ -1988,9 +1604,8 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.ablate = p->tune.ablate;
     long blocks = batch * a.ntiles;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
-    if constexpr (MODE != MODE_A && MODE != MODE_CA) a.psplit = 0;
     if (!a.h_out) a.h_out = a.h;
-    const dim3 grid((unsigned)(blocks * (SP ? 2 : 1)), a.psplit ? 4u : 1u), block(C * G);
+    const dim3 grid((unsigned)(blocks * (SP ? 2 : 1))), block(C * G);
     const int kind = MODE == MODE_A ? 0 : MODE == MODE_CA ? 2 : MODE == MODE_C ? 3 : 5;
     auto launch = [&](auto kern, DevOnce& once) -> int {
         if (int rc_ = set_lds(once, kern, lds)) return rc_;
@@ -2062,9 +1677,7 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
     if constexpr ((N == 128 || N == 256) && (MODE == MODE_A || MODE == MODE_CA || MODE == MODE_C)) {
         const int force = p->tune.small_tiles;
         const long tiles = batch * ((p->m + Cfg<T, N>::COLS - 1) / Cfg<T, N>::COLS);
-        // (plane-split launches have four times the workgroups already: they keep the wide tiles -- whole 128-byte lines per
-        //  row, ONE exchange per 256-point transform at 16 elements per lane -- unless TCFD_SMALL_TILES=1 forces the narrow ones)
-        if (force == 1 || (force != 0 && tiles < 2 * 256 && !a.psplit)) return launch_cols_v<T, N, MODE, 4, 4>(p, a, batch, st);
+        if (force == 1 || (force != 0 && tiles < 2 * 256)) return launch_cols_v<T, N, MODE, 4, 4>(p, a, batch, st);
     }
     // 512-point fp64 tiles are 64 KB: capping the update kernels at 128 VGPRs lets TWO workgroups share a CU,
     // so one tile's memory phases overlap the other's transforms (measured at 512^2 x 256: CA 1.05 -> 0.87 ms)
@@ -2078,38 +1691,6 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
 static long rows_grid(const tcfd_ns2d_plan* p, long want, int dflt_per_cu) {
     const int per_cu = p->tune.rows_blocks_per_cu > 0 ? p->tune.rows_blocks_per_cu : dflt_per_cu;
     return std::min<long>(want, 256L * per_cu);
-}
-
-template <typename T, int N, int EPT, int THR>
-static int launch_rows_advect3(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
-                               long batch, hipStream_t st) {
-    using Gm = RowGeom<T, N, EPT, THR>;
-    auto kern = k_rows_advect3<T, N, EPT, THR>;
-    static DevOnce lds_once;
-    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
-    const long npairs = batch * (N / 2);
-    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, 8);
-    ProfScope prof(p, 1, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
-                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <typename T, int N, int EPT, int THR>
-static int launch_rows_advect4(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
-                               long batch, hipStream_t st) {
-    using Gm = RowGeom<T, N, EPT, THR>;
-    auto kern = k_rows_advect4<T, N, EPT, THR>;
-    static DevOnce lds_once;
-    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
-    const long npairs = batch * (N / 2);
-    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, 8);
-    ProfScope prof(p, 1, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
-                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
-    HIP_TRY(hipGetLastError());
-    return 0;
 }
 
 template <typename T, int N, int EPT, int THR, int SP, int MINW, int PF = 1, int NYQ = 0>
@@ -2151,28 +1732,7 @@ static int launch_rows_advect7(const tcfd_ns2d_plan* p, const cx<T>* planes, siz
     return 0;
 }
 
-template <typename T, int N, int EPT, int THR, int SP, int MINW>
-static int launch_rows_advect6(const tcfd_ns2d_plan* p, const cx<T>* planes, size_t plane_stride, cx<T>* adv,
-                               long batch, hipStream_t st) {
-    using Gm = RowGeom6<T, N, EPT, THR>;
-    auto kern = k_rows_advect6<T, N, EPT, THR, SP, MINW>;
-    static DevOnce lds_once;
-    if (int rc_ = set_lds(lds_once, kern, Gm::LDS_BYTES)) return rc_;
-    const long npairs = batch * (N / 2);
-    constexpr int WG_WAVES = Gm::THREADS / 64;
-    constexpr int BY_REGS = (4 * MINW / WG_WAVES) > 0 ? (4 * MINW / WG_WAVES) : 1;
-    constexpr int BY_LDS = (int)((160 * 1024) / Gm::LDS_BYTES) > 0 ? (int)((160 * 1024) / Gm::LDS_BYTES) : 1;
-    const long blocks = rows_grid(p, (npairs + Gm::GROUPS - 1) / Gm::GROUPS, BY_REGS < BY_LDS ? BY_REGS : BY_LDS);
-    ProfScope prof(p, 1, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::THREADS), Gm::LDS_BYTES, st, planes, plane_stride, adv,
-                       (const cx<T>*)p->tw, npairs, p->ldw, p->keep_cols > 0 ? p->keep_cols : N);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// Row-pass kernel of a size.  5 = register-staged rows (default everywhere); 6 = LDS-DMA staged rows, opt-in
-// (TCFD_ROWS_V=6): measured 0.644 ms against 0.603 ms per launch at 1024^2 x 64 fp64 and no gain at 512^2 -- the
-// per-transform address arithmetic it needs to stay under 256 VGPRs costs more than the staging saves.
+// Row-pass kernel of a size.  5 = register-staged rows (default everywhere but 1024^2 fp64).
 template <typename T, int N>
 static constexpr int rows_default_version() {
     // 7 = cross-lane transforms (1024 points fp64): equal to 5 while the row pass streams from HBM (0.616 vs 0.607 ms
@@ -2192,22 +1752,10 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         return launch_rows_advect5<T, N, EPT, THR, 0, 1, 1>(p, planes, plane_stride, adv, batch, st, 0);
     } else {
     const bool split = use_split<T, N>(p);
-    if (p->tune.rows_v == 4) {   // round-1 kernels (two planes per transform), kept for A/B measurements
-        if (split) return launch_rows_advect4<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
-        return launch_rows_advect3<T, N, EPT, THR>(p, planes, plane_stride, adv, batch, st);
-    }
     if constexpr (N == 128 || N == 256) {
         const int force = p->tune.small_tiles;
         if (!split && (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256)))
             return launch_rows_advect5<T, N, 8, 64, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
-    }
-    if constexpr (RowGeom6<T, N, EPT, THR>::OK) {
-        if (p->tune.rows_v == 6) {   // LDS-DMA staged rows: opt-in (measured slower)
-            if constexpr (N >= 16) {
-                if (split) return launch_rows_advect6<T, N, EPT, THR, 1, 2>(p, planes, plane_stride, adv, batch, st);
-            }
-            return launch_rows_advect6<T, N, EPT, THR, 0, 2>(p, planes, plane_stride, adv, batch, st);
-        }
     }
     if constexpr (N == 1024 && sizeof(T) == 8) {
         if (p->tune.rows_v == 7 || p->tune.rows_v == 0) {   // cross-lane transforms: the default here
@@ -2231,7 +1779,6 @@ struct Ws {
     cx<T>* planes;
     cx<T>* upad;          // state in the line-aligned internal pitch (stages 1.. of a call)
     cx<T>* upad2;         // intermediate state of schedules whose later stages restart from the step's initial state
-    cx<T>* h2;
     size_t plane_stride;  // elements
 };
 template <typename T>
@@ -2244,7 +1791,6 @@ static Ws<T> carve(const tcfd_ns2d_plan* p, void* ws, long batch) {
     w.planes = (cx<T>*)(base + 2 * fb);
     w.upad = (cx<T>*)(base + 6 * fb);
     w.upad2 = (cx<T>*)(base + 7 * fb);
-    w.h2 = (cx<T>*)(base + 8 * fb);     // second RK accumulator of the plane-split passes (only plans that are psplit_capable)
     w.plane_stride = fb / sizeof(cx<T>);
     return w;
 }
@@ -2372,13 +1918,6 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
     a.u_in = (const cx<T>*)w_in;
     a.u_in_ld = p->m;
     a.nyq = p->nyq_a;
-    // plane-split column passes (small one-round launches): four workgroups per tile, each emits one plane; state and
-    // accumulator are then written to the buffer that is NOT being read (upad <-> upad2, h <-> h2)
-    // (not under graph replay: a step is an odd number of buffer swaps, the captured step would read the wrong copy every
-    //  other replay)
-    const bool graph_wanted = steps >= 3 && !(p->prof && p->prof->on) && p->tune.graph == 1;
-    const bool ps = !base0 && !graph_wanted && psplit_now(p, batch, Cfg<T, N>::COLS);
-    a.psplit = ps ? 1 : 0;
     if ((rc = launch_cols<T, N, MODE_A>(p, a, batch, st))) return rc;
     int planes_packed = p->nyq_a;   // how the planes in the workspace were written: the row pass reads them that way
     cx<T>* h_cur = W.h;
@@ -2406,7 +1945,6 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.u_in_ld = from_u0 ? u0_ld : u_src_ld;
             cx<T>* dst = W.upad;
             if (u0_needed_later && (const cx<T>*)dst == u0) dst = W.upad2;
-            if (ps && (const cx<T>*)dst == u_src) dst = W.upad2;      // never the buffer the sibling workgroups still read
             a.u_out = last ? (cx<T>*)w_out : dst;
             a.u_out_ld = last ? p->m : p->ldw;
             a.beta = (T)beta[k];
@@ -2417,8 +1955,7 @@ static int step_impl(const tcfd_ns2d_plan* p, const void* w_in, void* w_out, voi
             a.load_h = (k != 0);  // h starts from 0 every step (equations.py:353)
             a.store_h = (k != nstages - 1);
             a.h = h_cur;
-            a.h_out = (ps && !last) ? (h_cur == W.h ? W.h2 : W.h) : h_cur;
-            a.psplit = (ps && !last) ? 1 : 0;
+            a.h_out = h_cur;
             a.dwdt = last ? (cx<T>*)dwdt : nullptr;
             a.w0 = (const cx<T>*)w_in;
             a.dwdt_scale = (T)inv_total_dt;
@@ -2959,9 +2496,9 @@ static int variant_impl(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
     if (split) *split = sp ? 1 : 0;
     if (rows_kernel) {
         int v = p->tune.rows_v;
-        if (v != 4 && v != 5 && v != 6 && v != 7) v = rows_default_version<T, N>();
+        if (v == 4 || v == 6) v = 5;                 // (removed kernels)
+        if (v != 5 && v != 7) v = rows_default_version<T, N>();
         if (v == 7 && !(N == 1024 && sizeof(T) == 8)) v = 5;
-        if (v == 6 && !RowGeom6<T, N, Cfg<T, N>::ROW_EPT, Cfg<T, N>::ROW_THREADS>::OK) v = 5;
         *rows_kernel = v;
     }
     return 0;

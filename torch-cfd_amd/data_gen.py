@@ -106,25 +106,29 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     if on_gpu:
         torch.cuda.synchronize(device)
     t_setup = time.perf_counter()
-    for start, count in layout[rank]:
-        seeds = [random_state + start + k for k in range(count)]
-        w = plan.rfft2(vorticity_field(grid, peak_wavenumber, batch_seeds=seeds, device=device))
-        handover.start_allocation()     # page-lock the result now: under the warm-up steps, not under the CPU noise above
-        if warmup_steps > 0:
-            w, _ = op._fused_steps(w, dt, warmup_steps, want_dwdt=False)
+    try:
+        for start, count in layout[rank]:
+            seeds = [random_state + start + k for k in range(count)]
+            w = plan.rfft2(vorticity_field(grid, peak_wavenumber, batch_seeds=seeds, device=device))
+            handover.start_allocation()     # page-lock the result now: under the warm-up steps, not under the CPU noise above
+            if warmup_steps > 0:
+                w, _ = op._fused_steps(w, dt, warmup_steps, want_dwdt=False)
 
-        def sink(rec, fields, start=start, count=count):
-            packed = torch.empty((count, len(TRAJECTORY_FIELDS), ns, ns), dtype=dtype, device=device)
-            for f, name in enumerate(TRAJECTORY_FIELDS):
-                packed[:, f] = spectral_to_physical(fields[name], ns, dtype)
-            handover.push(start, rec, packed)
+            def sink(rec, fields, start=start, count=count):
+                packed = torch.empty((count, len(TRAJECTORY_FIELDS), ns, ns), dtype=dtype, device=device)
+                for f, name in enumerate(TRAJECTORY_FIELDS):
+                    packed[:, f] = spectral_to_physical(fields[name], ns, dtype)
+                handover.push(start, rec, packed)
 
-        get_trajectory_imex(op, w, dt, num_steps=total_steps, record_every_steps=record_every_steps, dtype=cdtype,
-                            to_cpu=False, record_sink=sink)
-    if on_gpu:
-        torch.cuda.current_stream(device).synchronize()
-    t_stepped = time.perf_counter()
-    full = handover.finish()
+            get_trajectory_imex(op, w, dt, num_steps=total_steps, record_every_steps=record_every_steps, dtype=cdtype,
+                                to_cpu=False, record_sink=sink)
+        if on_gpu:
+            torch.cuda.current_stream(device).synchronize()
+        t_stepped = time.perf_counter()
+        full = handover.finish()
+    except BaseException:
+        handover.close()      # stop the page-locking helper, wait for copies in flight, unlock: the result is being dropped
+        raise
     t_end = time.perf_counter()
     if stats is not None and handover.trace is not None:
         stats["trace"] = list(handover.trace)

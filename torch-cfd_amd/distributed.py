@@ -203,19 +203,37 @@ class RecordHandover:
                 self._registered: list = []
                 self._lock_warned = False
 
+                self._stop = threading.Event()      # close(): the helper stops before its next region
+
                 def allocate():
                     import time as _time
 
                     from . import _lib as L
 
                     lib = L.load()
+                    PAGE = 4096
                     try:
                         self._trace("page-lock begin")
+                        edge_pages = set()              # first / last page of every range locked so far
                         for f, s0, c in order:
+                            if self._stop.is_set():
+                                break
                             view = self.host[f][s0:s0 + c]
-                            ptr = view.data_ptr()
-                            if lib.tcfd_host_register(ptr, view.numel() * view.element_size()) == 0:
-                                self._registered.append(ptr)
+                            # whole pages, each locked ONCE: regions are disjoint byte ranges, so only their first / last page
+                            # can already belong to a neighbour's lock (overlapping registrations are not portable)
+                            first = view.data_ptr() // PAGE * PAGE
+                            last = (view.data_ptr() + view.numel() * view.element_size() - 1) // PAGE * PAGE
+                            if first in edge_pages:
+                                first += PAGE
+                            if last in edge_pages:
+                                last -= PAGE
+                            if last < first:                # wholly inside pages its neighbours locked
+                                self._host_ready[(f, s0)].set()
+                                continue
+                            if lib.tcfd_host_register(first, last + PAGE - first) == 0:
+                                self._registered.append(first)
+                                edge_pages.add(first)
+                                edge_pages.add(last)
                             elif not self._lock_warned:
                                 # (a locked-memory limit, say): the copies into this region still work -- through the
                                 # runtime's own staging buffers, blocking the side stream's host thread instead of overlapping
@@ -482,6 +500,38 @@ class RecordHandover:
             torch.cuda.current_stream(self.device).synchronize()
         self._sends.clear()
         return None
+
+
+    def close(self):
+        """Release what a hand-over holds when it is dropped BEFORE ``finish`` (an exception in the stepping loop, a cancelled
+        job): stop the page-locking helper and wait for it, wait for the copies in flight on the side stream (they write into
+        the host result), unregister every page-locked region.  Idempotent; ``finish`` leaves nothing for it to do."""
+        stop = getattr(self, "_stop", None)
+        if stop is not None:
+            stop.set()
+        th = getattr(self, "_alloc_thread", None)
+        if th is not None and th.is_alive():
+            for ev in getattr(self, "_host_ready", {}).values():
+                ev.set()
+            th.join()
+        if getattr(self, "on_gpu", False) and getattr(self, "side", None) is not None:
+            try:
+                self.side.synchronize()
+            except Exception:
+                pass
+        self._deferred = []
+        self._keep = []
+        registered, self._registered = getattr(self, "_registered", None) or [], []
+        lib = getattr(self, "_clib", None)
+        if lib is not None:
+            for ptr in registered:
+                lib.tcfd_host_unregister(ptr)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _Done:

@@ -132,6 +132,23 @@ def _fused_xy(X: int, Y: int) -> bool:
     return all(4 <= n <= 1024 for n in (X, Y))
 
 
+def _fft_len(n: int) -> bool:
+    """Lengths of the FFT kernels (tcfd_fno.hip fft_len): 2^k in [8, 1024], 3 * 2^k in [96, 768], 5 * 2^k in [80, 640]."""
+    return (8 <= n <= 1024 and (n & (n - 1)) == 0) or n in (96, 192, 384, 768, 80, 160, 320, 640)
+
+
+def _library_takes(X: int, Y: int, T: int, t_pad: int, t_out: int, modes, t_keep: int, device, real=torch.float32) -> bool:
+    """Whether the library's transform kernels take this call (``tcfd_fno_plan_supports``): FFT lengths always; the pruned
+    direct-DFT kernels of the other sizes hold a (Y x time) slab in LDS and know at most 16 time modes -- beyond that the
+    layers run the dense GEMM transforms (``dense_spectral_conv``), as they do for sizes outside [4, 1024]."""
+    if not _fused_xy(X, Y):
+        return False
+    if _fft_len(Y) and os.environ.get("TCFD_FNO_DFT", "0") != "1":
+        return True
+    plan = _plan((X, Y, T, t_pad, t_out) + tuple(modes), device, real)
+    return bool(plan.lib.tcfd_fno_plan_supports(plan.handle, int(t_keep)))
+
+
 def dense_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad: int = 0, t_out: Optional[int] = None,
                         t_keep: Optional[int] = None, norm: str = "backward", out_xy=None, post=None,
                         use_mfma: bool = True) -> torch.Tensor:
@@ -190,7 +207,8 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
     co = weights[0].shape[1]
     t_out = T + t_pad if t_out is None else t_out
     t_keep = t_out if t_keep is None else t_keep
-    if not _fused_xy(X, Y):      # 96^2, 272^2 (= 256 + 2 * 8 of spatial_padding), ...: the same pruned transforms as thin GEMMs
+    if not _library_takes(X, Y, T, t_pad, t_out, modes, t_keep, v.device, real):
+        # sizes outside [4, 1024], or a slab the direct-DFT kernels cannot hold: the same pruned transforms as thin GEMMs
         return dense_spectral_conv(v, weights, bias, delta, modes, t_pad, t_out, t_keep, norm, use_mfma=use_mfma)
     params = list(weights) + (list(bias) if bias is not None else [])
     if torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params)):
@@ -815,6 +833,8 @@ def hip_spectral_layer(conv, v, lin1, act1, lin2, skip_conv=None, act2=None, ski
     if cargs is None:
         return None
     weights, bias, delta, modes, t_pad, t_out, t_keep, norm = cargs
+    if not _library_takes(v.shape[2], v.shape[3], v.shape[4], t_pad, t_out, modes, t_keep, v.device):
+        return None          # (the composed path: conv(v) then differentiates through the dense transforms)
     conv_params = list(weights) + (list(bias) if bias is not None else [])
     pw = lambda m, a: getattr(m, a) if m is not None else None
     pw_t = [pw(lin1, "weight"), pw(lin1, "bias"), lin2.weight, lin2.bias, pw(skip_conv, "weight"), pw(skip_conv, "bias")]
@@ -1257,14 +1277,17 @@ class SpectralConvS(SpectralConv):
         Xo, Yo, To = out_size
         mx, my, mt = self.modes
         wants_grad = torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if wants_grad or not (_fused_xy(X, Y) and _fused_xy(Xo, Yo)):
+        ok = not wants_grad and _library_takes(X, Y, T, 0, T, self.modes, T, v.device, v.dtype) and _fused_xy(Xo, Yo)
+        if ok:      # ... and the inverse plan on the output grid
+            inv = _plan((Xo, Yo, T, 0, To, mx, my, mt, X, Y), v.device, _real_of(v.dtype))
+            ok = bool(inv.lib.tcfd_fno_plan_supports(inv.handle, int(To)))
+        if not ok:
             # gradients of a resampled layer (super-resolution fine-tuning differentiates it, fno/base.py:229-237) and grids
             # off the fused kernels: the dense pruned transforms (differentiable)
             return dense_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, 0, To, To, self.norm,
                                        out_xy=(Xo, Yo))
         vh, _ = hip_truncated_rfftn(v, self.modes, norm=self.norm)
         oh = hip_contract(vh, list(self.weight), self._bias_list(), self.delta, self.modes)
-        inv = _plan((Xo, Yo, T, 0, To, mx, my, mt, X, Y), v.device, _real_of(v.dtype))
         _, scale = _norm_scales(self.norm, X * Y * T, Xo * Yo * To)
         return hip_truncated_irfftn(oh, inv, To, scale=scale)
 
@@ -1293,6 +1316,8 @@ class SpectralConvT(SpectralConvS):
         if out_steps is None and self.out_steps is not None:
             out_steps = self.out_steps
         t_pad = v.size(-1) if self.temporal_padding else 0
+        if out_steps is None:      # (the reference fails later, on `out_steps + t_pad`; say what is missing)
+            raise ValueError("SpectralConvT needs out_steps: pass it to forward() or to the constructor")
         if keep_steps is not None:
             if not 0 < keep_steps <= out_steps:
                 raise ValueError(f"keep_steps = {keep_steps} outside (0, {out_steps}]")
@@ -1305,7 +1330,8 @@ class SpectralConvT(SpectralConvS):
             # so it acts on the kept modes only -- transform, contract, project, inverse-transform
             if not v.is_cuda or v.dtype not in (torch.float32, torch.float64):
                 raise _lib.TcfdError("expected an fp32 / fp64 HIP device tensor (torch-cfd_amd has no CPU fallback)")
-            if not _fused_xy(v.shape[2], v.shape[3]):
+            if not _library_takes(v.shape[2], v.shape[3], v.shape[4], t_pad, out_steps + t_pad, self.modes, out_steps, v.device,
+                                  v.dtype):
                 post = (lambda oh: self.postprocess.forward_truncated(oh, self.modes, v.shape[-3])) if hasattr(
                     self.postprocess, "forward_truncated") else self.postprocess
                 return dense_spectral_conv(v, list(self.weight), self._bias_list(), self.delta, self.modes, t_pad,
@@ -1472,6 +1498,9 @@ class HelmholtzProjection(nn.Module):
         return uhat - g / lap[None, None, :, :, None]
 
 
+_LIFT_TABLE_MODES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # LiftingOperator -> (key, table modes, last table slice)
+
+
 class LiftingOperator(nn.Module):
     def __init__(self, width: int, modes_x: int, modes_y: int, modes_t: int, latent_steps: int = 10,
                  norm: str = "backward", activation: ActivationType = "GELU", beta: float = 0.1,
@@ -1516,6 +1545,8 @@ class LiftingOperator(nn.Module):
             return None
         weights, bias, delta, modes, t_pad, t_out, t_keep, norm = cargs
         b, _, X, Y, T = vin.shape
+        if not _library_takes(X, Y, T, t_pad, t_out, modes, t_keep, vin.device):
+            return None
         q = self.pe.encoding(vin)
         fold = _lift_fold(vin, q, self.norm, self.proj, consts=self.pe.table_constants(vin))
         if fold is None:
@@ -1529,7 +1560,9 @@ class LiftingOperator(nn.Module):
         # (a table behind a learned projection -- spatial_random_feats -- changes with its weights: formed per call then)
         fixed_table = isinstance(self.pe.proj, nn.Identity)
         key = (dev, X, Y, T, tuple(modes), t_pad, t_out, norm, qf.data_ptr(), q._version)
-        cached = getattr(self, "_table_modes", None) if fixed_table else None
+        # (kept OUTSIDE the module, keyed weakly by it: device tensors in a plain attribute would ride along with copy.deepcopy and
+        #  torch.save(model) and stay behind on .to())
+        cached = _LIFT_TABLE_MODES.get(self) if fixed_table else None
         if cached is None or cached[0] != key:
             with torch.no_grad():
                 fields = torch.cat([qf.view(C, 1, X, Y, T), torch.ones(1, 1, X, Y, T, dtype=torch.float32, device=dev)])
@@ -1537,7 +1570,10 @@ class LiftingOperator(nn.Module):
                 q_last = qf.view(C, X * Y, T)[..., -1].contiguous()
             cached = (key, th.reshape(C + 1, -1).contiguous(), q_last)
             # (not kept when formed inside a stream capture: its memory then belongs to the graph's private pool)
-            self._table_modes = cached if (fixed_table and not torch.cuda.is_current_stream_capturing()) else None
+            if fixed_table and not torch.cuda.is_current_stream_capturing():
+                _LIFT_TABLE_MODES[self] = cached
+            else:
+                _LIFT_TABLE_MODES.pop(self, None)
         _, table, q_last = cached
         vh, plan = hip_truncated_rfftn(vin, modes, t_pad=t_pad, t_out=t_out, norm=norm)
         K = vh[0, 0].numel()
@@ -1620,7 +1656,7 @@ class OutConv(nn.Module):
                 or os.environ.get("TCFD_FNO_FUSED_OUT", "1") == "0"):
             return None
         b, C, X, Y, T = v.shape
-        if (T % 2) or not _fused_xy(X, Y) or b == 0 or tuple(v_res.shape[:3]) != (b, X, Y) or any(
+        if (T % 2) or not (_fft_len(X) and _fft_len(Y)) or b == 0 or tuple(v_res.shape[:3]) != (b, X, Y) or any(
                 p.dtype != torch.float32 for p in reduction.parameters()):
             return None
         lib = _lib.load()
