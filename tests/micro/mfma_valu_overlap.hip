@@ -41,6 +41,37 @@ __global__ __launch_bounds__(256) void kb(float* out, int iters) {
     for (int j = 0; j < 8; ++j) s += v[j];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// fp64: v_mfma_f64_16x16x4_f64 beside v_fma_f64 (would a radix-16 stage of the row pass's 1024-point transform
+// on the matrix pipe run BESIDE the fp64 butterflies of the vector pipe?)
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int M, int V>
+__global__ __launch_bounds__(256) void kd(float* out, int iters) {
+    d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    double v[8] = {a, b, a + 1, b + 1, a + 2, b + 2, a + 3, b + 3};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j & 7] = __builtin_fma(v[j & 7], 1.0001, 0.5);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    double s = 0;
+    for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+    for (int j = 0; j < 8; ++j) s += v[j];
+    out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
+template <int M, int V>
+static void rund(int wgs_per_cu, float* d) {
+    const int iters = 20000, blocks = 256 * wgs_per_cu;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kd<M, V>), dim3(blocks), dim3(256), 0, 0, d, 100);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kd<M, V>), dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("f64 16x16x4: M=%d V=%2d waves/SIMD=%d : %8.3f ms  -> %6.1f ns per iteration\n", M, V, wgs_per_cu, ms, ms * 1e6 / iters);
+}
 template <int M, int V>
 static void runb(int wgs_per_cu, float* d) {
     const int iters = 20000, blocks = 256 * wgs_per_cu;
@@ -72,6 +103,9 @@ int main() {
     }
     for (int w = 1; w <= 2; ++w) {
         runb<4, 0>(w, d); runb<4, 8>(w, d); runb<4, 16>(w, d); runb<4, 32>(w, d);
+    }
+    for (int w = 1; w <= 2; ++w) {
+        rund<4, 0>(w, d); rund<4, 8>(w, d); rund<4, 16>(w, d); rund<4, 32>(w, d); rund<0, 32>(w, d);
     }
     return 0;
 }
