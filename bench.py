@@ -78,7 +78,7 @@ def parse(argv=None):
     ap.add_argument("--c4-samples", type=int, default=512)
     ap.add_argument("--c4-only", action="store_true",
                     help="run ONLY the C4 ensemble job and print its JSON (what a multi-rank run starts as a separate job)")
-    ap.add_argument("--c4-timeout", type=float, default=420.0, help="seconds the separate C4 job of a multi-rank run may take")
+    ap.add_argument("--c4-timeout", type=float, default=180.0, help="seconds the separate C4 job of a multi-rank run may take")
     ap.add_argument("--host-only", action="store_true",
                     help="launcher / timing / reduction path only, on CPU over gloo with a no-op step (no kernels): "
                          "what the CPU test of the N-rank spawner runs")

@@ -23,7 +23,8 @@
 //   g1    <- transposes of g1^T                      (TM tiles)
 //   dx^T  = g1 . W1   (A = g1 tile),  ds^T = g2 . Ws (A = g2 tile)                      TI x (ksteps(CM) + ksteps(CO))
 //   dW2 += g2^T ^T h^T,  dW1 += g1^T ^T x^T,  dWs += g2^T ^T s^T    (contractions over the 16 points, OT tiles on both sides)
-//   db2 += sum g2^T,  db1 += sum g1^T                 plain adds
+//   db1, db2: a constant-1 channel in a free slot of the last x / s tile, so they are a column of dW1 / dWs (plain adds only
+//             where no slot is free -- CI a multiple of 16 -- or the block has no skip convolution)
 // The forward output (ReLU) or pre-activation (GELU, SiLU, tanh) of the block comes from the caller: nothing of z2 is recomputed,
 // and the hidden layer exists in ONE orientation.  Matrix instructions per 16 points: width 10: 59 (the round-4 kernel: 71),
 // 16: 88, 20: 196, 24: 244, 32: 352.  A partly filled channel tile deals its channels to the rows 4q + r with r < ceil(n / 4)
@@ -52,6 +53,13 @@ struct Ch {
     __host__ __device__ static constexpr int chan(int t, int slot) {                          // channel of a tile slot, or -1
         const int q = slot >> 2, r = slot & 3, i = q * rv(t) + r;
         return (r < rv(t) && i < n(t)) ? 16 * t + i : -1;
+    }
+    // a slot of the LAST tile that holds no channel (-1 when N is a multiple of 16): a constant-1 "channel" put there makes the
+    // bias gradient fall out of the weight-gradient products (column `free_slot` of the last tile) instead of costing vector adds
+    __host__ __device__ static constexpr int free_slot() {
+        for (int s = 0; s < 16; ++s)
+            if (chan(T - 1, s) < 0) return s;
+        return -1;
     }
 };
 
@@ -178,6 +186,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
     const int wid = blockIdx.x * 4 + wave, wstride = gridDim.x * 4;
     const unsigned P4 = (unsigned)a.P * 4u;
     constexpr unsigned OOB = 0xffffffffu;                    // beyond every buffer: the bounds check returns 0
+    constexpr int BSLOT = IT::free_slot();                    // slot of the constant-1 channel beside x / s, or -1 (CI % 16 == 0)
     unsigned i_off[TI], o_off[TO];                           // byte offset of this lane's channel row inside ONE sample, or OOB
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) { const int ch = IT::chan(ti, c); i_off[ti] = ch >= 0 ? (unsigned)ch * P4 : OOB; }
@@ -198,15 +207,17 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         const int ibytes = (int)((unsigned)CI * P4), obytes = (int)((unsigned)CO * P4);
         const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * CI * a.P, 0, ibytes, 0x00020000);
         const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout) + (size_t)b * CO * a.P, 0, obytes, 0x00020000);
+        const float one = (BSLOT >= 0 && c == BSLOT && live) ? 1.f : 0.f;      // the constant-1 channel (0 in every other lane)
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
             const unsigned off = (live && i_off[ti] != OOB) ? i_off[ti] + po : OOB;
+            const float k1 = ti == TI - 1 ? one : 0.f;
             const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-            in.xb[ti] = f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            in.xb[ti] = f4{__uint_as_float(v.x) + k1, __uint_as_float(v.y) + k1, __uint_as_float(v.z) + k1, __uint_as_float(v.w) + k1};
             if constexpr (MODE == 1) {
                 const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.s) + (size_t)b * CI * a.P, 0, ibytes, 0x00020000);
                 const u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-                in.sb[ti] = f4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+                in.sb[ti] = f4{__uint_as_float(w.x) + k1, __uint_as_float(w.y) + k1, __uint_as_float(w.z) + k1, __uint_as_float(w.w) + k1};
             } else {
                 in.sb[ti] = f4{0.f, 0.f, 0.f, 0.f};
             }
@@ -226,18 +237,9 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         }
     };
 
-    // Prefetch distance: the loads of group G + PF strides are issued while group G is computed.  The launch is a memory-LATENCY
-    // problem before it is anything else: a wave keeps 1 KB per tensor in flight, and at ~2 us of loaded HBM latency 8 ... 16 waves
-    // per CU with one group in flight cap the chip near 3 TB/s (measured: every width 4 ... 16 sat there).  Two groups in flight
-    // where the registers allow (WPS >= 2, i.e. the narrow widths), one at the wide widths (matrix bound, one wave per SIMD).
-    constexpr int PF = WPS >= 2 ? 2 : 1;
-    In cur, nx1;
-    load(wid < total ? wid : total - 1, cur);
-    if constexpr (PF == 2) load(wid + wstride < total ? wid + wstride : total - 1, nx1);
-    for (int G = wid; G < total; G += wstride) {
-        In nxt;
-        load(G + PF * wstride < total ? G + PF * wstride : total - 1, nxt);   // unconditional (clamped): no branch around the prefetch
-        __builtin_amdgcn_sched_barrier(0);                          // ... and issued HERE, PF iterations ahead of its use
+    // One group of loads in flight per wave, issued a whole group ahead of its use (two in flight measured no faster: the kernel
+    // is bound by instruction issue, not by memory latency); the two input buffers alternate, so no register is ever copied.
+    auto body = [&](const int G, const In& cur) {
         const int b = G / gpb;
         const long pb = (long)(G - b * gpb) * 16 + 4 * q;
         const bool live = pb < a.P;
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         // register-only work while the tiles are on their way: the skip convolution's weight gradient, the output bias gradient
 #pragma unroll
         for (int to = 0; to < TO; ++to) {
-            accB2[to] += (g2T[to][0] + g2T[to][1]) + (g2T[to][2] + g2T[to][3]);
+            if constexpr (!(MODE == 1 && BSLOT >= 0)) accB2[to] += (g2T[to][0] + g2T[to][1]) + (g2T[to][2] + g2T[to][3]);
             if constexpr (MODE == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         // ---- weight gradients: contractions over the 16 points (while the g1 tiles are on their way)
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            accB1[t] += (dhT[t][0] + dhT[t][1]) + (dhT[t][2] + dhT[t][3]);
+            if constexpr (BSLOT < 0) accB1[t] += (dhT[t][0] + dhT[t][1]) + (dhT[t][2] + dhT[t][3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -399,7 +401,29 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (PF == 2) { cur = nx1; nx1 = nxt; } else { cur = nxt; }
+    };
+    if constexpr (WPS == 2) {                                           // narrow widths: the two input buffers alternate (no register copies)
+        In A, B;
+        load(wid < total ? wid : total - 1, A);
+        for (int G = wid; G < total; G += 2 * wstride) {
+            load(G + wstride < total ? G + wstride : total - 1, B);     // unconditional (clamped): no branch around the prefetch
+            __builtin_amdgcn_sched_barrier(0);                           // ... and issued HERE, a whole group ahead of its use
+            body(G, A);
+            if (G + wstride >= total) break;
+            load(G + 2 * wstride < total ? G + 2 * wstride : total - 1, A);
+            __builtin_amdgcn_sched_barrier(0);
+            body(G + wstride, B);
+        }
+    } else {                                                            // wide widths: one body (two would spill), the buffer is copied
+        In A;
+        load(wid < total ? wid : total - 1, A);
+        for (int G = wid; G < total; G += wstride) {
+            In B;
+            load(G + wstride < total ? G + wstride : total - 1, B);
+            __builtin_amdgcn_sched_barrier(0);
+            body(G, A);
+            A = B;
+        }
     }
 
     // ---- this wave's row of partial sums, in the layout of tcfd_fno_pointwise_bwd:
@@ -423,18 +447,34 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
                 if (hq >= 0 && ic >= 0) o1[hq * Lay::CIP + ic] = accW1[t][ti][r];
             }
         }
-        float s = accB1[t];                                   // lanes (q, c), q = 0 .. 3, hold partial sums of the same channel
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (q == 0 && hc >= 0) o1[hc * Lay::CIP + CI] = s;
+        if constexpr (BSLOT >= 0) {                            // db1 = column BSLOT of the last ci tile of dW1
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hq = HT::chan(t, 4 * q + r);
+                if (c == BSLOT && hq >= 0) o1[hq * Lay::CIP + CI] = accW1[t][TI - 1][r];
+            }
+        } else {
+            float s = accB1[t];                               // lanes (q, c), q = 0 .. 3, hold partial sums of the same channel
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (q == 0 && hc >= 0) o1[hc * Lay::CIP + CI] = s;
+        }
     }
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
         const int oc = OT::chan(to, c);
-        float s = accB2[to];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (q == 0 && oc >= 0) out[oc * Lay::CB + CM] = s;
+        if constexpr (MODE == 1 && BSLOT >= 0) {               // db2 (= dbs) = column BSLOT of the last ci tile of dWs
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oq = OT::chan(to, 4 * q + r);
+                if (c == BSLOT && oq >= 0) out[oq * Lay::CB + CM] = accWs[to][TI - 1][r];
+            }
+        } else {
+            float s = accB2[to];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (q == 0 && oc >= 0) out[oc * Lay::CB + CM] = s;
+        }
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -641,14 +681,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwf_tiles(PwArgs a, int batch) {
         }
     };
 
-    constexpr int PF = 2;                                    // two groups of loads in flight per wave (see k_pwb_tiles)
-    In cur, nx1;
-    load(wid < total ? wid : total - 1, cur);
-    load(wid + wstride < total ? wid + wstride : total - 1, nx1);
-    for (int G = wid; G < total; G += wstride) {
-        In nxt;
-        load(G + PF * wstride < total ? G + PF * wstride : total - 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
+    auto body = [&](const int G, const In& cur) {
         const int b = G / gpb;
         const long pb = (long)(G - b * gpb) * 16 + 4 * q;
         const bool live = pb < a.P;
@@ -740,7 +773,19 @@ __global__ __launch_bounds__(256, WPS) void k_pwf_tiles(PwArgs a, int batch) {
                 __builtin_nontemporal_store(y, reinterpret_cast<f4*>(a.out + o));
             }
         }
-        cur = nx1; nx1 = nxt;
+    };
+    {
+        In A, B;                                             // the two input buffers alternate: no register copies
+        load(wid < total ? wid : total - 1, A);
+        for (int G = wid; G < total; G += 2 * wstride) {
+            load(G + wstride < total ? G + wstride : total - 1, B);
+            __builtin_amdgcn_sched_barrier(0);
+            body(G, A);
+            if (G + wstride >= total) break;
+            load(G + 2 * wstride < total ? G + 2 * wstride : total - 1, A);
+            __builtin_amdgcn_sched_barrier(0);
+            body(G + wstride, B);
+        }
     }
 }
 #undef PWF_MFMA
