@@ -147,6 +147,7 @@ def test_contraction_staging_variants(nm, b, ci, co, modes, dev, monkeypatch):
     from torch_cfd_amd import fno
 
     monkeypatch.setenv("TCFD_CONTRACT_NM", str(nm))
+    monkeypatch.setenv("TCFD_CONTRACT_LANES", "0")          # the matrix-pipe kernel also at the narrow shapes
     g = torch.Generator().manual_seed(b + ci)
     mx, my, mt = modes
     for real, tol in ((torch.float32, 2e-6), (torch.float64, 1e-14)):
@@ -160,6 +161,86 @@ def test_contraction_staging_variants(nm, b, ci, co, modes, dev, monkeypatch):
         other = fno.hip_contract(vh, w, bias, 0.7, modes, use_mfma=True)
         monkeypatch.setenv("TCFD_CONTRACT_NM", str(nm))
         assert torch.equal(torch.view_as_real(a), torch.view_as_real(other))
+
+
+@pytest.mark.parametrize("b,ci,co,modes", [(32, 10, 10, (4, 4, 5)), (7, 4, 9, (3, 5, 2)), (5, 5, 5, (2, 2, 3)), (9, 6, 11, (4, 6, 4)),
+                                           (3, 8, 8, (8, 4, 5)), (33, 12, 7, (2, 3, 5)), (1, 10, 1, (1, 1, 1))])
+def test_contraction_lanes_kernel(b, ci, co, modes, dev, monkeypatch):
+    """k_contract_lanes (narrow fp32 layers: one mode per lane, weights in registers, the batch sliced over waves): ragged output
+    channel groups, batches that do not divide into the slices, corner blocks that are not multiples of 64 modes, bias, every
+    slicing of the batch -- against the oracle, the plain kernel and the matrix-pipe kernel; the adjoint (the same kernel on the
+    conjugate-transposed weights) against the matrix-pipe kernel's."""
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    g = torch.Generator().manual_seed(3 * b + ci)
+    mx, my, mt = modes
+    vh = torch.view_as_complex(torch.randn(b, ci, 2 * mx, 2 * my, mt, 2, generator=g))
+    w = [torch.view_as_complex(torch.randn(ci, co, *modes, 2, generator=g)) for _ in range(4)]
+    bias = [torch.view_as_complex(torch.randn(*modes, 2, generator=g)) for _ in range(4)]
+    ref = OF.spectral_contract(vh.to(torch.complex128), [x.to(torch.complex128) for x in w], modes,
+                               bias=[x.to(torch.complex128) for x in bias], delta=0.7)
+    vd, wd, bd = vh.to(dev), [x.to(dev) for x in w], [x.to(dev) for x in bias]
+    plain = fno.hip_contract(vd, wd, bd, 0.7, modes, use_mfma=False)
+    monkeypatch.setenv("TCFD_CONTRACT_LANES", "0")
+    mfma = fno.hip_contract(vd, wd, bd, 0.7, modes)
+    gh = torch.view_as_complex(torch.randn(b, co, 2 * mx, 2 * my, mt, 2, generator=g)).to(dev)
+    lib_adjoint = lambda: fno._contract_vjp(gh, vd, [torch.view_as_real(x) for x in wd], (0.7, modes, True, False), True, [False] * 4)[0]
+    adj_mfma = lib_adjoint()
+    monkeypatch.setenv("TCFD_CONTRACT_LANES", "1")
+    for bg, pf in ((0, 1), (1, 1), (2, 0), (3, 1), (b, 0), (64, 1)):
+        monkeypatch.setenv("TCFD_CONTRACT_BG", str(bg))
+        monkeypatch.setenv("TCFD_CONTRACT_PF", str(pf))
+        out = fno.hip_contract(vd, wd, bd, 0.7, modes)
+        assert rel_l2(out, ref.to(torch.complex64)) < 2e-6, (bg, pf)
+        assert rel_l2(out, plain) < 2e-6 and rel_l2(out, mfma) < 2e-6, (bg, pf)
+        nob = fno.hip_contract(vd, wd, None, 1.0, modes)
+        assert rel_l2(nob, fno.hip_contract(vd, wd, None, 1.0, modes, use_mfma=False)) < 2e-6
+        assert rel_l2(lib_adjoint(), adj_mfma) < 2e-6, (bg, pf)
+
+
+@pytest.mark.parametrize("b,ci,co,modes", [(32, 16, 16, (4, 4, 5)), (7, 20, 13, (3, 5, 2)), (33, 32, 32, (2, 2, 4)), (5, 14, 24, (2, 3, 3)),
+                                           (3, 7, 9, (2, 2, 5)), (70, 5, 31, (1, 2, 3)), (2, 33, 17, (2, 2, 2))])
+def test_contraction_per_mode_product_kernel(b, ci, co, modes, dev, monkeypatch):
+    """k_modes_gemm (wide fp32 layers: 16 modes per workgroup, the k axis streamed through LDS) in its three uses -- contraction,
+    adjoint, weight + bias gradient -- against the oracle under autograd and against the other kernels of the library: k not a
+    multiple of the stage, more than 32 samples (two row tiles), corner blocks that are not multiples of 16 modes."""
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    g = torch.Generator().manual_seed(5 * b + ci)
+    mx, my, mt = modes
+    vh = torch.view_as_complex(torch.randn(b, ci, 2 * mx, 2 * my, mt, 2, generator=g))
+    w = [torch.randn(ci, co, *modes, 2, generator=g) for _ in range(4)]
+    bias = [torch.randn(*modes, 2, generator=g) for _ in range(4)]
+    cot = torch.view_as_complex(torch.randn(b, co, 2 * mx, 2 * my, mt, 2, generator=g))
+    vr = vh.to(torch.complex128).clone().requires_grad_(True)
+    wr = [x.double().clone().requires_grad_(True) for x in w]
+    br = [x.double().clone().requires_grad_(True) for x in bias]
+    ref = OF.spectral_contract(vr, [torch.view_as_complex(x) for x in wr], modes, bias=[torch.view_as_complex(x) for x in br], delta=0.3)
+    torch.autograd.backward(ref, cot.to(torch.complex128))
+
+    def run():
+        vd = vh.detach().to(dev).requires_grad_(True)
+        wd = [x.clone().to(dev).requires_grad_(True) for x in w]
+        bd = [x.clone().to(dev).requires_grad_(True) for x in bias]
+        out = fno._ContractFn.apply(vd, 0.3, modes, True, True, *wd, *bd)
+        torch.autograd.backward(out, cot.to(dev))
+        return [out.detach(), vd.grad] + [x.grad for x in wd] + [x.grad for x in bd]
+
+    monkeypatch.setenv("TCFD_CONTRACT_LANES", "0")
+    monkeypatch.setenv("TCFD_CONTRACT_GEMM", "1")
+    monkeypatch.setenv("TCFD_WGRAD_GEMM", "1")
+    new = run()
+    monkeypatch.setenv("TCFD_CONTRACT_GEMM", "0")
+    monkeypatch.setenv("TCFD_WGRAD_GEMM", "0")
+    old = run()
+    want = [ref.detach(), vr.grad] + [x.grad for x in wr] + [x.grad for x in br]
+    for k, (n_, o_, r_) in enumerate(zip(new, old, want)):
+        assert n_.shape == o_.shape and torch.isfinite(torch.view_as_real(n_) if n_.is_complex() else n_).all(), k
+        assert rel_l2(n_, o_) < 2e-6, k
+        if ci <= 32 and co <= 32:
+            assert rel_l2(n_, r_.to(n_.dtype)) < 2e-6, k
 
 
 @pytest.mark.parametrize("real,use_mfma,tol,complex_params", [(torch.float32, True, 2e-6, False), (torch.float32, False, 2e-6, True),

@@ -658,6 +658,286 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
     }
 }
 
+// Lanes-along-the-modes form for NARROW layers (fp32, ci <= 12): the weights are unique per mode, so a mode is its own
+// (b x ci) . (ci x co) product and at width 10 the 16 x 16 x 4 tiles of the kernel above are mostly padding, while its
+// stage-through-LDS structure (64-byte runs per row, three barriers) leaves the launch latency-bound: 42 us for 82 MB at config 5.
+// Here a lane owns ONE mode and COG output channels: CI x COG weights in registers, the batch as the loop (the next sample's
+// spectrum values are in flight while this one is multiplied), every load and store a run of consecutive modes across the
+// lanes.  A wave = 64 consecutive modes x one group of output channels x one slice of the batch; the waves that share weights
+// (batch slices) and spectrum values (channel groups) of a chunk of modes are dealt to the SAME XCD, next to each other, so
+// the re-reads are L2 hits.
+template <int CI, int COG, bool PREFETCH>
+__global__ __launch_bounds__(64) void k_contract_lanes(ContractArgsT<float> a, int n_cg, int n_bg, int nb, int cpb) {
+    typedef cx<float> cf;
+    typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
+    const int L = a.my * a.mt, MB = a.mx * L, M = 4 * MB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, combos = n_cg * n_bg;
+    const int chunk = (slot / combos) * 8 + xcd;              // chunks of 64 modes never straddle a corner block
+    if (chunk >= 4 * cpb) return;
+    const int combo = slot % combos, cg = combo % n_cg, bg = combo / n_cg;
+    const int blk = chunk / cpb, ix = blk & 1, iy = blk >> 1;
+    const int g_raw = (chunk - blk * cpb) * 64 + (int)threadIdx.x;
+    const bool valid = g_raw < MB;
+    const int wm = valid ? g_raw : MB - 1;                     // mode inside the corner block (= index into its weights)
+    // run kx of my * mt consecutive modes: contiguous in the spectrum and in the weights
+    const int kx = wm / L, within = wm - kx * L;
+    const int mode = ((kx + ix * a.mx) * 2 * a.my + iy * a.my) * a.mt + within;
+    // every address = wave-uniform base (buffer descriptor) + wave-uniform channel offset (scalar) + 8 * the lane's mode
+    const unsigned voff_w = (unsigned)wm * 8u, voff_s = (unsigned)mode * 8u;
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(a.w[blk]), 0, (int)((unsigned)(CI * a.co * MB) * 8u), 0x00020000);
+    const int o0 = cg * COG;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 wv[CI][COG];                                            // (re, im) pairs: a complex multiply-add is two v_pk_fma_f32
+    const int si = a.adjoint ? 1 : a.co, su = a.adjoint ? CI : 1;   // weight (i, o) sits at i * si + o * su blocks of MB modes
+    const float conj_sign = a.adjoint ? -1.f : 1.f;
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+        for (int u = 0; u < COG; ++u) {
+            const int o = min(o0 + u, a.co - 1);
+            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_w, (unsigned)((i * si + o * su) * MB) * 8u, 0);
+            wv[i][u] = (f2){__uint_as_float(v[0]), __uint_as_float(v[1]) * conj_sign};
+        }
+    f2 bias = {0.f, 0.f};
+    if (a.bias[blk]) {
+        const cf bv = a.bias[blk][wm];
+        bias = (f2){bv.x * a.delta, bv.y * a.delta};
+    }
+    const int b0 = bg * nb, b1 = min(a.b, b0 + nb);
+    if (b0 >= b1) return;
+    const unsigned in_bytes = (unsigned)(CI * M) * 8u, out_bytes = (unsigned)(a.co * M) * 8u;
+    auto load_x = [&](int bb, f2 (&x)[CI]) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(a.vin) + (size_t)bb * CI * M, 0, (int)in_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_s, (unsigned)(i * M) * 8u, 0);
+            x[i] = (f2){__uint_as_float(v[0]), __uint_as_float(v[1])};
+        }
+    };
+    f2 xn[CI];
+    if constexpr (PREFETCH) load_x(b0, xn);
+    for (int bb = b0; bb < b1; ++bb) {
+        f2 xc[CI];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) xc[i] = xn[i];
+            load_x(min(bb + 1, b1 - 1), xn);                   // clamped: no branch around the prefetch
+        } else {
+            load_x(bb, xc);
+        }
+        f2 pr[COG], pi[COG];                                   // pr = sum x.re * (w.re, w.im),  pi = sum x.im * (w.re, w.im)
+#pragma unroll
+        for (int u = 0; u < COG; ++u) { pr[u] = bias; pi[u] = (f2){0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < CI; ++i)
+#pragma unroll
+            for (int u = 0; u < COG; ++u) {
+                // one half of x against both halves of w: the half is picked by op_sel, no broadcast copies, no rotated weights
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(pr[u]) : "v"(xc[i]), "v"(wv[i][u]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(pi[u]) : "v"(xc[i]), "v"(wv[i][u]));
+            }
+        f2 acc[COG];
+#pragma unroll
+        for (int u = 0; u < COG; ++u) acc[u] = (f2){pr[u].x - pi[u].y, pr[u].y + pi[u].x};
+        if (valid) {
+            const auto ro = __builtin_amdgcn_make_buffer_rsrc(a.vout + (size_t)bb * a.co * M, 0, (int)out_bytes, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < COG; ++u)
+                if (o0 + u < a.co) {
+                    const u2v v = {__float_as_uint(acc[u].x), __float_as_uint(acc[u].y)};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, ro, voff_s, (unsigned)((o0 + u) * M) * 8u, 0);
+                }
+        }
+    }
+}
+
+// Per-mode products for WIDE layers (fp32, 13 ... 32 channels): C[r][c] = sum_k opA(A[k][r]) . opB(B[k][c]) for every kept mode,
+// which is the contraction (k = input channel, r = sample, c = output channel), its adjoint (k = output channel, B = conj W^T)
+// and the weight gradient (k = sample, r = input channel, A = conj of the spectrum) -- three uses of one kernel that differ in
+// strides only.  The matrix-pipe kernel above stages WHOLE operands of 4 - 8 modes in LDS (82 - 131 KB at widths 20 - 32: one
+// workgroup per CU, four barriers, 1.0 TB/s); here a workgroup owns 16 consecutive modes (one 128-byte line per operand row)
+// and 16 lanes share a mode: lane (m, tc, tr) accumulates rows {4 j + tr} x columns {4 j + tc} (8 x CT complex accumulators)
+// while the k axis streams through LDS four k at a time, double buffered: the loads of the next four are in flight during the
+// products of this four, one barrier per stage.  Interleaved rows / columns make every LDS read of a wave one contiguous
+// 128-byte run per row (broadcast across tc) resp. 4 adjacent runs (columns): conflict free.
+struct ModesGemmArgs {
+    const cx<float>* a[4];    // operand bases per corner block (equal for spectra)
+    const cx<float>* b[4];
+    cx<float>* c[4];
+    const cx<float>* bias[4]; // added (times delta) to every C[r][c] of the mode, or null
+    cx<float>* gb[4];         // delta * sum_{k, c} B[k][c] per mode (the bias gradient of the weight-gradient use), or null
+    int a_blk, b_blk, c_blk;  // 1: indexed inside a corner block (weights: stride MB, index wm); 0: a spectrum (stride M, index mode)
+    int sAk, sAr, sBk, sBc, sCr;   // element strides in units of the operand's mode stride (C: column stride 1)
+    float conj_a, conj_b;     // factor on the imaginary part: -1 conjugates
+    float delta;
+    int R, Cn, K, mx, my, mt;
+    unsigned a_bytes, b_bytes, c_bytes;   // sizes of one operand tensor (bounds of the buffer descriptors)
+};
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void k_modes_gemm(ModesGemmArgs a, int cpb) {
+    typedef cx<float> cf;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
+    constexpr int RT = 8, KC = 4, NR = 4 * RT, NCP = CT <= 4 ? 16 : 32, NA = KC * NR / 16, NB = KC * NCP / 16;
+    constexpr int STAGE = KC * (NR + NCP) * 16;                 // complex elements of one buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char mg_raw[];
+    f2* lds = reinterpret_cast<f2*>(mg_raw);
+    const int L = a.my * a.mt, MB = a.mx * L, M = 4 * MB;
+    const int blk = blockIdx.x / cpb, ix = blk & 1, iy = blk >> 1;
+    const int t = threadIdx.x, m = t & 15, tc = (t >> 4) & 3, tr = t >> 6, q0 = t >> 4;
+    const int g_raw = (blockIdx.x - blk * cpb) * 16 + m;
+    const bool valid = g_raw < MB;
+    const int wm = valid ? g_raw : MB - 1;
+    const int kx = wm / L, within = wm - kx * L;
+    const int mode = ((kx + ix * a.mx) * 2 * a.my + iy * a.my) * a.mt + within;
+    const int r0 = blockIdx.y * NR;
+    const unsigned strA = a.a_blk ? MB : M, strB = a.b_blk ? MB : M, strC = a.c_blk ? MB : M;
+    const unsigned idxA = a.a_blk ? wm : mode, idxB = a.b_blk ? wm : mode, idxC = a.c_blk ? wm : mode;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(a.a[blk]), 0, (int)a.a_bytes, 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(a.b[blk]), 0, (int)a.b_bytes, 0x00020000);
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc(a.c[blk], 0, (int)a.c_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;                       // beyond every descriptor: loads return 0, stores are dropped
+    // staging: element q = q0 + 16 n of a stage is (k = n / 2, row or column = q & 31) resp. (k = n, column = q0) for NCP = 16
+    unsigned offA[NA], offB[NB];
+#pragma unroll
+    for (int n = 0; n < NA; ++n) {
+        const int r = r0 + ((q0 + 16 * n) & (NR - 1)), kk = (q0 + 16 * n) / NR;
+        offA[n] = r < a.R ? ((unsigned)(kk * a.sAk + r * a.sAr) * strA + idxA) * 8u : OOB;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int c = (q0 + 16 * n) & (NCP - 1), kk = (q0 + 16 * n) / NCP;
+        offB[n] = c < a.Cn ? ((unsigned)(kk * a.sBk + c * a.sBc) * strB + idxB) * 8u : OOB;
+    }
+    const unsigned stepA = (unsigned)(KC * a.sAk) * strA * 8u, stepB = (unsigned)(KC * a.sBk) * strB * 8u;
+    f2 sa[NA], sb[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            const int kk = (16 * n) / NR;                         // uniform: q0 < 16 never carries into the k index
+            const unsigned off = (k0 + kk < a.K && offA[n] != OOB) ? offA[n] + (unsigned)(k0 / KC) * stepA : OOB;
+            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(ra, off, 0, 0);
+            sa[n] = (f2){__uint_as_float(v[0]), __uint_as_float(v[1]) * a.conj_a};
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int kk = (16 * n) / NCP;
+            const unsigned off = (k0 + kk < a.K && offB[n] != OOB) ? offB[n] + (unsigned)(k0 / KC) * stepB : OOB;
+            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rb, off, 0, 0);
+            sb[n] = (f2){__uint_as_float(v[0]), __uint_as_float(v[1]) * a.conj_b};
+        }
+    };
+    auto stash = [&](int buf) {                                   // element q of the stage, mode m  ->  slot q * 16 + m = t + 256 n
+        f2* A_ = lds + buf * STAGE;
+        f2* B_ = A_ + KC * NR * 16;
+#pragma unroll
+        for (int n = 0; n < NA; ++n) A_[t + 256 * n] = sa[n];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) B_[t + 256 * n] = sb[n];
+    };
+    f2 acc[RT][CT];
+    {
+        f2 bias = {0.f, 0.f};
+        if (a.bias[blk]) {
+            const cf bv = a.bias[blk][wm];
+            bias = (f2){bv.x * a.delta, bv.y * a.delta};
+        }
+#pragma unroll
+        for (int jr = 0; jr < RT; ++jr)
+#pragma unroll
+            for (int jc = 0; jc < CT; ++jc) acc[jr][jc] = bias;
+    }
+    f2 bsum = {0.f, 0.f};
+    const bool want_gb = a.gb[blk] != nullptr && tr == 0 && blockIdx.y == 0;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int k0 = 0, cur = 0; k0 < a.K; k0 += KC, cur ^= 1) {
+        const bool more = k0 + KC < a.K;
+        if (more) fetch(k0 + KC);
+        const f2* A_ = lds + cur * STAGE;
+        const f2* B_ = A_ + KC * NR * 16;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            f2 bv[CT], br[CT];
+#pragma unroll
+            for (int jc = 0; jc < CT; ++jc) {
+                bv[jc] = B_[(kk * NCP + jc * 4 + tc) * 16 + m];
+                br[jc] = (f2){-bv[jc].y, bv[jc].x};
+            }
+            if (want_gb) {
+#pragma unroll
+                for (int jc = 0; jc < CT; ++jc) bsum += bv[jc];
+            }
+#pragma unroll
+            for (int jr = 0; jr < RT; ++jr) {
+                if (r0 + jr * 4 + tr < a.R) {                     // wave-uniform
+                    const f2 av = A_[(kk * NR + jr * 4 + tr) * 16 + m];
+#pragma unroll
+                    for (int jc = 0; jc < CT; ++jc) {             // acc += a.re * (b.re, b.im) + a.im * (-b.im, b.re)
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[jr][jc]) : "v"(av), "v"(bv[jc]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[jr][jc]) : "v"(av), "v"(br[jc]));
+                    }
+                }
+            }
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int jr = 0; jr < RT; ++jr) {
+        const int r = r0 + jr * 4 + tr;
+#pragma unroll
+        for (int jc = 0; jc < CT; ++jc) {
+            const int c = jc * 4 + tc;
+            const unsigned off = (valid && r < a.R && c < a.Cn) ? ((unsigned)(r * a.sCr + c) * strC + idxC) * 8u : OOB;
+            const u2v v = {__float_as_uint(acc[jr][jc].x), __float_as_uint(acc[jr][jc].y)};
+            __builtin_amdgcn_raw_buffer_store_b64(v, rc, off, 0, 0);
+        }
+    }
+    if (a.gb[blk] != nullptr && tr == 0 && blockIdx.y == 0) {      // wave 0: the four column groups of a mode sit 16 lanes apart
+        bsum.x += __shfl_xor(bsum.x, 16); bsum.y += __shfl_xor(bsum.y, 16);
+        bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32);
+        if (tc == 0 && valid) a.gb[blk][wm] = mk<float>(a.delta * bsum.x, a.delta * bsum.y);
+    }
+}
+
+static int launch_modes_gemm(ModesGemmArgs& a, long a_elems, long b_elems, long c_elems, int row_tiles, hipStream_t st) {
+    if (a.Cn > 32 || a.Cn < 1 || a.K < 1 || a.R < 1) return -1;
+    if (a_elems * 8 >= (1L << 31) || b_elems * 8 >= (1L << 31) || c_elems * 8 >= (1L << 31)) return -1;
+    a.a_bytes = (unsigned)(a_elems * 8); a.b_bytes = (unsigned)(b_elems * 8); a.c_bytes = (unsigned)(c_elems * 8);
+    const int MB = a.mx * a.my * a.mt, cpb = (MB + 15) / 16;
+    const int ct = a.Cn <= 16 ? 4 : a.Cn <= 20 ? 5 : a.Cn <= 24 ? 6 : 8;
+    const int ncp = ct <= 4 ? 16 : 32;
+    const size_t lds = (size_t)2 * 4 * (32 + ncp) * 16 * sizeof(cx<float>);
+#define TCFD_MG(CT_)                                                                                        \
+    {                                                                                                       \
+        auto kern = k_modes_gemm<CT_>;                                                                      \
+        if (int rc = set_lds_attr(kern, lds)) return rc;                                                    \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(4 * cpb), (unsigned)row_tiles), dim3(256), lds, st, a, cpb); \
+    }
+    if (ct == 4) TCFD_MG(4) else if (ct == 5) TCFD_MG(5) else if (ct == 6) TCFD_MG(6) else TCFD_MG(8)
+#undef TCFD_MG
+    return 0;
+}
+
+// the contraction / its adjoint through the per-mode product kernel
+static int launch_contract_gemm(const ContractArgsT<float>& c, hipStream_t st) {
+    if (c.co > 32) return -1;
+    const long MB = (long)c.mx * c.my * c.mt, M = 4 * MB;
+    ModesGemmArgs g;
+    for (int k = 0; k < 4; ++k) { g.a[k] = c.vin; g.b[k] = c.w[k]; g.c[k] = c.vout; g.bias[k] = c.bias[k]; g.gb[k] = nullptr; }
+    g.a_blk = 0; g.b_blk = 1; g.c_blk = 0;
+    g.sAk = 1; g.sAr = c.ci;                                     // A[k = input channel][r = sample] = vin[(b * ci + i)]
+    if (c.adjoint) { g.sBk = 1; g.sBc = c.ci; g.conj_b = -1.f; }  // B[k = o'][c = i'] = conj(W[i'][o']),  W blocks are (co, ci) here
+    else { g.sBk = c.co; g.sBc = 1; g.conj_b = 1.f; }
+    g.sCr = c.co; g.conj_a = 1.f; g.delta = c.delta;
+    g.R = c.b; g.Cn = c.co; g.K = c.ci; g.mx = c.mx; g.my = c.my; g.mt = c.mt;
+    return launch_modes_gemm(g, (long)c.b * c.ci * M, (long)c.ci * c.co * MB, (long)c.b * c.co * M, (c.b + 31) / 32, st);
+}
+static int launch_contract_gemm(const ContractArgsT<double>&, hipStream_t) { return -1; }
+
 // ------------------------------------------------------------------ host side
 
 // ---- launchers of the any-size kernels
@@ -927,6 +1207,41 @@ static int launch_contract_mfma(const ContractArgsT<T>& a, size_t lds, hipStream
     hipLaunchKernelGGL(kern, dim3((unsigned)(4 * MB / NM)), dim3(256), lds, st, a);
     return 0;
 }
+// the lanes kernel: CI as instantiated, COG = 5 when it divides co (width 10), else 4; the batch is sliced until ~1300 waves
+// are in flight (TCFD_CONTRACT_BG overrides the number of slices; config 5: 4 slices 17.3 us, 8 slices 19.0, 2 slices 19.8,
+// the matrix-pipe kernel 43.9 -- profiles/r05_contract_timing.json)
+template <int CI>
+static int launch_contract_lanes_ci(const ContractArgsT<float>& a, hipStream_t st) {
+    const int MB = a.mx * a.my * a.mt, cpb = (MB + 63) / 64;
+    const int cog = a.co % 5 == 0 ? 5 : 4, n_cg = (a.co + cog - 1) / cog;
+    int n_bg = env_int("TCFD_CONTRACT_BG", 0);
+    if (n_bg <= 0) n_bg = (int)std::max<long>(1, (1280 + 4L * cpb * n_cg - 1) / (4L * cpb * n_cg));   // ~1.3 waves per SIMD measured best
+    n_bg = std::min(n_bg, a.b);
+    const int nb = (a.b + n_bg - 1) / n_bg;
+    n_bg = (a.b + nb - 1) / nb;
+    const unsigned blocks = (unsigned)(((4 * cpb + 7) / 8) * 8 * n_cg * n_bg);
+    const bool pf = env_int("TCFD_CONTRACT_PF", 1) != 0;
+#define TCFD_LANES(COG_, PF_) hipLaunchKernelGGL((k_contract_lanes<CI, COG_, PF_>), dim3(blocks), dim3(64), 0, st, a, n_cg, n_bg, nb, cpb)
+    if (cog == 5) { if (pf) TCFD_LANES(5, true); else TCFD_LANES(5, false); }
+    else { if (pf) TCFD_LANES(4, true); else TCFD_LANES(4, false); }
+#undef TCFD_LANES
+    return 0;
+}
+static int launch_contract_lanes(const ContractArgsT<float>& a, hipStream_t st) {
+    const long M = 4L * a.mx * a.my * a.mt;                  // 32-bit byte offsets inside one sample / one weight block
+    if ((long)std::max(a.ci, a.co) * M * 8 >= (1L << 31) || (long)a.ci * a.co * (M / 4) * 8 >= (1L << 31)) return -1;
+    switch (a.ci) {
+        case 4: return launch_contract_lanes_ci<4>(a, st);
+        case 5: return launch_contract_lanes_ci<5>(a, st);
+        case 6: return launch_contract_lanes_ci<6>(a, st);
+        case 8: return launch_contract_lanes_ci<8>(a, st);
+        case 10: return launch_contract_lanes_ci<10>(a, st);
+        case 12: return launch_contract_lanes_ci<12>(a, st);
+        default: return -1;
+    }
+}
+static int launch_contract_lanes(const ContractArgsT<double>&, hipStream_t) { return -1; }
+
 template <typename T>
 static int do_contract(ContractArgsT<T> a, int use_mfma, hipStream_t st) {
     FnoProfScope prof(FNO_K_CONTRACT, st);
@@ -935,10 +1250,16 @@ static int do_contract(ContractArgsT<T> a, int use_mfma, hipStream_t st) {
     // whole 128-byte lines with half the workgroups: measured 40.5 against 39.2 us at the config-5 shape -- the launch is
     // ~1.4 rounds of workgroups moving in step (load burst, MFMAs, store burst), not a bandwidth or LDS problem
     const int force = env_int("TCFD_CONTRACT_NM", 0);
-    const size_t lds16 = contract_lds<T, 16>(a), lds8 = contract_lds<T, 8>(a);
+    const size_t lds16 = contract_lds<T, 16>(a), lds8 = contract_lds<T, 8>(a), lds4 = contract_lds<T, 4>(a);
     int rc = -1;
-    if (use_mfma && force == 16 && MB % 16 == 0 && lds16 <= 150 * 1024)
+    if (use_mfma && env_int("TCFD_CONTRACT_LANES", 1)) rc = launch_contract_lanes(a, st);   // narrow fp32 layers; -1: not its shape
+    if (rc < 0 && use_mfma && env_int("TCFD_CONTRACT_GEMM", 1)) rc = launch_contract_gemm(a, st);   // fp32 up to 32 output channels
+    if (rc >= 0)
+        ;
+    else if (use_mfma && force == 16 && MB % 16 == 0 && lds16 <= 150 * 1024)
         rc = launch_contract_mfma<T, 16>(a, lds16, st);
+    else if (use_mfma && MB % 4 == 0 && (force == 4 || (force == 0 && lds8 > 64 * 1024)) && lds4 <= 150 * 1024)
+        rc = launch_contract_mfma<T, 4>(a, lds4, st);            // wide layers: 8 modes would leave one workgroup per CU
     else if (use_mfma && MB % 8 == 0 && lds8 <= 150 * 1024)
         rc = launch_contract_mfma<T, 8>(a, lds8, st);
     else {
@@ -1142,10 +1463,17 @@ struct WgradArgsT {
 };
 
 template <typename T, int IC, int OC>
-__global__ __launch_bounds__(256) void k_contract_wgrad(WgradArgsT<T> a) {
+__global__ __launch_bounds__(256, 2) void k_contract_wgrad(WgradArgsT<T> a) {
+    // 64 consecutive modes x 4 slices of the batch per workgroup (one wave each): the sum over the batch is the only serial
+    // loop of this kernel, and with a whole batch per lane (round 4) a launch was 432 waves waiting on 32 dependent rounds of
+    // loads (52 us at config 5).  The four partial sums meet in LDS; wave 0 adds them IN ORDER (deterministic) and stores.
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_raw[];
+    T* part = reinterpret_cast<T*>(wg_raw);                       // [3 waves][IC * OC * 2][64 lanes]
     const int M = 4 * a.mx * a.my * a.mt;
-    const int mode = blockIdx.x * 256 + threadIdx.x;
-    if (mode >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mode_raw = blockIdx.x * 64 + lane;
+    const bool valid = mode_raw < M;
+    const int mode = valid ? mode_raw : M - 1;
     const int i0 = blockIdx.y * IC, o0 = blockIdx.z * OC;
     const int kt = mode % a.mt;
     const int kyi = (mode / a.mt) % (2 * a.my);
@@ -1154,15 +1482,57 @@ __global__ __launch_bounds__(256) void k_contract_wgrad(WgradArgsT<T> a) {
     const int blk = ix + 2 * iy;
     const long MB = (long)a.mx * a.my * a.mt;
     const long wm = ((long)(kxi - ix * a.mx) * a.my + (kyi - iy * a.my)) * a.mt + kt;
-    if (a.gw[blk]) {
-        // IC input x OC output channels of ONE mode in registers: every spectrum value is read co / OC (vh) resp. ci / IC (gh)
-        // times in all (one lane per (mode, input channel) read gh ci times: 0.09 ms, bound by the L2s)
-        T re[IC][OC], im[IC][OC];
+    cx<T>* gw = blk == 0 ? a.gw[0] : blk == 1 ? a.gw[1] : blk == 2 ? a.gw[2] : a.gw[3];
+    cx<T>* gb = blk == 0 ? a.gb[0] : blk == 1 ? a.gb[1] : blk == 2 ? a.gb[2] : a.gb[3];
+    const int nb = (a.b + 3) / 4, b0 = wave * nb, b1 = min(a.b, b0 + nb);
+    // IC input x OC output channels of ONE mode in registers: every spectrum value is read co / OC (vh) resp. ci / IC (gh) times
+    T re[IC][OC], im[IC][OC];
+#pragma unroll
+    for (int v = 0; v < IC; ++v)
+#pragma unroll
+        for (int u = 0; u < OC; ++u) re[v][u] = im[v][u] = 0;
+    T bre = 0, bim = 0;                                           // bias gradient: sum over (b, o) of gh, by the (0, *) workgroups
+    const bool do_bias = blockIdx.y == 0;
+    if constexpr (sizeof(T) == 4) {
+        // fp32: (re, im) of an accumulator as one register pair, conj(v) g = v.re * (g.re, g.im) + v.im * (g.im, -g.re) as two
+        // v_pk_fma_f32 (the half of v picked by op_sel)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 acc[IC][OC];
 #pragma unroll
         for (int v = 0; v < IC; ++v)
 #pragma unroll
-            for (int u = 0; u < OC; ++u) re[v][u] = im[v][u] = 0;
-        for (int bb = 0; bb < a.b; ++bb) {
+            for (int u = 0; u < OC; ++u) acc[v][u] = (f2){0.f, 0.f};
+        for (int bb = b0; bb < b1; ++bb) {
+            f2 vv[IC], gg[OC], gr[OC];
+#pragma unroll
+            for (int v = 0; v < IC; ++v) {
+                const cx<T> t = i0 + v < a.ci ? a.vh[((long)bb * a.ci + i0 + v) * M + mode] : mk<T>((T)0, (T)0);
+                vv[v] = (f2){t.x, t.y};
+            }
+#pragma unroll
+            for (int u = 0; u < OC; ++u) {
+                const cx<T> t = o0 + u < a.co ? a.gh[((long)bb * a.co + o0 + u) * M + mode] : mk<T>((T)0, (T)0);
+                gg[u] = (f2){t.x, t.y};
+                gr[u] = (f2){t.y, -t.x};
+            }
+#pragma unroll
+            for (int v = 0; v < IC; ++v)
+#pragma unroll
+                for (int u = 0; u < OC; ++u) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[v][u]) : "v"(vv[v]), "v"(gg[u]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[v][u]) : "v"(vv[v]), "v"(gr[u]));
+                }
+            if (do_bias) {
+#pragma unroll
+                for (int u = 0; u < OC; ++u) { bre += gg[u].x; bim += gg[u].y; }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < IC; ++v)
+#pragma unroll
+            for (int u = 0; u < OC; ++u) { re[v][u] = acc[v][u].x; im[v][u] = acc[v][u].y; }
+    } else {
+        for (int bb = b0; bb < b1; ++bb) {
             cx<T> vv[IC], gg[OC];
 #pragma unroll
             for (int v = 0; v < IC; ++v) vv[v] = i0 + v < a.ci ? a.vh[((long)bb * a.ci + i0 + v) * M + mode] : mk<T>((T)0, (T)0);
@@ -1175,22 +1545,73 @@ __global__ __launch_bounds__(256) void k_contract_wgrad(WgradArgsT<T> a) {
                     re[v][u] += vv[v].x * gg[u].x + vv[v].y * gg[u].y;          // conj(v) g
                     im[v][u] += vv[v].x * gg[u].y - vv[v].y * gg[u].x;
                 }
+            if (do_bias) {
+#pragma unroll
+                for (int u = 0; u < OC; ++u) { bre += gg[u].x; bim += gg[u].y; }
+            }
         }
+    }
+    constexpr int NACC = IC * OC * 2 + 2;
+    if (wave > 0) {
+        T* mine = part + (size_t)(wave - 1) * NACC * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < IC; ++v)
+#pragma unroll
+            for (int u = 0; u < OC; ++u) {
+                mine[(size_t)((v * OC + u) * 2) * 64] = re[v][u];
+                mine[(size_t)((v * OC + u) * 2 + 1) * 64] = im[v][u];
+            }
+        mine[(size_t)(NACC - 2) * 64] = bre;
+        mine[(size_t)(NACC - 1) * 64] = bim;
+    }
+    __syncthreads();
+    if (wave > 0 || !valid) return;
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        const T* other = part + (size_t)k * NACC * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < IC; ++v)
+#pragma unroll
+            for (int u = 0; u < OC; ++u) {
+                re[v][u] += other[(size_t)((v * OC + u) * 2) * 64];
+                im[v][u] += other[(size_t)((v * OC + u) * 2 + 1) * 64];
+            }
+        bre += other[(size_t)(NACC - 2) * 64];
+        bim += other[(size_t)(NACC - 1) * 64];
+    }
+    if (gw) {
 #pragma unroll
         for (int v = 0; v < IC; ++v)
 #pragma unroll
             for (int u = 0; u < OC; ++u)
-                if (i0 + v < a.ci && o0 + u < a.co) a.gw[blk][((long)(i0 + v) * a.co + o0 + u) * MB + wm] = mk<T>(re[v][u], im[v][u]);
+                if (i0 + v < a.ci && o0 + u < a.co) gw[((long)(i0 + v) * a.co + o0 + u) * MB + wm] = mk<T>(re[v][u], im[v][u]);
     }
-    if (a.gb[blk] && blockIdx.y == 0 && blockIdx.z == 0) {
-        T re = 0, im = 0;
-        for (long r = 0; r < (long)a.b * a.co; ++r) {
-            const cx<T> g = a.gh[r * M + mode];
-            re += g.x;
-            im += g.y;
-        }
-        a.gb[blk][wm] = mk<T>(a.delta * re, a.delta * im);
+    // the bias gradient needs every output channel: with one group of them (co <= OC) it is complete here, otherwise the
+    // groups add theirs into the zeroed buffer one after another -- see the host side (it launches such shapes with gb = null
+    // and a second, bias-only pass)
+    if (gb && do_bias) gb[wm] = mk<T>(a.delta * bre, a.delta * bim);
+}
+
+// bias gradient alone, for layers with more output channels than one group holds
+template <typename T>
+__global__ __launch_bounds__(256) void k_contract_bgrad(WgradArgsT<T> a) {
+    const int M = 4 * a.mx * a.my * a.mt;
+    const int mode = blockIdx.x * 256 + threadIdx.x;
+    if (mode >= M) return;
+    const int kt = mode % a.mt;
+    const int kyi = (mode / a.mt) % (2 * a.my);
+    const int kxi = mode / (a.mt * 2 * a.my);
+    const int ix = kxi >= a.mx, iy = kyi >= a.my;
+    const int blk = ix + 2 * iy;
+    const long wm = ((long)(kxi - ix * a.mx) * a.my + (kyi - iy * a.my)) * a.mt + kt;
+    if (!a.gb[blk]) return;
+    T re = 0, im = 0;
+    for (long r = 0; r < (long)a.b * a.co; ++r) {
+        const cx<T> g = a.gh[r * M + mode];
+        re += g.x;
+        im += g.y;
     }
+    a.gb[blk][wm] = mk<T>(a.delta * re, a.delta * im);
 }
 
 template <typename T>
@@ -1209,10 +1630,44 @@ static int do_contract_wgrad(const void* vh, const void* gh, void* const* gw, vo
     a.delta = (T)delta; a.b = batch; a.ci = cin; a.co = cout; a.mx = mx; a.my = my; a.mt = mt;
     const long M = 4L * mx * my * mt;
     if (M <= 0 || M > (1L << 30) || cin < 1 || cout < 1 || batch < 1) return FAIL(TCFD_EINVAL, "fno_contract_wgrad: bad shape");
+    if constexpr (sizeof(T) == 4) {
+        // wide fp32 layers: the per-mode product kernel (k = sample), every spectrum value read once.  TCFD_WGRAD_GEMM: 0 never,
+        // 1 always (shapes permitting), default: above 12 channels
+        const int mode = env_int("TCFD_WGRAD_GEMM", -1);
+        const bool all_w = a.gw[0] && a.gw[1] && a.gw[2] && a.gw[3];
+        if (all_w && cin <= 32 && cout <= 32 && (mode == 1 || (mode < 0 && std::max(cin, cout) > 12))) {
+            ModesGemmArgs g;
+            for (int k = 0; k < 4; ++k) { g.a[k] = a.vh; g.b[k] = a.gh; g.c[k] = a.gw[k]; g.bias[k] = nullptr; g.gb[k] = a.gb[k]; }
+            g.a_blk = 0; g.b_blk = 0; g.c_blk = 1;
+            g.sAk = cin; g.sAr = 1; g.sBk = cout; g.sBc = 1; g.sCr = cout;
+            g.conj_a = -1.f; g.conj_b = 1.f; g.delta = (float)delta;
+            g.R = cin; g.Cn = cout; g.K = batch; g.mx = mx; g.my = my; g.mt = mt;
+            const int rc = launch_modes_gemm(g, (long)batch * cin * M, (long)batch * cout * M, (long)cin * cout * (M / 4), 1, st);
+            if (rc >= 0) {
+                if (rc == 0) HIP_TRY(hipGetLastError());
+                return rc;
+            }
+        }
+    }
     constexpr int OC = 10, IC = sizeof(T) == 8 ? 2 : 5;      // 100 resp. 80 accumulator registers
-    hipLaunchKernelGGL((k_contract_wgrad<T, IC, OC>), dim3((unsigned)((M + 255) / 256), (cin + IC - 1) / IC, (cout + OC - 1) / OC),
-                       dim3(256), 0, st, a);
-    HIP_TRY(hipGetLastError());
+    const bool wide = cout > OC;                              // the bias gradient sums over ALL output channels: own pass then
+    WgradArgsT<T> aw = a;
+    if (wide) for (int k = 0; k < 4; ++k) aw.gb[k] = nullptr;
+    bool any_w = false, any_b = false;
+    for (int k = 0; k < 4; ++k) { any_w = any_w || a.gw[k]; any_b = any_b || a.gb[k]; }
+    if (any_w || !wide) {
+        auto kern = k_contract_wgrad<T, IC, OC>;
+        const size_t lds = (size_t)3 * (IC * OC * 2 + 2) * 64 * sizeof(T);
+        if (int rc = set_lds_attr(kern, lds)) return rc;
+        // without weight gradients the bias alone needs one group of input channels only
+        hipLaunchKernelGGL(kern, dim3((unsigned)((M + 63) / 64), any_w ? (cin + IC - 1) / IC : 1, (cout + OC - 1) / OC), dim3(256), lds,
+                           st, aw);
+        HIP_TRY(hipGetLastError());
+    }
+    if (wide && any_b) {
+        hipLaunchKernelGGL(k_contract_bgrad<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
