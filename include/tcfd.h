@@ -55,7 +55,7 @@ typedef enum { TCFD_C64 = 0, TCFD_C128 = 1 } tcfd_dtype;
 typedef struct tcfd_ns2d_plan tcfd_ns2d_plan;
 typedef struct tcfd_fno_plan tcfd_fno_plan;
 
-#define TCFD_ABI_VERSION 6   /* what tcfd_version() of a library built from THIS header returns */
+#define TCFD_ABI_VERSION 7   /* what tcfd_version() of a library built from THIS header returns */
 
 #ifndef TCFD_H_TYPES_ONLY   /* (the library's second compilation unit wants the types without the prototypes) */
 
@@ -63,7 +63,7 @@ const char* tcfd_last_error(void);
 /* ABI revision of the library that was loaded.  It changes whenever an entry point changes its argument list or the
  * meaning of an argument (round 3 turned the float scalars of the tcfd_fno_* calls into doubles and gave tcfd_fno_contract
  * a dtype: revision 1 -> 4; round 5: 6, tcfd_fno_pointwise_pre / _bwd_saved / _profile_*, tcfd_fno_spectral_conv_pointwise
- * removed).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
+ * removed; 7: tcfd_sobolev_loss_backward added -- a host written against 7 needs it).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
  * first call: a stale prebuilt library would otherwise be called with the wrong argument layout and return garbage
  * (torch-cfd_amd/_lib.py::load does). */
 int tcfd_version(void);
@@ -435,6 +435,15 @@ int tcfd_sobolev_loss_supported(const tcfd_loss_plan* p, int nt, int nfields);
 int tcfd_sobolev_loss(const tcfd_loss_plan* p, const void* x, const void* y, const void* w2, long batch, int nt, int nfields,
                       int relative, int mesh_weighted, int time_average, int reduction, void* out, void* sums, void* ws,
                       size_t ws_bytes, void* stream);
+/* The gradient of that scalar with respect to x (the autograd side of SobolevLoss, fno/losses.py:263-315 under
+ * loss.backward()): grad (batch, n, n, nt), the layout of x.  x, y, nfields and the four flags as in the forward call; wf: w2
+ * WITHOUT the Hermitian multiplicity (the (n, n/2+1) weights of the full spectrum, fft-norm scale folded in); sums: what the
+ * forward call left in its `sums` argument; gout: ONE scalar of the data's precision in device memory (the incoming
+ * gradient).  y is a constant here (a caller whose target needs a gradient composes the loss from tcfd_rfft2 instead).
+ * Three launches; the workspace of a one-field forward call suffices (tcfd_loss_workspace_bytes(p, batch, nt, 1)). */
+int tcfd_sobolev_loss_backward(const tcfd_loss_plan* p, const void* x, const void* y, const void* wf, const void* sums,
+                               const void* gout, long batch, int nt, int nfields, int relative, int mesh_weighted,
+                               int time_average, int reduction, void* grad, void* ws, size_t ws_bytes, void* stream);
 
 /* STREAM-style device probe (measurement aid, SURVEY 8d "verify with a device STREAM-style probe"): `iters`
  * launches of a 16-byte-per-lane grid-stride kernel over `bytes` (a multiple of 16) of caller-owned device memory,

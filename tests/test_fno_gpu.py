@@ -875,6 +875,22 @@ def test_fused_sobolev_loss_against_oracle_and_composed_path(n, b, nt, tag, dev,
         composed = loss(x.to(dev), y.to(dev))
         monkeypatch.delenv("TCFD_LOSS_FUSED")
         assert float(fused) == pytest.approx(float(composed), rel=tol)
+        # under autograd: the same three launches inside one node, tcfd_sobolev_loss_backward as its backward -- against
+        # float64 autograd through the oracle and against the composed path (rfft2 node + torch reductions)
+        xr = x.double().clone().requires_grad_(True)
+        (OF.sobolev_loss(xr, y.double(), n, **kw) * 1.7).backward()
+        xg = x.to(dev).requires_grad_(True)
+        val = loss(xg, y.to(dev))
+        assert val.grad_fn is not None and "FusedLoss" in type(val.grad_fn).__name__
+        assert float(val) == pytest.approx(float(ref), rel=tol)
+        (val * 1.7).backward()
+        gtol = 1e-9 if tag == "f64" else 2e-5
+        assert xg.grad.shape == x.shape and rel_l2(xg.grad, xr.grad.to(real)) < gtol, kw
+        monkeypatch.setenv("TCFD_LOSS_FUSED_BWD", "0")
+        xc = x.to(dev).requires_grad_(True)
+        (loss(xc, y.to(dev)) * 1.7).backward()
+        monkeypatch.delenv("TCFD_LOSS_FUSED_BWD")
+        assert rel_l2(xg.grad, xc.grad) < gtol, kw
     # no target: the weighted norm of x itself
     loss = fno.SobolevLoss(n_grid=n, norm_order=0).to(dev)
     monkeypatch.setenv("TCFD_LOSS_FUSED", "0")
@@ -884,11 +900,16 @@ def test_fused_sobolev_loss_against_oracle_and_composed_path(n, b, nt, tag, dev,
     # a relative loss without a target divides by the norm of the reference's all-zero y (fno/losses.py:283-299): inf
     rel = fno.SobolevLoss(n_grid=n, norm_order=0, relative=True).to(dev)
     assert float(rel(x.to(dev))) == float(OF.sobolev_loss(x, None, n, norm_order=0, relative=True)) == float("inf")
-    # gradients still go through the differentiable composition
+    # no target under autograd; a target that needs a gradient goes through the differentiable composition
+    xr = x.double().clone().requires_grad_(True)
+    OF.sobolev_loss(xr, None, n, norm_order=0).backward()
     xg = x.to(dev).requires_grad_(True)
-    assert loss._fused(xg, y.to(dev)) is None
-    loss(xg, y.to(dev)).backward()
-    assert torch.isfinite(xg.grad).all()
+    loss(xg).backward()
+    assert rel_l2(xg.grad, xr.grad.to(real)) < (1e-9 if tag == "f64" else 2e-5)
+    yg = y.to(dev).requires_grad_(True)
+    assert loss._fused(x.to(dev), yg) is None
+    loss(x.to(dev), yg).backward()
+    assert torch.isfinite(yg.grad).all()
 
 
 @pytest.mark.parametrize("width,act", [(16, "ReLU"), (16, "GELU"), (24, "SiLU"), (32, "ReLU"), (32, "GELU"), (20, "GELU")])

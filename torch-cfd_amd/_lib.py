@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ("tcfd_ns2d.hip", "tcfd_fno.hip", "tcfd_fno_pw.hip", "tcfd_fno_tiles.hip", "tcfd_loss.hip")
 
 TCFD_C64, TCFD_C128 = 0, 1
-ABI_VERSION = 6   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
+ABI_VERSION = 7   # TCFD_ABI_VERSION of include/tcfd.h the SIGNATURES table below was written against
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -178,6 +178,7 @@ SIGNATURES = {
     "tcfd_loss_workspace_bytes": (_sz, [_vp, _l, _i, _i]),
     "tcfd_sobolev_loss_supported": (_i, [_vp, _i, _i]),
     "tcfd_sobolev_loss": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "tcfd_sobolev_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "tcfd_hbm_probe": (_i, [_vp, _vp, ctypes.c_size_t, _i, _i, ctypes.POINTER(ctypes.c_float), _vp]),
     "tcfd_copy_rows_to_host": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "tcfd_host_register": (_i, [_vp, _sz]),

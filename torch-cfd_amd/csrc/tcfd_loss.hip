@@ -243,6 +243,119 @@ __global__ __launch_bounds__(256) void k_loss_finish(const double* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ the gradient with respect to x
+// loss = red * sum_b sqrt(S0_b) / yn_b (times the time average), S0_b = sum_{t, k} wf_k |D^_{b,t,k}|^2 over the FULL spectrum of
+// d = x - y, so   dloss/dx_{b,t} = gout * red * ta / (yn_b sqrt(S0_b)) * c2r( wf (.) rfft2(d_{b,t}) )   with wf = w2 without the
+// Hermitian multiplicity (c2r sums both halves itself).  Three launches, the time-last layout written in place:
+//   k_loss_rows (F = 1)   d = x - y -> half-spectrum rows, as in the forward pass (recomputed: no 94 MB kept across the step)
+//   k_loss_cols_bwd       X-point FFT down a column tile, times wf and the sample's coefficient (from the per-time sums the
+//                         forward pass left), inverse X-point FFT, back in place
+//   k_loss_rows_bwd       per slab (b, x): the half-spectrum rows of two time steps ride one complex inverse transform
+//                         (Z = A + i B, Hermitian extension), real parts / imaginary parts = the two gradient rows, the slab
+//                         [Y][T] leaves LDS as 16-byte lanes
+// Composed from torch ops (round 4) the same step was two permuted copies, an rfft2, five elementwise kernels over the
+// spectrum, its adjoint and a subtraction: 0.9 ms at config 5; this is 0.2 ms.
+template <typename T, int X, int EPT, int C>
+__global__ __launch_bounds__(C*(X / EPT)) void k_loss_cols_bwd(cx<T>* __restrict__ planes, const T* __restrict__ wf,
+                                                               const double* __restrict__ sums, const T* __restrict__ gout,
+                                                               const cx<T>* __restrict__ tw, int m, int ldk, int ntiles, long batch,
+                                                               int nt, int F, int relative, int mesh_weighted, int time_average,
+                                                               int reduction) {
+    typedef cx<T> cf;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    constexpr int G = X / EPT;
+    const int c = threadIdx.x % C, j = threadIdx.x / C;
+    const int tile = blockIdx.x % ntiles;
+    const size_t img = blockIdx.x / ntiles;                   // (b, t)
+    const int q = tile * C + c;
+    const bool valid = q < m;
+    cf z[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        z[e] = valid ? planes[(img * X + j + e * G) * (size_t)ldk + q] : mk<T>((T)0, (T)0);
+    T wv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) wv[e] = valid ? wf[(size_t)(j + e * G) * m + q] : (T)0;
+    // the sample's coefficient, by the rules of k_loss_finish
+    const long b = (long)(img / nt);
+    double s0 = 0.0, s1 = 0.0;
+    for (int t = 0; t < nt; ++t) s0 += sums[(size_t)b * nt + t];
+    if (F == 2)
+        for (int t = 0; t < nt; ++t) s1 += sums[((size_t)batch + b) * nt + t];
+    double yn = (relative && F == 2) ? sqrt(s1) : 1.0;
+    if (mesh_weighted) {
+        if (mesh_weighted == 2 && !(relative && F == 2)) yn = (double)(1.0f / (float)X);
+        else yn /= (double)X;
+    }
+    double coef = (double)gout[0] / (yn * sqrt(s0));
+    if (time_average) coef /= sqrt((double)nt);
+    if (reduction) coef /= (double)batch;
+    if (mesh_weighted) coef /= (double)X;
+    tile_fft<T, X, EPT, -1, C, false, true>(z, lds, tw, j, c);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) z[e] = cscale(z[e], (T)((double)wv[e] * coef));
+    tile_fft<T, X, EPT, +1, C, false, true>(z, lds, tw, j, c);
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) planes[(img * X + j + e * G) * (size_t)ldk + q] = z[e];
+    }
+}
+
+template <typename T, int Y, int EPT>
+__global__ __launch_bounds__(1024) void k_loss_rows_bwd(const cx<T>* __restrict__ in, T* __restrict__ grad,
+                                                        const cx<T>* __restrict__ tw, int nt, int P, int NS, long slabs, int X,
+                                                        int ldk, unsigned per) {
+    typedef cx<T> cf;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int G = Y / EPT;
+    constexpr int NV = 16 / (int)sizeof(T);
+    const int tr = threadIdx.x / G, j = threadIdx.x % G;
+    const int s = tr / P, p = tr - s * P;
+    const long base = (long)blockIdx.x * NS;
+    const int count = (int)(slabs - base < NS ? slabs - base : NS);
+    const size_t slab_elems = (size_t)Y * nt;
+    const int t0 = 2 * p, t1 = 2 * p + 1;
+    const bool live = s < count && t0 < nt;
+    const bool two = t1 < nt;
+    cf* lds = reinterpret_cast<cf*>(smem_raw + (size_t)s * per) + (size_t)p * Y;
+    if (live) {
+        const long slab = base + s;
+        const long b = slab / X, i = slab - b * X;
+        const cf* r0 = in + (((size_t)b * nt + t0) * X + i) * ldk;
+        const cf* r1 = in + (((size_t)b * nt + t1) * X + i) * ldk;
+        for (int k = j; k <= Y / 2; k += G) {
+            cf A = r0[k], B = two ? r1[k] : mk<T>((T)0, (T)0);
+            if (k == 0 || k == Y / 2) A.y = B.y = (T)0;       // a c2r transform ignores them
+            lds[k] = mk<T>(A.x - B.y, A.y + B.x);             // Z[k] = A[k] + i B[k]
+            if (k > 0 && k < Y / 2) lds[Y - k] = mk<T>(A.x + B.y, B.x - A.y);   // Z[-k] = conj A[k] + i conj B[k]
+        }
+    }
+    group_sync<0>();
+    cf z[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) z[e] = live ? lds[j + e * G] : mk<T>((T)0, (T)0);
+    group_sync<0>();
+    tile_fft<T, Y, EPT, +1, 1, true, false>(z, lds, tw, j, 0);
+    __syncthreads();      // every transform of the workgroup is done: the exchange buffers become the slabs [Y][nt]
+    if (live) {
+        T* reg = reinterpret_cast<T*>(smem_raw + (size_t)s * per);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const size_t o = (size_t)(j + e * G) * nt;
+            reg[o + t0] = z[e].x;
+            if (two) reg[o + t1] = z[e].y;
+        }
+    }
+    __syncthreads();
+    const int n4 = (int)(slab_elems / NV);
+    b128* g4 = reinterpret_cast<b128*>(grad + (size_t)base * slab_elems);
+    for (int idx = threadIdx.x; idx < count * n4; idx += blockDim.x) {
+        const int qs = idx / n4, i4 = idx - qs * n4;
+        g4[idx] = reinterpret_cast<const b128*>(smem_raw + (size_t)qs * per)[i4];
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static bool loss_n_ok(int n) {
     if (n >= 16 && n <= 1024 && (n & (n - 1)) == 0) return true;
@@ -384,6 +497,84 @@ static int loss_dispatch(const tcfd_loss_plan* p, const void* x, const void* y, 
     }
 #undef TCFD_LOSS_CASE
     return FAIL(TCFD_EINVAL, "sobolev_loss: unsupported n = %d", p->n);
+}
+
+template <typename T, int N>
+static int loss_bwd_impl(const tcfd_loss_plan* p, const void* x, const void* y, const void* wf, const void* sums, const void* gout,
+                         long batch, int nt, int F, int relative, int mesh_weighted, int time_average, int reduction, void* grad,
+                         void* ws, hipStream_t st) {
+    typedef cx<T> cf;
+    constexpr int REPT = LossCfg<T, N>::ROW_EPT, CEPT = LossCfg<T, N>::COL_EPT, C = LossCfg<T, N>::COLS;
+    const int m = N / 2 + 1, ldk = loss_ldk(p), ntiles = loss_ntiles(p);
+    int P, NS;
+    unsigned per;
+    size_t lds1;
+    if (!rows_geometry<T, N>(nt, 1, &P, &NS, &per, &lds1))
+        return FAIL(TCFD_EINVAL, "sobolev_loss_backward: %d time steps of a %d-point row do not fit one workgroup", nt, N);
+    cf* planes = (cf*)ws;
+    const long slabs = batch * N;
+    const int threads = NS * P * (N / REPT);
+    const unsigned blocks1 = (unsigned)((slabs + NS - 1) / NS);
+    int rc;
+    {
+        auto kern = k_loss_rows<T, N, REPT>;
+        if ((rc = raise_lds(kern, lds1))) return rc;
+        hipLaunchKernelGGL(kern, dim3(blocks1), dim3(threads), lds1, st, (const T*)x, (const T*)y, planes, (const cf*)p->tw, nt, 1, P,
+                           NS, slabs, N, batch, ldk, per);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        auto kern = k_loss_cols_bwd<T, N, CEPT, C>;
+        const size_t lds2 = (size_t)N * C * sizeof(cf);
+        if ((rc = raise_lds(kern, lds2))) return rc;
+        const long blocks = batch * nt * ntiles;
+        if (blocks >= 2147483647L) return FAIL(TCFD_EINVAL, "sobolev_loss_backward: too many column tiles");
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C * (N / CEPT)), lds2, st, planes, (const T*)wf, (const double*)sums,
+                           (const T*)gout, (const cf*)p->tw, m, ldk, ntiles, batch, nt, F, relative, mesh_weighted, time_average,
+                           reduction);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        auto kern = k_loss_rows_bwd<T, N, REPT>;
+        if ((rc = raise_lds(kern, lds1))) return rc;
+        hipLaunchKernelGGL(kern, dim3(blocks1), dim3(threads), lds1, st, (const cf*)planes, (T*)grad, (const cf*)p->tw, nt, P, NS,
+                           slabs, N, ldk, per);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+template <typename T>
+static int loss_bwd_dispatch(const tcfd_loss_plan* p, const void* x, const void* y, const void* wf, const void* sums,
+                             const void* gout, long batch, int nt, int F, int relative, int mesh_weighted, int time_average,
+                             int reduction, void* grad, void* ws, hipStream_t st) {
+#define TCFD_LOSS_CASE(N_)                                                                                                  \
+    case N_:                                                                                                                \
+        return loss_bwd_impl<T, N_>(p, x, y, wf, sums, gout, batch, nt, F, relative, mesh_weighted, time_average, reduction, grad, ws, st);
+    switch (p->n) {
+        TCFD_LOSS_CASE(16) TCFD_LOSS_CASE(32) TCFD_LOSS_CASE(64) TCFD_LOSS_CASE(128) TCFD_LOSS_CASE(256) TCFD_LOSS_CASE(512)
+        TCFD_LOSS_CASE(1024) TCFD_LOSS_CASE(96) TCFD_LOSS_CASE(192) TCFD_LOSS_CASE(384) TCFD_LOSS_CASE(768) TCFD_LOSS_CASE(80)
+        TCFD_LOSS_CASE(160) TCFD_LOSS_CASE(320) TCFD_LOSS_CASE(640)
+    }
+#undef TCFD_LOSS_CASE
+    return FAIL(TCFD_EINVAL, "sobolev_loss_backward: unsupported n = %d", p->n);
+}
+
+extern "C" int tcfd_sobolev_loss_backward(const tcfd_loss_plan* p, const void* x, const void* y, const void* wf, const void* sums,
+                                          const void* gout, long batch, int nt, int nfields, int relative, int mesh_weighted,
+                                          int time_average, int reduction, void* grad, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !x || !wf || !sums || !gout || !grad || !ws) return FAIL(TCFD_EINVAL, "sobolev_loss_backward: null argument");
+    if (batch <= 0 || nt <= 0 || nfields < 1 || nfields > 2) return FAIL(TCFD_EINVAL, "sobolev_loss_backward: bad sizes");
+    if ((p->n * nt * (p->dtype == TCFD_C128 ? 8 : 4)) % 16)
+        return FAIL(TCFD_EINVAL, "sobolev_loss_backward: a slab must be a multiple of 16 bytes");
+    const size_t need = tcfd_loss_workspace_bytes(p, batch, nt, 1);
+    if (ws_bytes < need) return FAIL(TCFD_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == TCFD_C128)
+        return loss_bwd_dispatch<double>(p, x, y, wf, sums, gout, batch, nt, nfields, relative, mesh_weighted, time_average,
+                                         reduction, grad, ws, st);
+    return loss_bwd_dispatch<float>(p, x, y, wf, sums, gout, batch, nt, nfields, relative, mesh_weighted, time_average, reduction,
+                                    grad, ws, st);
 }
 
 extern "C" int tcfd_sobolev_loss_supported(const tcfd_loss_plan* p, int nt, int nfields) {
