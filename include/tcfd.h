@@ -63,7 +63,7 @@ const char* tcfd_last_error(void);
 /* ABI revision of the library that was loaded.  It changes whenever an entry point changes its argument list or the
  * meaning of an argument (round 3 turned the float scalars of the tcfd_fno_* calls into doubles and gave tcfd_fno_contract
  * a dtype: revision 1 -> 4; round 5: 6, tcfd_fno_pointwise_pre / _bwd_saved / _profile_*, tcfd_fno_spectral_conv_pointwise
- * removed; 7: tcfd_sobolev_loss_backward added -- a host written against 7 needs it).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
+ * removed; 7: tcfd_sobolev_loss_backward, tcfd_fno_forward_trunc_kt / _inverse_trunc_kt added -- a host written against 7 needs them).  A host compares it with the TCFD_ABI_VERSION it was written against BEFORE the
  * first call: a stale prebuilt library would otherwise be called with the wrong argument layout and return garbage
  * (torch-cfd_amd/_lib.py::load does). */
 int tcfd_version(void);
@@ -251,6 +251,15 @@ int tcfd_fno_inverse_trunc(const tcfd_fno_plan* plan, const void* vh, void* out,
  * gradient of a layer input that also feeds the skip path is finished by the transform that produces its spectral part. */
 int tcfd_fno_inverse_trunc_acc(const tcfd_fno_plan* plan, const void* vh, void* out, const void* acc, int batch, int c,
                                int t_keep, double inv_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* tcfd_fno_forward_trunc / tcfd_fno_inverse_trunc_acc / _last with ONE real factor per kept time mode (kt_scale: plan mt values
+ * of the data's real precision, device memory; NULL = none) folded into the transform's t-DFT table.  The adjoints of the r2c /
+ * c2r time transforms weigh the interior time modes by 2 resp. 1 / 2 (torch's convention for the gradient of a half spectrum):
+ * with this argument a layer's backward needs no elementwise pass over its spectra.  acc / last: as in
+ * tcfd_fno_inverse_trunc_acc / tcfd_fno_inverse_trunc_last, at most one of them non-NULL. */
+int tcfd_fno_forward_trunc_kt(const tcfd_fno_plan* plan, const void* v, void* vh, int batch, int c, double fwd_scale,
+                              const void* kt_scale, void* ws, size_t ws_bytes, void* stream);
+int tcfd_fno_inverse_trunc_kt(const tcfd_fno_plan* plan, const void* vh, void* out, const void* acc, const void* last, int batch,
+                              int c, int t_keep, double inv_scale, const void* kt_scale, void* ws, size_t ws_bytes, void* stream);
 /* The contraction alone on truncated spectra (batch, c, 2mx, 2my, mt), dtype TCFD_C64 / TCFD_C128 (tests). */
 int tcfd_fno_contract(const void* vin, const void* const* weights, const void* const* bias, double delta,
                       void* vout, int batch, int cin, int cout, int mx, int my, int mt, int use_mfma, int dtype,

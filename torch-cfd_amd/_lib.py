@@ -141,6 +141,8 @@ SIGNATURES = {
     "tcfd_fno_inverse_trunc": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _vp, _sz, _vp]),
     "tcfd_fno_inverse_trunc_acc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _sz, _vp]),
     "tcfd_fno_inverse_trunc_last": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _sz, _vp]),
+    "tcfd_fno_forward_trunc_kt": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _sz, _vp]),
+    "tcfd_fno_inverse_trunc_kt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _sz, _vp]),
     "tcfd_fno_contract": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _d, _vp, _i, _i, _i, _i, _i,
                                _i, _i, _i, _vp]),
     "tcfd_fno_contract_adjoint": (_i, [_vp, ctypes.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -189,7 +189,7 @@ template <typename T, int Y, int EPT>
 __global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>* __restrict__ w1,
                                                   const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_tf, int T_in,
                                                   int t_pad, int mt, int my, T scale, int P, int NS, long slabs,
-                                                  unsigned mt_magic) {
+                                                  unsigned mt_magic, const T* __restrict__ kts) {
     typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(1024) void k_fwd_ty2(const T* __restrict__ v, cx<T>
                 }
             }
         }
-        for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
+        // kts: one real factor per kept time mode (the c2r multiplicities of a backward pass), folded into the t-DFT table
+        for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = kts ? cscale(tw_tf[i], kts[i / Tp]) : tw_tf[i];
     }
     __syncthreads();
     cf x[EPT];
@@ -291,7 +292,7 @@ template <typename T, int Y, int EPT>
 __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, T* out /* may be == acc: no restrict */,
                                                   const cx<T>* __restrict__ tw_y, const cx<T>* __restrict__ tw_ti, int T_out,
                                                   int t_keep, int mt, int my, T scale, int P, int NS, long slabs, int Ys,
-                                                  const T* acc, const T* __restrict__ accb, int accT) {
+                                                  const T* acc, const T* __restrict__ accb, int accT, const T* __restrict__ kts) {
     typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int G = Y / EPT;
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(1024) void k_inv_ty2(const cx<T>* __restrict__ w2, 
     {
         const cf* src = w2 + (size_t)base * Q;
         for (int i = threadIdx.x; i < count * Q; i += blockDim.x) win[i] = src[i];
-        for (int i = threadIdx.x; i < t_keep * mt; i += blockDim.x) twt[i] = tw_ti[(size_t)t0 * mt + i];
+        for (int i = threadIdx.x; i < t_keep * mt; i += blockDim.x)
+            twt[i] = kts ? cscale(tw_ti[(size_t)t0 * mt + i], kts[i % mt]) : tw_ti[(size_t)t0 * mt + i];
 #pragma unroll
         for (int t = 0; t < EPT; ++t) lds[j + t * G] = mk<T>((T)0, (T)0);   // zero this transform's spectrum (the padding)
     }
@@ -940,6 +942,14 @@ static int launch_contract_gemm(const ContractArgsT<double>&, hipStream_t) { ret
 
 // ------------------------------------------------------------------ host side
 
+// Per-time-mode factors of the t / y kernels (tcfd_fno_forward_trunc_kt / tcfd_fno_inverse_trunc_kt): the entry point parks
+// the device pointer here for the launchers of ITS call (a thread's calls are sequential; plans stay immutable and shared).
+static thread_local const void* t_kt_scale = nullptr;
+struct KtScaleScope {
+    explicit KtScaleScope(const void* p) { t_kt_scale = p; }
+    ~KtScaleScope() { t_kt_scale = nullptr; }
+};
+
 // ---- launchers of the any-size kernels
 template <typename T>
 static int launch_fwd_ty_dft(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long slabs, T scale, hipStream_t st) {
@@ -955,7 +965,7 @@ static int launch_fwd_ty_dft(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long
         auto kern = k_fwd_ty_dft<T, MT_>;                                                                                       \
         if (int rc = set_lds_attr(kern, lds)) return rc;                                                                        \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, v, w1, (const ct*)p->tw_y, (const ct*)p->tw_tf, p->Y, p->T_in, \
-                           p->t_pad, p->mt, p->my, scale, NS, slabs);                                                          \
+                           p->t_pad, p->mt, p->my, scale, NS, slabs, (const T*)t_kt_scale);                                    \
         HIP_TRY(hipGetLastError());                                                                                             \
         return 0;                                                                                                               \
     }
@@ -1003,7 +1013,7 @@ static int launch_inv_ty_dft(const tcfd_fno_plan* p, const cx<T>* w2, T* out, lo
         auto kern = k_inv_ty_dft<T, MT_>;                                                                                        \
         if (int rc = set_lds_attr(kern, lds)) return rc;                                                                         \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, w2, out, (const ct*)p->tw_y, (const ct*)p->tw_ti, p->Y,   \
-                           p->Ys, p->T_out, t_keep, p->mt, p->my, scale, NS, slabs, acc, accb, accT);                            \
+                           p->Ys, p->T_out, t_keep, p->mt, p->my, scale, NS, slabs, acc, accb, accT, (const T*)t_kt_scale);      \
         HIP_TRY(hipGetLastError());                                                                                              \
         return 0;                                                                                                                \
     }
@@ -1060,7 +1070,7 @@ static int launch_fwd_ty2(const tcfd_fno_plan* p, const T* v, cx<T>* w1, long sl
     if ((rc = set_lds_attr(kern, lds))) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, v, w1, (const ct*)p->tw_y,
                        (const ct*)p->tw_tf, p->T_in, p->t_pad, p->mt, p->my, scale, P, NS, slabs,
-                       p->mt > 1 ? (unsigned)(((1ull << 32) + p->mt - 1) / p->mt) : 0u);
+                       p->mt > 1 ? (unsigned)(((1ull << 32) + p->mt - 1) / p->mt) : 0u, (const T*)t_kt_scale);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1083,7 +1093,8 @@ static int launch_inv_ty2(const tcfd_fno_plan* p, const cx<T>* w2, T* out, long 
     auto kern = k_inv_ty2<T, Y, EPT>;
     if ((rc = set_lds_attr(kern, lds))) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)((slabs + NS - 1) / NS)), dim3(NS * P * G), lds, st, w2, out, (const ct*)p->tw_y,
-                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys, acc, accb, accT);
+                       (const ct*)p->tw_ti, p->T_out, t_keep, p->mt, p->my, scale, P, NS, slabs, p->Ys, acc, accb, accT,
+                       (const T*)t_kt_scale);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1412,6 +1423,23 @@ extern "C" int tcfd_fno_inverse_trunc_last(const tcfd_fno_plan* p, const void* v
     if ((rc = do_inv_x<float>(p, (const cf*)vh, (cf*)ws, (long)batch * c, st))) return rc;
     return do_inv_ty<float>(p, (const cf*)ws, (float*)out, (long)batch * c * p->X, t_keep, (float)inv_scale, st, nullptr,
                             (const float*)last, -1);
+}
+// The same transforms with one real factor per kept time mode (kt_scale: mt values of the data's real precision in device memory)
+// folded into their t-DFT tables: the adjoint of an r2c / c2r pair weighs the interior time modes by 2 resp. 1 / 2, which
+// otherwise is an elementwise pass over the spectrum before and after the contraction of every layer's backward.
+// acc / last: as tcfd_fno_inverse_trunc_acc / _last (at most one of them).
+extern "C" int tcfd_fno_forward_trunc_kt(const tcfd_fno_plan* p, const void* v, void* vh, int batch, int c, double fwd_scale,
+                                         const void* kt_scale, void* ws, size_t ws_bytes, void* stream) {
+    KtScaleScope scope(kt_scale);
+    return tcfd_fno_forward_trunc(p, v, vh, batch, c, fwd_scale, ws, ws_bytes, stream);
+}
+extern "C" int tcfd_fno_inverse_trunc_kt(const tcfd_fno_plan* p, const void* vh, void* out, const void* acc, const void* last,
+                                         int batch, int c, int t_keep, double inv_scale, const void* kt_scale, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    if (acc && last) return FAIL(TCFD_EINVAL, "fno_inverse_trunc_kt: acc and last are exclusive");
+    KtScaleScope scope(kt_scale);
+    if (last) return tcfd_fno_inverse_trunc_last(p, vh, out, last, batch, c, t_keep, inv_scale, ws, ws_bytes, stream);
+    return tcfd_fno_inverse_trunc_acc(p, vh, out, acc, batch, c, t_keep, inv_scale, ws, ws_bytes, stream);
 }
 extern "C" int tcfd_fno_inverse_trunc(const tcfd_fno_plan* p, const void* vh, void* out, int batch, int c, int t_keep,
                                       double inv_scale, void* ws, size_t ws_bytes, void* stream) {

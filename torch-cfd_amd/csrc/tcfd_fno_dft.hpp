@@ -26,7 +26,7 @@ using namespace tcfd;
 template <typename T, int MT>
 __global__ __launch_bounds__(256) void k_fwd_ty_dft(const T* __restrict__ v, cx<T>* __restrict__ w1, const cx<T>* __restrict__ tw_y,
                                                     const cx<T>* __restrict__ tw_tf, int Y, int T_in, int t_pad, int mt, int my,
-                                                    T scale, int NS, long slabs) {
+                                                    T scale, int NS, long slabs, const T* __restrict__ kts) {
     typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Tp = T_in + t_pad, Q = 2 * my * mt;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_fwd_ty_dft(const T* __restrict__ v, cx<
     const long base = (long)blockIdx.x * NS;
     const int count = (int)(slabs - base < NS ? slabs - base : NS);
     for (int i = threadIdx.x; i < Y; i += blockDim.x) twy[i] = tw_y[i];
-    for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = tw_tf[i];
+    for (int i = threadIdx.x; i < mt * Tp; i += blockDim.x) twt[i] = kts ? cscale(tw_tf[i], kts[i / Tp]) : tw_tf[i];   // per-mode factor
     __syncthreads();
     // phase 1: W1a[y][kt] = sum_t v[y][t] w[kt][t_pad + t]
     for (int r = threadIdx.x; r < count * Y; r += blockDim.x) {
@@ -170,7 +170,7 @@ template <typename T, int MT>
 __global__ __launch_bounds__(1024) void k_inv_ty_dft(const cx<T>* __restrict__ w2, T* out, const cx<T>* __restrict__ tw_y,
                                                     const cx<T>* __restrict__ tw_ti, int Y, int Ys, int T_out, int t_keep, int mt,
                                                     int my, T scale, int NS, long slabs, const T* acc, const T* __restrict__ accb,
-                                                    int accT) {
+                                                    int accT, const T* __restrict__ kts) {
     typedef cx<T> cf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Q = 2 * my * mt, t0 = T_out - t_keep;
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(1024) void k_inv_ty_dft(const cx<T>* __restrict__ w
     const long base = (long)blockIdx.x * NS;
     const int count = (int)(slabs - base < NS ? slabs - base : NS);
     for (int i = threadIdx.x; i < Y; i += blockDim.x) twy[i] = tw_y[i];
-    for (int i = threadIdx.x; i < t_keep * mt; i += blockDim.x) twt[i] = tw_ti[(size_t)t0 * mt + i];
+    for (int i = threadIdx.x; i < t_keep * mt; i += blockDim.x)
+        twt[i] = kts ? cscale(tw_ti[(size_t)t0 * mt + i], kts[i % mt]) : tw_ti[(size_t)t0 * mt + i];
     {
         const cf* src = w2 + (size_t)base * Q;
         for (int i = threadIdx.x; i < count * Q; i += blockDim.x) win[(size_t)(i / Q) * (Q + 2 * mt) + (i % Q)] = src[i];

@@ -243,9 +243,10 @@ def hip_spectral_conv(v: torch.Tensor, weights, bias, delta: float, modes, t_pad
 
 # ----------------------------------------------------------------------------- the pruned transforms and the contraction, one call each
 def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[int] = None, norm="backward",
-                        scale: Optional[float] = None):
+                        scale: Optional[float] = None, kt_scale: Optional[torch.Tensor] = None):
     """Kept modes of rfftn(left_pad_t(v)): (b, C, X, Y, T) real -> (b, C, 2mx, 2my, mt) complex of the same precision
-    (fp32 / fp64), plus the plan.  ``scale`` overrides the normalisation factor of ``norm``."""
+    (fp32 / fp64), plus the plan.  ``scale`` overrides the normalisation factor of ``norm``; ``kt_scale``: (mt,) real device
+    tensor, one factor per kept time mode, folded into the transform's t-DFT table (``tcfd_fno_forward_trunc_kt``)."""
     b, c, X, Y, T = v.shape
     mx, my, mt = modes
     t_out = T + t_pad if t_out is None else t_out
@@ -255,20 +256,28 @@ def hip_truncated_rfftn(v: torch.Tensor, modes, t_pad: int = 0, t_out: Optional[
     ws = plan.workspace(b, c, c)
     fs, _ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
     fs = fs if scale is None else float(scale)
+    kts = _kt_factors(kt_scale, mt, plan) if kt_scale is not None else None
     with torch.cuda.device(v.device):
-        rc = plan.lib.tcfd_fno_forward_trunc(plan.handle, v.data_ptr(), vh.data_ptr(), b, c, fs, ws.data_ptr(), ws.numel(),
-                                             ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        rc = plan.lib.tcfd_fno_forward_trunc_kt(plan.handle, v.data_ptr(), vh.data_ptr(), b, c, fs, kts.data_ptr() if kts is not None else None,
+                                                ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_forward_trunc")
     return vh, plan
 
 
+def _kt_factors(kt_scale: torch.Tensor, mt: int, plan) -> torch.Tensor:
+    if kt_scale.numel() != mt or kt_scale.dtype != plan.real or not kt_scale.is_cuda or not kt_scale.is_contiguous():
+        raise ValueError(f"kt_scale must be a contiguous ({mt},) device tensor of the transform's precision")
+    return kt_scale
+
+
 def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="backward",
                          scale: Optional[float] = None, accumulate: Optional[torch.Tensor] = None,
-                         add_last: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         add_last: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                         kt_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """irfftn of a spectrum that is zero outside the kept modes: (b, C, 2mx, 2my, mt) -> (b, C, X, Y, t_keep).
     ``accumulate``: a contiguous tensor of the output's shape that the result is ADDED to, in place, by the transform's own
     store loop (``tcfd_fno_inverse_trunc_acc``) -- it is returned.  ``add_last``: (b, C, X, Y[, 1]) added to the LAST kept step
-    only, by the same store loop (``tcfd_fno_inverse_trunc_last``)."""
+    only, by the same store loop (``tcfd_fno_inverse_trunc_last``).  ``kt_scale``: as in ``hip_truncated_rfftn``."""
     X, Y, T, t_pad, t_out, mx, my, mt = plan.key
     b, c = vh.shape[:2]
     if tuple(vh.shape[2:]) != (2 * mx, 2 * my, mt) or not vh.is_complex():
@@ -291,17 +300,15 @@ def hip_truncated_irfftn(vh: torch.Tensor, plan: "_FnoPlan", t_keep: int, norm="
         if accumulate is not None or add_last.numel() != b * c * X * Y or add_last.dtype != plan.real or add_last.device != vh.device:
             raise ValueError("add_last must be a (b, C, X, Y) tensor of the output's precision and device, without accumulate")
         last = add_last.detach().contiguous()
-        with torch.cuda.device(vh.device):
-            rc = plan.lib.tcfd_fno_inverse_trunc_last(plan.handle, vh.data_ptr(), out.data_ptr(), last.data_ptr(), b, c, t_keep, is_,
-                                                      ws.data_ptr(), ws.numel(),
-                                                      ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
-        _lib.check(rc, "tcfd_fno_inverse_trunc_last")
-        return out
+    else:
+        last = None
+    kts = _kt_factors(kt_scale, mt, plan) if kt_scale is not None else None
     with torch.cuda.device(vh.device):
-        rc = plan.lib.tcfd_fno_inverse_trunc_acc(plan.handle, vh.data_ptr(), out.data_ptr(),
-                                                 out.data_ptr() if accumulate is not None else None, b, c, t_keep, is_,
-                                                 ws.data_ptr(), ws.numel(),
-                                                 ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
+        rc = plan.lib.tcfd_fno_inverse_trunc_kt(plan.handle, vh.data_ptr(), out.data_ptr(),
+                                                out.data_ptr() if accumulate is not None else None,
+                                                last.data_ptr() if last is not None else None, b, c, t_keep, is_,
+                                                kts.data_ptr() if kts is not None else None, ws.data_ptr(), ws.numel(),
+                                                ctypes.c_void_p(torch.cuda.current_stream(vh.device).cuda_stream))
     _lib.check(rc, "tcfd_fno_inverse_trunc")
     return out
 
@@ -332,14 +339,15 @@ def hip_contract(vh: torch.Tensor, weights, bias, delta, modes, use_mfma=True) -
 _C2R_WEIGHTS: Dict[tuple, torch.Tensor] = {}
 
 
-def _c2r_weights(mt: int, T: int, device, dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """Multiplicity of the kept time modes in a length-T c2r transform: 1 for kt = 0 and the Nyquist mode, else 2.  Cached:
-    built in place (``c[0] = 1.0``) it cost a host-to-device copy of a scalar per call -- ten blocking copies per training
-    iteration, and a capture-breaking one under a graph."""
-    key = (mt, T, torch.device(device), _real_of(dtype))
+def _c2r_weights(mt: int, T: int, device, dtype: torch.dtype = torch.float32, inverse: bool = False) -> torch.Tensor:
+    """Multiplicity of the kept time modes in a length-T c2r transform: 1 for kt = 0 and the Nyquist mode, else 2 (``inverse``:
+    their reciprocals).  Cached: built in place (``c[0] = 1.0``) it cost a host-to-device copy of a scalar per call -- ten blocking
+    copies per training iteration, and a capture-breaking one under a graph.  The backward transforms take the table as their
+    per-time-mode factor (``kt_scale``): no pass over the spectrum."""
+    key = (mt, T, torch.device(device), _real_of(dtype), inverse)
     c = _C2R_WEIGHTS.get(key)
     if c is None:
-        host = [2.0] * mt
+        host = [0.5 if inverse else 2.0] * mt
         host[0] = 1.0
         if T % 2 == 0 and T // 2 < mt:
             host[T // 2] = 1.0
@@ -354,16 +362,17 @@ def _fwd_trunc_vjp(z, cfg, accumulate=None, add_last=None):
     Tp = T + t_pad
     fs, _ = _norm_scales(norm, X * Y * Tp, X * Y * t_out)
     plan = _plan((X, Y, T, t_pad, Tp) + modes, z.device, _real_of(z.dtype))       # its inverse reconstructs Tp steps
-    zh = (z / _c2r_weights(modes[2], Tp, z.device, z.dtype)).contiguous()
-    return hip_truncated_irfftn(zh, plan, T, scale=fs, accumulate=accumulate, add_last=add_last)
+    return hip_truncated_irfftn(z, plan, T, scale=fs, accumulate=accumulate, add_last=add_last,
+                                kt_scale=_c2r_weights(modes[2], Tp, z.device, z.dtype, inverse=True))
 
 
 def _inv_trunc_vjp(dy, cfg):
     """G^T(dy) for the zero-padded inverse transform G (cfg of ``_InvTruncFn``)."""
     (X, Y, T, t_pad, t_out, mx, my, mt), t_keep, norm = cfg
     _, is_ = _norm_scales(norm, X * Y * (T + t_pad), X * Y * t_out)
-    gh, _ = hip_truncated_rfftn(dy.contiguous(), (mx, my, mt), t_pad=t_out - t_keep, t_out=t_out, scale=is_)
-    return gh * _c2r_weights(mt, t_out, dy.device, dy.dtype)
+    gh, _ = hip_truncated_rfftn(dy.contiguous(), (mx, my, mt), t_pad=t_out - t_keep, t_out=t_out, scale=is_,
+                                kt_scale=_c2r_weights(mt, t_out, dy.device, dy.dtype))
+    return gh
 
 
 def _contract_vjp(gh, vh, params, cfg, need_v, need_params):
