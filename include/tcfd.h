@@ -314,6 +314,12 @@ int tcfd_row_moments_f64(const void* x, void* stats, int rows, long L, void* str
  *     skip_mode 2 (only its last time slice is used, fno/sfno.py:258-259) from the full dL/dz2. */
 int tcfd_sum_rows_slices(long rows);
 int tcfd_sum_rows(const void* in, void* out, void* scratch, long rows, long cols, void* stream);
+/* tcfd_sum_rows whose final pass writes sub-matrices of the summed row as fp32 into dense tensors of their own: nseg <= 8 segments,
+ * segs = nseg x {src_off, nrows, ncols, pitch} (host longs: element (r, c) of segment k is sum[src_off + r * pitch + c]), dst = nseg
+ * device pointers (host array), segment k written as (nrows, ncols) row-major.  The parameter gradients of a pointwise block leave
+ * the [dW2 | db2 | dWs] / [dW1 | db1] layout of tcfd_fno_pointwise_bwd this way.  scratch as for tcfd_sum_rows. */
+int tcfd_sum_rows_scatter(const void* in, void* scratch, long rows, long cols, int nseg, const long* segs, void* const* dst,
+                          void* stream);
 int tcfd_sum_t_into_last(const void* d, void* g, long rows, int T, int sT, void* stream);
 
 /* ---- per-launch event timing (measurement aid; no reference counterpart) -------

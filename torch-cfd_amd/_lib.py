@@ -156,6 +156,7 @@ SIGNATURES = {
     "tcfd_row_moments_f64": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_sum_rows_slices": (_i, [_l]),
     "tcfd_sum_rows": (_i, [_vp, _vp, _vp, _l, _l, _vp]),
+    "tcfd_sum_rows_scatter": (_i, [_vp, _vp, _l, _l, _i, _vp, _vp, _vp]),
     "tcfd_sum_t_into_last": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "tcfd_row_moments": (_i, [_vp, _vp, _i, _l, _vp]),
     "tcfd_fno_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(_i),

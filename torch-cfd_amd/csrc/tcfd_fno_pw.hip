@@ -986,6 +986,51 @@ extern "C" int tcfd_sum_rows(const void* in, void* out, void* scratch, long rows
     return 0;
 }
 
+// The same sums delivered where they belong: up to 8 segments (src_off, nrows, ncols, pitch) of the summed row -- sub-matrices
+// of the [dW2 | db2 | dWs] / [dW1 | db1] blocks a backward kernel accumulates -- written as fp32 into their own dense tensors by
+// the final pass (the parameter gradients of a block were one conversion and six strided copies after tcfd_sum_rows).
+struct SumSegs {
+    long src_off[8], pitch[8];
+    int nrows[8], ncols[8];
+    float* dst[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_sum_rows_final_scatter(const double* __restrict__ scratch, long cols, int slices, SumSegs sg) {
+    const long c = blockIdx.x * 256L + threadIdx.x;
+    if (c >= cols) return;
+    double a = 0;
+    for (int s = 0; s < slices; ++s) a += scratch[(long)s * cols + c];
+    for (int k = 0; k < sg.n; ++k) {
+        const long rel = c - sg.src_off[k];
+        if (rel < 0) continue;
+        const long r = rel / sg.pitch[k], col = rel - r * sg.pitch[k];
+        if (r < sg.nrows[k] && col < sg.ncols[k]) sg.dst[k][r * sg.ncols[k] + col] = (float)a;
+    }
+}
+// segs: nseg x 4 longs {src_off, nrows, ncols, pitch} (host), dst: nseg device pointers (host array)
+extern "C" int tcfd_sum_rows_scatter(const void* in, void* scratch, long rows, long cols, int nseg, const long* segs,
+                                     void* const* dst, void* stream) {
+    if (!in || !scratch || rows <= 0 || cols <= 0 || nseg < 1 || nseg > 8 || !segs || !dst)
+        return FAIL(TCFD_EINVAL, "sum_rows_scatter: bad argument");
+    SumSegs sg;
+    sg.n = nseg;
+    for (int k = 0; k < nseg; ++k) {
+        sg.src_off[k] = segs[4 * k]; sg.nrows[k] = (int)segs[4 * k + 1]; sg.ncols[k] = (int)segs[4 * k + 2]; sg.pitch[k] = segs[4 * k + 3];
+        sg.dst[k] = (float*)dst[k];
+        if (!dst[k] || sg.pitch[k] < 1 || sg.src_off[k] < 0 || sg.nrows[k] < 1 || sg.ncols[k] < 1 || sg.ncols[k] > sg.pitch[k] ||
+            sg.src_off[k] + (long)(sg.nrows[k] - 1) * sg.pitch[k] + sg.ncols[k] > cols)
+            return FAIL(TCFD_EINVAL, "sum_rows_scatter: segment %d out of the row", k);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int slices = tcfd_sum_rows_slices(rows);
+    const unsigned bx = (unsigned)((cols + 255) / 256);
+    hipLaunchKernelGGL(k_sum_rows_stage, dim3(bx, (unsigned)slices), dim3(256), 0, st, (const float*)in, (double*)scratch, rows, cols,
+                       slices);
+    hipLaunchKernelGGL(k_sum_rows_final_scatter, dim3(bx), dim3(256), 0, st, (const double*)scratch, cols, slices, sg);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // g (rows, sT) = 0 except g[r][sT - 1] = sum_t d[r][t], d (rows, T): the gradient of a skip input of which only the LAST time
 // slice was used, broadcast over the T output steps (lifting operator, fno/sfno.py:258-259), from the full dL/dz2 in one pass
 // (zeros_like + sum(dim=-1) + strided copy before: 1.1 ms at config 5).

@@ -605,18 +605,24 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
                                             ptr(b2v), ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1,
                                             c2, mode, 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd_out")
-    tot = _sum_rows(partials, dims[5], per_row).float()
-    A = tot[: COP * CB].view(COP, CB)
+    # the summed row is A (COP x CB) = [dW2 | db2 | dWs] followed by B (CM1 x CIP) = [dW1 | db1]: every gradient leaves the final
+    # pass of the row sum as a dense tensor of its parameter's shape (tcfd_sum_rows_scatter)
     ch = cm if has_l1 else ci
-    g_w2 = A[:co, :ch].reshape(w2.shape)
-    g_b2 = A[:co, ch].contiguous() if b2 is not None else None
-    g_ws = A[:co, ch + 1: ch + 1 + ci].reshape(ws.shape) if mode == 1 else None
-    g_bs = A[:co, ch].contiguous() if (mode == 1 and bs is not None) else None
-    g_w1 = g_b1 = None
-    if has_l1:
-        Bm = tot[COP * CB:].view(CM1, CIP)
-        g_w1 = Bm[:cm, :ci].reshape(w1.shape)
-        g_b1 = Bm[:cm, ci].contiguous() if b1 is not None else None
+    new = lambda like: torch.empty(like.shape, dtype=torch.float32, device=dev)
+    g_w2, g_b2 = new(w2), (new(b2) if b2 is not None else None)
+    g_ws = new(ws) if mode == 1 else None
+    g_bs = new(bs) if (mode == 1 and bs is not None) else None
+    g_w1 = new(w1) if has_l1 else None
+    g_b1 = new(b1) if (has_l1 and b1 is not None) else None
+    segs = [(g_w2, 0, co, ch, CB), (g_b2, ch, co, 1, CB), (g_ws, ch + 1, co, ci, CB), (g_bs, ch, co, 1, CB),
+            (g_w1, COP * CB, cm, ci, CIP), (g_b1, COP * CB + ci, cm, 1, CIP)]
+    segs = [sg for sg in segs if sg[0] is not None]
+    table = (ctypes.c_long * (4 * len(segs)))(*[v for sg in segs for v in sg[1:]])
+    dsts = (ctypes.c_void_p * len(segs))(*[sg[0].data_ptr() for sg in segs])
+    scratch = torch.empty(lib.tcfd_sum_rows_slices(int(dims[5])) * per_row, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.tcfd_sum_rows_scatter(partials.data_ptr(), scratch.data_ptr(), int(dims[5]), per_row, len(segs), table, dsts,
+                                             ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tcfd_sum_rows_scatter")
     if mode == 2:   # the skip's last time slice was broadcast over t: its gradient is the t-sum of dL/dz2
         # (compact_skip: the sums alone, (b, co, X, Y, 1) -- the caller joins them to the last step of another gradient itself)
         g_skip = (torch.empty(*skip.shape[:-1], 1, dtype=skip.dtype, device=dev) if compact_skip
