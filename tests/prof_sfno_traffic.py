@@ -21,6 +21,7 @@ ALGO = {  # kernel-name prefix -> (algorithmic bytes per launch, what moves)
     "k_x<float, 256, 8, 16, true": (W + V, "read planes, write kept kx"),
     "k_x<float, 256, 8, 16, false": (V + W, "read kept kx, write planes"),
     "k_contract_mfma": (2 * V + 4 * C * C * mx * my * mt * 8, "spectrum in / out + the four weight blocks"),
+    "k_contract_lanes": (2 * V + 4 * C * C * mx * my * mt * 8, "spectrum in / out + the four weight blocks"),
     # (inference forms the projection's LAST time slice only -- LiftingOperator._through_the_spectrum; the full projection, A_1 + A_H,
     #  runs in training)
     "k_pointwise<10, 10, 10": ((A_1 + A_H) // T, "lifting projection, last time slice: one-channel input (+ L2-resident table) -> (b, C, X, Y, 1)"),

@@ -147,7 +147,8 @@ def test_contraction_staging_variants(nm, b, ci, co, modes, dev, monkeypatch):
     from torch_cfd_amd import fno
 
     monkeypatch.setenv("TCFD_CONTRACT_NM", str(nm))
-    monkeypatch.setenv("TCFD_CONTRACT_LANES", "0")          # the matrix-pipe kernel also at the narrow shapes
+    monkeypatch.setenv("TCFD_CONTRACT_LANES", "0")          # the matrix-pipe kernel also at the narrow shapes ...
+    monkeypatch.setenv("TCFD_CONTRACT_GEMM", "0")           # ... and at the wide fp32 ones the per-mode product kernel would take
     g = torch.Generator().manual_seed(b + ci)
     mx, my, mt = modes
     for real, tol in ((torch.float32, 2e-6), (torch.float64, 1e-14)):
@@ -183,6 +184,7 @@ def test_contraction_lanes_kernel(b, ci, co, modes, dev, monkeypatch):
     vd, wd, bd = vh.to(dev), [x.to(dev) for x in w], [x.to(dev) for x in bias]
     plain = fno.hip_contract(vd, wd, bd, 0.7, modes, use_mfma=False)
     monkeypatch.setenv("TCFD_CONTRACT_LANES", "0")
+    monkeypatch.setenv("TCFD_CONTRACT_GEMM", "0")
     mfma = fno.hip_contract(vd, wd, bd, 0.7, modes)
     gh = torch.view_as_complex(torch.randn(b, co, 2 * mx, 2 * my, mt, 2, generator=g)).to(dev)
     lib_adjoint = lambda: fno._contract_vjp(gh, vd, [torch.view_as_real(x) for x in wd], (0.7, modes, True, False), True, [False] * 4)[0]

@@ -998,8 +998,15 @@ struct SumSegs {
 __global__ __launch_bounds__(256) void k_sum_rows_final_scatter(const double* __restrict__ scratch, long cols, int slices, SumSegs sg) {
     const long c = blockIdx.x * 256L + threadIdx.x;
     if (c >= cols) return;
-    double a = 0;
-    for (int s = 0; s < slices; ++s) a += scratch[(long)s * cols + c];
+    // eight loads in flight per lane (the launch is a handful of workgroups: one dependent chain of `slices` loads took 19 us)
+    double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int s = 0;
+    for (; s + 8 <= slices; s += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p8[u] += scratch[(long)(s + u) * cols + c];
+    }
+    for (; s < slices; ++s) p8[0] += scratch[(long)s * cols + c];
+    const double a = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     for (int k = 0; k < sg.n; ++k) {
         const long rel = c - sg.src_off[k];
         if (rel < 0) continue;
