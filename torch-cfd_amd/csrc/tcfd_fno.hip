@@ -776,12 +776,12 @@ struct ModesGemmArgs {
     unsigned a_bytes, b_bytes, c_bytes;   // sizes of one operand tensor (bounds of the buffer descriptors)
 };
 
-template <int CT>
+template <int CT, int KC>
 __global__ __launch_bounds__(256, 2) void k_modes_gemm(ModesGemmArgs a, int cpb) {
     typedef cx<float> cf;
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
-    constexpr int RT = 8, KC = 4, NR = 4 * RT, NCP = CT <= 4 ? 16 : 32, NA = KC * NR / 16, NB = KC * NCP / 16;
+    constexpr int RT = 8, NR = 4 * RT, NCP = CT <= 4 ? 16 : 32, NA = KC * NR / 16, NB = KC * NCP / 16;
     constexpr int STAGE = KC * (NR + NCP) * 16;                 // complex elements of one buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char mg_raw[];
     f2* lds = reinterpret_cast<f2*>(mg_raw);
@@ -912,14 +912,23 @@ static int launch_modes_gemm(ModesGemmArgs& a, long a_elems, long b_elems, long 
     const int MB = a.mx * a.my * a.mt, cpb = (MB + 15) / 16;
     const int ct = a.Cn <= 16 ? 4 : a.Cn <= 20 ? 5 : a.Cn <= 24 ? 6 : 8;
     const int ncp = ct <= 4 ? 16 : 32;
-    const size_t lds = (size_t)2 * 4 * (32 + ncp) * 16 * sizeof(cx<float>);
-#define TCFD_MG(CT_)                                                                                        \
+    // k values per stage (LDS: 2 buffers x kc x (32 + ncp) x 16 modes).  At 17 ... 24 columns the registers allow three workgroups
+    // per CU and 2 k per stage let LDS allow them too (width 20: 54.8 -> 46.4 us, weight gradient 63.1 -> 49.8); at 32 columns
+    // (two workgroups either way) and at <= 16 the longer stage wins.  TCFD_GEMM_KC = 2 / 4 overrides.
+    const int kc_env = env_int("TCFD_GEMM_KC", 0);
+    const int kc = kc_env == 2 || kc_env == 4 ? kc_env : ((ct == 5 || ct == 6) ? 2 : 4);
+    const size_t lds = (size_t)2 * kc * (32 + ncp) * 16 * sizeof(cx<float>);
+#define TCFD_MG(CT_, KC_)                                                                                   \
     {                                                                                                       \
-        auto kern = k_modes_gemm<CT_>;                                                                      \
+        auto kern = k_modes_gemm<CT_, KC_>;                                                                 \
         if (int rc = set_lds_attr(kern, lds)) return rc;                                                    \
         hipLaunchKernelGGL(kern, dim3((unsigned)(4 * cpb), (unsigned)row_tiles), dim3(256), lds, st, a, cpb); \
     }
-    if (ct == 4) TCFD_MG(4) else if (ct == 5) TCFD_MG(5) else if (ct == 6) TCFD_MG(6) else TCFD_MG(8)
+    if (kc == 4) {
+        if (ct == 4) TCFD_MG(4, 4) else if (ct == 5) TCFD_MG(5, 4) else if (ct == 6) TCFD_MG(6, 4) else TCFD_MG(8, 4)
+    } else {
+        if (ct == 4) TCFD_MG(4, 2) else if (ct == 5) TCFD_MG(5, 2) else if (ct == 6) TCFD_MG(6, 2) else TCFD_MG(8, 2)
+    }
 #undef TCFD_MG
     return 0;
 }
@@ -1620,26 +1629,46 @@ __global__ __launch_bounds__(256, 2) void k_contract_wgrad(WgradArgsT<T> a) {
     if (gb && do_bias) gb[wm] = mk<T>(a.delta * bre, a.delta * bim);
 }
 
-// bias gradient alone, for layers with more output channels than one group holds
+// bias gradient alone, for layers with more output channels than one group holds: 64 modes x 4 slices of the (sample, channel)
+// rows per workgroup, the four partial sums added in order through LDS (one lane per mode walking all b * co rows: 153 us at
+// width 20)
 template <typename T>
 __global__ __launch_bounds__(256) void k_contract_bgrad(WgradArgsT<T> a) {
+    __shared__ T part[3][2][64];
     const int M = 4 * a.mx * a.my * a.mt;
-    const int mode = blockIdx.x * 256 + threadIdx.x;
-    if (mode >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mode_raw = blockIdx.x * 64 + lane;
+    const bool valid = mode_raw < M;
+    const int mode = valid ? mode_raw : M - 1;
     const int kt = mode % a.mt;
     const int kyi = (mode / a.mt) % (2 * a.my);
     const int kxi = mode / (a.mt * 2 * a.my);
     const int ix = kxi >= a.mx, iy = kyi >= a.my;
     const int blk = ix + 2 * iy;
     const long wm = ((long)(kxi - ix * a.mx) * a.my + (kyi - iy * a.my)) * a.mt + kt;
-    if (!a.gb[blk]) return;
-    T re = 0, im = 0;
-    for (long r = 0; r < (long)a.b * a.co; ++r) {
-        const cx<T> g = a.gh[r * M + mode];
-        re += g.x;
-        im += g.y;
+    cx<T>* gb = blk == 0 ? a.gb[0] : blk == 1 ? a.gb[1] : blk == 2 ? a.gb[2] : a.gb[3];
+    const long rows = (long)a.b * a.co, per = (rows + 3) / 4, r0 = wave * per, r1 = r0 + per < rows ? r0 + per : rows;
+    T re[4] = {0, 0, 0, 0}, im[4] = {0, 0, 0, 0};
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const cx<T> g = a.gh[(r + u) * M + mode];
+            re[u] += g.x;
+            im[u] += g.y;
+        }
     }
-    a.gb[blk][wm] = mk<T>(a.delta * re, a.delta * im);
+    for (; r < r1; ++r) {
+        const cx<T> g = a.gh[r * M + mode];
+        re[0] += g.x;
+        im[0] += g.y;
+    }
+    T sre = (re[0] + re[1]) + (re[2] + re[3]), sim = (im[0] + im[1]) + (im[2] + im[3]);
+    if (wave > 0) { part[wave - 1][0][lane] = sre; part[wave - 1][1][lane] = sim; }
+    __syncthreads();
+    if (wave > 0 || !valid || !gb) return;
+    for (int k = 0; k < 3; ++k) { sre += part[k][0][lane]; sim += part[k][1][lane]; }
+    gb[wm] = mk<T>(a.delta * sre, a.delta * sim);
 }
 
 template <typename T>
@@ -1693,7 +1722,7 @@ static int do_contract_wgrad(const void* vh, const void* gh, void* const* gw, vo
         HIP_TRY(hipGetLastError());
     }
     if (wide && any_b) {
-        hipLaunchKernelGGL(k_contract_bgrad<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_contract_bgrad<T>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
     return 0;
