@@ -247,11 +247,22 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         // ---- g2^T from the saved output / pre-activation; x^T and g2^T go through the transposition tiles
         f4 g2T[TO];
 #pragma unroll
-        for (int to = 0; to < TO; ++to)
+        for (int to = 0; to < TO; ++to) {
+            if constexpr (ACT == 2) {                       // GELU: the gate of two values at a time on packed math
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                g2T[to][r] = ACT >= 0 ? gate_saved<(ACT >= 0 ? ACT : 0)>(cur.dzb[to][r], cur.yob[to][r])
-                                      : gate_saved_rt(cur.dzb[to][r], cur.yob[to][r], a.act2);
+                for (int r = 0; r < 4; r += 2) {
+                    v2f hv, dv;
+                    pw_gelu_pair_pk(v2f{cur.yob[to][r], cur.yob[to][r + 1]}, hv, dv);
+                    g2T[to][r] = cur.dzb[to][r] * dv.x;
+                    g2T[to][r + 1] = cur.dzb[to][r + 1] * dv.y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    g2T[to][r] = ACT >= 0 ? gate_saved<(ACT >= 0 ? ACT : 0)>(cur.dzb[to][r], cur.yob[to][r])
+                                          : gate_saved_rt(cur.dzb[to][r], cur.yob[to][r], a.act2);
+            }
+        }
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) put(ti, cur.xb[ti]);
 #pragma unroll
@@ -330,7 +341,17 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
             zT[t][r] = hv;                                                 \
             dhT[t][r] *= dv;                                               \
         }
-            if constexpr (ACT >= 0) { PWB_ACT_ALL(ACT >= 0 ? ACT : 0) }
+            if constexpr (ACT == 2) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        v2f hv, dv;
+                        pw_gelu_pair_pk(v2f{zT[t][r], zT[t][r + 1]}, hv, dv);
+                        zT[t][r] = hv.x; zT[t][r + 1] = hv.y;
+                        dhT[t][r] *= dv.x; dhT[t][r + 1] *= dv.y;
+                    }
+            } else if constexpr (ACT >= 0) { PWB_ACT_ALL(ACT >= 0 ? ACT : 0) }
             else {
                 switch (a.act1) {
                     case 1: PWB_ACT_ALL(1) break;
