@@ -1,7 +1,6 @@
 """The 4-corner contraction, its adjoint and its weight gradient at the config-5 shape (b 32, width 10, modes 24 x 24 x 5), timed by
 the library's own events around each launch (tcfd_fno_profile_begin / _end):  python tests/micro/contract_timing.py
-    lanes kernel (TCFD_CONTRACT_LANES=1, default for narrow fp32 layers) with TCFD_CONTRACT_BG slices of the batch, with / without
-    the prefetch of the next sample, against the matrix-pipe kernel (TCFD_CONTRACT_LANES=0) and the plain kernel (use_mfma=False)."""
+    lanes kernel (TCFD_CONTRACT_LANES=1, default for narrow fp32 layers) with TCFD_CONTRACT_BG slices of the batch, against the matrix-pipe kernel (TCFD_CONTRACT_LANES=0) and the plain kernel (use_mfma=False)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -34,8 +33,7 @@ for width in widths:
 
     timed("mfma", TCFD_CONTRACT_LANES=0)
     for bg in (0, 2, 4, 8, 16):
-        for pf in (1, 0):
-            timed(f"lanes_bg{bg}_pf{pf}", TCFD_CONTRACT_LANES=1, TCFD_CONTRACT_BG=bg, TCFD_CONTRACT_PF=pf)
+        timed(f"lanes_bg{bg}", TCFD_CONTRACT_LANES=1, TCFD_CONTRACT_BG=bg)
     # the training side: adjoint + weight gradient through autograd of the contraction alone
     vr = vh.clone().requires_grad_(True)
     wr = [torch.view_as_real(x).clone().requires_grad_(True) for x in w]

@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void k_contract_mfma(ContractArgsT<T> a) {
 // lanes.  A wave = 64 consecutive modes x one group of output channels x one slice of the batch; the waves that share weights
 // (batch slices) and spectrum values (channel groups) of a chunk of modes are dealt to the SAME XCD, next to each other, so
 // the re-reads are L2 hits.
-template <int CI, int COG, bool PREFETCH>
+template <int CI, int COG>
 __global__ __launch_bounds__(64) void k_contract_lanes(ContractArgsT<float> a, int n_cg, int n_bg, int nb, int cpb) {
     typedef cx<float> cf;
     typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
@@ -717,16 +717,13 @@ __global__ __launch_bounds__(64) void k_contract_lanes(ContractArgsT<float> a, i
         }
     };
     f2 xn[CI];
-    if constexpr (PREFETCH) load_x(b0, xn);
+    load_x(b0, xn);
     for (int bb = b0; bb < b1; ++bb) {
         f2 xc[CI];
-        if constexpr (PREFETCH) {
 #pragma unroll
-            for (int i = 0; i < CI; ++i) xc[i] = xn[i];
-            load_x(min(bb + 1, b1 - 1), xn);                   // clamped: no branch around the prefetch
-        } else {
-            load_x(bb, xc);
-        }
+        for (int i = 0; i < CI; ++i) xc[i] = xn[i];
+        load_x(min(bb + 1, b1 - 1), xn);                       // the next sample in flight (clamped: no branch around the prefetch);
+                                                               // without it 17.3 -> 32.7 us at config 5
         f2 pr[COG], pi[COG];                                   // pr = sum x.re * (w.re, w.im),  pi = sum x.im * (w.re, w.im)
 #pragma unroll
         for (int u = 0; u < COG; ++u) { pr[u] = bias; pi[u] = (f2){0.f, 0.f}; }
@@ -1240,11 +1237,8 @@ static int launch_contract_lanes_ci(const ContractArgsT<float>& a, hipStream_t s
     const int nb = (a.b + n_bg - 1) / n_bg;
     n_bg = (a.b + nb - 1) / nb;
     const unsigned blocks = (unsigned)(((4 * cpb + 7) / 8) * 8 * n_cg * n_bg);
-    const bool pf = env_int("TCFD_CONTRACT_PF", 1) != 0;
-#define TCFD_LANES(COG_, PF_) hipLaunchKernelGGL((k_contract_lanes<CI, COG_, PF_>), dim3(blocks), dim3(64), 0, st, a, n_cg, n_bg, nb, cpb)
-    if (cog == 5) { if (pf) TCFD_LANES(5, true); else TCFD_LANES(5, false); }
-    else { if (pf) TCFD_LANES(4, true); else TCFD_LANES(4, false); }
-#undef TCFD_LANES
+    if (cog == 5) hipLaunchKernelGGL((k_contract_lanes<CI, 5>), dim3(blocks), dim3(64), 0, st, a, n_cg, n_bg, nb, cpb);
+    else hipLaunchKernelGGL((k_contract_lanes<CI, 4>), dim3(blocks), dim3(64), 0, st, a, n_cg, n_bg, nb, cpb);
     return 0;
 }
 static int launch_contract_lanes(const ContractArgsT<float>& a, hipStream_t st) {
