@@ -1185,6 +1185,8 @@ def test_sfno_training_step_gradients_golden_at_widths_16_and_20(tag, width, act
     (20, 80, 20, True, 1, "ReLU"), (20, 80, 20, True, 1, "GELU"), (20, 80, 20, True, 2, "ReLU"), (24, 96, 24, True, 1, "Tanh"),
     (24, 96, 24, True, 2, "GELU"), (32, 128, 32, True, 1, "ReLU"), (32, 128, 32, True, 1, "GELU"), (32, 128, 32, True, 2, "ReLU"),
     (32, 128, 32, True, 0, None), (10, 40, 10, True, 1, "SiLU"),
+    # one output channel (the reduction in front of the output operator): the streaming kernel k_pwb_reduce1 when P % 4 == 0
+    (16, 16, 1, False, 0, "GELU"), (20, 20, 1, False, 0, "ReLU"), (32, 32, 1, False, 0, None), (4, 4, 1, False, 0, "SiLU"),
 ])
 @pytest.mark.parametrize("X", [7, 6])   # P = 630 (not a multiple of 4: the LDS-staged kernels) / 540 (P % 16 = 12: the all-MFMA kernel, ragged last group)
 def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, X, dev, monkeypatch):

@@ -596,6 +596,85 @@ static int launch_pw_bwd(PwBwdArgs a, int batch, int max_waves, int* dims, hipSt
     return 0;
 }
 
+// Single layer with ONE output channel (the channel reduction in front of the output operator, fno/sfno.py:313): dx[c] = w[c] g,
+// dW[c] = sum g x[c], db = sum g with g = dout act'(z) -- a streaming job (read x and dout, write dx: 1.76 GB at config 5) that the
+// general one-wave kernel above ran at 3.1 TB/s through its LDS staging.  Here a lane owns four consecutive points as 16-byte
+// lanes, the 2 CI + 1 accumulators of a wave meet in its row of partial sums (the layout of k_pointwise_bwd: A[0][c], A[0][CI]).
+template <int CI>
+__global__ __launch_bounds__(256) void k_pwb_reduce1(PwBwdArgs a, long chunks_per_batch, long total_chunks) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    using Gm = PwBwdGeom<CI, CI, 1, false>;
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    float w[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) w[c] = a.w2t[c];
+    const float bias = a.b2 ? a.b2[0] : 0.f;
+    float dw[CI], db = 0.f;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) dw[c] = 0.f;
+    for (long ch = wid; ch < total_chunks; ch += nw) {
+        const long b = ch / chunks_per_batch;
+        const long p = (ch - b * chunks_per_batch) * 256 + 4 * lane;
+        const bool live = p < a.P;                              // P % 4 == 0: a lane's four points are all inside or all outside
+        const long pc = live ? p : 0;
+        f4 xv[CI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) xv[c] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.x + ((size_t)b * CI + c) * a.P + pc));
+        f4 g = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.dout + (size_t)b * a.P + pc));
+        if (a.act2 != 0) {                                      // the gate of the output activation from the recomputed pre-activation
+            f4 z = {bias, bias, bias, bias};
+#pragma unroll
+            for (int c = 0; c < CI; ++c) z += w[c] * xv[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h, d;
+                switch (a.act2) {
+                    case 1: pw_act_pair<1>(z[r], h, d); break;
+                    case 2: pw_act_pair<2>(z[r], h, d); break;
+                    case 3: pw_act_pair<3>(z[r], h, d); break;
+                    default: pw_act_pair<4>(z[r], h, d); break;
+                }
+                g[r] *= d;
+            }
+        }
+        if (!live) g = f4{0.f, 0.f, 0.f, 0.f};
+        db += (g[0] + g[1]) + (g[2] + g[3]);
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+            const f4 t = g * xv[c];
+            dw[c] += (t[0] + t[1]) + (t[2] + t[3]);
+            if (live && a.dx) __builtin_nontemporal_store(w[c] * g, reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + c) * a.P + pc));
+        }
+    }
+    // the wave's sums (butterflies: deterministic), its row of partials written by lane 0
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        db += __shfl_xor(db, off, 64);
+#pragma unroll
+        for (int c = 0; c < CI; ++c) dw[c] += __shfl_xor(dw[c], off, 64);
+    }
+    if (lane == 0) {
+        float* out = a.partials + (size_t)wid * Gm::TOTAL;
+#pragma unroll
+        for (int c = 0; c < CI; ++c) out[c] = dw[c];
+        out[CI] = db;
+    }
+}
+template <int CI>
+static int launch_pwb_reduce1(PwBwdArgs a, int batch, int max_waves, int* dims, hipStream_t st) {
+    FnoProfScope prof(FNO_K_POINTWISE_BWD_1, st);
+    using Gm = PwBwdGeom<CI, CI, 1, false>;
+    dims[0] = Gm::COP; dims[1] = Gm::CB; dims[2] = Gm::CM1; dims[3] = Gm::CIP; dims[4] = Gm::TOTAL;
+    const long cpb = (a.P + 255) / 256, total = cpb * batch;
+    int blocks = (int)std::min<long>({(total + 3) / 4, (long)(max_waves / 4), 2048L});     // <= 8 waves per SIMD's worth of rows
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_pwb_reduce1<CI>, dim3(blocks), dim3(256), 0, st, a, cpb, total);
+    HIP_TRY(hipGetLastError());
+    dims[5] = blocks * 4;
+    return 0;
+}
+
 // Backward of tcfd_fno_pointwise (shared weights; skip_mode 2 writes dL/dz2 (b, co, P) into dskip).  `partials` holds `max_waves` rows of
 // dims[4] floats; on return dims = {COP, CB, CM1, CIP, floats per row, rows written}: row-major padded tiles
 //   A (COP x CB):  A[o][0:ch] = dW2[o][.] (ch = cm, single layer: ci),  A[o][ch] = db2[o] (= dbs),  A[o][ch+1 : ch+1+ci] = dWs[o][.]
@@ -677,6 +756,12 @@ static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, c
         int handled = 0;
         const int rc = tcfd_pwb_tiles_dispatch(a, batch, ci, cm, co, max_waves, dims, st, &handled);
         if (handled) return rc;
+    }
+    // one output channel, no skip: the streaming kernel (TCFD_PWB_REDUCE1=0: the general kernel below, its cross-check)
+    if (x && !l1 && co == 1 && skip_mode == 0 && !pe && !per_sample && P % 4 == 0 && max_waves >= 4 && env_int("TCFD_PWB_REDUCE1", 1)) {
+#define PWB_R1(CI_) if (ci == CI_) return launch_pwb_reduce1<CI_>(a, batch, max_waves, dims, st);
+        PWB_R1(4) PWB_R1(6) PWB_R1(8) PWB_R1(10) PWB_R1(12) PWB_R1(14) PWB_R1(16) PWB_R1(20) PWB_R1(24) PWB_R1(32)
+#undef PWB_R1
     }
     // the LDS-staged one-wave kernel: the single-layer forms, P % 4 != 0, and the cross-check of the tiled kernel
     PWB_CASE(4, 16, 4, true) PWB_CASE(8, 32, 8, true) PWB_CASE(10, 40, 10, true)
