@@ -343,7 +343,9 @@ int tcfd_fno_profile_end(int capacity, int* count, int* kinds, float* ms);
 
 /* Backward of tcfd_fno_pointwise (shared weights): one pass over x / skip / dout recomputes the
  * block per point and writes dx (batch, ci, P), dskip (skip_mode 1: (batch, ci, P), may be NULL; skip_mode 2:
- * dL/d(pre-activation) (batch, co, P), which the caller sums over t into the skip's last time slice) and per-wave partial weight
+ * dL/d(pre-activation) (batch, co, P), which the caller sums over t into the skip's last time slice; skip_mode 3 = skip_mode 2 with
+ * that sum done by the kernel: dskip is (batch, co, P / T) -- two-layer blocks on the tiled kernel with T | 16 or T | 80 and P a
+ * multiple of 16 resp. 80, TCFD_EINVAL otherwise, also at the layout query) and per-wave partial weight
  * gradients into `partials` (max_waves rows).  On return dims[6] = {COP, CB, CM1, CIP, floats per row, rows
  * written}; a row holds two row-major zero-padded tiles, A (COP x CB) then B (CM1 x CIP), with ch = cm (single
  * layer: ci):  A[o][0:ch] = dW2[o][.],  A[o][ch] = db2[o] = dbs[o],  A[o][ch+1 : ch+1+ci] = dWs[o][.];

@@ -1275,6 +1275,50 @@ def test_tiled_backward_from_the_kept_tensor_equals_the_recomputing_kernel(width
         assert torch.isfinite(t).all() and rel_l2(t, b) < 5e-6
 
 
+@pytest.mark.parametrize("width,act,T,XY,fused", [(10, "ReLU", 10, (12, 16), True), (10, "GELU", 10, (8, 8), True), (16, "GELU", 8, (6, 6), True),
+                                                   (20, "ReLU", 5, (8, 8), True), (32, "ReLU", 20, (4, 8), True), (8, "SiLU", 4, (5, 8), True),
+                                                   (4, "ReLU", 16, (3, 5), True), (10, "ReLU", 6, (8, 8), False), (10, "ReLU", 10, (6, 6), False)])
+def test_lifting_tail_skip_gradient_summed_over_t_inside_the_kernel(width, act, T, XY, fused, dev, monkeypatch):
+    """skip_mode 3 of tcfd_fno_pointwise_bwd: the tiled backward of the lifting tail (skip = last time slice, broadcast over t) adds
+    the T steps of every row of dL/dz2 itself -- a wave owns 1 (T | 16) or 5 (T | 80) consecutive groups of 16 points -- and
+    writes the compact (b, co, X, Y, 1) gradient; against the path that writes dL/dz2 and sums it in a second pass
+    (TCFD_PWB_TSUM=0).  T = 6 and a point count that is not a multiple of 80 stay on that path by themselves."""
+    import torch.nn as nn
+    from torch_cfd_amd import fno
+
+    torch.manual_seed(width + T)
+    ci = co = width
+    cm = 4 * width
+    X, Y = XY
+    lin1, lin2 = nn.Conv3d(ci, cm, 1).to(dev), nn.Conv3d(cm, co, 1).to(dev)
+    a = getattr(nn, act)()
+    x = torch.randn(3, ci, X, Y, T, device=dev)
+    s = torch.randn(3, co, X, Y, 7, device=dev)
+    spec = (True, a, a, 2, None)
+    kind = fno._saved_kind(spec, ci, cm, co, X * Y * T)
+    with torch.no_grad():
+        pre = torch.empty(3, co, X, Y, T, device=dev) if kind == 2 else None
+        out = fno.hip_pointwise(x, lin1, a, lin2, skip=s, act2=a, skip_last_slice=True, pre=pre)
+    kept = out if kind == 1 else pre
+    dout = torch.randn_like(out)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_PWB_TSUM", flag)
+        calls = []
+        real = fno._pointwise_bwd_layout
+        monkeypatch.setattr(fno, "_pointwise_bwd_layout", lambda *a_: (calls.append(a_[-1]), real(*a_))[1])
+        res[flag] = fno._hip_pointwise_backward(spec, dout, x, s, lin1.weight, lin1.bias, lin2.weight, lin2.bias, None, None, None, None,
+                                                out=kept, compact_skip=True)
+        monkeypatch.setattr(fno, "_pointwise_bwd_layout", real)
+        assert res[flag] is not None and res[flag][1].shape == (3, co, X, Y, 1)
+        if flag == "1":
+            assert (calls == [3]) == fused, calls             # the layout query of mode 3 answered / refused
+    ref = None
+    for k, (t, b) in enumerate(zip(res["1"], res["0"])):
+        if t is not None:
+            assert torch.isfinite(t).all() and rel_l2(t, b) < 2e-6, k
+
+
 @pytest.mark.parametrize("random_feats", [False, True])
 @pytest.mark.parametrize("shape,modes,width", [((2, 16, 16, 10), (4, 4, 3), 4), ((3, 32, 64, 10), (8, 8, 5), 10), ((2, 96, 96, 6), (8, 8, 3), 8)])
 def test_lifting_operator_through_the_spectrum_equals_the_materialised_projection(shape, modes, width, random_feats, dev, monkeypatch):

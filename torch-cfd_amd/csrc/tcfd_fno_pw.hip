@@ -736,7 +736,9 @@ static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, c
     if (!dims) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: null dims");
     if (x && (!dout || !w2t || !partials || batch <= 0 || P <= 0 || max_waves < 2))
         return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad argument");
-    if (skip_mode < 0 || skip_mode > 2) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode %d not supported", skip_mode);
+    if (skip_mode < 0 || skip_mode > 3) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode %d not supported", skip_mode);
+    const bool tsum = skip_mode == 3;       // mode 2 whose skip gradient leaves the kernel summed over t: dskip is (b, co, P / T)
+    if (tsum) skip_mode = 2;
     if (x && skip_mode == 1 && (!skip || !wst)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip input missing");
     if (x && skip_mode == 2 && (!skip || T <= 0 || skip_T <= 0 || P % T != 0)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: bad T");
     PwBwdArgs a;
@@ -747,16 +749,24 @@ static int pointwise_bwd_impl(const void* pe, const void* x, const void* skip, c
     a.wst = (const float*)wst; a.bs = (const float*)bs; a.partials = (float*)partials;
     a.P = P; a.act1 = act1; a.act2 = act2; a.skip_mode = skip_mode; a.T = T; a.sT = skip_T;
     a.per_sample = per_sample; a.batch = batch;
+    a.ds_tsum = 0; a.tsum_groups = 0;
     a.chunks_per_batch = a.total_chunks = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool l1 = cm != ci || w1 != nullptr;
 #define PWB_CASE(CI_, CM_, CO_, L1_) \
     if (ci == CI_ && cm == CM_ && co == CO_ && l1 == L1_) return launch_pw_bwd<CI_, CM_, CO_, L1_>(a, batch, max_waves, dims, st);
+    if (tsum) {   // whole rows of T steps inside `tsum_groups` consecutive groups of 16 points: T | 16 (one group) or T | 80 (five)
+        a.ds_tsum = 1;
+        a.tsum_groups = (T > 0 && 16 % T == 0) ? 1 : ((T > 0 && 80 % T == 0) ? 5 : 0);
+        if (!l1 || !pwb_tiles_selected() || !a.tsum_groups || P % (16 * a.tsum_groups) != 0)
+            return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode 3 (t-summed skip gradient) not instantiated for this shape");
+    }
     if (l1 && pwb_tiles_selected()) {
         int handled = 0;
         const int rc = tcfd_pwb_tiles_dispatch(a, batch, ci, cm, co, max_waves, dims, st, &handled);
         if (handled) return rc;
     }
+    if (tsum) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: skip_mode 3 (t-summed skip gradient) not instantiated for this shape");
     // one output channel, no skip: the streaming kernel (TCFD_PWB_REDUCE1=0: the general kernel below, its cross-check)
     if (x && !l1 && co == 1 && skip_mode == 0 && !pe && !per_sample && P % 4 == 0 && max_waves >= 4 && env_int("TCFD_PWB_REDUCE1", 1)) {
 #define PWB_R1(CI_) if (ci == CI_) return launch_pwb_reduce1<CI_>(a, batch, max_waves, dims, st);

@@ -27,6 +27,9 @@ struct PwBwdArgs {
     int T, sT;           // skip_mode 2: s is (b, CO, P / T * sT), its last time slice is added; ds receives dL/dz2 (b, CO, P)
     int per_sample;      // 1: wave w only visits batch element w % batch, so its partial sums belong to ONE sample
     int batch;
+    int ds_tsum;         // skip_mode 2 only: ds is (b, CO, P / T) and receives the SUM over t of dL/dz2 (the tiled kernel adds the T steps
+                         // of a row itself; `tsum_groups` consecutive groups of 16 points hold whole rows)
+    int tsum_groups;
 };
 
 template <int CI, int CM, int CO, bool HAS_L1>

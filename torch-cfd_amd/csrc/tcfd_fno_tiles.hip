@@ -99,6 +99,11 @@ struct TilesGeom {
     static constexpr int SCR = (TI + TO > TM ? TI + TO : TM);   // transposition tiles per wave
     static constexpr int TILE = 16 * 20;                     // floats per tile (pitch 20)
     static constexpr size_t LDS = ((size_t)NG * 256 + (size_t)4 * SCR * TILE) * sizeof(float);
+    // skip_mode 2 with the t-sum in the kernel (PwBwdArgs::ds_tsum): per wave, CO channels x 80 points of dL/dz2 (pitch 84: the
+    // 16-byte lane writes of neighbouring channels fall on distinct banks)
+    static constexpr int TS_PITCH = 84;
+    static constexpr size_t TSUM = (size_t)4 * CO * TS_PITCH * sizeof(float);    // (one row per CHANNEL: width 10 keeps 4 workgroups per CU)
+    static constexpr size_t lds_of(int mode) { return LDS + (mode == 2 ? TSUM : 0); }
 };
 
 #define PWB_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
 
     // One group of loads in flight per wave, issued a whole group ahead of its use (two in flight measured no faster: the kernel
     // is bound by instruction issue, not by memory latency); the two input buffers alternate, so no register is ever copied.
-    auto body = [&](const int G, const In& cur) {
+    float* const tsb = smem + Gm::NG * 256 + 4 * (Gm::SCR * Gm::TILE) + wave * (CO * Gm::TS_PITCH);   // (MODE 2, ds_tsum) this wave's rows
+    auto body = [&](const int G, const In& cur, const int sub = 0) {
         const int b = G / gpb;
         const long pb = (long)(G - b * gpb) * 16 + 4 * q;
         const bool live = pb < a.P;
@@ -278,12 +284,41 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
                     for (int ti = 0; ti < TI; ++ti) accWs[to][ti] = PWB_MFMA(g2T[to][r], cur.sb[ti][r], accWs[to][ti]);
             }
         }
-        if constexpr (MODE == 2) {     // dL/dz2 itself is the skip gradient before its t-sum (tcfd_sum_t_into_last)
-            if (a.ds) {
+        if constexpr (MODE == 2) {     // dL/dz2 itself is the skip gradient before its t-sum (tcfd_sum_t_into_last) ...
+            if (a.ds && !a.ds_tsum) {
 #pragma unroll
                 for (int to = 0; to < TO; ++to) {
                     const int ch = OT::chan(to, c);
                     if (ch >= 0 && live) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CO + ch) * a.P + pb) = g2T[to];
+                }
+            } else if (a.ds) {
+                // ... or summed over t HERE: a wave takes `tsum_groups` consecutive groups (1 when T | 16, 5 when T | 80: whole
+                // rows of T steps), parks their dL/dz2 in its LDS rows and, after the last of them, adds each row's T values in
+                // order and stores (b, co, P / T) -- the 839 MB tensor and the pass that summed it are gone (config 5: 0.3 ms)
+                const int gin = G - b * gpb;
+#pragma unroll
+                for (int to = 0; to < TO; ++to) {
+                    const int ch = OT::chan(to, c);
+                    if (ch >= 0) *reinterpret_cast<f4*>(tsb + ch * Gm::TS_PITCH + 16 * sub + 4 * q) = g2T[to];
+                }
+                if (sub == a.tsum_groups - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int rows = 16 * a.tsum_groups / a.T;                    // rows of T steps in the super-group
+                    const long row0 = (long)(gin - sub) * 16 / a.T;               // first of them inside the sample
+                    const long rows_per_sample = a.P / a.T;
+#pragma unroll
+                    for (int to = 0; to < TO; ++to) {
+                        const int ch = OT::chan(to, c);
+                        for (int row = q; row < rows; row += 4) {                  // lane (q, c): slot c, rows q, q + 4, ...
+                            const float* src = tsb + (ch >= 0 ? ch : 0) * Gm::TS_PITCH + row * a.T;
+                            float sum = 0.f;
+                            for (int t = 0; t < a.T; ++t) sum += src[t];
+                            if (ch >= 0) a.ds[((size_t)b * CO + ch) * rows_per_sample + row0 + row] = sum;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -423,7 +458,45 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     };
-    if constexpr (WPS == 2) {                                           // narrow widths: the two input buffers alternate (no register copies)
+    if (MODE == 2 && a.ds_tsum) {
+        // a wave owns whole super-groups: groups ng * s + 0 .. ng - 1 for s = wid, wid + wstride, ...  (the host checked
+        // P % (16 ng) == 0); the position inside the super-group is carried along, not divided out
+        const int ng = a.tsum_groups, supers = total / ng;
+        int g_cur = ng * wid, sub_cur = 0;                               // the group a body call works on
+        auto next = [&](int& g, int& sub) { if (++sub == ng) { sub = 0; g += ng * (wstride - 1) + 1; } else ++g; };
+        const int g_end = ng * supers;
+        if constexpr (WPS == 2) {
+            In A, B;
+            load(g_cur < g_end ? g_cur : total - 1, A);
+            while (g_cur < g_end) {
+                int g_n = g_cur, sub_n = sub_cur;
+                next(g_n, sub_n);
+                load(g_n < g_end ? g_n : total - 1, B);
+                __builtin_amdgcn_sched_barrier(0);
+                body(g_cur, A, sub_cur);
+                if (g_n >= g_end) break;
+                g_cur = g_n; sub_cur = sub_n;
+                next(g_n, sub_n);
+                load(g_n < g_end ? g_n : total - 1, A);
+                __builtin_amdgcn_sched_barrier(0);
+                body(g_cur, B, sub_cur);
+                g_cur = g_n; sub_cur = sub_n;
+            }
+        } else {
+            In A;
+            load(g_cur < g_end ? g_cur : total - 1, A);
+            while (g_cur < g_end) {
+                int g_n = g_cur, sub_n = sub_cur;
+                next(g_n, sub_n);
+                In B;
+                load(g_n < g_end ? g_n : total - 1, B);
+                __builtin_amdgcn_sched_barrier(0);
+                body(g_cur, A, sub_cur);
+                A = B;
+                g_cur = g_n; sub_cur = sub_n;
+            }
+        }
+    } else if constexpr (WPS == 2) {                                    // narrow widths: the two input buffers alternate (no register copies)
         In A, B;
         load(wid < total ? wid : total - 1, A);
         for (int G = wid; G < total; G += 2 * wstride) {
@@ -521,10 +594,10 @@ int launch_tiles(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st
     int dev = 0, cus = 256, per_cu = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !lds_set_dev[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::lds_of(MODE)));
         if (dev >= 0 && dev < 64) lds_set_dev[dev] = 1;
     }
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, Gm::LDS));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, Gm::lds_of(MODE)));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const long groups = ((a.P + 15) / 16) * batch;
     if (groups >= (1L << 30)) return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: %ld groups of 16 points exceed the kernel's index range", groups);
@@ -532,7 +605,7 @@ int launch_tiles(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st
         return FAIL(TCFD_EINVAL, "fno_pointwise_bwd: a SAMPLE of 4 GiB and more is beyond the kernel's 32-bit buffer offsets");
     long blocks = std::min<long>({(groups + 3) / 4, (long)max_rows / 4, (long)std::max(per_cu, 1) * cus});
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), Gm::LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), Gm::lds_of(MODE), st, a);
     HIP_TRY(hipGetLastError());
     dims[5] = (int)(blocks * 4);     // every wave writes its row, also one that found no work
     return 0;

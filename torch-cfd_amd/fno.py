@@ -576,7 +576,15 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     lib = _lib.load()
     T = x.shape[-1]
     sT = skip.shape[-1] if mode == 2 else 0
-    dims = _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode)
+    # the lifting tail's compact skip gradient can leave the kernel already summed over t (skip_mode 3: whole rows of T steps inside
+    # 1 or 5 consecutive groups of 16 points) -- no (b, co, P) tensor of dL/dz2 and no pass that adds it up
+    kept_ok = (out is not None and out.dtype == torch.float32 and out.device == x.device and out.numel() == dout.numel()
+               and out.shape[:2] == dout.shape[:2])     # (what the call below hands to the kernel as the kept tensor)
+    tsum = (mode == 2 and compact_skip and (kept_ok or c2 == 0) and os.environ.get("TCFD_PWB_TSUM", "1") != "0")
+    dims = _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, 3) if tsum else None
+    tsum = dims is not None
+    if dims is None:
+        dims = _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode)
     if dims is None:
         return None
     COP, CB, CM1, CIP, per_row, _ = list(dims)
@@ -590,8 +598,11 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     vec = lambda t: t.detach().contiguous() if t is not None else None
     b1v, b2v, bsv = vec(b1), vec(b2), vec(bs)
     dx = torch.empty_like(xs) if need_dx else None
-    ds = torch.empty_like(sk) if mode == 1 else (torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=dev)
-                                                 if mode == 2 else None)
+    if tsum:
+        ds = torch.empty(*skip.shape[:-1], 1, dtype=torch.float32, device=dev)       # (b, co, X, Y, 1): the t-sums themselves
+    else:
+        ds = torch.empty_like(sk) if mode == 1 else (torch.empty(b, co, *x.shape[2:], dtype=torch.float32, device=dev)
+                                                     if mode == 2 else None)
     max_waves = max(2048, int(dims[5]))     # (the layout query of the tiled kernel reports the rows of a launch that fills the device)
     # zeros: the all-MFMA kernel writes only the entries of a row that mean something (one row per wave)
     partials = torch.zeros(max_waves, per_row, dtype=torch.float32, device=dev)
@@ -603,7 +614,7 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     with torch.cuda.device(dev):
         rc = lib.tcfd_fno_pointwise_bwd_out(ptr(xs), ptr(sk), ptr(dz), ptr(ys), ptr(dx), ptr(ds), ptr(w1m), ptr(b1v), ptr(w2t),
                                             ptr(b2v), ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1,
-                                            c2, mode, 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                                            c2, 3 if tsum else mode, 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd_out")
     # the summed row is A (COP x CB) = [dW2 | db2 | dWs] followed by B (CM1 x CIP) = [dW1 | db1]: every gradient leaves the final
     # pass of the row sum as a dense tensor of its parameter's shape (tcfd_sum_rows_scatter)
@@ -623,7 +634,9 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
     with torch.cuda.device(dev):
         _lib.check(lib.tcfd_sum_rows_scatter(partials.data_ptr(), scratch.data_ptr(), int(dims[5]), per_row, len(segs), table, dsts,
                                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tcfd_sum_rows_scatter")
-    if mode == 2:   # the skip's last time slice was broadcast over t: its gradient is the t-sum of dL/dz2
+    if tsum:
+        g_skip = ds.to(skip.dtype) if skip.dtype != ds.dtype else ds
+    elif mode == 2:   # the skip's last time slice was broadcast over t: its gradient is the t-sum of dL/dz2
         # (compact_skip: the sums alone, (b, co, X, Y, 1) -- the caller joins them to the last step of another gradient itself)
         g_skip = (torch.empty(*skip.shape[:-1], 1, dtype=skip.dtype, device=dev) if compact_skip
                   else torch.empty_like(skip, memory_format=torch.contiguous_format))
