@@ -27,7 +27,7 @@
 //             where no slot is free -- CI a multiple of 16 -- or the block has no skip convolution)
 // The forward output (ReLU) or pre-activation (GELU, SiLU, tanh) of the block comes from the caller: nothing of z2 is recomputed,
 // and the hidden layer exists in ONE orientation.  Matrix instructions per 16 points: width 10: 59 (the round-4 kernel: 71),
-// 16: 88, 20: 196, 24: 244, 32: 352.  A partly filled channel tile deals its channels to the rows 4q + r with r < ceil(n / 4)
+// 16: 88, 20: 119 + 77 small ones (TilesGeom::REM4: the products whose N or M side is the 4-channel tile as 4 x 4 x 1 blocks), 24: 244, 32: 352.  A partly filled channel tile deals its channels to the rows 4q + r with r < ceil(n / 4)
 // (slot -> channel map `Ch::chan`), so the k-steps that would multiply padding are never issued.
 // Weight fragments: groups of four consecutive k-steps interleaved per lane, one ds_read_b128 at an immediate offset per group.
 #include <hip/hip_runtime.h>
@@ -95,7 +95,15 @@ struct TilesGeom {
     static constexpr int G_W2B = G_W1A + TM * TI;            // [t][to]  B of dh^T:  W2[co(to, 4q + r)][hid(t, c)]
     static constexpr int G_W1B = G_W2B + TM * TO;            // [t][ti]  B of dx^T:  W1[hid(t, 4q + r)][ci(ti, c)]
     static constexpr int G_WSB = G_W1B + TM * TI;            // [to][ti] B of ds^T:  Ws[co(to, 4q + r)][ci(ti, c)]
-    static constexpr int NG = G_WSB + TO * TI;               // groups of 4 fragments = 1 KB each
+    // REM4 (width 20): the last ci / co tile holds 4 channels.  Wherever such a tile is the N or M side of a product it would fill
+    // a quarter of a 16 x 16 x 4 instruction (77 of the 196 per 16 points); those products run as v_mfma_f32_4x4x1_16b instead --
+    // 16 independent 4 x 4 blocks, block (q, mb) = lanes 16 q + 4 mb .. + 3, 11 cycles against 32 (tests/micro/mfma_4x4.hip) --
+    // with the OTHER operand taken as it is (a 4-row / 4-column slice of a 16 x 16 x 4 operand IS a block operand) and the
+    // 4-channel operand replicated over mb by one lane shuffle.  Their B fragments:
+    static constexpr bool REM4 = TI > 1 && TO > 1 && IT::n(TI - 1) == 4 && OT::n(TO - 1) == 4;
+    static constexpr int G_W1R = G_WSB + TO * TI;            // [t]      W1[hid(t, 4q + r)][ci 16 (TI-1) + (c & 3)]   (dx^T, last ci tile)
+    static constexpr int G_WSR = G_W1R + (REM4 ? TM : 0);    // [to]     Ws[co(to, 4q + r)][ci 16 (TI-1) + (c & 3)]    (ds^T, last ci tile)
+    static constexpr int NG = G_WSR + (REM4 ? TO : 0);       // groups of 4 fragments = 1 KB each
     static constexpr int SCR = (TI + TO > TM ? TI + TO : TM);   // transposition tiles per wave
     static constexpr int TILE = 16 * 20;                     // floats per tile (pitch 20)
     static constexpr size_t LDS = ((size_t)NG * 256 + (size_t)4 * SCR * TILE) * sizeof(float);
@@ -107,6 +115,7 @@ struct TilesGeom {
 };
 
 #define PWB_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32((A_), (B_), (C_), 0, 0, 0)
+#define PWB_M44(A_, B_, C_) __builtin_amdgcn_mfma_f32_4x4x1f32((A_), (B_), (C_), 0, 0, 0)
 
 // MODE = skip_mode (0 none, 1 skip convolution, 2 broadcast last slice).  ACT >= 0: both activations are that code at compile
 // time; ACT = -1: a.act1 / a.act2 at run time (one uniform switch per tile set).  WPS = waves per SIMD the registers must allow.
@@ -118,6 +127,9 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
     using OT = typename Gm::OT;
     using Lay = PwBwdGeom<CI, CM, CO, true>;
     constexpr int TI = Gm::TI, TM = Gm::TM, TO = Gm::TO;
+    constexpr bool REM4 = Gm::REM4;
+    constexpr int TIF = REM4 ? TI - 1 : TI, TOF = REM4 ? TO - 1 : TO;   // tiles that take the N / M side of a 16 x 16 x 4 product
+    constexpr int CIR = 16 * (TI - 1), COR = 16 * (TO - 1);             // first channel of the 4-channel tiles (REM4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ldsw = smem;
     const int tid = threadIdx.x;
@@ -154,6 +166,14 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
                     const int ic = IT::chan(ti, fc);
                     ldsw[(Gm::G_WSB + to * TI + ti) * 256 + tid] = pick(a.wst, ic * CO + ok, ok >= 0 && ic >= 0);
                 }
+                if constexpr (REM4) ldsw[(Gm::G_WSR + to) * 256 + tid] = pick(a.wst, (CIR + (fc & 3)) * CO + ok, ok >= 0);
+            }
+        }
+        if constexpr (REM4) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int hk = HT::chan(t, 4 * fq + fi);
+                ldsw[(Gm::G_W1R + t) * 256 + tid] = pick(a.w1, hk * CI + CIR + (fc & 3), hk >= 0);
             }
         }
     }
@@ -170,6 +190,8 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < TM; ++t) { const int hc = HT::chan(t, c); b1v[t] = (hc >= 0 && a.b1) ? a.b1[hc] : 0.f; }
     f4 accW2[TO][TM], accW1[TM][TI], accWs[TO][TI];
+    // REM4: the 4 x 4 block accumulators of the products with the 4-channel tiles (the [.][TI - 1] / [TO - 1][.] entries above stay unused)
+    f4 accW1R[TM], accW2R[TM], accWsRa[TO], accWsRb[TI], accWsRc = f4{0.f, 0.f, 0.f, 0.f};
     float accB1[TM], accB2[TO];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
@@ -178,12 +200,14 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         for (int to = 0; to < TO; ++to) accW2[to][t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) accW1[t][ti] = f4{0.f, 0.f, 0.f, 0.f};
+        accW1R[t] = accW2R[t] = f4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
         accB2[to] = 0.f;
+        accWsRa[to] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) accWs[to][ti] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int ti = 0; ti < TI; ++ti) { accWs[to][ti] = f4{0.f, 0.f, 0.f, 0.f}; accWsRb[ti] = f4{0.f, 0.f, 0.f, 0.f}; }
     }
 
     const int gpb = (int)((a.P + 15) / 16);                 // groups of 16 points per batch element
@@ -191,7 +215,8 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
     const int wid = blockIdx.x * 4 + wave, wstride = gridDim.x * 4;
     const unsigned P4 = (unsigned)a.P * 4u;
     constexpr unsigned OOB = 0xffffffffu;                    // beyond every buffer: the bounds check returns 0
-    constexpr int BSLOT = IT::free_slot();                    // slot of the constant-1 channel beside x / s, or -1 (CI % 16 == 0)
+    constexpr int BSLOT = REM4 ? -1 : IT::free_slot();        // slot of the constant-1 channel beside x / s, or -1 (CI % 16 == 0; REM4:
+                                                              // the last tile's products are 4 x 4 blocks with no spare column)
     unsigned i_off[TI], o_off[TO];                           // byte offset of this lane's channel row inside ONE sample, or OOB
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) { const int ch = IT::chan(ti, c); i_off[ti] = ch >= 0 ? (unsigned)ch * P4 : OOB; }
@@ -273,15 +298,39 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         for (int ti = 0; ti < TI; ++ti) put(ti, cur.xb[ti]);
 #pragma unroll
         for (int to = 0; to < TO; ++to) put(TI + to, g2T[to]);
+        // REM4: the 4-channel tiles as block operands -- lane (q, 4 mb + j) takes channel j of its row of 16 lanes, which the
+        // point-major layout keeps in lane (q, 4 j)
+        f4 xrep = f4{0.f, 0.f, 0.f, 0.f}, srep = xrep, g2rep = xrep;
+        if constexpr (REM4) {
+            const int src = (lane & 48) | ((lane & 3) << 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xrep[r] = __shfl(cur.xb[TI - 1][r], src, 64);
+                g2rep[r] = __shfl(g2T[TO - 1][r], src, 64);
+                if constexpr (MODE == 1) srep[r] = __shfl(cur.sb[TI - 1][r], src, 64);
+            }
+        }
         // register-only work while the tiles are on their way: the skip convolution's weight gradient, the output bias gradient
 #pragma unroll
         for (int to = 0; to < TO; ++to) {
             if constexpr (!(MODE == 1 && BSLOT >= 0)) accB2[to] += (g2T[to][0] + g2T[to][1]) + (g2T[to][2] + g2T[to][3]);
             if constexpr (MODE == 1) {
+                if (to < TOF) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int ti = 0; ti < TI; ++ti) accWs[to][ti] = PWB_MFMA(g2T[to][r], cur.sb[ti][r], accWs[to][ti]);
+                        for (int ti = 0; ti < TIF; ++ti) accWs[to][ti] = PWB_MFMA(g2T[to][r], cur.sb[ti][r], accWs[to][ti]);
+                        if constexpr (REM4) accWsRa[to] = PWB_M44(g2T[to][r], srep[r], accWsRa[to]);       // (co tile) x (4 ci)
+                    }
+                }
+            }
+        }
+        if constexpr (REM4 && MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int ti = 0; ti < TIF; ++ti) accWsRb[ti] = PWB_M44(g2rep[r], cur.sb[ti][r], accWsRb[ti]);   // (4 co) x (ci tile)
+                accWsRc = PWB_M44(g2rep[r], srep[r], accWsRc);                                                 // (4 co) x (4 ci)
             }
         }
         if constexpr (MODE == 2) {     // dL/dz2 itself is the skip gradient before its t-sum (tcfd_sum_t_into_last) ...
@@ -409,9 +458,13 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int to = 0; to < TO; ++to) accW2[to][t] = PWB_MFMA(g2T[to][r], zT[t][r], accW2[to][t]);
+                for (int to = 0; to < TOF; ++to) accW2[to][t] = PWB_MFMA(g2T[to][r], zT[t][r], accW2[to][t]);
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) accW1[t][ti] = PWB_MFMA(dhT[t][r], cur.xb[ti][r], accW1[t][ti]);
+                for (int ti = 0; ti < TIF; ++ti) accW1[t][ti] = PWB_MFMA(dhT[t][r], cur.xb[ti][r], accW1[t][ti]);
+                if constexpr (REM4) {
+                    accW2R[t] = PWB_M44(g2rep[r], zT[t][r], accW2R[t]);      // (4 co) x (hidden tile): rows = co, columns = hidden slots
+                    accW1R[t] = PWB_M44(dhT[t][r], xrep[r], accW1R[t]);      // (hidden tile) x (4 ci)
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -420,20 +473,33 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
             f4 dxT[TI][2];
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti) dxT[ti][0] = dxT[ti][1] = f4{0.f, 0.f, 0.f, 0.f};
+            f4 dxR[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 const f4 g1 = get(t);
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) {
+                for (int ti = 0; ti < TIF; ++ti) {
                     const f4 w = wf[(Gm::G_W1B + t * TI + ti) * 64];
 #pragma unroll
                     for (int r = 0; r < HT::rv(t); ++r) dxT[ti][r & 1] = PWB_MFMA(g1[r], w[r], dxT[ti][r & 1]);
                 }
+                if constexpr (REM4) {                        // block (q, mb): rows = points 4 mb .., ONE hidden slot 4 q + r per instruction
+                    const f4 w = wf[(Gm::G_W1R + t) * 64];
+#pragma unroll
+                    for (int r = 0; r < HT::rv(t); ++r) dxR[r & 1] = PWB_M44(g1[r], w[r], dxR[r & 1]);
+                }
             }
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) {
+            for (int ti = 0; ti < TIF; ++ti) {
                 const int ch = IT::chan(ti, c);
                 if (ch >= 0 && live) *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + ch) * a.P + pb) = dxT[ti][0] + dxT[ti][1];
+            }
+            if constexpr (REM4) {                            // the four q hold the partial sums over their hidden slots
+                f4 v = dxR[0] + dxR[1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] += __shfl_xor(v[i], 16, 64); v[i] += __shfl_xor(v[i], 32, 64); }
+                const long pr = (long)(G - b * gpb) * 16 + 4 * (c >> 2);          // lane (0, 4 mb + j): channel j at points 4 mb ..
+                if (q == 0 && pr < a.P) *reinterpret_cast<f4*>(a.dx + ((size_t)b * CI + CIR + (c & 3)) * a.P + pr) = v;
             }
         }
         if constexpr (MODE == 1) {
@@ -441,18 +507,32 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
                 f4 dsT[TI][2];
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti) dsT[ti][0] = dsT[ti][1] = f4{0.f, 0.f, 0.f, 0.f};
+                f4 dsR[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int to = 0; to < TO; ++to)
+                for (int to = 0; to < TO; ++to) {
 #pragma unroll
-                    for (int ti = 0; ti < TI; ++ti) {
+                    for (int ti = 0; ti < TIF; ++ti) {
                         const f4 w = wf[(Gm::G_WSB + to * TI + ti) * 64];
 #pragma unroll
                         for (int r = 0; r < OT::rv(to); ++r) dsT[ti][r & 1] = PWB_MFMA(g2[to][r], w[r], dsT[ti][r & 1]);
                     }
+                    if constexpr (REM4) {
+                        const f4 w = wf[(Gm::G_WSR + to) * 64];
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) {
+                        for (int r = 0; r < OT::rv(to); ++r) dsR[r & 1] = PWB_M44(g2[to][r], w[r], dsR[r & 1]);
+                    }
+                }
+#pragma unroll
+                for (int ti = 0; ti < TIF; ++ti) {
                     const int ch = IT::chan(ti, c);
                     if (ch >= 0 && live) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + ch) * a.P + pb) = dsT[ti][0] + dsT[ti][1];
+                }
+                if constexpr (REM4) {
+                    f4 v = dsR[0] + dsR[1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] += __shfl_xor(v[i], 16, 64); v[i] += __shfl_xor(v[i], 32, 64); }
+                    const long pr = (long)(G - b * gpb) * 16 + 4 * (c >> 2);
+                    if (q == 0 && pr < a.P) *reinterpret_cast<f4*>(a.ds + ((size_t)b * CI + CIR + (c & 3)) * a.P + pr) = v;
                 }
             }
         }
@@ -531,14 +611,25 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int hq = HT::chan(t, 4 * q + r);
 #pragma unroll
-            for (int to = 0; to < TO; ++to) {
+            for (int to = 0; to < TOF; ++to) {
                 const int oq = OT::chan(to, 4 * q + r);
                 if (oq >= 0 && hc >= 0) out[oq * Lay::CB + hc] = accW2[to][t][r];
             }
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) {
+            for (int ti = 0; ti < TIF; ++ti) {
                 const int ic = IT::chan(ti, c);
                 if (hq >= 0 && ic >= 0) o1[hq * Lay::CIP + ic] = accW1[t][ti][r];
+            }
+        }
+        if constexpr (REM4) {      // block accumulators: register i of lane (q, 4 mb + j), summed over the four q (their point groups)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float w2 = accW2R[t][i], w1 = accW1R[t][i];
+                w2 += __shfl_xor(w2, 16, 64); w2 += __shfl_xor(w2, 32, 64);
+                w1 += __shfl_xor(w1, 16, 64); w1 += __shfl_xor(w1, 32, 64);
+                const int hr = HT::chan(t, 4 * (c >> 2) + i);                 // dW1: row = hidden slot 4 mb + i, column = ci CIR + j
+                if (q == 0 && hc >= 0) out[(COR + i) * Lay::CB + hc] = w2;    // dW2: row = co COR + i, column = hidden slot c
+                if (q == 0 && hr >= 0) o1[hr * Lay::CIP + CIR + (c & 3)] = w1;
             }
         }
         if constexpr (BSLOT >= 0) {                            // db1 = column BSLOT of the last ci tile of dW1
@@ -570,19 +661,46 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
             if (q == 0 && oc >= 0) out[oc * Lay::CB + CM] = s;
         }
         if constexpr (MODE == 1) {
+            if (to < TOF) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oq = OT::chan(to, 4 * q + r);
+                for (int r = 0; r < 4; ++r) {
+                    const int oq = OT::chan(to, 4 * q + r);
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) {
-                    const int ic = IT::chan(ti, c);
-                    if (oq >= 0 && ic >= 0) out[oq * Lay::CB + CM + 1 + ic] = accWs[to][ti][r];
+                    for (int ti = 0; ti < TIF; ++ti) {
+                        const int ic = IT::chan(ti, c);
+                        if (oq >= 0 && ic >= 0) out[oq * Lay::CB + CM + 1 + ic] = accWs[to][ti][r];
+                    }
+                }
+                if constexpr (REM4) {                          // (co tile) x (4 ci): row = co slot 4 mb + i, column = ci CIR + j
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = accWsRa[to][i];
+                        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                        const int orow = OT::chan(to, 4 * (c >> 2) + i);
+                        if (q == 0 && orow >= 0) out[orow * Lay::CB + CM + 1 + CIR + (c & 3)] = v;
+                    }
                 }
             }
         }
     }
+    if constexpr (REM4 && MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int ti = 0; ti < TIF; ++ti) {                 // (4 co) x (ci tile): row = co COR + i, column = ci slot c
+                float v = accWsRb[ti][i];
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                const int ic = IT::chan(ti, c);
+                if (q == 0 && ic >= 0) out[(COR + i) * Lay::CB + CM + 1 + ic] = v;
+            }
+            float v = accWsRc[i];                              // (4 co) x (4 ci): every mb holds the same block
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (q == 0 && c < 4) out[(COR + i) * Lay::CB + CM + 1 + CIR + c] = v;
+        }
+    }
 }
 #undef PWB_MFMA
+#undef PWB_M44
 
 template <int CI, int CM, int CO, int MODE, int ACT, int WPS>
 int launch_tiles(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st) {
