@@ -1187,6 +1187,8 @@ def test_sfno_training_step_gradients_golden_at_widths_16_and_20(tag, width, act
     (32, 128, 32, True, 0, None), (10, 40, 10, True, 1, "SiLU"),
     # one output channel (the reduction in front of the output operator): the streaming kernel k_pwb_reduce1 when P % 4 == 0
     (16, 16, 1, False, 0, "GELU"), (20, 20, 1, False, 0, "ReLU"), (32, 32, 1, False, 0, None), (4, 4, 1, False, 0, "SiLU"),
+    # width 20 without a skip path and with run-time activations (the 4 x 4 block products of its 4-channel tiles in every mode)
+    (20, 80, 20, True, 0, "SiLU"), (20, 80, 20, True, 2, "Tanh"), (20, 80, 20, True, 0, None),
 ])
 @pytest.mark.parametrize("X", [7, 6])   # P = 630 (not a multiple of 4: the LDS-staged kernels) / 540 (P % 16 = 12: the all-MFMA kernel, ragged last group)
 def test_pointwise_backward_kernel_matches_autograd(ci, cm, co, two, mode, act, X, dev, monkeypatch):
