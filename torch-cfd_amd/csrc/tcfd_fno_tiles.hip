@@ -948,11 +948,15 @@ __global__ __launch_bounds__(256, WPS) void k_pwf_tiles(PwArgs a, int batch) {
         // ---- h^T = act1(z1^T), transposed tile by tile
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
+            if constexpr (ACT == 2) {                      // GELU two values at a time on packed math
+                const v2f g0 = gelu_pk(v2f{zT[t][0], zT[t][1]}), g1 = gelu_pk(v2f{zT[t][2], zT[t][3]});
+                zT[t] = f4{g0.x, g0.y, g1.x, g1.y};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (ACT == 1) zT[t][r] = relu_bits(zT[t][r]);
-                else if constexpr (ACT == 2) zT[t][r] = gelu_f(zT[t][r]);
-                else zT[t][r] = pw_act(zT[t][r], a.act1);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (ACT == 1) zT[t][r] = relu_bits(zT[t][r]);
+                    else zT[t][r] = pw_act(zT[t][r], a.act1);
+                }
             }
             put(t, zT[t]);
         }
@@ -973,11 +977,15 @@ __global__ __launch_bounds__(256, WPS) void k_pwf_tiles(PwArgs a, int batch) {
         for (int to = 0; to < TO; ++to) {
             const int oc = OT::chan(to, c);
             f4 z = oT[to][0] + oT[to][1], y;
+            if constexpr (ACT == 2) {
+                const v2f g0 = gelu_pk(v2f{z[0], z[1]}), g1 = gelu_pk(v2f{z[2], z[3]});
+                y = f4{g0.x, g0.y, g1.x, g1.y};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (ACT == 1) y[r] = relu_bits(z[r]);
-                else if constexpr (ACT == 2) y[r] = gelu_f(z[r]);
-                else y[r] = pw_act(z[r], a.act2);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (ACT == 1) y[r] = relu_bits(z[r]);
+                    else y[r] = pw_act(z[r], a.act2);
+                }
             }
             if (oc >= 0 && live) {
                 const size_t o = ((size_t)b * CO + oc) * a.P + pb;
