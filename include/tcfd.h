@@ -376,10 +376,11 @@ int tcfd_fno_pointwise_bwd_saved(int ci, int cm, int co, long P, int act1, int a
 int tcfd_fno_pointwise_bwd_pe(const void* x1, const void* pe, const void* dout, void* dx, const void* w2t, const void* b2,
                               void* partials, int max_waves, int* dims, int batch, int ci, int co, long P, int per_sample,
                               void* stream);
-/* Per-sample sums of outer products over the points, on MFMA: partials (waves_per_sample, batch, 16 x 16) with, after adding
- * the waves (tcfd_sum_rows), tile[o][c] = sum_p dy[b][o][p] xin[b][c][p] for c < C and tile[o][C] = sum_p dy[b][o][p]; xin = x
+/* Per-sample sums of outer products over the points, on MFMA: partials (waves_per_sample, batch, R16, C16) row-major with
+ * R16 = 16 ceil(co / 16), C16 = 16 ceil((C + 1) / 16) and, after adding the waves (tcfd_sum_rows),
+ * M[o][c] = sum_p dy[b][o][p] xin[b][c][p] for c < C and M[o][C] = sum_p dy[b][o][p]; xin = x
  * (batch, C, P), or x (batch, P) + pe (C, P) when pe is given.  What the backward of proj(LayerNormnd(xin)) (fno/sfno.py:252-254,
- * fno/base.py:61-83) needs from the data.  C <= 15, co <= 16, P % 16 == 0, waves_per_sample a multiple of 4. */
+ * fno/base.py:61-83) needs from the data.  C <= 47, co <= 32, P % 16 == 0, waves_per_sample a multiple of 4. */
 int tcfd_fno_sample_outer_sums(const void* dy, const void* x, const void* pe, void* partials, int batch, int c, int co, long P,
                                int waves_per_sample, void* stream);
 /* per_sample = 1: the rows written (dims[5], a multiple of batch) are per-SAMPLE partial sums, row r belongs to batch

@@ -51,12 +51,14 @@ def test_sum_t_into_last(rows, T, sT, dev, lib):
     assert torch.allclose(g, ref, rtol=1e-6, atol=1e-6) and float(g[:, :-1].abs().max() if sT > 1 else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("C,co", [(7, 5), (15, 16), (16, 16), (20, 20), (32, 32), (31, 17), (40, 9)])
 @pytest.mark.parametrize("with_table", [False, True])
-def test_sample_outer_sums(with_table, dev, lib):
+def test_sample_outer_sums(with_table, C, co, dev, lib):
     from torch_cfd_amd import _lib
 
     g = torch.Generator().manual_seed(3)
-    b, C, co, P, wps = 3, 7, 5, 16 * 41, 8
+    b, P, wps = 3, 16 * 41, 8
+    R16, C16 = 16 * ((co + 15) // 16), 16 * ((C + 16) // 16)          # wide layers: more 16 x 16 tiles (C + 1 columns, co rows)
     dy = torch.randn(b, co, P, generator=g).to(dev)
     if with_table:
         x1, pe = torch.randn(b, P, generator=g).to(dev), torch.randn(C, P, generator=g).to(dev)
@@ -64,13 +66,13 @@ def test_sample_outer_sums(with_table, dev, lib):
     else:
         xin = torch.randn(b, C, P, generator=g).to(dev)
         xp, pp = xin.data_ptr(), None
-    tiles = torch.empty(wps, b, 256, device=dev)
+    tiles = torch.empty(wps, b, R16 * C16, device=dev)
     _lib.check(lib.tcfd_fno_sample_outer_sums(dy.data_ptr(), xp, pp, tiles.data_ptr(), b, C, co, P, wps, _stream(dev)),
                "tcfd_fno_sample_outer_sums")
-    M = tiles.double().sum(0).view(b, 16, 16)
+    M = tiles.double().sum(0).view(b, R16, C16)
     assert rel_l2(M[:, :co, :C], torch.einsum("bop,bcp->boc", dy.double(), xin.double())) < 1e-6
     assert rel_l2(M[:, :co, C], dy.double().sum(-1)) < 1e-6
-    assert float(M[:, co:].abs().max()) == 0.0 and float(M[:, :, C + 1:].abs().max()) == 0.0
+    assert float(M[:, co:].abs().max() if co < R16 else 0.0) == 0.0 and float(M[:, :, C + 1:].abs().max() if C + 1 < C16 else 0.0) == 0.0
     # loud on shapes it does not cover
     assert lib.tcfd_fno_sample_outer_sums(dy.data_ptr(), xp, pp, tiles.data_ptr(), b, C, co, P - 4, wps, _stream(dev)) != 0
 

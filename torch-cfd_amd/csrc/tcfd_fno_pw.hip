@@ -1168,6 +1168,10 @@ extern "C" int tcfd_sum_t_into_last(const void* d, void* g, long rows, int T, in
 // {4q + r}, so the 16 x 16 tile of sums grows by four v_mfma_f32_16x16x4_f32 per group and nothing else: the kernel runs at
 // the rate its two loads arrive (the LDS-staged k_pointwise_bwd<10,10,10,false> spent 0.59 ms on the same sums at config 5).
 // partials: (waves_per_sample, batch, 256) floats, row-major 16 x 16 tiles [o][c]; added up by tcfd_sum_rows.
+// TR x TC tiles of 16 x 16 (co <= 16 TR rows, C + 1 <= 16 TC columns): wide layers run the same kernel with more tiles -- before,
+// C > 15 fell to the LDS-staged k_pointwise_bwd<C, C, C, false> with per-sample rows: 36 ms at width 32, a third of its training step.
+// partials: (waves_per_sample, batch, 16 TR, 16 TC) floats, row-major.
+template <int TR, int TC>
 __global__ __launch_bounds__(256) void k_sample_outer_mfma(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ pe, float* __restrict__ partials, long P,
                                                            int C, int CO, int waves_per_sample, int batch) {
@@ -1175,33 +1179,68 @@ __global__ __launch_bounds__(256) void k_sample_outer_mfma(const float* __restri
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), b = blockIdx.y;
     const long groups = P / 16;
-    const float* dyr = dy + ((size_t)b * CO + (c < CO ? c : 0)) * P + 4 * q;
-    const float* xr = pe ? x + (size_t)b * P + 4 * q : x + ((size_t)b * C + (c < C ? c : 0)) * P + 4 * q;
-    const float* per = pe ? pe + (size_t)(c < C ? c : 0) * P + 4 * q : nullptr;
-    const float ones = c == C ? 1.f : 0.f;
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    const float* dyr[TR];
+    const float* xr[TC];
+    const float* per[TC];
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr) { const int o = 16 * tr + c; dyr[tr] = dy + ((size_t)b * CO + (o < CO ? o : 0)) * P + 4 * q; }
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+        const int ch = 16 * tc + c, chc = ch < C ? ch : 0;
+        xr[tc] = pe ? x + (size_t)b * P + 4 * q : x + ((size_t)b * C + chc) * P + 4 * q;
+        per[tc] = pe ? pe + (size_t)chc * P + 4 * q : nullptr;
+    }
+    f4 acc[TR][TC];
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) acc[tr][tc] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (long g = w; g < groups; g += waves_per_sample) {
-        f4 a = *reinterpret_cast<const f4*>(dyr + g * 16);
-        f4 v = *reinterpret_cast<const f4*>(xr + g * 16);
-        if (per) v += *reinterpret_cast<const f4*>(per + g * 16);
-        if (c >= CO) a = f4{0.f, 0.f, 0.f, 0.f};
-        if (c >= C) v = f4{ones, ones, ones, ones};
+        f4 a[TR], v[TC];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], v[r], acc, 0, 0, 0);
+        for (int tr = 0; tr < TR; ++tr) {
+            a[tr] = *reinterpret_cast<const f4*>(dyr[tr] + g * 16);
+            if (16 * tr + c >= CO) a[tr] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const int ch = 16 * tc + c;
+            if (16 * tc < C) {                                    // (a tile past the channels holds the column of ones only: no load)
+                v[tc] = *reinterpret_cast<const f4*>(xr[tc] + g * 16);
+                if (per[tc]) v[tc] += *reinterpret_cast<const f4*>(per[tc] + g * 16);
+            }
+            if (ch >= C) { const float ones = ch == C ? 1.f : 0.f; v[tc] = f4{ones, ones, ones, ones}; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) acc[tr][tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr][r], v[tc][r], acc[tr][tc], 0, 0, 0);
     }
-    float* out = partials + ((size_t)w * batch + b) * 256;
+    float* out = partials + ((size_t)w * batch + b) * (256 * TR * TC);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(4 * q + r) * 16 + c] = acc[r];
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * tr + 4 * q + r) * (16 * TC) + 16 * tc + c] = acc[tr][tc][r];
 }
+// co <= 32, c <= 47; the caller's partials hold (waves_per_sample, batch, 16 ceil(co / 16), 16 ceil((c + 1) / 16)) floats
 extern "C" int tcfd_fno_sample_outer_sums(const void* dy, const void* x, const void* pe, void* partials, int batch, int c, int co,
                                           long P, int waves_per_sample, void* stream) {
-    if (!dy || !x || !partials || batch <= 0 || c < 1 || c > 15 || co < 1 || co > 16 || P <= 0 || P % 16 != 0 ||
+    if (!dy || !x || !partials || batch <= 0 || c < 1 || c > 47 || co < 1 || co > 32 || P <= 0 || P % 16 != 0 ||
         waves_per_sample < 4 || waves_per_sample % 4 != 0)
-        return FAIL(TCFD_EINVAL, "fno_sample_outer_sums: bad argument (needs c <= 15, co <= 16, P %% 16 == 0, whole workgroups)");
-    hipLaunchKernelGGL(k_sample_outer_mfma, dim3((unsigned)(waves_per_sample / 4), (unsigned)batch), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)dy, (const float*)x, (const float*)pe, (float*)partials, P, c, co,
-                       waves_per_sample, batch);
+        return FAIL(TCFD_EINVAL, "fno_sample_outer_sums: bad argument (needs c <= 47, co <= 32, P %% 16 == 0, whole workgroups)");
+    const int tr = (co + 15) / 16, tc = (c + 16) / 16;
+    const dim3 grid((unsigned)(waves_per_sample / 4), (unsigned)batch);
+#define TCFD_OUTER(TR_, TC_)                                                                                                         \
+    if (tr == TR_ && tc == TC_)                                                                                                      \
+        hipLaunchKernelGGL((k_sample_outer_mfma<TR_, TC_>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, \
+                           (const float*)pe, (float*)partials, P, c, co, waves_per_sample, batch);
+    TCFD_OUTER(1, 1) TCFD_OUTER(1, 2) TCFD_OUTER(1, 3) TCFD_OUTER(2, 1) TCFD_OUTER(2, 2) TCFD_OUTER(2, 3)
+#undef TCFD_OUTER
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -681,16 +681,17 @@ def _hip_norm_proj_backward(eps, dout, x, w, bias, gamma, beta, need_dx: bool = 
     stats = moments if moments is not None else torch.empty(b, 2, dtype=torch.float64, device=dev)   # (sum, sum of squares) per sample
     W = w.detach().reshape(co, C)
     w2t = W.t().contiguous()
-    if C <= 15 and co <= 16 and P % 16 == 0 and os.environ.get("TCFD_OUTER_SUMS_MFMA", "1") != "0":
+    if C <= 47 and co <= 32 and P % 16 == 0 and os.environ.get("TCFD_OUTER_SUMS_MFMA", "1") != "0":
         # the sums on MFMA straight from two 16-byte loads per lane (tcfd_fno_sample_outer_sums)
         wps = int(os.environ.get("TCFD_OUTER_WPS", 128))    # 64: 0.49 ms, 128: 0.30, 256: 0.33 at config 5 (tests/micro/outer_sums_timing.py)
-        tiles = torch.empty(wps, b, 256, dtype=torch.float32, device=dev)
+        R16, C16 = 16 * ((co + 15) // 16), 16 * ((C + 16) // 16)      # the sums come as (R16 x C16) matrices of 16 x 16 tiles
+        tiles = torch.empty(wps, b, R16 * C16, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if moments is None:
                 _lib.check(lib.tcfd_row_moments(xs.data_ptr(), stats.data_ptr(), b, L, stream), "tcfd_row_moments")
             _lib.check(lib.tcfd_fno_sample_outer_sums(dz.data_ptr(), xs.data_ptr(), table.data_ptr() if table is not None else None,
                                                       tiles.data_ptr(), b, C, co, P, wps, stream), "tcfd_fno_sample_outer_sums")
-        M = _sum_rows(tiles, wps, b * 256).view(b, 16, 16)
+        M = _sum_rows(tiles, wps, b * R16 * C16).view(b, R16, C16)
         return _norm_proj_grads(eps, dz, xs, W, bias, gamma, beta, M[:, :co, :C], M[:, :co, C], stats, need_dx, w, x, L, P, stream)
     max_waves = 2048 + b
     partials = torch.empty(max_waves, per_row, dtype=torch.float32, device=dev)
