@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
         int g_cur = ng * wid, sub_cur = 0;                               // the group a body call works on
         auto next = [&](int& g, int& sub) { if (++sub == ng) { sub = 0; g += ng * (wstride - 1) + 1; } else ++g; };
         const int g_end = ng * supers;
-        if constexpr (WPS == 2) {
+        if constexpr (WPS == 2 && TM <= 4) {
             In A, B;
             load(g_cur < g_end ? g_cur : total - 1, A);
             while (g_cur < g_end) {
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, WPS) void k_pwb_tiles(PwBwdArgs a) {
                 g_cur = g_n; sub_cur = sub_n;
             }
         }
-    } else if constexpr (WPS == 2) {                                    // narrow widths: the two input buffers alternate (no register copies)
+    } else if constexpr (WPS == 2 && TM <= 4) {                         // narrow widths: the two input buffers alternate (no register copies)
         In A, B;
         load(wid < total ? wid : total - 1, A);
         for (int G = wid; G < total; G += 2 * wstride) {
@@ -732,7 +732,10 @@ int launch_tiles(PwBwdArgs a, int batch, int max_rows, int* dims, hipStream_t st
 // both activations ReLU, both GELU (the reference's choices, fno/train.py:303), or anything at run time
 template <int CI, int CM, int CO, int MODE, int WPS>
 int launch_tiles_act(const PwBwdArgs& a, int batch, int max_rows, int* dims, hipStream_t st) {
-    if (a.act1 == 1 && a.act2 == 1) return launch_tiles<CI, CM, CO, MODE, 1, WPS>(a, batch, max_rows, dims, st);
+    // width 20 with ReLU fits two waves per SIMD (8 spilled registers in mode 1, none in mode 2): 5.12 -> 4.47 ms per launch; its
+    // GELU / run-time variants would spill 34 ... 52 and stay at one
+    constexpr int WPS_RELU = (CI == 20 || CI == 24) ? 2 : WPS;
+    if (a.act1 == 1 && a.act2 == 1) return launch_tiles<CI, CM, CO, MODE, 1, WPS_RELU>(a, batch, max_rows, dims, st);
     if (a.act1 == 2 && a.act2 == 2) return launch_tiles<CI, CM, CO, MODE, 2, WPS>(a, batch, max_rows, dims, st);
     return launch_tiles<CI, CM, CO, MODE, -1, WPS>(a, batch, max_rows, dims, st);
 }
