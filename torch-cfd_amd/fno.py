@@ -532,13 +532,23 @@ def _pointwise_reference(spec, x, skip, w1, b1, w2, b2, ws, bs, gamma, beta):
     return act2(o) if act2 is not None else o
 
 
+_BWD_LAYOUTS: Dict[tuple, Optional[tuple]] = {}
+
+
 def _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode):
     """Layout query of ``tcfd_fno_pointwise_bwd`` (no data): the six geometry numbers, or None when the backward kernel is
-    not instantiated for the combination."""
+    not instantiated for the combination.  Remembered per (device, shape, switches): the query asks the runtime for an
+    occupancy figure, ~40 us that a small-batch training iteration pays six times."""
+    key = (torch.cuda.current_device(), has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode,
+           os.environ.get("TCFD_PW_BWD_TILES"), os.environ.get("TCFD_PWB_REDUCE1"))
+    if key in _BWD_LAYOUTS:
+        hit = _BWD_LAYOUTS[key]
+        return (ctypes.c_int * 6)(*hit) if hit is not None else None
     dims = (ctypes.c_int * 6)()
     one = ctypes.c_void_p(1) if has_l1 else None   # only null / non-null of w1 matters
     rc = _lib.load().tcfd_fno_pointwise_bwd(None, None, None, None, None, one, None, None, None, None, None, None, 0, dims, b, ci,
                                             cm, co, P, T, sT, c1, c2, mode, 0, None)
+    _BWD_LAYOUTS[key] = tuple(dims) if rc == 0 else None
     return dims if rc == 0 else None
 
 
