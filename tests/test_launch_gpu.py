@@ -85,6 +85,28 @@ def test_bench_c4_job_as_a_separate_process_tree():
     assert "did not finish" in out["c4_ensemble"]["error"] and out["value"] > 10
 
 
+def test_bench_secondary_workloads_are_a_job_of_their_own():
+    """The secondary workloads run as bench_secondary.py with a time limit after the headline; a few scalars reach the line (read
+    the way the driver reads it: last brace-bearing line of stdout + stderr), the full record goes to the detail file; a job that
+    cannot finish in time leaves the headline standing."""
+    from test_bench_record import read_like_the_driver
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BENCH_SECONDARY_ONLY"] = "notebook"
+    cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--regions", "3", "--no-cpu-baseline", "--no-probe", "--no-c4", "--batch", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = read_like_the_driver(r.stdout.decode(), r.stderr.decode())
+    assert out["value"] > 10 and len(out["timing"]["regions_ms_per_step"]) == 3 and 0 < out["roofline"]["frac"] < 1
+    assert out["sfno_notebook_training"]["iterations_per_s"] > 10 and out["sfno_notebook_training"]["finite"] is True
+    detail = json.load(open(os.path.join(ROOT, out["detail_file"])))
+    assert detail["secondary"]["sfno_notebook_training"]["graph_replay"]["iterations_per_s"] > 10 and len(detail["regions"]) == 3
+    r = subprocess.run(cmd + ["--secondary-timeout", "0.5"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = read_like_the_driver(r.stdout.decode(), r.stderr.decode())
+    assert out["value"] > 10 and "did not finish" in out["secondary_error"]
+
+
 def test_bench_c4_ensemble_line_small():
     """The C4 job line on one GPU with 16 samples: phases split out, dataset finite, hand-over through the pitched copies."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
