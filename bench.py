@@ -304,6 +304,7 @@ def c4_ensemble(dev, world, rank, total, as_rank0_of=None):
             "seconds": round(el, 3), "sample_steps_per_s": round(total * 650 / el, 1),
             "setup_s": round(setup, 3), "stepping_s": round(stepping, 3), "handover_tail_s": round(tail, 3),
             "dataset_GB": round(gb, 3), "finite": ok, "scaling": "strong (fixed 512-sample job)",
+            "handover_mode": stats.get("handover_mode"),
             "note": "max over ranks of each phase; handover_tail_s = gather + D2H left after the last step finished"}
 
 
@@ -316,26 +317,40 @@ def c4_as_separate_job(world, samples, timeout):
     """The C4 ensemble job of a multi-rank run, started by rank 0 as its OWN set of `world` ranks (this script with --c4-only,
     through the spawner above) with a time limit: its hand-over uses point-to-point RCCL traffic that the step benchmark does
     not, and whatever happens to it -- an error, a hang -- must not take the scaling measurement down with it.  The parent
-    ranks idle meanwhile (their GPUs are shared with the job: a few GB of their 288)."""
+    ranks idle meanwhile (their GPUs are shared with the job: a few GB of their 288).
+    The hand-over's point-to-point traffic is among a SUBSET of the communicator's ranks (a peer and rank 0), the one RCCL
+    call pattern no test of this repository has seen with a real peer: if the job fails or runs out of time in that mode
+    (and the caller did not pick a mode), it is run ONCE more with one gather per record interval on every rank
+    (TCFD_HANDOVER=collective, torch-cfd_amd/distributed.py); `handover_mode` / `first_attempt` say what happened."""
     import signal
     import subprocess
 
-    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--c4-only", "--c4-samples", str(samples)]
-    try:
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, start_new_session=True)
+    def attempt(extra_env):
+        env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+        env.update(extra_env)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--c4-only", "--c4-samples", str(samples)]
         try:
-            out, _ = proc.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, signal.SIGKILL)      # the job's own process group (start_new_session): the spawner and its ranks
-            proc.communicate()
-            return {"error": f"the separate C4 job did not finish within {timeout:.0f} s and was stopped"}
-        lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
-        if proc.returncode != 0 or not lines:
-            return {"error": f"the separate C4 job exited with status {proc.returncode}"}
-        return json.loads(lines[-1])
-    except Exception as e:
-        return {"error": repr(e)}
+            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, start_new_session=True)
+            try:
+                out, _ = proc.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)      # the job's own process group (start_new_session): the spawner and its ranks
+                proc.communicate()
+                return {"error": f"the separate C4 job did not finish within {timeout:.0f} s and was stopped"}
+            lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+            if proc.returncode != 0 or not lines:
+                return {"error": f"the separate C4 job exited with status {proc.returncode}"}
+            return json.loads(lines[-1])
+        except Exception as e:
+            return {"error": repr(e)}
+
+    res = attempt({})
+    if "error" in res and world > 1 and not os.environ.get("TCFD_HANDOVER"):
+        again = attempt({"TCFD_HANDOVER": "collective"})
+        again["first_attempt"] = {"handover_mode": "p2p", "error": res["error"]}
+        again.setdefault("handover_mode", "gather")
+        return again
+    return res
 
 
 def sanitize_stderr():
@@ -460,7 +475,9 @@ def compose_line(out, detail):
         line["strong_scaling_proxy"] = {k: v for k, v in out["strong_scaling_proxy"].items() if k in ("predicted_speedup", "ms_per_step", "error")}
     c4 = out.get("c4_ensemble")
     if isinstance(c4, dict):
-        line["c4_ensemble"] = _few(c4, ("seconds", "sample_steps_per_s", "stepping_s", "handover_tail_s", "dataset_GB", "finite"))
+        line["c4_ensemble"] = _few(c4, ("seconds", "sample_steps_per_s", "stepping_s", "handover_tail_s", "dataset_GB", "finite", "handover_mode"))
+        if isinstance(c4.get("first_attempt"), dict):
+            line["c4_ensemble"]["first_attempt"] = _few(c4["first_attempt"], ("handover_mode",))
         px = c4.get("strong_scaling_proxy_8gpu")
         if isinstance(px, dict):
             line["c4_ensemble"]["proxy_8gpu"] = _few(px, ("seconds", "stepping_s", "predicted_speedup_whole_job", "predicted_speedup_stepping"))

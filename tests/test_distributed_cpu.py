@@ -149,6 +149,72 @@ def test_record_handover_world8(total, batch, dst):
     assert [r[1] for r in res if r[1]][0] == (total, 3, 4, 4)
 
 
+def _handover_modes_worker(rank, world, port, cases, n_rec, q):
+    """Every case (total, batch, dst) through the three hand-over modes on ONE process group: the subset point-to-point form,
+    one batched point-to-point call per interval on every rank, one gather per interval on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch_cfd_amd.distributed import TRAJECTORY_FIELDS, RecordHandover, batch_layout
+
+        verdicts = []
+        for total, batch, dst in cases:
+            layout = batch_layout(total, world, batch)
+            got = {}
+            for mode in ("p2p", "uniform", "collective"):
+                ho = RecordHandover(TRAJECTORY_FIELDS, total, n_rec, (4, 4), torch.float32, layout, "cpu", dst=dst, mode=mode)
+                assert ho.mode == {"collective": "gather"}.get(mode, mode)
+                for start, count in layout[rank]:
+                    for rec in range(n_rec):
+                        ho.push(start, rec, _fake_packed(start, count, rec))
+                got[mode] = ho.finish()
+                dist.barrier()
+            if rank == dst:
+                want = [torch.equal(got["p2p"][name][:, rec], _fake_packed(0, total, rec)[:, f])
+                        for f, name in enumerate(TRAJECTORY_FIELDS) for rec in range(n_rec)]
+                same = [torch.equal(got["p2p"][name], got[m][name]) for name in TRAJECTORY_FIELDS for m in ("uniform", "collective")]
+                verdicts.append("ok" if all(want) and all(same) else "mismatch")
+            else:
+                verdicts.append("none" if all(v is None for v in got.values()) else "unexpected")
+        q.put(verdicts)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cases", [(2, [(7, 2, 1), (1, 4, 0)]),
+                                         (8, [(37, 2, 5), (5, 1, 0), (16, 1, 3)])])   # ragged batches, ranks without a sample
+def test_record_handover_group_call_modes_equal_point_to_point(world, cases, monkeypatch):
+    """TCFD_HANDOVER = uniform / collective (the fall-backs for a collective library that rejects point-to-point traffic among a
+    subset of a communicator's ranks): every rank makes one group call per record interval; the host
+    result is bit-equal to the point-to-point mode's, with ragged last batches, ranks that run out of records early and ranks
+    that never had one."""
+    monkeypatch.delenv("TCFD_HANDOVER", raising=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_handover_modes_worker, args=(r, world, port, cases, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for i in range(len(cases)):
+        assert sorted(v[i] for v in res) == ["none"] * (world - 1) + ["ok"], (cases[i], res)
+
+
+def test_record_handover_mode_from_the_environment(monkeypatch):
+    from torch_cfd_amd.distributed import RecordHandover, batch_layout
+
+    monkeypatch.setenv("TCFD_HANDOVER", "collective")
+    ho = RecordHandover(("a",), 2, 1, (4, 4), torch.float32, batch_layout(2, 1, 2), "cpu")
+    assert ho.mode == "p2p"                 # no process group: nothing to make uniform
+    monkeypatch.setenv("TCFD_HANDOVER", "broadcast")
+    with pytest.raises(ValueError, match="hand-over mode"):
+        RecordHandover(("a",), 2, 1, (4, 4), torch.float32, batch_layout(2, 1, 2), "cpu")
+
+
+
 def _handover_subgroup_worker(rank, world, port, total, batch, n_rec, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

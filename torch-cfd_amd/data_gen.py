@@ -134,7 +134,7 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
         stats["trace"] = list(handover.trace)
     if stats is not None:
         stats.update(setup_s=t_setup - t_begin, stepping_s=t_stepped - t_setup, handover_tail_s=t_end - t_stepped,
-                     batches=len(layout[rank]), samples=sum(c for _, c in layout[rank]))
+                     batches=len(layout[rank]), samples=sum(c for _, c in layout[rank]), handover_mode=handover.mode)
     if full is None:
         return None
     full = dict(full)

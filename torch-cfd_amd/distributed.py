@@ -142,11 +142,32 @@ class RecordHandover:
     blocking copies.  Device tensors over a gloo group (``staged``): gloo moves host memory only, so a peer's record goes
     device -> page-locked staging buffer (side stream, event) -> gloo -> ``dst``'s host result, while ``dst``'s own records
     keep the side-stream pitched copies -- the form a one-GPU box can run with two ranks (RCCL refuses two ranks on one
-    device: "Duplicate GPU detected"), exercising the stream / event ordering and the slicing of the page-locked result."""
+    device: "Duplicate GPU detected"), exercising the stream / event ordering and the slicing of the page-locked result.
+
+    ``mode`` (default: the environment's ``TCFD_HANDOVER``, else ``"p2p"``) picks how a record travels between ranks:
+
+      * ``"p2p"``     a peer and ``dst`` meet in batched point-to-point calls that only the two of them (and the other peers
+                      with a record at that moment) post -- point-to-point traffic among a SUBSET of the group's ranks;
+      * ``"uniform"`` record interval k is ONE ``batch_isend_irecv`` on EVERY rank of the group: a peer sends its k-th record,
+                      or a one-element dummy when it has none left; ``dst`` receives from every peer;
+      * ``"gather"``  (alias ``"collective"``) record interval k is ONE ``dist.gather`` to ``dst`` on every rank, records padded
+                      to the interval's largest batch, dummies from ranks without a record.
+
+    The last two are the fall-backs for a collective library that rejects subset point-to-point traffic on a group
+    communicator: every rank makes the same sequence of group calls (intervals beyond a rank's own records run in
+    ``finish``; intervals in which no peer has a record are skipped by everyone).  All three fill the same host result bit
+    for bit (tests/test_distributed_cpu.py)."""
 
     def __init__(self, fields: Sequence[str], total: int, n_rec: int, trailing: Tuple[int, ...], dtype: torch.dtype,
                  layout: List[List[Tuple[int, int]]], device, dst: int = 0, group: Optional[dist.ProcessGroup] = None,
-                 lazy_host: bool = True):
+                 lazy_host: bool = True, mode: Optional[str] = None):
+        import os
+
+        mode = (mode or os.environ.get("TCFD_HANDOVER") or "p2p").lower()
+        mode = {"collective": "gather"}.get(mode, mode)
+        if mode not in ("p2p", "uniform", "gather"):
+            raise ValueError(f"hand-over mode {mode!r}: expected p2p, uniform or gather (collective)")
+        self.mode = mode
         self.fields, self.total, self.n_rec = tuple(fields), total, n_rec
         self.trailing, self.dtype = tuple(trailing), dtype
         self.device = torch.device(device)
@@ -158,17 +179,21 @@ class RecordHandover:
             raise ValueError(f"layout describes {len(layout)} ranks, the group has {self.world}")
         self.items = [[(s, c, j) for (s, c) in batches for j in range(n_rec)] for batches in layout]
         self.cursor = [0] * self.world
+        self._interval = 0             # uniform / gather: the next record interval this rank takes part in
+        self._intervals = max((len(it) for it in self.items), default=0)
         self.on_gpu = self.device.type == "cuda"
         self.row_bytes = int(torch.tensor([], dtype=dtype).element_size())
         for d in self.trailing:
             self.row_bytes *= d
         self._keep: list = []          # device buffers a copy or a send still reads
+        self._dummies: list = []       # uniform mode, dst: the one-element receive targets of peers without a record
         self._sends: list = []
         self.staged = bool(self.distributed and self.on_gpu and dist.get_backend(group) == "gloo")
+        if self.staged or not self.distributed or self.world == 1:
+            self.mode = "p2p"          # the staged form and a single process have no group calls to make uniform
         self._outbox: list = []        # staged peers: (event, page-locked copy) of records not yet handed to gloo
         self._inbox: list = []         # staged dst: (work, staging tensor, start, count, record) of receives in flight
         self.host: Optional[Dict[str, torch.Tensor]] = None
-        import os
         import time
 
         self.trace = [] if os.environ.get("TCFD_HANDOVER_TRACE") == "1" else None
@@ -421,6 +446,66 @@ class RecordHandover:
                 self._land(stage, s, c, j, work=works[0] if i == 0 else _Done())
         return True
 
+    # -- uniform / gather: one group call per record interval on every rank
+    def _run_interval(self, k: int, packed: Optional[torch.Tensor]):
+        """Record interval k: every rank of the group makes the same call.  ``packed`` is this rank's k-th record on a peer
+        that has one (``dst`` lands its own records itself and passes None, like a peer past its last record)."""
+        peers = [r for r in range(self.world) if r != self.dst]
+        have = [r for r in peers if k < len(self.items[r])]
+        if not have:
+            return                                   # nobody has anything to hand over: every rank skips the interval
+        where = self.device if self.on_gpu else torch.device("cpu")
+        gdst = _global_rank(self.group, self.dst)
+        if self.mode == "gather":
+            cmax = max(self.items[r][k][1] for r in have)
+            shape = (cmax, len(self.fields)) + self.trailing
+            if self.rank == self.dst:
+                slots = [torch.empty(shape, dtype=self.dtype, device=where) for _ in range(self.world)]
+                work = dist.gather(slots[self.dst], slots, dst=gdst, group=self.group, async_op=True)
+                first = True
+                for r in have:
+                    s0, c, j = self.items[r][k]
+                    self._land(slots[r][:c], s0, c, j, work=work if first else _Done())
+                    first = False
+                return
+            if packed is not None and packed.shape[0] == cmax:
+                mine = packed
+            else:                                    # a smaller (last) batch or no record at all: padded / dummy payload
+                mine = torch.empty(shape, dtype=self.dtype, device=where)
+                if packed is not None:
+                    mine[:packed.shape[0]].copy_(packed)
+            work = dist.gather(mine, None, dst=gdst, group=self.group, async_op=True)
+            self._sends.append(([work], mine))
+            return
+        # uniform: one batched point-to-point call per rank, a one-element dummy where there is no record
+        if self.rank == self.dst:
+            ops, meta = [], []
+            for r in peers:
+                if r in have:
+                    s0, c, j = self.items[r][k]
+                    stage = torch.empty((c, len(self.fields)) + self.trailing, dtype=self.dtype, device=where)
+                    meta.append((stage, s0, c, j))
+                else:
+                    stage = torch.empty(1, dtype=self.dtype, device=where)
+                    meta.append(None)
+                    self._dummies.append(stage)
+                ops.append(dist.P2POp(dist.irecv, stage, _global_rank(self.group, r), group=self.group))
+            works = dist.batch_isend_irecv(ops)
+            coalesced = len(works) != len(ops)
+            first = True
+            for i, m in enumerate(meta):
+                if m is None:
+                    continue
+                w = (works[0] if first else _Done()) if coalesced else works[i]
+                first = False
+                self._land(m[0], m[1], m[2], m[3], work=w)
+            if not coalesced:
+                self._sends.extend(([works[i]], ops[i].tensor) for i, m in enumerate(meta) if m is None)
+            return
+        mine = packed if packed is not None else torch.zeros(1, dtype=self.dtype, device=where)
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, gdst, group=self.group)])
+        self._sends.append((works, mine))
+
     # -- every rank
     def push(self, start: int, rec: int, packed: torch.Tensor):
         mine = self.items[self.rank]
@@ -438,7 +523,12 @@ class RecordHandover:
         if self.on_gpu:
             self._flush_deferred(block=False)
             self._release_finished()
-        if self.rank == self.dst:
+        if self.mode != "p2p":
+            if self.rank == self.dst:
+                self._land(packed, start, count, rec)
+            self._run_interval(self._interval, None if self.rank == self.dst else packed)
+            self._interval += 1
+        elif self.rank == self.dst:
             self._land(packed, start, count, rec)
             if self.world > 1:
                 self._post_receives()
@@ -464,10 +554,18 @@ class RecordHandover:
         if self.cursor[self.rank] != len(self.items[self.rank]):
             raise RuntimeError(f"rank {self.rank}: {len(self.items[self.rank]) - self.cursor[self.rank]} records were "
                                "never pushed")
+        while self.mode != "p2p" and self._interval < self._intervals:
+            self._run_interval(self._interval, None)     # the intervals past this rank's own records
+            self._interval += 1
         if self.rank == self.dst:
-            while self.world > 1 and self._post_receives():
+            while self.mode == "p2p" and self.world > 1 and self._post_receives():
                 pass
             self._drain_inbox(block=True)
+            for works, _ in self._sends:                 # (uniform mode: the dummy receives)
+                for work in works:
+                    work.wait()
+            self._sends.clear()
+            self._dummies.clear()
             if self._alloc_pending is not None:
                 self.start_allocation()
                 self._alloc_thread.join()
