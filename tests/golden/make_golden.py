@@ -493,8 +493,70 @@ def gen_legacy_cn():
     save("ns2d_legacy_cn.npz", **out)
 
 
+def gen_legacy_cn_trajectory():
+    """The legacy driver around that step (fno/data_gen/solvers.py:268-448: record schedule, c2r, bilinear subsample) and
+    ``backdiff`` (:19-35), fp64."""
+    import solvers
+
+    solvers.tqdm = __import__("tqdm").tqdm
+    torch.set_default_dtype(torch.float64)
+    out = {}
+    n = 32
+    grid = Grid(shape=(n, n), domain=((0, L), (0, L)))
+    w0 = torch.stack([vorticity_field(grid, 4, s).data for s in (0, 1, 2)])
+    f = SinCosForcing(grid=grid, scale=0.1, k=1.0, diam=L)(grid, None)
+    out["w0"], out["f"] = npy(w0), npy(f)
+    for tag, kw in (("s1", dict(subsample=1, dealias=True)), ("s2", dict(subsample=2, dealias=True)),
+                    ("s1_nodealias", dict(subsample=1, dealias=False)), ("s2_one", dict(subsample=2, dealias=True))):
+        ww = w0[:1] if tag == "s2_one" else w0
+        res = solvers.get_trajectory_imex_crank_nicolson(ww, f, visc=1e-3, T=0.02, delta_t=1e-3, record_steps=4, diam=L,
+                                                         pbar=False, **kw)
+        for k, v in res.items():
+            out[f"{tag}_{k}"] = npy(v)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 4, 4, 8, generator=g)
+    out["bdf_x"] = npy(x)
+    for order in (1, 2, 3, 4, 5):
+        out[f"bdf_{order}"] = npy(solvers.backdiff(x, order))
+    save("ns2d_legacy_cn_trajectory.npz", **out)
+
+
+def gen_kolmogorov_dataset():
+    """The batch loop of fno/data_gen/data_gen_Kolmogorov2d.py:119-192 at a small size, restated line by line from the
+    reference's own components (the driver module itself needs h5py / xarray and is not importable here): Kolmogorov forcing,
+    drag 0.1, per-sample filtered-velocity initial condition with the driver's seed rule, warm-up steps, get_trajectory_imex,
+    irfft2 -> float32 -> bilinear subsample, random_states."""
+    import solvers
+    import torch.nn.functional as F
+
+    solvers.tqdm = __import__("tqdm").tqdm
+    torch.set_default_dtype(torch.float64)
+    n, total_samples, batch_size, random_state, subsample = 32, 4, 2, 7, 2
+    dt, warmup_steps, total_steps, record_every = 1e-3, 5, 6, 3
+    ns = n // subsample
+    grid = Grid(shape=(n, n), domain=((0, L), (0, L)))
+    fn = KolmogorovForcing(grid=grid, scale=1.0, wave_number=4, swap_xy=False)
+    ns2d = NavierStokes2DSpectral(viscosity=1e-3, grid=grid, drag=0.1, smooth=True, forcing_fn=fn, solver=RK4CrankNicolsonStepper())
+    batches = []
+    for i, idx in enumerate(range(0, total_samples, batch_size)):
+        vort_init = torch.stack([curl_2d(filtered_velocity_field(grid, 5, 4, random_state=random_state + i + k)).data
+                                 for k in range(batch_size)])
+        vort_hat = torch.fft.rfft2(vort_init)
+        for j in range(warmup_steps):
+            vort_hat, _ = ns2d.step(vort_hat, dt)
+        result = solvers.get_trajectory_imex(ns2d, vort_hat, dt, num_steps=total_steps, record_every_steps=record_every, pbar=False)
+        for field, value in result.items():
+            value = torch.fft.irfft2(value).real.cpu().to(torch.float32)
+            result[field] = F.interpolate(value, size=(ns, ns), mode="bilinear")
+        result["random_states"] = torch.tensor([random_state + idx + k for k in range(batch_size)], dtype=torch.int32)
+        batches.append(result)
+    out = {k: npy(torch.cat([b[k] for b in batches])) for k in batches[0]}
+    out["params"] = np.array([n, total_samples, batch_size, random_state, subsample, warmup_steps, total_steps, record_every])
+    save("ns2d_kolmogorov_dataset.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tables", "steps", "c1", "mcwilliams", "velocity_ic", "trajectory", "irfft2", "fno", "sfno", "sfno_padding", "grads", "grads_wide", "imex",
-                             "helmholtz", "legacy_cn"]
+                             "helmholtz", "legacy_cn", "legacy_cn_trajectory", "kolmogorov_dataset"]
     for w in which:
         globals()["gen_" + w]()

@@ -845,6 +845,56 @@ def test_sobolev_loss_fft_norms_and_cutoff(norm, dev):
         assert float(loss(x.to(dev), y.to(dev))) == pytest.approx(float(ref), rel=2e-5)
 
 
+@pytest.mark.parametrize("kw", [dict(norm_order=0, relative=True), dict(norm_order=-1, relative=False, time_average=False)])
+def test_second_order_gradients_through_the_fused_loss(kw, dev, monkeypatch):
+    """create_graph=True through SobolevLoss: a gradient penalty d/dx |dL/dx|^2 and a Hessian-vector product
+    d/dx <dL/dx, v> through the fused loss node must equal those of float64 autograd through the oracle (the reference's
+    pure-torch loss differentiates any number of times, fno/losses.py:263-315) and of the composed path (TCFD_LOSS_FUSED=0);
+    the fused node's raw-pointer backward alone would return the gradient of a constant.  Also: the module pickles / deep-copies
+    without its device-side tables, and a non-contiguous prediction is copied once."""
+    import copy
+
+    from oracle import fno as OF
+    from torch_cfd_amd import fno
+
+    n, b, nt = 32, 2, 5
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, n, n, nt, generator=g, dtype=torch.float64)
+    y = x + 0.3 * torch.randn(b, n, n, nt, generator=g, dtype=torch.float64)
+    v = torch.randn(b, n, n, nt, generator=g, dtype=torch.float64)
+
+    def second_order(loss_of, x0, v0):
+        xr = x0.clone().requires_grad_(True)
+        val = loss_of(xr)
+        (gx,) = torch.autograd.grad(val, xr, create_graph=True)
+        assert gx.requires_grad, "the first gradient must itself be differentiable"
+        (pen,) = torch.autograd.grad(gx.pow(2).sum(), xr, retain_graph=True)
+        (hvp,) = torch.autograd.grad((gx * v0).sum(), xr)
+        return gx.detach(), pen, hvp
+
+    ref = second_order(lambda t: OF.sobolev_loss(t, y, n, **kw), x, v)
+    loss = fno.SobolevLoss(n_grid=n, **kw).to(dev)
+    xd, yd, vd = x.to(dev), y.to(dev), v.to(dev)
+    probe = loss(xd.clone().requires_grad_(True), yd)
+    assert "FusedLoss" in type(probe.grad_fn).__name__
+    fused = second_order(lambda t: loss(t, yd), xd, vd)
+    monkeypatch.setenv("TCFD_LOSS_FUSED", "0")
+    composed = second_order(lambda t: loss(t, yd), xd, vd)
+    monkeypatch.delenv("TCFD_LOSS_FUSED")
+    for name, a, c, r in zip(("gradient", "gradient penalty", "Hessian-vector product"), fused, composed, ref):
+        assert torch.linalg.norm(r) > 0 and rel_l2(a, r) < 1e-8, name
+        assert rel_l2(a, c) < 1e-8, name
+    # a non-contiguous prediction (time-first storage viewed time-last): same value and gradient as its contiguous copy
+    xt = xd.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1).requires_grad_(True)
+    assert not xt.is_contiguous()
+    (gt,) = torch.autograd.grad(loss(xt, yd), xt)
+    assert rel_l2(gt, fused[0]) < 1e-12
+    # the module travels without its device tables
+    twin = copy.deepcopy(loss)
+    assert "_w2_cache" in loss.__dict__ and "_w2_cache" not in twin.__dict__ and not hasattr(loss, "_ws")
+    assert float(twin(xd, yd)) == pytest.approx(float(loss(xd, yd)), rel=1e-13)
+
+
 @pytest.mark.parametrize("n,b,nt,tag", [(16, 2, 10, "f32"), (32, 3, 7, "f32"), (64, 2, 1, "f32"), (256, 3, 10, "f32"), (128, 2, 10, "f64"),
                                         (512, 1, 4, "f32"), (1024, 1, 2, "f32"), (256, 2, 20, "f32"), (64, 5, 3, "f64"),
                                         (96, 2, 10, "f32"), (80, 3, 4, "f64"), (192, 2, 5, "f32"), (160, 2, 10, "f32"), (768, 1, 2, "f32"),

@@ -9,6 +9,7 @@ reference's own fp32 results <= 2e-6 @1 step, <= 1e-5 @10 steps, <= 5e-4 @1000
 import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -789,6 +790,73 @@ def test_legacy_crank_nicolson_step_golden(dealias, dev):
     assert rel_l2(res, g[f"{tag}_res"]) < 1e-6
     res2 = solvers.update_residual(w_next, dwdt, f, 1e-3, mesh, lap, dealias_filter=filt, dealias=bool(dealias))
     assert rel_l2(res2, g[f"{tag}_res_update"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["s1", "s2", "s1_nodealias", "s2_one"])
+def test_legacy_crank_nicolson_trajectory_golden(tag, dev):
+    """the legacy driver get_trajectory_imex_crank_nicolson (fno/data_gen/solvers.py:268-448)
+    against what the imported reference returned: 20 steps, 4 records (every 5th step), subsample 1 and 2, de-aliasing on / off,
+    a batch of one (the reference's squeeze())."""
+    from torch_cfd_amd import solvers
+
+    torch.set_default_dtype(torch.float64)
+    g = load_golden("ns2d_legacy_cn_trajectory.npz")
+    w0 = torch.from_numpy(g["w0"]).to(dev)
+    f = torch.from_numpy(g["f"]).to(dev)
+    if tag == "s2_one":
+        w0 = w0[:1]
+    out = solvers.get_trajectory_imex_crank_nicolson(w0, f, visc=1e-3, T=0.02, delta_t=1e-3, record_steps=4, diam=L, pbar=False,
+                                                     subsample=2 if tag.startswith("s2") else 1, dealias="nodealias" not in tag)
+    assert sorted(out) == ["residual", "stream", "t_steps", "vorticity", "vorticity_t"]
+    ns = 16 if tag.startswith("s2") else 32
+    for k in ("vorticity", "vorticity_t", "stream", "residual"):
+        ref = torch.from_numpy(g[f"{tag}_{k}"])
+        assert out[k].shape == ref.shape == (w0.shape[0], 4, ns, ns) and out[k].device.type == "cpu" and out[k].dtype == ref.dtype
+    assert rel_l2(out["vorticity"], g[f"{tag}_vorticity"]) < 1e-11
+    assert rel_l2(out["stream"], g[f"{tag}_stream"]) < 1e-11
+    assert rel_l2(out["vorticity_t"], g[f"{tag}_vorticity_t"]) < 1e-8
+    # the residual is what is left of O(1) terms that cancel to the de-aliasing error: measured against dw/dt
+    assert scaled_err(out["residual"], torch.from_numpy(g[f"{tag}_residual"]), torch.from_numpy(g[f"{tag}_vorticity_t"])) < 1e-9
+    assert torch.allclose(out["t_steps"], torch.from_numpy(g[f"{tag}_t_steps"]).to(out["t_steps"].dtype), rtol=1e-6)
+    with pytest.raises(IndexError):       # 11 steps, 4 slots, a record every 2: the reference runs past its buffers
+        solvers.get_trajectory_imex_crank_nicolson(w0, f, T=0.011, delta_t=1e-3, record_steps=4, diam=L, pbar=False)
+
+
+def test_backdiff_golden(dev):
+    from torch_cfd_amd import solvers
+
+    torch.set_default_dtype(torch.float64)
+    g = load_golden("ns2d_legacy_cn_trajectory.npz")
+    x = torch.from_numpy(g["bdf_x"]).to(dev)
+    for order in (1, 2, 3, 4, 5):
+        assert rel_l2(solvers.backdiff(x, order), g[f"bdf_{order}"]) < 1e-14
+    with pytest.raises(NotImplementedError):
+        solvers.backdiff(x, 6)
+
+
+def test_kolmogorov_dataset_golden(dev, tmp_path):
+    """the loop of fno/data_gen/data_gen_Kolmogorov2d.py:119-192 (forced operator, per-sample
+    filtered-velocity initial condition with the driver's seed rule, warm-up, get_trajectory_imex, irfft2 -> float32 ->
+    bilinear subsample, random_states) against the same loop run with the imported reference's components."""
+    from torch_cfd_amd.data_gen import generate_kolmogorov_dataset
+
+    torch.set_default_dtype(torch.float64)
+    g = load_golden("ns2d_kolmogorov_dataset.npz")
+    n, total, batch, seed, sub, warm, steps, every = (int(v) for v in g["params"])
+    path = str(tmp_path / "kolmogorov.pt")
+    data = generate_kolmogorov_dataset(n, total, batch, 1e-3, warm, steps, every, viscosity=1e-3, peak_wavenumber=4, max_velocity=5,
+                                       scale=1.0, random_state=seed, subsample=sub, device=dev, path=path)
+    assert sorted(data) == ["random_states", "residual", "stream", "vort_t", "vorticity"]
+    assert torch.equal(data["random_states"], torch.from_numpy(g["random_states"])) and data["random_states"].dtype == torch.int32
+    for k in ("vorticity", "stream", "vort_t", "residual"):
+        assert data[k].shape == g[k].shape == (total, 2, n // sub, n // sub) and data[k].dtype == torch.float32
+    # the driver draws sample k of batch i from seed + i + k: sample 1 (batch 0, k = 1) and sample 2 (batch 1, k = 0) coincide
+    assert torch.equal(data["vorticity"][1], data["vorticity"][2]) and np.array_equal(g["vorticity"][1], g["vorticity"][2])
+    assert rel_l2(data["vorticity"], g["vorticity"]) < 1e-6 and rel_l2(data["stream"], g["stream"]) < 1e-6
+    assert scaled_err(data["vort_t"], torch.from_numpy(g["vort_t"]), torch.from_numpy(g["vorticity"]) / 1e-3) < 1e-6
+    assert scaled_err(data["residual"], torch.from_numpy(g["residual"]), torch.from_numpy(g["vort_t"])) < 1e-3
+    saved = torch.load(path)
+    assert all(torch.equal(saved[k], data[k]) for k in data)
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])

@@ -71,6 +71,58 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     0's batches -- with nobody to receive from: the one-GPU PROXY of the N-GPU job's wall time that ``bench.py`` reports
     (the rows of the other ranks stay uninitialised; what the proxy leaves out is the receive + D2H of their records on the
     side streams)."""
+    def make_operator(grid):
+        return NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=0, smooth=True, forcing_fn=None,
+                                      solver=RK4CrankNicolsonStepper())
+
+    def initial_vorticity(grid, start, count, device):
+        return vorticity_field(grid, peak_wavenumber, batch_seeds=[random_state + start + k for k in range(count)], device=device)
+
+    return _generate_dataset(n, total_samples, batch_size, dt, warmup_steps, total_steps, record_every_steps, make_operator,
+                             initial_vorticity, diam, random_state, subsample, dtype, cdtype, device, dst, path, stats, as_rank0_of)
+
+
+def generate_kolmogorov_dataset(n: int, total_samples: int, batch_size: int, dt: float, warmup_steps: int,
+                                total_steps: int, record_every_steps: int, viscosity: float = 1e-3,
+                                diam: float = 2 * torch.pi, peak_wavenumber: float = 4, max_velocity: float = 5,
+                                scale: float = 1.0, drag: float = 0.1, random_state: int = 0, subsample: int = 1,
+                                dtype: torch.dtype = torch.float32, cdtype: torch.dtype = torch.complex64, device="cuda",
+                                dst: int = 0, path: Optional[str] = None, stats: Optional[dict] = None,
+                                as_rank0_of: Optional[int] = None) -> Optional[Dict[str, torch.Tensor]]:
+    """Forced-turbulence ensemble: the loop of fno/data_gen/data_gen_Kolmogorov2d.py:119-192 -- Kolmogorov forcing
+    ``scale * sin(peak_wavenumber * y)`` (``:121-126``), drag 0.1, RK4-CN (``:128-135``), initial vorticity
+    ``curl_2d(filtered_velocity_field(grid, max_velocity, peak_wavenumber, random_state=...))`` per sample (``:144-155``),
+    ``warmup_steps`` unrecorded steps (``:158-168``), then ``get_trajectory_imex`` with a record every
+    ``record_every_steps`` (``:170-177``), irfft2 -> bilinear subsample -> cast (``:179-189``), ``random_states`` (``:191-193``).
+    Same dataset dict, hand-over and multi-rank split as ``generate_mcwilliams_dataset``.
+
+    Seeds as the reference draws them: sample k of batch i is generated from ``random_state + i + k`` -- the batch INDEX, not
+    the sample offset ``idx`` (``:151``) -- while ``random_states`` records ``random_state + idx + k`` (``:192``); with more
+    than one sample per batch consecutive batches therefore share initial conditions.  Restated, not corrected; the batch
+    index of a sample is that of the serial loop (global index // batch_size) however the samples are cut across ranks."""
+    from .forcings import KolmogorovForcing
+    from .initial_conditions import curl_2d, filtered_velocity_field
+
+    def make_operator(grid):
+        forcing = KolmogorovForcing(grid=grid, scale=scale, wave_number=peak_wavenumber, swap_xy=False)
+        return NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=drag, smooth=True, forcing_fn=forcing,
+                                      solver=RK4CrankNicolsonStepper())
+
+    def initial_vorticity(grid, start, count, device):
+        seeds = [random_state + g // batch_size + g % batch_size for g in range(start, start + count)]
+        return curl_2d(filtered_velocity_field(grid, max_velocity, peak_wavenumber, batch_seeds=seeds, device=device), grid)
+
+    return _generate_dataset(n, total_samples, batch_size, dt, warmup_steps, total_steps, record_every_steps, make_operator,
+                             initial_vorticity, diam, random_state, subsample, dtype, cdtype, device, dst, path, stats, as_rank0_of)
+
+
+def _generate_dataset(n: int, total_samples: int, batch_size: int, dt: float, warmup_steps: int, total_steps: int,
+                      record_every_steps: int, make_operator, initial_vorticity, diam: float, random_state: int,
+                      subsample: int, dtype: torch.dtype, cdtype: torch.dtype, device, dst: int, path: Optional[str],
+                      stats: Optional[dict], as_rank0_of: Optional[int]) -> Optional[Dict[str, torch.Tensor]]:
+    """The batch loop both drivers share (fno/data_gen/data_gen_McWilliams2d.py:119-171, data_gen_Kolmogorov2d.py:134-192):
+    ``make_operator(grid)`` builds the equation, ``initial_vorticity(grid, start, count, device)`` the (count, n, n) physical
+    initial vorticity of the samples with global indices start .. start + count - 1."""
     import time
 
     import torch.distributed as dist
@@ -88,8 +140,7 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
             raise ValueError("as_rank0_of is the single-process proxy of a multi-rank job")
         layout = [batch_layout(total_samples, as_rank0_of, batch_size)[0]]
     grid = Grid(shape=(n, n), domain=((0, diam), (0, diam)), device=device)
-    op = NavierStokes2DSpectral(viscosity=viscosity, grid=grid, drag=0, smooth=True, forcing_fn=None,
-                                solver=RK4CrankNicolsonStepper()).to(device)
+    op = make_operator(grid).to(device)
     real = torch.get_default_dtype()
     plan = fft_plan(n, torch.complex128 if real == torch.float64 else torch.complex64, device, diam)
     ns = n // subsample
@@ -108,8 +159,7 @@ def generate_mcwilliams_dataset(n: int, total_samples: int, batch_size: int, dt:
     t_setup = time.perf_counter()
     try:
         for start, count in layout[rank]:
-            seeds = [random_state + start + k for k in range(count)]
-            w = plan.rfft2(vorticity_field(grid, peak_wavenumber, batch_seeds=seeds, device=device))
+            w = plan.rfft2(initial_vorticity(grid, start, count, device))
             handover.start_allocation()     # page-lock the result now: under the warm-up steps, not under the CPU noise above
             if warmup_steps > 0:
                 w, _ = op._fused_steps(w, dt, warmup_steps, want_dwdt=False)

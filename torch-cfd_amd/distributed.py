@@ -236,7 +236,9 @@ class RecordHandover:
                     from . import _lib as L
 
                     lib = L.load()
-                    PAGE = 4096
+                    import mmap
+
+                    PAGE = mmap.PAGESIZE
                     try:
                         self._trace("page-lock begin")
                         edge_pages = set()              # first / last page of every range locked so far

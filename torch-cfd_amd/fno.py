@@ -597,7 +597,8 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
         dims = _pointwise_bwd_layout(has_l1, b, ci, cm, co, P, T, sT, c1, c2, mode)
     if dims is None:
         return None
-    COP, CB, CM1, CIP, per_row, _ = list(dims)
+    queried = tuple(dims)
+    COP, CB, CM1, CIP, per_row, _ = queried
     dev = x.device
     xs, dz = x.detach().contiguous(), dout.detach().contiguous()
     sk = skip.detach().contiguous() if mode else None
@@ -626,6 +627,12 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
                                             ptr(b2v), ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1,
                                             c2, 3 if tsum else mode, 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd_out")
+    if tuple(dims) != queried:
+        # the launch rewrites `dims` with the geometry of the kernel it actually ran; the buffers above were sized and the
+        # scatter below is laid out from the data-less query.  They differ only if the launch declined the kernel the query
+        # chose (a kept tensor it rejects, a switch flipped between the forward and the backward): the partial sums then have
+        # another row layout and every weight gradient would be silently wrong.
+        raise _lib.TcfdError(f"tcfd_fno_pointwise_bwd_out ran with row layout {tuple(dims)}, the layout query said {queried}")
     # the summed row is A (COP x CB) = [dW2 | db2 | dWs] followed by B (CM1 x CIP) = [dW1 | db1]: every gradient leaves the final
     # pass of the row sum as a dense tensor of its parameter's shape (tcfd_sum_rows_scatter)
     ch = cm if has_l1 else ci

@@ -59,18 +59,30 @@ class _FusedLossFn(torch.autograd.Function):
     spectrum: 0.9 -> 0.3 ms of a config-5 training step."""
 
     @staticmethod
-    def forward(ctx, x, yc, plan, w2, wf, ws, flags):
-        xc = x.detach().contiguous()
+    def forward(ctx, x, yc, plan, w2, wf, ws, flags, module):
+        xc = x.detach()           # contiguous: SobolevLoss._fused hands over the contiguous form (a view of the caller's tensor when it is)
         sums = torch.empty(flags[0] * xc.shape[0] * xc.shape[-1], dtype=torch.float64, device=xc.device)
         out = _fused_forward(plan, xc, yc, w2, ws, flags, sums)
-        ctx.save_for_backward(xc, yc if yc is not None else xc.new_empty(0), wf, sums)
-        ctx.cfg = (plan, ws, flags, yc is not None)
+        # x itself, not its detached twin: a backward pass under create_graph=True differentiates through it again
+        ctx.save_for_backward(x, yc if yc is not None else xc.new_empty(0), wf, sums)
+        ctx.cfg = (plan, ws, flags, yc is not None, module)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        xc, yc, wf, sums = ctx.saved_tensors
-        plan, ws, flags, has_y = ctx.cfg
+        x, yc, wf, sums = ctx.saved_tensors
+        plan, ws, flags, has_y, module = ctx.cfg
+        if torch.is_grad_enabled():
+            # create_graph=True (gradient penalties, Hessian-vector products through the loss): the raw-pointer launches below
+            # would return a constant.  Form the gradient from the composed loss -- Rfft2 (autograd.py, differentiable any number
+            # of times) plus tensor operations -- as FusedExplicitTerms.backward does for the solver, and as the reference's
+            # pure-torch loss allows (fno/losses.py:263-315).
+            with torch.enable_grad():
+                xin = x if x.requires_grad else x.detach().requires_grad_(True)
+                loss = module._composed(xin, yc if has_y else None)
+                (grad,) = torch.autograd.grad(loss, xin, gout.to(loss.dtype), create_graph=True)
+            return grad, None, None, None, None, None, None, None
+        xc = x.detach()
         nf, relative, mesh, tavg, red = flags
         g = gout.detach().to(xc.dtype).contiguous()
         grad = torch.empty_like(xc)
@@ -79,7 +91,23 @@ class _FusedLossFn(torch.autograd.Function):
                 plan, xc.data_ptr(), yc.data_ptr() if has_y else None, wf.data_ptr(), sums.data_ptr(), g.data_ptr(), xc.shape[0],
                 xc.shape[-1], nf, relative, mesh, tavg, red, grad.data_ptr(), ws.data_ptr(), ws.numel(),
                 ctypes.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)), "tcfd_sobolev_loss_backward")
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
+
+
+# workspaces of the fused loss, per (device, bytes needed rounded up): outside the modules (a device tensor in a plain module
+# attribute rides along with copy.deepcopy / torch.save(module), is not moved by .to() and would pin a CUDA graph's private pool
+# if first allocated during capture)
+_LOSS_WORKSPACES: Dict[torch.device, torch.Tensor] = {}
+
+
+def _loss_workspace(device: torch.device, need: int) -> torch.Tensor:
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(need, dtype=torch.uint8, device=device)     # belongs to the capture, never cached
+    ws = _LOSS_WORKSPACES.get(device)
+    if ws is None or ws.numel() < need:
+        _LOSS_WORKSPACES.pop(device, None)
+        ws = _LOSS_WORKSPACES[device] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
 
 
 class SobolevLoss(nn.Module):
@@ -116,11 +144,16 @@ class SobolevLoss(nn.Module):
         self.register_buffer("ky", ky[None, :, :, None])
         self.register_buffer("weight", weight[None, :, :, None])
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_w2_cache", None)      # a device-side table rebuilt on demand: not part of a pickled / deep-copied module
+        return state
+
     def _half_spectrum_weights(self, device, dtype):
         """(n, n/2+1) table: multiplier^2 x Hermitian multiplicity x fft-norm scale.  Built once per (device, dtype) and
         state of the ``weight`` buffer -- it took ~20 small launches per call, more than the loss kernels themselves."""
         key = (torch.device(device), dtype, self.weight.data_ptr(), self.weight._version, self.norm_order, self._sq_scale)
-        cached = getattr(self, "_w2_cache", None)
+        cached = self.__dict__.get("_w2_cache")
         if cached is not None and cached[0] == key:
             return cached[1]
         n = self.n_grid
@@ -167,21 +200,15 @@ class SobolevLoss(nn.Module):
         xc = x.contiguous()
         yc = y.contiguous() if y is not None else None
         w2 = self._half_spectrum_weights(x.device, x.dtype)
-        need = lib.tcfd_loss_workspace_bytes(plan, bsz, nt, nf)
-        ws = getattr(self, "_ws", None)
-        if ws is None or ws.numel() < need or ws.device != x.device:
-            self._ws = None
-            ws = self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        ws = _loss_workspace(x.device, lib.tcfd_loss_workspace_bytes(plan, bsz, nt, nf))
         flags = (nf, int(bool(self.relative and y is not None)),
                  (2 if torch.get_default_dtype() == torch.float32 else 1) if self.mesh_weighted else 0,
                  int(bool(self.time_average)), int(bool(self.reduction)))
         if wants_grad:
-            return _FusedLossFn.apply(x, yc, plan, w2, self._w2_cache[2], ws, flags)
+            return _FusedLossFn.apply(xc, yc, plan, w2, self._w2_cache[2], ws, flags, self)
         return _fused_forward(plan, xc, yc, w2, ws, flags, None)
 
     def forward(self, x, y=None):
-        from .equations import fft_plan
-
         if not self.inp_time_last:
             x = x.permute(0, 2, 3, 1)
             y = y.permute(0, 2, 3, 1) if y is not None else None
@@ -194,6 +221,16 @@ class SobolevLoss(nn.Module):
         fused = self._fused(x, y)
         if fused is not None:
             return fused if no_target is None else fused / no_target
+        loss = self._composed(x, y)
+        return loss if no_target is None else loss / no_target
+
+    def _composed(self, x, y=None):
+        """The loss of time-last x (and y) composed from the HIP rfft2 (``autograd.Rfft2`` under autograd: differentiable any
+        number of times) and tensor operations: what runs outside the fused kernels' cover, and what the fused node's backward
+        differentiates when a graph of the gradient itself is asked for."""
+        from .equations import fft_plan
+
+        bsz, n, _, nt = x.shape
         plan = fft_plan(n, torch.complex64 if x.dtype == torch.float32 else torch.complex128, x.device, self.diam)
         w2 = self._half_spectrum_weights(x.device, x.dtype)
 
@@ -217,5 +254,4 @@ class SobolevLoss(nn.Module):
         loss = loss / yn
         loss = loss / math.sqrt(nt) if self.time_average else loss
         loss = loss.mean(0) if self.reduction else loss.sum(0)
-        loss = loss / n if self.mesh_weighted else loss
-        return loss if no_target is None else loss / no_target
+        return loss / n if self.mesh_weighted else loss

@@ -165,3 +165,106 @@ def imex_crank_nicolson_step(w, f, visc, delta_t, diam: float = 1, rfftmesh=None
     if output_rfft:
         return w_next, dwdt, w, psi_h, res_h, (kx, ky), laplacian, dealias_filter
     return w_next, dwdt, w, psi_h, res_h
+
+
+# ----------------------------------------------------------------------------- legacy driver around that step
+_BDF_WEIGHTS = {
+    1: [1, -1],
+    2: [3 / 2, -2, 0.5],
+    3: [11 / 6, -3, 3 / 2, -1 / 3],
+    4: [25 / 12, -4, 3, -4 / 3, 1 / 4],
+    5: [137 / 60, -5, 5, -10 / 3, 5 / 4, -1 / 5],
+}
+
+
+def backdiff(x: torch.Tensor, order: int = 3) -> torch.Tensor:
+    """Backward-difference (BDF) combination of the last ``order + 1`` time samples of x (b, *, x, y, t): the unscaled
+    time derivative at the last sample (fno/data_gen/solvers.py:19-35; weights in the default dtype, newest sample first)."""
+    if order > 5:
+        raise NotImplementedError("only bdf order <= 5 is implemented")
+    weights = torch.as_tensor(_BDF_WEIGHTS[order]).to(x.device)
+    return (x[..., -(order + 1):].flip(-1) * weights).sum(-1)
+
+
+def get_trajectory_imex_crank_nicolson(w0: torch.Tensor, f: torch.Tensor, visc: float = 1e-3, T: float = 1, delta_t: float = 1e-3,
+                                       record_steps: int = 1, diam: float = 1, dealias: bool = True, subsample: int = 1,
+                                       dtype: Optional[torch.dtype] = None, pbar: bool = True, **kwargs) -> Dict[str, torch.Tensor]:
+    """The legacy data-generation loop (fno/data_gen/solvers.py:268-448; caller fno/data_gen/data_gen_fno_legacy.py:181-207):
+    ``ceil(T / delta_t)`` first-order IMEX Crank-Nicolson steps from the PHYSICAL initial vorticity w0 (B, n, n) under the
+    fixed physical forcing f ((n, n) or (B, n, n)), a record every ``floor(total_steps / record_steps)`` steps of
+    {vorticity, its time derivative, stream function, PDE residual (``update_residual`` of the NEW state with the step's
+    dw/dt)} in physical space, bilinearly subsampled to n // subsample (``F.interpolate(size=, mode="bilinear")``, :37-46).
+    Returns ``dict(vorticity, vorticity_t, stream, residual: (B, record_steps, ns, ns); t_steps: (record_steps,))`` on the
+    CPU in the default dtype, as the reference allocates them.
+
+    Device side: r2c / c2r are the HIP transforms, the convection term of every step and of every record's residual the
+    fused column / row / column kernels (``_convection_hat``); records are subsampled inside the c2r row pass for
+    power-of-two factors and copied to the host once at the end.  The reference tests the state for NaNs after EVERY step
+    (one host round trip each, :386-388); here the test runs when a record is taken and after the last step, with the same
+    ``ValueError``.  A schedule that would produce more records than ``record_steps`` fails with the reference's
+    ``IndexError`` (its ``vort[:, c] = ...`` past the end), raised before any step is taken."""
+    from .data_gen import spectral_to_physical
+    from .equations import _COMPLEX_OF, fft_plan
+
+    real = w0.dtype if dtype is None else dtype
+    device = w0.device
+    bsz, n = w0.size(0), w0.size(-1)
+    ns = n // subsample
+    k_max = math.floor(n / 2.0)
+    total_steps = math.ceil(T / delta_t)
+    record_every_n_steps = math.floor(total_steps / record_steps)
+    if record_every_n_steps < 1 or total_steps // record_every_n_steps > record_steps:
+        raise IndexError(f"{total_steps} steps with a record every {record_every_n_steps} give "
+                         f"{total_steps // max(record_every_n_steps, 1)} records for {record_steps} slots")
+    plan = fft_plan(n, _COMPLEX_OF[w0.dtype], device, diam)
+    w_h = plan.rfft2(w0.contiguous())
+    f_h = plan.rfft2(f.to(device=device, dtype=w0.dtype).contiguous().reshape(-1, n, n)).reshape(*f.shape[:-2], n, n // 2 + 1)
+    if f_h.ndim < w_h.ndim:
+        f_h = f_h.unsqueeze(0)
+    k = torch.fft.fftfreq(n, d=diam / n, dtype=real, device=device)
+    kx, ky = torch.meshgrid([k, k], indexing="ij")
+    kx, ky = kx[..., : k_max + 1], ky[..., : k_max + 1]
+    k_cut = (1 / diam) * k_max
+    lap = -4 * (math.pi**2) * (kx**2 + ky**2)
+    lap[0, 0] = 1.0
+    kx, ky, lap = kx[None, ...], ky[None, ...], lap[None, ...]
+    dealias_filter = (torch.logical_and(torch.abs(kx) <= (2.0 / 3.0) * k_cut, torch.abs(ky) <= (2.0 / 3.0) * k_cut).to(real)
+                      if dealias else None)
+    out_real = torch.get_default_dtype()
+    names = ("vorticity", "vorticity_t", "stream", "residual")
+    dev_out = {key: torch.empty(bsz, record_steps, ns, ns, dtype=out_real, device=device) for key in names}
+    t_steps = torch.empty(record_steps, device="cpu")
+    bar = None
+    if pbar:
+        from tqdm import tqdm
+
+        bar = tqdm(total=total_steps)
+
+    def diverged(w):
+        if torch.isnan(torch.view_as_real(w)).any():
+            raise ValueError(f"Solution diverged with norm {torch.linalg.norm(w[~torch.isnan(w)])}")
+
+    c, t = 0, 0.0
+    for j in range(total_steps):
+        w_h, w_h_t, _, psi_h, _ = imex_crank_nicolson_step(w_h, f_h, visc, delta_t, diam=diam, rfftmesh=(kx, ky), laplacian=lap,
+                                                           dealias_filter=dealias_filter, dealias=dealias, **kwargs)
+        t += delta_t
+        if (j + 1) % record_every_n_steps == 0:
+            diverged(w_h)
+            res_h = update_residual(w_h, w_h_t, f_h, visc, (kx, ky), lap, dealias_filter=dealias_filter, dealias=dealias)
+            for key, val in zip(names, (w_h, w_h_t, psi_h, res_h)):
+                dev_out[key][:, c] = spectral_to_physical(val.contiguous(), ns, val.real.dtype)
+            t_steps[c] = t
+            c += 1
+            if bar is not None:
+                enstrophy = torch.linalg.norm(dev_out["vorticity"][:, c - 1], dim=(-1, -2)).mean().item() / n
+                res_l2 = torch.linalg.norm(dev_out["residual"][:, c - 1], dim=(-1, -2)).mean().item() / n
+                bar.set_description(f"{datetime.now():%d-%b-%Y %H:%M:%S} - enstrophy w: {enstrophy:.4f}  ||L(w, psi) - f||_2: {res_l2:.4e}")
+        if bar is not None:
+            bar.update()
+    diverged(w_h)
+    if bar is not None:
+        bar.close()
+    out = {key: val.cpu() for key, val in dev_out.items()}
+    out["t_steps"] = t_steps
+    return out
