@@ -26,15 +26,16 @@ def measure(root):
     assert os.path.abspath(tc.__file__).startswith(os.path.abspath(root)), tc.__file__
 
     dev = torch.device("cuda", 0)
-    torch.set_default_dtype(torch.float64)
-    n, B, L, K = 1024, 64, 2 * math.pi, 20
+    f64 = os.environ.get("AB_DTYPE", "f64") == "f64"
+    torch.set_default_dtype(torch.float64 if f64 else torch.float32)
+    n, B, L, K = int(os.environ.get("AB_N", 1024)), int(os.environ.get("AB_B", 64)), 2 * math.pi, int(os.environ.get("AB_STEPS", 20))
     grid = tc.Grid(shape=(n, n), domain=((0, L), (0, L)))
     dt = tc.stable_time_step(dx=L / n, dt=None, max_velocity=5.0, max_courant_number=0.5, viscosity=1e-3)
     op = tc.NavierStokes2DSpectral(1e-3, grid, drag=0.1, smooth=True, forcing_fn=tc.KolmogorovForcing(grid=grid, scale=1.0, wave_number=4),
                                    solver=tc.RK4CrankNicolsonStepper()).to(dev)
-    plan_fft = tc.fft_plan(n, torch.complex128, dev)
+    plan_fft = tc.fft_plan(n, torch.complex128 if f64 else torch.complex64, dev)
     with torch.no_grad():
-        w = plan_fft.rfft2(torch.cat([vorticity_field(grid, 4, batch_seeds=list(range(i, i + 8)), device=dev) for i in range(0, B, 8)]))
+        w = plan_fft.rfft2(torch.cat([vorticity_field(grid, 4, batch_seeds=list(range(i, min(i + 8, B))), device=dev) for i in range(0, B, 8)]))
         for _ in range(20):
             w, _ = op(w, dt)
         regions = []
@@ -76,7 +77,7 @@ def measure(root):
 def main():
     trees = sys.argv[1:]
     runs = {t: [] for t in trees}
-    for rep in range(4):
+    for rep in range(int(os.environ.get("AB_REPS", 4))):
         for t in trees:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--measure", t], stdout=subprocess.PIPE, timeout=600)
             assert r.returncode == 0, t
@@ -93,7 +94,8 @@ def main():
                            "event_sum_ms_per_step_median": round(statistics.median(m["event_sum_ms_per_step"] for m in runs[t]), 4),
                            "hbm_probe_copy_GBps": [m["hbm_probe"]["copy_GBps"] for m in runs[t]], "runs": runs[t]}
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/r06_solver_ab.json", "w"), indent=1)
+    out["config"] = {k: os.environ.get(k) for k in ("AB_N", "AB_B", "AB_DTYPE", "AB_STEPS")}
+    json.dump(out, open(os.environ.get("AB_OUT", "gpurun_out/r06_solver_ab.json"), "w"), indent=1)
     print(json.dumps({t: {k: v for k, v in d.items() if k != "runs"} for t, d in out["trees"].items()}, indent=1))
 
 

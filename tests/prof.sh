@@ -16,4 +16,8 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   rocprofv3 --pmc $pmc --output-format csv -d $out/pmc$i -o pmc -- $CMD > $out/pmc$i.log 2>&1
 done
 python tests/prof_summarize.py $out > $out/summary.txt 2>&1
+# keep what is read afterwards (kernel stats, per-dispatch counter tables, logs); the raw traces are tens of MB per run and
+# gpurun only brings back 64 MB in total
+find $out -type f \( -name '*kernel_trace.csv' -o -name '*.db' -o -name '*agent_info.csv' -o -name '*.json' -o -name '*.pftrace' \) -delete
+find $out -type f -name '*counter_collection.csv' -size +6M -delete
 cat $out/summary.txt

@@ -722,8 +722,8 @@ def test_batch_chunking_is_bit_identical(n, tag, B, dev, monkeypatch):
 
 @pytest.mark.parametrize("n,tag", [(64, "f64"), (512, "f64"), (1024, "f64"), (1024, "f32"), (256, "f32")])
 def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
-    """Row pass: the register-staged Stockham kernel (TCFD_ROWS_V=5) and the cross-lane kernel (7: 1024 points fp64 only,
-    the default there) are the same arithmetic in a different order: explicit terms and a step agree to round-off.  The plan
+    """Row pass: the register-staged Stockham kernel (TCFD_ROWS_V=5) and the cross-lane kernel (7: 1024 points, fp64 and --
+    since round 6 -- fp32; the default there) are the same arithmetic in a different order: explicit terms and a step agree to round-off.  The plan
     reports which kernel it launches; the values of removed kernels (4, 6) mean 5."""
     from oracle import ns2d as O
 
@@ -738,7 +738,7 @@ def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
         kern[v] = op._plan(w0).info()["rows_kernel"]
         res[v] = (out, op.explicit_terms(w0))
     monkeypatch.delenv("TCFD_ROWS_V")
-    x7 = 7 if (n, tag) == (1024, "f64") else 5    # cross-lane transforms: 1024 points fp64 only
+    x7 = 7 if n == 1024 else 5    # cross-lane transforms: 1024 points
     assert kern["5"] == 5 and kern["4"] == 5 and kern["7"] == x7 and kern["0"] == x7
     tols = (1e-13, 1e-12) if tag == "f64" else (5e-7, 2e-6)
     for v in ("7", "4", "0"):

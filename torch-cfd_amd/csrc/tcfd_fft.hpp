@@ -35,6 +35,74 @@ template <typename T> __device__ __forceinline__ cx<T> cscale(cx<T> a, T s) { re
 template <typename T> __device__ __forceinline__ cx<T> mul_i(cx<T> a) { return mk<T>(-a.y, a.x); }
 template <typename T> __device__ __forceinline__ cx<T> mul_mi(cx<T> a) { return mk<T>(a.y, -a.x); }
 
+// e + i o  and  e - i o  (the quarter-turn butterflies): generic form; the packed fp32 form below is one instruction
+template <typename T> __device__ __forceinline__ cx<T> add_i(cx<T> e, cx<T> o) { return mk<T>(e.x - o.y, e.y + o.x); }
+template <typename T> __device__ __forceinline__ cx<T> sub_i(cx<T> e, cx<T> o) { return mk<T>(e.x + o.y, e.y - o.x); }
+// v (c + i s) for real c, s
+template <typename T> __device__ __forceinline__ cx<T> crot(cx<T> v, T c, T s) { return mk<T>(v.x * c - v.y * s, v.x * s + v.y * c); }
+
+// ---- packed fp32 (gfx950: v_pk_add / mul / fma_f32 issue at the rate of ONE fp32 or fp64 vector instruction and do two) ----
+// A cx<float> is an aligned (re, im) register pair, so complex add / subtract are one instruction instead of two, a complex
+// product two (v_pk_mul + v_pk_fma with the halves picked by op_sel and the sign by neg_lo) instead of four, and e +- i o one
+// (the swap and the sign ride on the operand modifiers).  hipcc packs the plain vector forms by itself (with broadcast
+// op_sel for `.xx` and SGPR pairs for constants) but not a swapped operand: those three are inline asm.  Non-template
+// overloads, so every butterfly / twiddle / k-space expression written on cx<T> picks them up for T = float.  The fp32
+// solver kernels were bound by vector issue at the same instruction count as fp64 with half the bytes (round 5: 0.56 of the
+// HBM peak on the C4 shard against 0.70 in fp64).  TCFD_PK32=0 compiles the scalar forms (cross-check / A-B).
+#ifndef TCFD_PK32
+#define TCFD_PK32 1
+#endif
+#ifndef TCFD_PK32_ADD
+#define TCFD_PK32_ADD 1     // (the three groups can be switched off one by one: A/B builds)
+#endif
+#ifndef TCFD_PK32_CMUL
+#define TCFD_PK32_CMUL 1
+#endif
+#ifndef TCFD_PK32_ROT
+#define TCFD_PK32_ROT 1
+#endif
+#if TCFD_PK32
+typedef float pk2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2f pk(cx<float> a) { return __builtin_bit_cast(pk2f, a); }
+__device__ __forceinline__ cx<float> unpk(pk2f v) { return __builtin_bit_cast(cx<float>, v); }
+#if TCFD_PK32_ADD
+__device__ __forceinline__ cx<float> operator+(cx<float> a, cx<float> b) { return unpk(pk(a) + pk(b)); }
+__device__ __forceinline__ cx<float> operator-(cx<float> a, cx<float> b) { return unpk(pk(a) - pk(b)); }
+__device__ __forceinline__ cx<float> cscale(cx<float> a, float s) { return unpk(pk(a) * s); }
+#endif
+#if TCFD_PK32_CMUL
+__device__ __forceinline__ cx<float> cmul(cx<float> a, cx<float> b) {
+    pk2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(pk(a)), "v"(pk(b)));                 // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                 // + (-a.y b.y, a.y b.x)
+        : "+v"(t) : "v"(pk(a)), "v"(pk(b)));
+    return unpk(t);
+}
+#endif
+#if TCFD_PK32_ROT
+__device__ __forceinline__ cx<float> add_i(cx<float> e, cx<float> o) {      // (e.x - o.y, e.y + o.x)
+    pk2f t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(pk(e)), "v"(pk(o)));
+    return unpk(t);
+}
+__device__ __forceinline__ cx<float> sub_i(cx<float> e, cx<float> o) {      // (e.x + o.y, e.y - o.x)
+    pk2f t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(pk(e)), "v"(pk(o)));
+    return unpk(t);
+}
+__device__ __forceinline__ cx<float> crot(cx<float> v, float c, float s) {  // v c + (i v) s
+    pk2f t = pk(v) * c;
+    const pk2f ss = {s, s};
+    if (__builtin_constant_p(s)) {
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+v"(t) : "v"(pk(v)), "s"(ss));
+    } else {
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+v"(t) : "v"(pk(v)), "v"(ss));
+    }
+    return unpk(t);
+}
+#endif
+#endif
+
 // Reciprocal by v_rcp + Newton steps: ~1-2 ulp, a third of the instructions of an IEEE division
 // (the column kernel needs three per spectral element per RK stage).
 __device__ __forceinline__ float fast_rcp(float d) {
@@ -63,16 +131,16 @@ __device__ __forceinline__ cx<T> rot(cx<T> v) {
         return DIR > 0 ? mul_i(v) : mul_mi(v);
     } else if constexpr (k16 == 2) {
         constexpr T h = (T)0.70710678118654752440;
-        // (c + i*s*DIR) with c = s = h
-        return DIR > 0 ? mk<T>((v.x - v.y) * h, (v.x + v.y) * h) : mk<T>((v.x + v.y) * h, (v.y - v.x) * h);
+        // (c + i*s*DIR) with c = s = h:  h (v + i v)  resp.  h (v - i v)
+        return cscale(DIR > 0 ? add_i(v, v) : sub_i(v, v), h);
     } else if constexpr (k16 == 6) {
         constexpr T h = (T)0.70710678118654752440;
-        // c = -h, s = h
-        return DIR > 0 ? mk<T>((-v.x - v.y) * h, (v.x - v.y) * h) : mk<T>((v.y - v.x) * h, (-v.x - v.y) * h);
+        // c = -h, s = h:  h (i v - v) = -h (v - i v)  resp.  -h (v + i v)
+        return cscale(DIR > 0 ? sub_i(v, v) : add_i(v, v), -h);
     } else {
         constexpr T c = (T)(k16 < 4 ? cos16(k16) : -cos16(8 - k16));
         constexpr T s = (T)(k16 < 4 ? cos16(4 - k16) : cos16(k16 - 4)) * (T)DIR;
-        return mk<T>(v.x * c - v.y * s, v.x * s + v.y * c);
+        return crot(v, c, s);
     }
 }
 
@@ -90,9 +158,14 @@ struct Dft {
     template <int K>
     static __device__ __forceinline__ void combine(cx<T> (&v)[R], cx<T> (&e)[R / 2], cx<T> (&o)[R / 2]) {
         if constexpr (K < R / 2) {
-            cx<T> t = rot<R, K, DIR, T>(o[K]);
-            v[K] = e[K] + t;
-            v[K + R / 2] = e[K] - t;
+            if constexpr (K * (16 / R) == 4) {      // t = +- i o: the quarter turn rides on the add / subtract
+                v[K] = DIR > 0 ? add_i(e[K], o[K]) : sub_i(e[K], o[K]);
+                v[K + R / 2] = DIR > 0 ? sub_i(e[K], o[K]) : add_i(e[K], o[K]);
+            } else {
+                cx<T> t = rot<R, K, DIR, T>(o[K]);
+                v[K] = e[K] + t;
+                v[K + R / 2] = e[K] - t;
+            }
             combine<K + 1>(v, e, o);
         }
     }
@@ -277,6 +350,15 @@ __device__ __forceinline__ void store_stream(cx<T>* p, cx<T> v) {
     __builtin_nontemporal_store(w, reinterpret_cast<vec2*>(p));
 }
 
+#if TCFD_PK32
+// fp32: as an asm statement.  With the packed forms above hipcc merges the two arms of `if (nt) store_stream(p, v); else *p = v;`
+// into ONE plain store (the arms became identical vector stores; merging drops the hint): every one of the 1,344 non-temporal
+// stores of the fp32 solver unit had disappeared, and the small cache-resident problems lost the 5 % the hint is there for.
+__device__ __forceinline__ void store_stream(cx<float>* p, cx<float> v) {
+    asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(pk(v)) : "memory");
+}
+#endif
+
 // load with the same hint: data that is read exactly once by this launch
 template <typename T>
 __device__ __forceinline__ cx<T> load_stream(const cx<T>* p) {
@@ -324,6 +406,9 @@ __device__ __forceinline__ cx<T> ldtw(const cx<T>* __restrict__ tw, int idx) {
 // the address arithmetic is redone per transform while the twiddle loads stay loop-invariant).
 template <typename T>
 __device__ __forceinline__ cx<T> csquare(cx<T> w) { return mk<T>((w.x - w.y) * (w.x + w.y), (T)2 * w.x * w.y); }
+#if TCFD_PK32 && TCFD_PK32_CMUL
+__device__ __forceinline__ cx<float> csquare(cx<float> w) { return cmul(w, w); }   // two packed instructions instead of five
+#endif
 
 // TWSQ = 2: as 1, but the per-pass twiddles are not loaded at all: the caller read them once (load_pass_tw, forward
 // sign) into `trg[P]`, P = index of the pass among those with a twiddle.  This is what keeps them in registers

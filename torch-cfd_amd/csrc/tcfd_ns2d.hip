@@ -1218,6 +1218,10 @@ struct Tuning {
     int split;               // TCFD_SPLIT: radix-2 split of the column transform across the row pass
     int small_tiles;         // TCFD_SMALL_TILES: 4-column tiles / 64-lane row groups for small problems
     int two_wg;              // TCFD_TWO_WG: 128-VGPR cap (two workgroups per CU) for the 512-point fp64 column tiles
+    int f32_cols8;           // TCFD_F32_COLS8: fp32 512-point column tiles of 8 columns (64-byte segments, pairs on one XCD) on the
+                             // cross-lane transforms for the plane-emitting passes (1 = default); 0 = 16-column Stockham tiles
+    int cols_lds_pad;        // TCFD_COLS_LDS_PAD: extra dynamic LDS bytes of the column kernels (experiments)
+    int rows7_minw;          // TCFD_ROWS7_MINW: waves per SIMD of the fp32 cross-lane row kernel (2 / 4)
     int rows_blocks_per_cu;  // TCFD_ROWS_BLOCKS_PER_CU: persistent row-pass grid
     int pair_xcd;            // TCFD_PAIR_XCD: put the 2 / 4 column tiles that share a 128-byte line on one XCD (0 off, 2 pairs only)
     int ablate;              // TCFD_ABLATE: timing ablations (results are WRONG when non-zero)
@@ -1471,6 +1475,9 @@ TCFD_API int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const
     p->tune.split = env_int("TCFD_SPLIT", -1);
     p->tune.small_tiles = env_int("TCFD_SMALL_TILES", -1);
     p->tune.two_wg = env_int("TCFD_TWO_WG", 1);
+    p->tune.f32_cols8 = env_int("TCFD_F32_COLS8", 1);
+    p->tune.rows7_minw = env_int("TCFD_ROWS7_MINW", 4);
+    p->tune.cols_lds_pad = env_int("TCFD_COLS_LDS_PAD", 0);
     p->tune.rows_blocks_per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 0);
     p->tune.pair_xcd = env_int("TCFD_PAIR_XCD", 1);
     p->tune.ablate = env_int("TCFD_ABLATE", 0);
@@ -1577,7 +1584,8 @@ template <typename T, int N, int MODE, int EPT, int C, int MINW = 1, int SP = 0>
 static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStream_t st) {
     constexpr int NT = N >> SP;
     constexpr int G = NT / EPT;
-    constexpr size_t lds = (size_t)lds_elems<NT, EPT, C, false>() * sizeof(cx<T>) + 3 * (size_t)NT * sizeof(T);
+    // + TCFD_COLS_LDS_PAD bytes: an experiment knob that caps the workgroups a CU takes (occupancy A/B without a rebuild)
+    const size_t lds = (size_t)lds_elems<NT, EPT, C, false>() * sizeof(cx<T>) + 3 * (size_t)NT * sizeof(T) + (size_t)p->tune.cols_lds_pad;
     a.m = p->m;
     a.ldw = p->ldw;
     a.ntiles = (p->m + C - 1) / C;
@@ -1658,6 +1666,9 @@ static int launch_cols_split(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, 
     constexpr int EPT = Cfg<T, H>::COL_EPT, C = Cfg<T, H>::COLS;
     // 128 VGPRs per lane = two 512-lane workgroups per CU for the half-size fp64 tiles
     constexpr int MINW = (C * (H / EPT) == 512 && (MODE != MODE_A || TCFD_SPLIT_A_MINW4)) ? 4 : 1;
+    if constexpr (N == 1024 && sizeof(T) == 4 && (MODE == MODE_A || MODE == MODE_CA)) {   // (see launch_cols: the same at 1024^2 x 64: CA 1.86 -> 1.74 ms)
+        if (p->tune.f32_cols8) return launch_cols_v<T, N, MODE, 8, 8, 4, 1>(p, a, batch, st);
+    }
     if constexpr (N >= 16 && MODE != MODE_FWD && MODE != MODE_INV)
         return launch_cols_v<T, N, MODE, EPT, C, MINW, 1>(p, a, batch, st);
     else
@@ -1683,6 +1694,12 @@ static int launch_cols(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipStr
     // so one tile's memory phases overlap the other's transforms (measured at 512^2 x 256: CA 1.05 -> 0.87 ms)
     if constexpr (N == 512 && sizeof(T) == 8 && (MODE == MODE_CA || MODE == MODE_C)) {
         if (p->tune.two_wg) return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);
+    }
+    // fp32 512-point tiles: 8 columns on the cross-lane transforms (one LDS exchange instead of two, 512-thread workgroups: two
+    // per CU) for the passes that emit planes; the update-only pass keeps the 16-column Stockham tiles (measured per step at
+    // 512^2 x 64: CA 0.453 -> 0.411 ms, C 0.086 -> 0.094, profiles/r06_f32_variants.txt).  TCFD_F32_COLS8=0: 16 columns everywhere
+    if constexpr (N == 512 && sizeof(T) == 4 && (MODE == MODE_A || MODE == MODE_CA)) {
+        if (p->tune.f32_cols8) return launch_cols_v<T, N, MODE, 8, 8, 4>(p, a, batch, st);
     }
     return launch_cols_v<T, N, MODE, Cfg<T, N>::COL_EPT, Cfg<T, N>::COLS>(p, a, batch, st);
 }
@@ -1738,7 +1755,8 @@ static constexpr int rows_default_version() {
     // 7 = cross-lane transforms (1024 points fp64): equal to 5 while the row pass streams from HBM (0.616 vs 0.607 ms
     // per launch on the whole batch) and ahead of it once the planes come from the Infinity Cache (chunked calls:
     // 7.54 vs 7.82 ms per step)
-    return (N == 1024 && sizeof(T) == 8) ? 7 : 5;
+    // fp32 at 1024 points (round 6): 7 as well -- 1.36 against 2.08 ms per step of 64 fields at four waves per SIMD
+    return N == 1024 ? 7 : 5;
 }
 
 template <typename T, int N>
@@ -1757,6 +1775,17 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
         if (!split && (force == 1 || (force != 0 && batch * (N / 2) < 16 * 256)))
             return launch_rows_advect5<T, N, 8, 64, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
+    if constexpr (N == 1024 && sizeof(T) == 4) {
+        if (p->tune.rows_v == 7 || p->tune.rows_v == 0) {   // cross-lane transforms in fp32 (half the registers of fp64: four waves
+                                                            // per SIMD fit): per step at 1024^2 x 64 2.08 -> 1.36 ms against the Stockham rows
+            if (p->tune.rows7_minw == 2) {
+                if (split) return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st, nyq);
+                return launch_rows_advect7<T, 0, 2, 1>(p, planes, plane_stride, adv, batch, st, nyq);
+            }
+            if (split) return launch_rows_advect7<T, 1, 4, 1>(p, planes, plane_stride, adv, batch, st, nyq);
+            return launch_rows_advect7<T, 0, 4, 1>(p, planes, plane_stride, adv, batch, st, nyq);
+        }
+    }
     if constexpr (N == 1024 && sizeof(T) == 8) {
         if (p->tune.rows_v == 7 || p->tune.rows_v == 0) {   // cross-lane transforms: the default here
             if (split) return launch_rows_advect7<T, 1, 2, 1>(p, planes, plane_stride, adv, batch, st, nyq);
@@ -1768,6 +1797,11 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
     if constexpr (N >= 16) {
         if (split) return launch_rows_advect5<T, N, EPT, THR, 1, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
+    // 512-point fp32 rows: 164 registers with the packed arithmetic (tcfd_fft.hpp) -- three workgroups per CU (three waves per
+    // SIMD) instead of one: the pass is bound by the latency of its dependent chains, not by issue (per step at 512^2 x 64:
+    // 0.465 -> 0.352 ms, profiles/r06_rows_sweep.txt)
+    if constexpr (N == 512 && sizeof(T) == 4)
+        return launch_rows_advect5<T, N, EPT, THR, 0, 3>(p, planes, plane_stride, adv, batch, st, nyq);
     return launch_rows_advect5<T, N, EPT, THR, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
 }
@@ -2498,7 +2532,7 @@ static int variant_impl(const tcfd_ns2d_plan* p, int* split, int* rows_kernel) {
         int v = p->tune.rows_v;
         if (v == 4 || v == 6) v = 5;                 // (removed kernels)
         if (v != 5 && v != 7) v = rows_default_version<T, N>();
-        if (v == 7 && !(N == 1024 && sizeof(T) == 8)) v = 5;
+        if (v == 7 && N != 1024) v = 5;
         *rows_kernel = v;
     }
     return 0;

@@ -627,9 +627,10 @@ def _hip_pointwise_backward(spec, dout, x, skip, w1, b1, w2, b2, ws, bs, gamma, 
                                             ptr(b2v), ptr(wst), ptr(bsv), ptr(partials), max_waves, dims, b, ci, cm, co, P, T, sT, c1,
                                             c2, 3 if tsum else mode, 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, "tcfd_fno_pointwise_bwd_out")
-    if tuple(dims) != queried:
-        # the launch rewrites `dims` with the geometry of the kernel it actually ran; the buffers above were sized and the
-        # scatter below is laid out from the data-less query.  They differ only if the launch declined the kernel the query
+    if tuple(dims)[:5] != queried[:5]:
+        # the launch rewrites `dims` with the geometry of the kernel it actually ran (entry 5, the rows a launch fills, is
+        # not part of the row layout: the LDS-staged kernel reports it only from a launch); the buffers above were sized and
+        # the scatter below is laid out from the data-less query.  They differ only if the launch declined the kernel the query
         # chose (a kept tensor it rejects, a switch flipped between the forward and the backward): the partial sums then have
         # another row layout and every weight gradient would be silently wrong.
         raise _lib.TcfdError(f"tcfd_fno_pointwise_bwd_out ran with row layout {tuple(dims)}, the layout query said {queried}")
