@@ -779,6 +779,14 @@ def main():
             tc._lib.check(lib.tcfd_hbm_probe(a_buf.data_ptr(), b_buf.data_ptr(), nbytes, mode, 10, ctypes.byref(t_ms), st),
                           "hbm_probe")
             probe[name] = round(traffic_x * nbytes / (t_ms.value * 1e-3) / 1e9, 1)
+        # the same three loops on 2 x 96 MB: buffers that stay in the 256 MB Infinity Cache, as a chunk of the step does (its
+        # 239 MB working set) -- the ceiling the per-kernel algorithmic rates of a chunked step are to be read against
+        res_bytes = 96 << 20
+        for mode, name, traffic_x in ((0, "resident_copy_GBps", 2), (1, "resident_read_GBps", 1), (2, "resident_fill_GBps", 1)):
+            t_ms = ctypes.c_float(0)
+            tc._lib.check(lib.tcfd_hbm_probe(a_buf.data_ptr(), b_buf.data_ptr(), res_bytes, mode, 20, ctypes.byref(t_ms), st),
+                          "hbm_probe")
+            probe[name] = round(traffic_x * res_bytes / (t_ms.value * 1e-3) / 1e9, 1)
         del a_buf, b_buf
     except Exception as e:
         probe = {"error": repr(e)}

@@ -1802,6 +1802,9 @@ static int launch_rows_advect(const tcfd_ns2d_plan* p, const cx<T>* planes, size
     // 0.465 -> 0.352 ms, profiles/r06_rows_sweep.txt)
     if constexpr (N == 512 && sizeof(T) == 4)
         return launch_rows_advect5<T, N, EPT, THR, 0, 3>(p, planes, plane_stride, adv, batch, st, nyq);
+    // ... and fp64 (240 registers): two per CU, 0.644 -> 0.587 ms per step (three: 0.80), profiles/r06_f64_rows_percu.txt
+    if constexpr (N == 512 && sizeof(T) == 8)
+        return launch_rows_advect5<T, N, EPT, THR, 0, 2>(p, planes, plane_stride, adv, batch, st, nyq);
     return launch_rows_advect5<T, N, EPT, THR, 0, 1>(p, planes, plane_stride, adv, batch, st, nyq);
     }
 }

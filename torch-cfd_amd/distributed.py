@@ -123,6 +123,18 @@ def batch_layout(total: int, world_size: int, batch_size: int) -> List[List[Tupl
     return table
 
 
+def _page_aligned_empty(shape, dtype: torch.dtype) -> torch.Tensor:
+    """Uninitialised CPU tensor whose first byte sits on a page boundary (a view into a slightly larger byte buffer)."""
+    import mmap
+
+    nbytes = int(torch.tensor([], dtype=dtype).element_size())
+    for d in shape:
+        nbytes *= int(d)
+    raw = torch.empty(nbytes + mmap.PAGESIZE, dtype=torch.uint8)
+    off = (-raw.data_ptr()) % mmap.PAGESIZE
+    return raw[off:off + nbytes].view(dtype).view(*shape)
+
+
 class RecordHandover:
     """Hands the post-processed records of an ensemble job to the host of rank ``dst`` WHILE the steps go on.
 
@@ -217,7 +229,10 @@ class RecordHandover:
                 # caller) only for its own region.
                 import threading
 
-                self.host = {f: torch.empty(shape, dtype=dtype) for f in self.fields}
+                # page-aligned fields: when a region (the rows of one batch in one field) is a whole number of pages -- every
+                # production shape: 64 x 10 x 256 x 256 floats -- each lock covers exactly its region and no pitched copy ever
+                # starts inside one registration and runs into the next; other shapes fall back to the edge-page rule below
+                self.host = {f: _page_aligned_empty(shape, dtype) for f in self.fields}
                 order = []          # (field, start, count): dst's own batches first, then batch k of every peer
                 ranks = [dst] + [r for r in range(self.world) if r != dst]
                 for k in range(max((len(bt) for bt in layout), default=0)):
