@@ -630,6 +630,8 @@ def main():
                                              for i in range(0, len(seeds), 8)]))
 
     def advance(w, k):
+        if k <= 0:
+            return w
         if args.fused_steps:
             out, _ = op(w, dt, steps=k)
             return out

@@ -720,6 +720,35 @@ def test_batch_chunking_is_bit_identical(n, tag, B, dev, monkeypatch):
             assert torch.equal(a, b), chunk
 
 
+@pytest.mark.parametrize("n", [512, 1024])
+def test_fp32_column_tile_variants_agree(n, dev, monkeypatch):
+    """Round 6: the plane-emitting column passes of the fp32 solver run 8-column cross-lane tiles (TCFD_F32_COLS8=1, default) or
+    the 16-column Stockham tiles (=0): the same arithmetic in another order -- a step, dw/dt and the explicit terms agree to fp32
+    round-off, and both agree with the fp64 kernels of the same build.  TCFD_NT_OUT=1 (non-temporal stores of the last stage's
+    outputs) changes no bit."""
+    from oracle import ns2d as O
+
+    B = 3
+    w0 = torch.stack([torch.fft.rfft2(O.mcwilliams_vorticity(n, L, 4, s, torch.float64)) for s in range(B)])
+    res = {}
+    for key, env in (("cols8", {"TCFD_F32_COLS8": "1"}), ("cols16", {"TCFD_F32_COLS8": "0"}), ("nt", {"TCFD_NT_OUT": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _, op = build_op(n, "f32", "kolmogorov", dev)
+        out, dwdt = op(w0.to(torch.complex64).to(dev), 1e-3, steps=2)
+        res[key] = (out, dwdt, op.explicit_terms(w0.to(torch.complex64).to(dev)))
+        for k in env:
+            monkeypatch.delenv(k)
+    _, op64 = build_op(n, "f64", "kolmogorov", dev)
+    ref = op64(w0.to(dev), 1e-3, steps=2)
+    for a, b in zip(res["cols8"], res["nt"]):
+        assert torch.equal(a, b)
+    assert rel_l2(res["cols8"][0], res["cols16"][0]) < 5e-7 and rel_l2(res["cols8"][2], res["cols16"][2]) < 2e-6
+    assert scaled_err(res["cols8"][1], res["cols16"][1], res["cols8"][0] / 2e-3) < 1e-6
+    for key in ("cols8", "cols16"):
+        assert rel_l2(res[key][0], ref[0]) < 2e-6, key
+
+
 @pytest.mark.parametrize("n,tag", [(64, "f64"), (512, "f64"), (1024, "f64"), (1024, "f32"), (256, "f32")])
 def test_row_kernel_variants_agree(n, tag, dev, monkeypatch):
     """Row pass: the register-staged Stockham kernel (TCFD_ROWS_V=5) and the cross-lane kernel (7: 1024 points, fp64 and --

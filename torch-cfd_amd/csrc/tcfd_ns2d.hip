@@ -189,6 +189,8 @@ struct ColArgs {
                    // 64 skip the packing of the Nyquist column into the planes, 128 skip that column's update
     int nyq;       // 1: packed Nyquist column (see emit_planes): no lone tile for column m - 1, the lanes of column 0 own it too
     int nt_planes; // plane stores with the non-temporal hint (small cache-resident problems, see launch_cols)
+    int nt_out;    // MODE_C: the new state and dw/dt go to the CALLER's arrays and are not read again by this call -- stored with
+                   // the non-temporal hint they do not push the next chunk's working set out of the Infinity Cache
     int pair_xcd;  // block->tile map: 0 = batch fastest; LG = 2 / 4: the LG tiles that share a 128-byte line on one XCD
     cx<T>* h_out;  // RK accumulator write (NULL: == h)
 };
@@ -571,12 +573,20 @@ __global__ __launch_bounds__(C*((N >> SP) / EPT), MINW) void k_cols(ColArgs<T> a
                         cx<T> rhs = u + cscale(hn, a.gdt) + cscale(cscale(u, L), a.mu);
                         const T den = fast_rcp((T)1 - a.mud * L);
                         x[t] = cscale(rhs, den);
-                        if (writer) a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                         if constexpr (MODE == MODE_C) {
+                            cx<T>* const po = a.u_out + (size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld;
+                            if (writer) {
+                                if (a.nt_out) store_stream(po, x[t]);
+                                else *po = x[t];
+                            }
                             if (a.dwdt) {   // (w_new - w_old) / (steps dt), equations.py:461-462, fused into the last stage
                                 const size_t gi = (size_t)b * N * a.m + jc + (size_t)i * a.m;
-                                a.dwdt[gi] = cscale(x[t] - w0v[tt], a.dwdt_scale);
+                                const cx<T> dv = cscale(x[t] - w0v[tt], a.dwdt_scale);
+                                if (a.nt_out) store_stream(a.dwdt + gi, dv);
+                                else a.dwdt[gi] = dv;
                             }
+                        } else {
+                            if (writer) a.u_out[(size_t)b * N * a.u_out_ld + jc + (size_t)i * a.u_out_ld] = x[t];
                         }
                     }
                 }
@@ -1220,6 +1230,7 @@ struct Tuning {
     int two_wg;              // TCFD_TWO_WG: 128-VGPR cap (two workgroups per CU) for the 512-point fp64 column tiles
     int f32_cols8;           // TCFD_F32_COLS8: fp32 512-point column tiles of 8 columns (64-byte segments, pairs on one XCD) on the
                              // cross-lane transforms for the plane-emitting passes (1 = default); 0 = 16-column Stockham tiles
+    int nt_out;              // TCFD_NT_OUT: non-temporal stores of the last stage's outputs (new state to the caller, dw/dt)
     int cols_lds_pad;        // TCFD_COLS_LDS_PAD: extra dynamic LDS bytes of the column kernels (experiments)
     int rows7_minw;          // TCFD_ROWS7_MINW: waves per SIMD of the fp32 cross-lane row kernel (2 / 4)
     int rows_blocks_per_cu;  // TCFD_ROWS_BLOCKS_PER_CU: persistent row-pass grid
@@ -1478,6 +1489,7 @@ TCFD_API int tcfd_ns2d_plan_create(tcfd_ns2d_plan** out, int n, int dtype, const
     p->tune.f32_cols8 = env_int("TCFD_F32_COLS8", 1);
     p->tune.rows7_minw = env_int("TCFD_ROWS7_MINW", 4);
     p->tune.cols_lds_pad = env_int("TCFD_COLS_LDS_PAD", 0);
+    p->tune.nt_out = env_int("TCFD_NT_OUT", 0);
     p->tune.rows_blocks_per_cu = env_int("TCFD_ROWS_BLOCKS_PER_CU", 0);
     p->tune.pair_xcd = env_int("TCFD_PAIR_XCD", 1);
     p->tune.ablate = env_int("TCFD_ABLATE", 0);
@@ -1610,6 +1622,7 @@ static int launch_cols_v(const tcfd_ns2d_plan* p, ColArgs<T> a, long batch, hipS
     a.tw = (const cx<T>*)(SP ? p->tw2 : p->tw);
     a.pair_xcd = line_group<T, C>(p);
     a.ablate = p->tune.ablate;
+    a.nt_out = (MODE == MODE_C && p->tune.nt_out && a.u_out_ld == p->m) ? 1 : 0;   // (the caller's array: pitch m, not ldw)
     long blocks = batch * a.ntiles;
     if (a.pair_xcd) blocks = ((((long)(a.ntiles + a.pair_xcd - 1) / a.pair_xcd) * batch + 7) / 8) * 8 * a.pair_xcd;
     if (!a.h_out) a.h_out = a.h;
