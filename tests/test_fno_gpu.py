@@ -1185,6 +1185,39 @@ def test_sfno_training_step_gradients_golden(dev):
             raise AssertionError("no descent along the negative gradient")
 
 
+def test_output_head_trains_on_its_inference_kernels(dev, monkeypatch):
+    """Round 6: channel reduction + output operator under autograd as ONE node on the inference kernels (no torch.cat of the
+    frames, the residual frame added by the inverse transform's store loop): loss and every parameter gradient against the
+    reference's autograd (fno_grads.npz) and against the composed path (TCFD_FNO_FUSED_OUT_TRAIN=0).  An input that needs a
+    gradient itself keeps the composed path (test_sfno_training_step_gradients_golden covers it)."""
+    from torch_cfd_amd import fno
+
+    g = load_golden("fno_grads.npz")
+    keys = sorted(k[8:] for k in g.files if k.startswith("sfno_sd_"))
+    x = torch.from_numpy(g["sfno_x"]).to(dev)
+    target = torch.from_numpy(g["sfno_target"]).to(dev)
+    grads, losses, nodes = {}, {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TCFD_FNO_FUSED_OUT_TRAIN", flag)
+        model = fno.SFNO(4, 4, 3, width=4, num_spectral_layers=3, latent_steps=10).train()
+        model.load_state_dict({k: torch.from_numpy(g["sfno_sd_" + k]) for k in keys})
+        model = model.to(dev)
+        out = model(x)
+        nodes[flag] = type(out.grad_fn).__name__
+        loss = fno.SobolevLoss(n_grid=16, norm_order=0, relative=True).to(dev)(out, target)
+        loss.backward()
+        losses[flag] = float(loss.detach())
+        grads[flag] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    monkeypatch.delenv("TCFD_FNO_FUSED_OUT_TRAIN")
+    assert "OutHead" in nodes["1"] and "OutHead" not in nodes["0"]
+    assert losses["1"] == pytest.approx(float(g["sfno_loss"]), rel=2e-5) and losses["1"] == pytest.approx(losses["0"], rel=1e-6)
+    assert set(grads["1"]) == set(grads["0"]) and len(grads["1"]) >= 30
+    for k, a in grads["1"].items():
+        ref = torch.from_numpy(g["sfno_g_" + k])
+        assert float((a.cpu() - ref).norm()) < 5e-5 * float(ref.norm()) + 2e-9, k
+        assert float((a - grads["0"][k]).norm()) < 2e-5 * float(grads["0"][k].norm()) + 2e-9, k
+
+
 @pytest.mark.parametrize("tag,width,act", [("w16_gelu", 16, "GELU"), ("w16_relu", 16, "ReLU"), ("w20_gelu", 20, "GELU")])
 def test_sfno_training_step_gradients_golden_at_widths_16_and_20(tag, width, act, dev, monkeypatch):
     """Tiny SFNOs at the reference's other widths (16: fno/sfno_pytest.py:258-270, 20: its notebooks) with GELU

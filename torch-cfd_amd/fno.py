@@ -742,8 +742,10 @@ def _norm_proj_grads(eps, dz, xs, W, bias, gamma, beta, Mx, M1, stats, need_dx, 
     Sx = r[:, None, None] * (Mx - mu[:, None, None] * M1[:, :, None])      # sum_p dy[o] x^[c]
     g_w = (g_[None, None, :] * Sx + b_[None, None, :] * M1[:, :, None]).sum(0)
     g_b = M1.sum(0)
-    G1 = torch.einsum("oc,bo->bc", Wd, M1)                                  # sum_p g[c]
-    Gx = torch.einsum("oc,boc->bc", Wd, Sx)                                 # sum_p g[c] x^[c]
+    # (broadcast products + sums, not einsum: these few hundred numbers would otherwise go through a vendor GEMM kernel, the
+    #  only library kernel in a config-5 training trace)
+    G1 = (Wd[None] * M1[:, :, None]).sum(1)                                 # sum_p g[c]        = sum_o W[o,c] M1[b,o]
+    Gx = (Wd[None] * Sx).sum(1)                                             # sum_p g[c] x^[c]  = sum_o W[o,c] Sx[b,o,c]
     g_beta, g_gamma = G1.sum(0), Gx.sum(0)
     cast = lambda t, like: t.to(like.dtype).reshape(like.shape) if like is not None else None
     if not need_dx:      # the block's input is data (e.g. the network input + positional encoding): pass 2 is not needed
@@ -1028,7 +1030,7 @@ def hip_pointwise(x: torch.Tensor, lin1, act1, lin2, skip=None, skip_conv=None, 
         W = lin2.weight.detach().reshape(co, ci).double()
         w2t = (W.t()[None] * (gamma[None, :, None] * rstd[:, None, None])).float().contiguous()      # (b, ci, co)
         shift = beta[None, :] - gamma[None, :] * (mu * rstd)[:, None]                               # (b, ci)
-        folded_bias = shift @ W.t()
+        folded_bias = (shift[:, None, :] * W[None]).sum(-1)        # (b, co); a broadcast sum: no vendor GEMM for b x ci x co numbers
         if lin2.bias is not None:
             folded_bias = folded_bias + lin2.bias.detach().double()[None]
         folded_bias = folded_bias.float().contiguous()                                              # (b, co)
@@ -1097,7 +1099,7 @@ def _hip_pointwise_f64(x, lin1, c1, lin2, skip, skip_conv, c2, skip_last_slice, 
         beta = norm.bias.detach() if norm.bias is not None else torch.zeros(ci, dtype=torch.float64, device=x.device)
         W = lin2.weight.detach().reshape(co, ci)
         w2t = (W.t()[None] * (gamma[None, :, None] * rstd[:, None, None])).contiguous()                 # (b, ci, co)
-        fb = (beta[None, :] - gamma[None, :] * (mu * rstd)[:, None]) @ W.t()
+        fb = ((beta[None, :] - gamma[None, :] * (mu * rstd)[:, None])[:, None, :] * W[None]).sum(-1)
         b2 = (fb + lin2.bias.detach()[None] if lin2.bias is not None else fb).contiguous()              # (b, co)
         w2_bs, b2_bs = ci * co, co
     ptr = lambda t: t.data_ptr() if t is not None else None
@@ -1676,6 +1678,47 @@ class LiftingOperator(nn.Module):
         return self.activation(v[..., -1:] + self.mlp(x1))
 
 
+class _OutHeadFn(torch.autograd.Function):
+    """Channel reduction + output operator of the SFNO (fno/sfno.py:313-328, 618-620) as ONE autograd node on the inference
+    kernels: the forward values come from ``OutConv.fused_forward`` (``tcfd_fno_reduce_frames``: the reduction writes its
+    latent steps behind the last input frame, no ``torch.cat``; ``tcfd_fno_inverse_trunc_residual``: the residual frame is
+    added in the store loop, no slice copy, no ``add``), the backward chains the adjoints the separate nodes use --
+    ``_inv_trunc_vjp``, ``_contract_vjp``, ``_fwd_trunc_vjp`` and the single-layer pointwise backward for the reduction.
+    The input frames ``v_res`` get no gradient here (the caller falls back to the composed path when they need one)."""
+
+    @staticmethod
+    def forward(ctx, out, vh, cfg, v, red_w, red_b, *conv_params):
+        ctx.cfg = cfg
+        ctx.has_rb = red_b is not None
+        ctx.save_for_backward(vh, v, red_w, *([red_b] if red_b is not None else []), *conv_params)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = list(ctx.saved_tensors)
+        vh, v, red_w = saved[:3]
+        red_b = saved[3] if ctx.has_rb else None
+        conv_params = saved[4 if ctx.has_rb else 3:]
+        fwd_cfg, contract_cfg, inv_cfg = ctx.cfg
+        need = ctx.needs_input_grad
+        g_oh = _inv_trunc_vjp(dout.unsqueeze(1), inv_cfg)
+        gv_h, grads = _contract_vjp(g_oh, vh, conv_params, contract_cfg, True, need[6:])
+        g_frames = _fwd_trunc_vjp(gv_h, fwd_cfg)                      # (b, 1, X, Y, T + 1): frame 0 is the input frame's
+        g_red = g_frames[..., 1:].contiguous()
+        spec = (False, None, None, 0, None)
+        hip = _hip_pointwise_backward(spec, g_red, v, None, None, None, red_w, red_b, None, None, None, None, need_dx=bool(need[3]))
+        if hip is None:       # (a width the pointwise backward is not instantiated for: the same sums as tensor ops)
+            b, C = v.shape[:2]
+            g2 = g_red.reshape(b, 1, -1)
+            dv = (red_w.detach().reshape(1, C, 1) * g2).view_as(v) if need[3] else None
+            gw = torch.einsum("bop,bcp->oc", g2, v.detach().reshape(b, C, -1)).reshape(red_w.shape)
+            gb = g2.sum(dim=(0, 2)) if red_b is not None else None
+        else:
+            dv, gw, gb = hip[0], hip[4], hip[5]
+        return (None, None, None, dv if need[3] else None, gw if need[4] else None, gb if (red_b is not None and need[5]) else None,
+                *grads)
+
+
 class OutConv(nn.Module):
     def __init__(self, modes_x: int, modes_y: int, modes_t: int, delta: float = 0.1, out_dim: int = 1,
                  diam: float = 1, n_grid: int = 64, out_steps: int = None, spatial_padding: int = 0,
@@ -1694,9 +1737,10 @@ class OutConv(nn.Module):
         (``tcfd_fno_reduce_frames``: no ``torch.cat``), the inverse transform produces only the kept steps and adds the residual
         frame in its store loop (``tcfd_fno_inverse_trunc_residual``: no slice copy, no ``add``).  None when not covered."""
         conv = self.conv
-        if (torch.is_grad_enabled() and (v.requires_grad or v_res.requires_grad or any(p.requires_grad for p in self.parameters())
-                                         or any(p.requires_grad for p in reduction.parameters()))):
-            return None
+        training = (torch.is_grad_enabled() and (v.requires_grad or v_res.requires_grad or any(p.requires_grad for p in self.parameters())
+                                                 or any(p.requires_grad for p in reduction.parameters())))
+        if training and (v_res.requires_grad or os.environ.get("TCFD_FNO_FUSED_OUT_TRAIN", "1") == "0"):
+            return None               # a gradient for the input frames themselves: the composed path
         if (not v.is_cuda or v.dtype != torch.float32 or v.dim() != 5 or v_res.dim() != 4 or v_res.dtype != torch.float32
                 or self.spatial_padding > 0 or self.size[0] != 1 or not _is_pointwise(reduction) or reduction.out_channels != 1
                 or type(conv).forward is not SpectralConvT.forward or not isinstance(conv.postprocess, nn.Identity)
@@ -1730,7 +1774,17 @@ class OutConv(nn.Module):
             _lib.check(lib.tcfd_fno_inverse_trunc_residual(plan.handle, oh.data_ptr(), out.data_ptr(), rc_.data_ptr(), rc_.shape[-1], b, 1,
                                                            out_steps, inv_scale, ws.data_ptr(), ws.numel(), stream),
                        "tcfd_fno_inverse_trunc_residual")
-        return out.squeeze(1)
+        out = out.squeeze(1)
+        if not training:
+            return out
+        # training: the same launches as ONE autograd node (the adjoints of the three pieces + the reduction's backward)
+        modes = tuple(conv.modes)
+        bias = conv._bias_list()
+        params = list(conv.weight) + (list(bias) if bias is not None else [])
+        cfg = (((b, 1, X, Y, T + 1), modes, t_pad, steps + t_pad, conv.norm),
+               (float(conv.delta), modes, True, bias is not None),
+               ((X, Y, T + 1, t_pad, steps + t_pad) + modes, out_steps, conv.norm))
+        return _OutHeadFn.apply(out, vh, cfg, v, reduction.weight, reduction.bias, *params)
 
     def forward(self, v, v_res, out_steps: int, **kwargs):
         v_res = v_res.unsqueeze(1).expand(-1, v.size(1), -1, -1, -1)
