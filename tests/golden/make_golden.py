@@ -513,6 +513,12 @@ def gen_legacy_cn_trajectory():
                                                          pbar=False, **kw)
         for k, v in res.items():
             out[f"{tag}_{k}"] = npy(v)
+    # a forcing per sample (B, n, n) and a time step that does not divide T (ceil(T / delta_t) = 13 steps, a record every 6)
+    fb = torch.stack([f, 2.0 * f, -0.5 * f])
+    res = solvers.get_trajectory_imex_crank_nicolson(w0, fb, visc=1e-3, T=0.0125, delta_t=1e-3, record_steps=2, diam=L, pbar=False,
+                                                     subsample=2, dealias=True)
+    for k, v in res.items():
+        out[f"batched_f_{k}"] = npy(v)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 3, 4, 4, 8, generator=g)
     out["bdf_x"] = npy(x)
