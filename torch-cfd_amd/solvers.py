@@ -168,22 +168,37 @@ def imex_crank_nicolson_step(w, f, visc, delta_t, diam: float = 1, rfftmesh=None
 
 
 # ----------------------------------------------------------------------------- legacy driver around that step
-_BDF_WEIGHTS = {
-    1: [1, -1],
-    2: [3 / 2, -2, 0.5],
-    3: [11 / 6, -3, 3 / 2, -1 / 3],
-    4: [25 / 12, -4, 3, -4 / 3, 1 / 4],
-    5: [137 / 60, -5, 5, -10 / 3, 5 / 4, -1 / 5],
-}
+# backward-difference weights of order 1 ... 5, newest sample first (fno/data_gen/solvers.py:26-32)
+_BDF_WEIGHTS = {1: (1.0, -1.0), 2: (1.5, -2.0, 0.5), 3: (11 / 6, -3.0, 1.5, -1 / 3), 4: (25 / 12, -4.0, 3.0, -4 / 3, 0.25),
+                5: (137 / 60, -5.0, 5.0, -10 / 3, 1.25, -0.2)}
 
 
 def backdiff(x: torch.Tensor, order: int = 3) -> torch.Tensor:
     """Backward-difference (BDF) combination of the last ``order + 1`` time samples of x (b, *, x, y, t): the unscaled
     time derivative at the last sample (fno/data_gen/solvers.py:19-35; weights in the default dtype, newest sample first)."""
-    if order > 5:
-        raise NotImplementedError("only bdf order <= 5 is implemented")
-    weights = torch.as_tensor(_BDF_WEIGHTS[order]).to(x.device)
-    return (x[..., -(order + 1):].flip(-1) * weights).sum(-1)
+    if order not in _BDF_WEIGHTS:
+        if order > 5:
+            raise NotImplementedError("only bdf order <= 5 is implemented")
+        raise KeyError(order)
+    newest_first = x[..., -(order + 1):].flip(-1)
+    return (newest_first * torch.as_tensor(_BDF_WEIGHTS[order]).to(x.device)).sum(-1)
+
+
+def _legacy_tables(n: int, diam: float, real: torch.dtype, device, dealias: bool):
+    """Wavenumber mesh, patched Laplacian and 2/3 mask of the legacy driver, each with a leading broadcast axis
+    (fno/data_gen/solvers.py:316-345: the mask compares |k| with 2/3 of the LARGEST wavenumber floor(n / 2) / diam)."""
+    half = n // 2
+    freq = torch.fft.fftfreq(n, d=diam / n, dtype=real, device=device)
+    kx = freq[:, None].expand(n, half + 1)[None]
+    ky = freq[None, : half + 1].expand(n, half + 1)[None]      # (slot n/2 holds -n/2 / diam, as the reference's sliced meshgrid does)
+    lap = (-4 * math.pi**2) * (kx * kx + ky * ky)
+    lap = lap.clone()
+    lap[0, 0, 0] = 1.0
+    mask = None
+    if dealias:
+        cut = (2.0 / 3.0) * (half / diam)
+        mask = ((kx.abs() <= cut) & (ky.abs() <= cut)).to(real)
+    return kx.contiguous(), ky.contiguous(), lap, mask
 
 
 def get_trajectory_imex_crank_nicolson(w0: torch.Tensor, f: torch.Tensor, visc: float = 1e-3, T: float = 1, delta_t: float = 1e-3,
@@ -207,64 +222,63 @@ def get_trajectory_imex_crank_nicolson(w0: torch.Tensor, f: torch.Tensor, visc: 
     from .equations import _COMPLEX_OF, fft_plan
 
     real = w0.dtype if dtype is None else dtype
-    device = w0.device
-    bsz, n = w0.size(0), w0.size(-1)
+    device, batch, n = w0.device, w0.shape[0], w0.shape[-1]
     ns = n // subsample
-    k_max = math.floor(n / 2.0)
-    total_steps = math.ceil(T / delta_t)
-    record_every_n_steps = math.floor(total_steps / record_steps)
-    if record_every_n_steps < 1 or total_steps // record_every_n_steps > record_steps:
-        raise IndexError(f"{total_steps} steps with a record every {record_every_n_steps} give "
-                         f"{total_steps // max(record_every_n_steps, 1)} records for {record_steps} slots")
+    n_steps = math.ceil(T / delta_t)
+    stride = n_steps // record_steps if record_steps > 0 else 0       # steps between two records
+    n_records = n_steps // stride if stride > 0 else 0
+    if stride < 1 or n_records > record_steps:
+        raise IndexError(f"{n_steps} steps with a record every {stride} give {n_records} records for {record_steps} slots")
     plan = fft_plan(n, _COMPLEX_OF[w0.dtype], device, diam)
     w_h = plan.rfft2(w0.contiguous())
     f_h = plan.rfft2(f.to(device=device, dtype=w0.dtype).contiguous().reshape(-1, n, n)).reshape(*f.shape[:-2], n, n // 2 + 1)
-    if f_h.ndim < w_h.ndim:
-        f_h = f_h.unsqueeze(0)
-    k = torch.fft.fftfreq(n, d=diam / n, dtype=real, device=device)
-    kx, ky = torch.meshgrid([k, k], indexing="ij")
-    kx, ky = kx[..., : k_max + 1], ky[..., : k_max + 1]
-    k_cut = (1 / diam) * k_max
-    lap = -4 * (math.pi**2) * (kx**2 + ky**2)
-    lap[0, 0] = 1.0
-    kx, ky, lap = kx[None, ...], ky[None, ...], lap[None, ...]
-    dealias_filter = (torch.logical_and(torch.abs(kx) <= (2.0 / 3.0) * k_cut, torch.abs(ky) <= (2.0 / 3.0) * k_cut).to(real)
-                      if dealias else None)
-    out_real = torch.get_default_dtype()
+    if f_h.dim() == w_h.dim() - 1:
+        f_h = f_h[None]
+    kx, ky, lap, mask = _legacy_tables(n, diam, real, device, dealias)
     names = ("vorticity", "vorticity_t", "stream", "residual")
-    dev_out = {key: torch.empty(bsz, record_steps, ns, ns, dtype=out_real, device=device) for key in names}
-    t_steps = torch.empty(record_steps, device="cpu")
+    records = {key: torch.empty(batch, record_steps, ns, ns, dtype=torch.get_default_dtype(), device=device) for key in names}
+    times = torch.empty(record_steps, device="cpu")
     bar = None
     if pbar:
         from tqdm import tqdm
 
-        bar = tqdm(total=total_steps)
+        bar = tqdm(total=n_steps)
 
-    def diverged(w):
-        if torch.isnan(torch.view_as_real(w)).any():
+    def check_finite(w):
+        bad = torch.isnan(torch.view_as_real(w)).any()
+        if bad:
             raise ValueError(f"Solution diverged with norm {torch.linalg.norm(w[~torch.isnan(w)])}")
 
-    c, t = 0, 0.0
-    for j in range(total_steps):
-        w_h, w_h_t, _, psi_h, _ = imex_crank_nicolson_step(w_h, f_h, visc, delta_t, diam=diam, rfftmesh=(kx, ky), laplacian=lap,
-                                                           dealias_filter=dealias_filter, dealias=dealias, **kwargs)
-        t += delta_t
-        if (j + 1) % record_every_n_steps == 0:
-            diverged(w_h)
-            res_h = update_residual(w_h, w_h_t, f_h, visc, (kx, ky), lap, dealias_filter=dealias_filter, dealias=dealias)
-            for key, val in zip(names, (w_h, w_h_t, psi_h, res_h)):
-                dev_out[key][:, c] = spectral_to_physical(val.contiguous(), ns, val.real.dtype)
-            t_steps[c] = t
-            c += 1
+    clock = [0.0]                            # physical time, accumulated step by step like the reference's `t += delta_t`
+
+    def advance(w, count):
+        out = None
+        for _ in range(count):
+            out = imex_crank_nicolson_step(w, f_h, visc, delta_t, diam=diam, rfftmesh=(kx, ky), laplacian=lap,
+                                           dealias_filter=mask, dealias=dealias, **kwargs)
+            w = out[0]
+            clock[0] += delta_t
             if bar is not None:
-                enstrophy = torch.linalg.norm(dev_out["vorticity"][:, c - 1], dim=(-1, -2)).mean().item() / n
-                res_l2 = torch.linalg.norm(dev_out["residual"][:, c - 1], dim=(-1, -2)).mean().item() / n
-                bar.set_description(f"{datetime.now():%d-%b-%Y %H:%M:%S} - enstrophy w: {enstrophy:.4f}  ||L(w, psi) - f||_2: {res_l2:.4e}")
+                bar.update()
+        return w, out
+
+    for slot in range(n_records):
+        w_h, last = advance(w_h, stride)
+        check_finite(w_h)
+        dw_h, psi_h = last[1], last[3]
+        res_h = update_residual(w_h, dw_h, f_h, visc, (kx, ky), lap, dealias_filter=mask, dealias=dealias)
+        for key, field in zip(names, (w_h, dw_h, psi_h, res_h)):
+            records[key][:, slot] = spectral_to_physical(field.contiguous(), ns, field.real.dtype)
+        times[slot] = clock[0]
         if bar is not None:
-            bar.update()
-    diverged(w_h)
+            enstrophy = torch.linalg.norm(records["vorticity"][:, slot], dim=(-1, -2)).mean().item() / n
+            res_l2 = torch.linalg.norm(records["residual"][:, slot], dim=(-1, -2)).mean().item() / n
+            bar.set_description(f"{datetime.now():%d-%b-%Y %H:%M:%S} - enstrophy w: {enstrophy:.4f}  ||L(w, psi) - f||_2: {res_l2:.4e}")
+    if n_steps - n_records * stride > 0:
+        w_h, _ = advance(w_h, n_steps - n_records * stride)        # the steps after the last record (their state is not returned)
+    check_finite(w_h)
     if bar is not None:
         bar.close()
-    out = {key: val.cpu() for key, val in dev_out.items()}
-    out["t_steps"] = t_steps
-    return out
+    result = {key: val.cpu() for key, val in records.items()}
+    result["t_steps"] = times
+    return result
